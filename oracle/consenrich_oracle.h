@@ -1,0 +1,111 @@
+/*
+ * consenrich_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, single thread, fp64 arithmetic on f32 storage) of the Consenrich
+ * Kalman forward filter / RTS smoother / fixed-background ECM hot path.  It exists to CHECK the
+ * HIP product path; it is never imported, linked or executed by consenrich_amd/ itself.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Parity is PINNED: validated bit-for-bit (store arrays) / <=1e-12 rel (scalar sums) against the real reference
+ * extension compiled into oracle/_ref (oracle/Makefile `ref`; tests/golden/make_golden.py) and against the golden
+ * vectors committed under tests/golden/.
+ *
+ * Every function cites the reference lines (src/consenrich/cconsenrich.pyx, "pyx") it restates.
+ */
+#ifndef CONSENRICH_ORACLE_H
+#define CONSENRICH_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cor_model {
+    int32_t state_dim;          /* 2 = levelTrend (pyx:291), 1 = level (pyx:538) */
+    double F[4];                /* row-major 2x2 transition, ignored for state_dim 1 */
+    double Q0[4];               /* row-major base process noise; level uses Q0[0] */
+    double state_init;          /* already a float32 value widened to double (pyx:6593) */
+    double state_covar_init;
+    double pad;                 /* (double)(float)pad (pyx:6595) */
+    double w_min, w_max;        /* lambda clamp (pyx:433) */
+    double k_min, k_max;        /* kappa clamp (pyx:395) */
+    double apn_min_q, apn_max_q, apn_thresh, apn_scale, apn_pc; /* pyx:510-527 */
+} cor_model;
+
+typedef struct cor_fwd_io {
+    int64_t m, n;
+    const float *data;          /* (m,n) C-order */
+    const float *munc;          /* (m,n) C-order */
+    const int32_t *block_map;   /* n */
+    int64_t block_count;
+    const float *lambda;        /* n or NULL  -> useLambda (pyx:6449) */
+    const float *kappa;         /* n or NULL  -> useProcPrec (pyx:6453) */
+    const float *qscale;        /* n or NULL  -> useProcessQScale (pyx:6452) */
+    int32_t use_apn;            /* after the qDiagBase<=1e-12 veto (pyx:6575) */
+    int32_t return_nll;
+    int32_t store_nll_in_d;
+    float *D;                   /* n, always written */
+    float *xf;                  /* (n,d) or NULL -> doStore (pyx:6444) */
+    float *Pf;                  /* (n,d,d) */
+    float *pnoise;              /* (n,d,d); entry k-1 written at step k */
+} cor_fwd_io;
+
+typedef struct cor_fwd_out {
+    double sum_d;
+    double sum_nll;
+    int64_t invalid_block_index;   /* -1 if none (pyx:389-392) */
+} cor_fwd_out;
+
+/* pyx:291-529 (trend) / pyx:538-707 (level) */
+void cor_forward(const cor_model *mdl, const cor_fwd_io *io, cor_fwd_out *out);
+
+/* pyx:6740-6848 (trend) / pyx:7116-7148 (level).  lag_rows = number of rows the lagCov buffer holds. */
+void cor_backward(const cor_model *mdl, int64_t m, int64_t n, const float *data,
+                  const float *xf, const float *Pf, const float *pnoise,
+                  float *xs, float *Ps, float *lag, int64_t lag_rows, float *resid);
+
+typedef struct cor_ecm_cfg {
+    int64_t max_iters;          /* ECM_fixedBackgroundIters */
+    int64_t inner_iters;        /* t_innerIters */
+    double rtol;                /* (double)(float) ECM_fixedBackgroundRtol */
+    double nu;                  /* (double)(float) ECM_robustTNu */
+    int32_t use_lambda;         /* ECM_useObsPrecisionReweighting */
+    int32_t use_kappa;          /* ECM_useProcessPrecisionReweighting && (!APN || qscale) (pyx:7912) */
+    int32_t use_apn;
+} cor_ecm_cfg;
+
+typedef struct cor_ecm_out {
+    int64_t iters_done;
+    double final_nll;
+    double initial_nll;
+    double abs_rel_change;
+    double rel_improvement;
+    int64_t stable_iters;
+    int64_t nll_increase_count;
+    int32_t converged;
+    int32_t skipped;            /* n <= 5 fallback (pyx:7998) */
+    int32_t has_initial_nll;
+    int64_t invalid_block_index;
+} cor_ecm_out;
+
+/* pyx:7660-8442 (trend) / pyx:7153-7657 (level).  lambda/kappa: n, in/out (warm start already clipped by
+ * the caller), may be NULL when the corresponding re-weighting is off.  Work buffers are caller-owned. */
+void cor_ecm(const cor_model *mdl, const cor_ecm_cfg *cfg,
+             int64_t m, int64_t n, const float *data, const float *munc,
+             const int32_t *block_map, int64_t block_count, const float *qscale,
+             float *lambda, float *kappa,
+             float *xf, float *Pf, float *pnoise,
+             float *xs, float *Ps, float *lag, float *resid,
+             float *D_scratch, double *nll_path /* max_iters or NULL */,
+             cor_ecm_out *out);
+
+/* pyx:710-815 (trend, d=2) / pyx:818-863 (level, d=1); float64 inputs */
+void cor_transition_sums(int32_t state_dim, int64_t n, const double *xs, const double *Ps,
+                         const double *lag, const double *F, double *sum_level, double *sum_trend,
+                         int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference hot path (oracle/_ref, built by `make -C oracle ref`).
+
+Runs only in the build container (needs /root/reference + oracle/_ref).  The committed .npz files hold DATA only:
+case parameters (seeds / shapes / flags, or small literal matrices) and the reference's outputs.  Inputs are
+re-synthesised from the seed by tests/golden/cases.py, which both this script and the tests import.
+
+Usage:  python tests/golden/make_golden.py          (rewrites every fixture, then cross-checks the C oracle bit-for-bit)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import cases  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+
+
+def main() -> int:
+    ref = ref_loader.load()
+    if ref is None:
+        print("reference build not available (make -C oracle ref)", file=sys.stderr)
+        return 2
+    n_written = 0
+    for case in cases.all_cases():
+        out_ref = cases.run_case(ref, case)
+        out_orc = cases.run_case(orc, case)
+        # the oracle restatement must reproduce the reference bit-for-bit on stored arrays
+        for key, val in out_ref.items():
+            other = out_orc[key]
+            if isinstance(val, np.ndarray) and val.dtype.kind == "f":
+                same = np.array_equal(val, other, equal_nan=True)
+                if not same:
+                    err = float(np.nanmax(np.abs(val.astype(np.float64) - other.astype(np.float64))))
+                    tol = 1e-12 * max(1.0, float(np.nanmax(np.abs(val))))
+                    if err > tol:
+                        raise SystemExit(f"oracle != reference for case {case['name']} key {key}: max|d|={err}")
+            else:
+                if not np.array_equal(np.asarray(val), np.asarray(other)):
+                    raise SystemExit(f"oracle != reference for case {case['name']} key {key}: {val} vs {other}")
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **cases.compact(case, out_ref))
+        n_written += 1
+        print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)} B)")
+    print(f"{n_written} fixtures written; oracle == reference on all of them")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
