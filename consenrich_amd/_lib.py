@@ -1,0 +1,155 @@
+"""ctypes binding of libconsenrich_amd.so (the C ABI in include/consenrich_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no MI355X is visible when a compute entry
+point is called, an exception is raised.  (The oracle under /oracle is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libconsenrich_amd.so")
+
+FP = C.POINTER(C.c_float)
+DP = C.POINTER(C.c_double)
+I64P = C.POINTER(C.c_int64)
+
+# flag bits (include/consenrich_amd.h)
+USE_LAMBDA, USE_KAPPA, USE_QSCALE, USE_APN, RETURN_NLL, NLL_IN_D = (1 << i for i in range(6))
+(ARR_D, ARR_XF, ARR_PF, ARR_PNOISE, ARR_XS, ARR_PS, ARR_LAG, ARR_RESID, ARR_LAMBDA, ARR_KAPPA, ARR_COUNT) = range(11)
+EXPORT_FORWARD, EXPORT_SMOOTH, EXPORT_RESID, EXPORT_MULT = 1, 2, 4, 8
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("state_dim", C.c_int32), ("reserved_", C.c_int32),
+        ("F", C.c_double * 4), ("Q0", C.c_double * 4),
+        ("state_init", C.c_double), ("state_covar_init", C.c_double), ("pad", C.c_double),
+        ("w_min", C.c_double), ("w_max", C.c_double), ("k_min", C.c_double), ("k_max", C.c_double),
+        ("apn_min_q", C.c_double), ("apn_max_q", C.c_double), ("apn_thresh", C.c_double),
+        ("apn_scale", C.c_double), ("apn_pc", C.c_double),
+    ]
+
+
+class FwdIO(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64), ("n", C.c_int64), ("data", FP), ("munc", FP), ("lam", FP), ("kappa", FP), ("qscale", FP),
+        ("flags", C.c_uint32), ("reserved_", C.c_uint32), ("D", FP), ("xf", FP), ("Pf", FP), ("pnoise", FP),
+    ]
+
+
+class FwdOut(C.Structure):
+    _fields_ = [("sum_d", C.c_double), ("sum_nll", C.c_double)]
+
+
+class EcmCfg(C.Structure):
+    _fields_ = [
+        ("max_iters", C.c_int64), ("inner_iters", C.c_int64), ("rtol", C.c_double), ("nu", C.c_double),
+        ("use_lambda", C.c_int32), ("use_kappa", C.c_int32), ("use_apn", C.c_int32), ("reserved_", C.c_int32),
+    ]
+
+
+class EcmOut(C.Structure):
+    _fields_ = [
+        ("iters_done", C.c_int64), ("final_nll", C.c_double), ("initial_nll", C.c_double),
+        ("abs_rel_change", C.c_double), ("rel_improvement", C.c_double), ("stable_iters", C.c_int64),
+        ("nll_increase_count", C.c_int64), ("converged", C.c_int32), ("skipped", C.c_int32),
+        ("has_initial_nll", C.c_int32), ("reserved_", C.c_int32),
+    ]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [
+        ("blocks", C.c_int64), ("fix_launches", C.c_int64), ("reruns_p", C.c_int64), ("reruns_x", C.c_int64),
+        ("reruns_b", C.c_int64), ("block_len", C.c_int32), ("warm_p", C.c_int32), ("warm_x", C.c_int32),
+        ("warm_b", C.c_int32),
+    ]
+
+
+# every symbol include/consenrich_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "csr_last_error": (C.c_char_p, []),
+    "csr_abi_version": (C.c_int, []),
+    "csr_device_count": (C.c_int, []),
+    "csr_create": (C.c_void_p, [C.c_int]),
+    "csr_destroy": (None, [C.c_void_p]),
+    "csr_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "csr_synchronize": (C.c_int, [C.c_void_p]),
+    "csr_batch_configure": (C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int64, C.c_int32, I64P]),
+    "csr_batch_set_model": (C.c_int, [C.c_void_p, C.POINTER(Model)]),
+    "csr_batch_upload": (C.c_int, [C.c_void_p, C.c_int32, FP, FP]),
+    "csr_batch_upload_multipliers": (C.c_int, [C.c_void_p, C.c_int32, FP, FP, FP]),
+    "csr_batch_synthesize": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "csr_batch_stats": (C.c_int, [C.c_void_p]),
+    "csr_batch_forward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
+    "csr_batch_backward": (C.c_int, [C.c_void_p]),
+    "csr_batch_ecm": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.POINTER(EcmOut), DP]),
+    "csr_batch_export": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "csr_batch_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "csr_batch_device_array": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), I64P]),
+    "csr_batch_chain_offset": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "csr_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "csr_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int32, C.POINTER(C.c_int32)]),
+    "csr_get_run_stats": (C.c_int, [C.c_void_p, C.POINTER(RunStats)]),
+    "csr_forward_pass": (C.c_int, [C.POINTER(Model), C.POINTER(FwdIO), C.POINTER(FwdOut)]),
+    "csr_backward_pass": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, C.c_int64, FP]),
+    "csr_fixed_background_ecm": (C.c_int, [C.POINTER(Model), C.POINTER(EcmCfg), C.c_int64, C.c_int64, FP, FP, FP, FP,
+                                           FP, FP, FP, FP, FP, DP, C.POINTER(EcmOut)]),
+    "csr_expected_transition_residual_sums": (C.c_int, [C.c_int32, C.c_int64, DP, DP, DP, DP, DP, DP, I64P]),
+}
+
+_lib = None
+
+
+class ConsenrichAMDError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library; raise if it has not been built (python -m consenrich_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ConsenrichAMDError(
+                f"{LIB_PATH} is missing: build it with `python -m consenrich_amd.build` (hipcc, gfx950). "
+                "consenrich_amd has no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)       # AttributeError if the ABI and the binding disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().csr_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise ConsenrichAMDError(last_error() or f"consenrich_amd call failed (rc={rc})")
+
+
+def device_count() -> int:
+    return int(lib().csr_device_count())
+
+
+def require_gpu() -> None:
+    if device_count() <= 0:
+        raise ConsenrichAMDError("no MI355X/HIP device visible: consenrich_amd has no CPU fallback")
+
+
+def fp(a):
+    return None if a is None else a.ctypes.data_as(FP)
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(DP)

@@ -1,0 +1,174 @@
+"""Device-resident multi-chain batch: the genome-level driver above the C ABI (include/consenrich_amd.h, level 2).
+
+The reference processes chromosomes sequentially (consenrich.py:8809); here every chain of a rank is packed into one
+batch so a single launch covers ~10^4-10^5 speculative blocks.  Inputs stay in HBM across sweeps.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+@dataclass
+class ModelParams:
+    """Estimator parameters that reach the hot path (defaults: reference constants.py:140-153, 247-249)."""
+    state_dim: int = 2
+    F: tuple = ((1.0, 1.0), (0.0, 1.0))
+    Q0: tuple = ((1.0e-3, 0.0), (0.0, 1.0e-4))
+    state_init: float = 0.0
+    state_covar_init: float = 1000.0
+    pad: float = 1.0e-4
+    lambda_bounds: tuple = (0.25, 4.0)
+    kappa_bounds: tuple = (5.0e-3, 5.0e3)
+    apn: tuple = (1.0e-4, 1000.0, 5.0, 10.0, 2.0)
+
+    def to_c(self) -> L.Model:
+        f32 = lambda v: float(np.float32(v))  # noqa: E731
+        mdl = L.Model()
+        mdl.state_dim = int(self.state_dim)
+        F = np.asarray(self.F, np.float32)
+        Q = np.asarray(self.Q0, np.float32)
+        mdl.F[:] = [float(F[0, 0]), float(F[0, 1]), float(F[1, 0]), float(F[1, 1])]
+        mdl.Q0[:] = [float(Q[0, 0]), float(Q[0, 1]), float(Q[1, 0]), float(Q[1, 1])]
+        mdl.state_init, mdl.state_covar_init, mdl.pad = f32(self.state_init), f32(self.state_covar_init), f32(self.pad)
+        mdl.w_min, mdl.w_max = f32(self.lambda_bounds[0]), f32(self.lambda_bounds[1])
+        mdl.k_min, mdl.k_max = f32(self.kappa_bounds[0]), f32(self.kappa_bounds[1])
+        mdl.apn_min_q, mdl.apn_max_q, mdl.apn_thresh, mdl.apn_scale, mdl.apn_pc = (f32(v) for v in self.apn)
+        return mdl
+
+
+_ARR = {"D": L.ARR_D, "xf": L.ARR_XF, "Pf": L.ARR_PF, "pnoise": L.ARR_PNOISE, "xs": L.ARR_XS, "Ps": L.ARR_PS,
+        "lag": L.ARR_LAG, "resid": L.ARR_RESID, "lambda": L.ARR_LAMBDA, "kappa": L.ARR_KAPPA}
+
+
+class DeviceBatch:
+    """One GPU, many chains.  Thin, explicit wrapper: every method is one C-ABI call."""
+
+    def __init__(self, device: int = 0, block_len: int = 0, warm=(-1, -1, -1)):
+        L.require_gpu()
+        self._lib = L.lib()
+        self._ctx = self._lib.csr_create(int(device))
+        if not self._ctx:
+            raise L.ConsenrichAMDError(L.last_error())
+        L.check(self._lib.csr_set_tuning(self._ctx, int(block_len), int(warm[0]), int(warm[1]), int(warm[2])))
+        self.chain_lens = []
+        self.m = 0
+        self.d = 2
+
+    def close(self):
+        if self._ctx:
+            self._lib.csr_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ---------------------------------------------------------------------------------------------------
+    def configure(self, model: ModelParams, m: int, chain_lens):
+        lens = np.ascontiguousarray(chain_lens, dtype=np.int64)
+        mdl = model.to_c()
+        L.check(self._lib.csr_batch_configure(self._ctx, C.byref(mdl), int(m), int(lens.size),
+                                              lens.ctypes.data_as(L.I64P)))
+        self.chain_lens = [int(v) for v in lens]
+        self.m, self.d = int(m), int(model.state_dim)
+
+    def set_model(self, model: ModelParams):
+        mdl = model.to_c()
+        L.check(self._lib.csr_batch_set_model(self._ctx, C.byref(mdl)))
+
+    def set_tuning(self, block_len=0, warm_p=-1, warm_x=-1, warm_b=-1):
+        L.check(self._lib.csr_set_tuning(self._ctx, int(block_len), int(warm_p), int(warm_x), int(warm_b)))
+
+    def upload(self, chain: int, data: np.ndarray, munc: np.ndarray):
+        data = np.ascontiguousarray(data, np.float32)
+        munc = np.ascontiguousarray(munc, np.float32)
+        if data.shape != (self.m, self.chain_lens[chain]) or munc.shape != data.shape:
+            raise ValueError("data/munc must have shape (m, chain_len)")
+        L.check(self._lib.csr_batch_upload(self._ctx, chain, L.fp(data), L.fp(munc)))
+
+    def upload_multipliers(self, chain: int, lam=None, kappa=None, qscale=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (lam, kappa, qscale)]
+        for a in arrs:
+            if a is not None and a.shape != (self.chain_lens[chain],):
+                raise ValueError("multiplier arrays must have shape (chain_len,)")
+        L.check(self._lib.csr_batch_upload_multipliers(self._ctx, chain, *(L.fp(a) for a in arrs)))
+
+    def synthesize(self, seed: int):
+        L.check(self._lib.csr_batch_synthesize(self._ctx, int(seed)))
+
+    # -- compute -------------------------------------------------------------------------------------------------
+    def stats(self):
+        L.check(self._lib.csr_batch_stats(self._ctx))
+
+    def forward(self, flags: int = L.RETURN_NLL, want_sums: bool = True):
+        nc = len(self.chain_lens)
+        if not want_sums:
+            L.check(self._lib.csr_batch_forward(self._ctx, int(flags), None, None))
+            return None, None
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        L.check(self._lib.csr_batch_forward(self._ctx, int(flags), L.dp(sd), L.dp(sn)))
+        return sd, sn
+
+    def backward(self):
+        L.check(self._lib.csr_batch_backward(self._ctx))
+
+    def ecm(self, max_iters=50, inner_iters=5, rtol=1.0e-6, nu=8.0, use_lambda=False, use_kappa=True,
+            use_apn=False, use_qscale=False):
+        nc = len(self.chain_lens)
+        cfg = L.EcmCfg(int(max_iters), int(inner_iters), float(np.float32(rtol)), float(np.float32(nu)),
+                       int(use_lambda), int(use_kappa), int(use_apn), 0)
+        outs = (L.EcmOut * nc)()
+        path = np.zeros(nc * max(int(max_iters), 1))
+        L.check(self._lib.csr_batch_ecm(self._ctx, C.byref(cfg), L.USE_QSCALE if use_qscale else 0, outs, L.dp(path)))
+        return list(outs), path.reshape(nc, -1)
+
+    def export(self, what: int):
+        L.check(self._lib.csr_batch_export(self._ctx, int(what)))
+
+    def synchronize(self):
+        L.check(self._lib.csr_synchronize(self._ctx))
+
+    # -- results -------------------------------------------------------------------------------------------------
+    def download(self, chain: int, name: str) -> np.ndarray:
+        n, d, m = self.chain_lens[chain], self.d, self.m
+        shape = {"D": (n,), "xf": (n, d), "Pf": (n, d, d), "pnoise": (max(n - 1, 0), d, d), "xs": (n, d),
+                 "Ps": (n, d, d), "lag": (max(n - 1, 0), d, d), "resid": (n, m), "lambda": (n,), "kappa": (n,)}[name]
+        out = np.empty(shape, np.float32)
+        L.check(self._lib.csr_batch_download(self._ctx, chain, _ARR[name], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def device_array(self, name: str):
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        L.check(self._lib.csr_batch_device_array(self._ctx, _ARR[name], C.byref(ptr), C.byref(cnt)))
+        return ptr.value, int(cnt.value)
+
+    def chain_offset(self, chain: int) -> int:
+        return int(self._lib.csr_batch_chain_offset(self._ctx, chain))
+
+    # -- instrumentation -----------------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        L.check(self._lib.csr_profile_enable(self._ctx, int(on)))
+
+    def kernel_times(self):
+        buf = (L.KernelTime * 64)()
+        n = C.c_int32()
+        L.check(self._lib.csr_profile_read(self._ctx, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n.value, 64))}
+
+    def run_stats(self):
+        rs = L.RunStats()
+        L.check(self._lib.csr_get_run_stats(self._ctx, C.byref(rs)))
+        return {k: getattr(rs, k) for k, _ in L.RunStats._fields_}

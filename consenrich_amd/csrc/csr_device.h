@@ -1,0 +1,1164 @@
+// csr_device.h -- gfx950 device code for the Consenrich estimator hot path (forward Kalman filter, RTS smoother,
+// ECM precision re-weighting).  Hand-written HIP for CDNA4; compiled with -ffp-contract=off so that every fused
+// multiply-add below is an explicit fma(): the arithmetic of a recurrence step is then identical in every kernel
+// and template instance that uses it (speculative run, warm-up, fix-up, sequential fallback), which is what makes
+// the bitwise carry validation meaningful.
+//
+// DATA LAYOUT
+//   natural  : the reference's layouts -- data/munc (m, Npad) row-major over the concatenated chains,
+//              per-bin outputs (Npad, ...) -- only at the API boundary.
+//   blocked  : every per-bin intermediate lives in a block-transposed layout.  Each chain is cut into blocks of B
+//              bins (blocks never span chains); block b = 64*G + l belongs to wave-group G, lane l; element (b, s)
+//              is stored at ((G*B + s)*64 + l).  A wavefront that walks 64 consecutive blocks in lock-step (one
+//              block per lane, step s) therefore touches one fully coalesced 64-element row per step -- the serial
+//              recurrences read/write HBM at full line efficiency with no LDS staging.
+//
+// TIME-PARALLEL RECURRENCES (SURVEY.md section 7 "hard parts")
+//   The reference recursions are strictly sequential in k and round their carries to float32 every step
+//   (pyx:405-406, 427-430, 478-479, 492-495).  A re-associated scan cannot reproduce that.  Instead every block
+//   runs the exact rounded recursion speculatively: it starts W bins early from a cold prior, discards the warm-up,
+//   and records the carry it entered its own range with.  A validation kernel then compares, bit for bit, each
+//   block's carry-in with its predecessor's carry-out and re-runs exactly the mismatching blocks from the true
+//   carry (iterated to a fixed point on the host), so the result equals the sequential recursion regardless of W.
+//   The forward pass is split into a covariance chain (independent of the data, short memory) and a state chain
+//   (affine in the state given the gains, 16 flops/step), and the per-bin NIS/NLL terms are evaluated afterwards by
+//   a fully parallel kernel from the stored predicted covariance and the previous filtered state.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csr {
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameters shared by all kernels (passed by value)
+// ---------------------------------------------------------------------------------------------------------------
+struct Prm {
+    int d;              // state dimension (2 = levelTrend, 1 = level)
+    int B;              // block length (bins), multiple of 32
+    int m;              // samples
+    int nchains;
+    int64_t NB;         // total blocks
+    int64_t NG;         // wave-groups = ceil(NB/64)
+    int64_t Npad;       // natural row stride (bins), chains start at multiples of 64
+    double F00, F01, F10, F11;
+    double Q00, Q01, Q10, Q11;
+    double init, cinit, pad;
+    double wMin, wMax, kMin, kMax;
+    double apnMinQ, apnMaxQ, apnThresh, apnScale, apnPC, qDiag;
+    double nu;          // ECM robust-t degrees of freedom
+    uint32_t flags;     // CSR_* bits
+    int warm;           // warm-up length in blocks for the kernel being launched
+
+    // block table: x = natural index of first bin, y = length, z = first block of chain, w = last block of chain
+    const int4 *blk;
+    const int *blkChain;
+    const unsigned char *chainActive;   // nullptr = all chains active
+
+    // natural inputs
+    const float *data;
+    const float *munc;
+
+    // blocked per-bin statistics (a1)
+    double *tS0u;       // sum_j 1/R_j
+    double *tZbar;      // weighted mean of z
+    double *tS2c;       // sum_j (z_j - zbar)^2 / R_j
+    double *tLogR;      // sum_j log R_j
+    // blocked multipliers
+    float *tLam, *tKap, *tQs;
+    // forward covariance chain outputs
+    float2 *tCp;        // trend: predicted (P00, P10) as float32 values
+    double *tPp;        // level: predicted variance (double, carries are not rounded in the level model)
+    double *tGs;        // S0/innovScale (total gain / P00pred)
+    float4 *tPf;        // filtered covariance (trend: 00,01,10,11; level: .x)
+    float4 *tQ;         // process noise used for the transition k -> k+1, stored at k (== pNoiseForward[k])
+    // forward state chain outputs
+    float2 *tXf;        // filtered state (level: .x)
+    double *tXd;        // level: filtered state in double (needed to rebuild the unrounded prediction)
+    float *tD;          // NIS or NLL per bin
+    // backward
+    float2 *tXs;
+    float4 *tPs;
+    float4 *tLag;
+    // per-block partial sums (deterministic reductions)
+    double *blkSumD, *blkSumNLL;
+    double *chainSumD, *chainSumNLL;
+    // speculation bookkeeping (raw bytes, sized for the largest carry)
+    void *carryIn;      // carry each block actually started from
+    void *carryOutA;    // ping
+    void *carryOutB;    // pong
+    unsigned int *rerunCount;
+};
+
+enum : uint32_t {
+    F_LAMBDA = 1u << 0, F_KAPPA = 1u << 1, F_QSCALE = 1u << 2, F_APN = 1u << 3, F_NLL = 1u << 4,
+    F_NLL_IN_D = 1u << 5
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double r32(double x) { return (double)(float)x; }   // the reference's <double><float32_t>
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) {
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// fast reciprocal for the serial chains: v_rcp_f64 + two Newton steps (<= ~1 ulp; the division it replaces is the
+// only multi-instruction operation on the dependent path of the forward covariance chain)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+__device__ __forceinline__ int64_t tbase(int64_t b, int B) { return ((b >> 6) * (int64_t)B) * 64 + (b & 63); }
+__device__ __forceinline__ int64_t tidx(int64_t b, int s, int B) { return tbase(b, B) + (int64_t)s * 64; }
+
+__device__ __forceinline__ bool chain_on(const Prm &p, int64_t b) {
+    return p.chainActive == nullptr || p.chainActive[p.blkChain[b]] != 0;
+}
+
+__device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// a1  per-bin sufficient statistics  (pyx:259-282 collapsed about the weighted mean)
+//     S0u = sum 1/R, zbar = sum z/R / S0u, S2c = sum (z-zbar)^2/R, logR = sum log R,  R = max(v + pad, 1e-12)
+//     The reference's S1, S2 about the predicted level x follow exactly:  S1 = S0 (zbar - x),
+//     S2 = S2c + S0 (zbar - x)^2  (no cancellation: both terms are non-negative).
+// ---------------------------------------------------------------------------------------------------------------
+struct BinStats {
+    double s0, zbar, s2c, logr;
+};
+
+template <int MT>
+__device__ __forceinline__ BinStats bin_stats_reg(const float *__restrict__ data, const float *__restrict__ munc,
+                                                  int64_t stride, int64_t g, int m, double pad) {
+    float z[MT], v[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int jj = j < m ? j : m - 1;
+        z[j] = data[(int64_t)jj * stride + g];
+        v[j] = munc[(int64_t)jj * stride + g];
+    }
+    double w[MT];
+    double s0 = 0.0, swz = 0.0, mant = 1.0;
+    int ex = 0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        double R = (double)v[j] + pad;
+        if (R < 1.0e-12) R = 1.0e-12;
+        const double wj = (j < m) ? 1.0 / R : 0.0;
+        w[j] = wj;
+        s0 += wj;
+        swz = fma(wj, (double)z[j], swz);
+        if (j < m) {
+            int e;
+            mant *= frexp(R, &e);
+            ex += e;
+        }
+        if ((j & 15) == 15) {
+            int e;
+            mant = frexp(mant, &e);
+            ex += e;
+        }
+    }
+    BinStats o;
+    o.s0 = s0;
+    o.zbar = (s0 > 0.0) ? swz / s0 : 0.0;
+    double s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const double dz = (double)z[j] - o.zbar;
+        s2 = fma(w[j], dz * dz, s2);
+    }
+    o.s2c = s2;
+    o.logr = log(mant) + (double)ex * 0.693147180559945309417232121458;
+    return o;
+}
+
+__device__ __forceinline__ BinStats bin_stats_any(const float *__restrict__ data, const float *__restrict__ munc,
+                                                  int64_t stride, int64_t g, int m, double pad) {
+    double s0 = 0.0, swz = 0.0, mant = 1.0;
+    int ex = 0;
+    for (int j = 0; j < m; ++j) {
+        double R = (double)munc[(int64_t)j * stride + g] + pad;
+        if (R < 1.0e-12) R = 1.0e-12;
+        const double wj = 1.0 / R;
+        s0 += wj;
+        swz = fma(wj, (double)data[(int64_t)j * stride + g], swz);
+        int e;
+        mant *= frexp(R, &e);
+        ex += e;
+        if ((j & 15) == 15) {
+            mant = frexp(mant, &e);
+            ex += e;
+        }
+    }
+    BinStats o;
+    o.s0 = s0;
+    o.zbar = (s0 > 0.0) ? swz / s0 : 0.0;
+    double s2 = 0.0;
+    for (int j = 0; j < m; ++j) {
+        double R = (double)munc[(int64_t)j * stride + g] + pad;
+        if (R < 1.0e-12) R = 1.0e-12;
+        const double dz = (double)data[(int64_t)j * stride + g] - o.zbar;
+        s2 = fma(1.0 / R, dz * dz, s2);
+    }
+    o.s2c = s2;
+    o.logr = log(mant) + (double)ex * 0.693147180559945309417232121458;
+    return o;
+}
+
+// One workgroup = one (wave-group G, 32-step) tile: 64 runs of 32 consecutive bins are read with 128-byte coalesced
+// segments, reduced over the m samples in registers, transposed through LDS and written as 32 coalesced rows.
+template <int MT>
+__global__ __launch_bounds__(256) void k_stats(Prm p) {
+    __shared__ double tile[4][32][65];
+    const int tilesPerGroup = p.B >> 5;
+    const int64_t G = blockIdx.x / tilesPerGroup;
+    const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
+    const int t = threadIdx.x;
+    const int r = t >> 5, si = t & 31;
+    const int s = s0 + si;
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int l = pass * 8 + r;
+        const int64_t b = G * 64 + l;
+        BinStats o = {0.0, 0.0, 0.0, 0.0};
+        if (b < p.NB) {
+            const int4 bi = p.blk[b];
+            if (s < bi.y && chain_on(p, b)) {
+                const int64_t g = (int64_t)bi.x + s;
+                if constexpr (MT > 0) o = bin_stats_reg<MT>(p.data, p.munc, p.Npad, g, p.m, p.pad);
+                else o = bin_stats_any(p.data, p.munc, p.Npad, g, p.m, p.pad);
+            }
+        }
+        tile[0][si][l] = o.s0;
+        tile[1][si][l] = o.zbar;
+        tile[2][si][l] = o.s2c;
+        tile[3][si][l] = o.logr;
+    }
+    __syncthreads();
+    const int lane = t & 63, r0 = t >> 6;
+    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + r0;
+        const int64_t o = rowBase + (int64_t)row * 64 + lane;
+        p.tS0u[o] = tile[0][row][lane];
+        p.tZbar[o] = tile[1][row][lane];
+        p.tS2c[o] = tile[2][row][lane];
+        p.tLogR[o] = tile[3][row][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// recurrence steps.  Each chain policy CH provides
+//   Carry, In, U (prefetch depth), FWD, load(), step<STORE>(), init_true(), init_cold(), same()
+// ---------------------------------------------------------------------------------------------------------------
+
+// ---- forward covariance chain, levelTrend (pyx:394-401, 408-435, 458, 481-495) -------------------------------
+struct FwdPTrend {
+    static constexpr bool FWD = true;
+    static constexpr int U = 8;
+    struct Carry {
+        float c00, c01, c11;   // filtered covariance after the float32 rounding (c10 == c01, pyx:494)
+        float pad_;
+    };
+    struct In {
+        double s0u;
+        float lam, kap, qs;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+        In in;
+        in.s0u = p.tS0u[i];
+        in.lam = (p.flags & F_LAMBDA) ? p.tLam[i] : 1.0f;
+        in.kap = (p.flags & F_KAPPA) ? p.tKap[i] : 1.0f;
+        in.qs = (p.flags & F_QSCALE) ? p.tQs[i] : 1.0f;
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) {
+        Carry c;
+        c.c00 = (float)p.cinit;
+        c.c01 = 0.0f;
+        c.c11 = (float)p.cinit;
+        c.pad_ = 0.0f;
+        return c;
+    }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return init_true(p); }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        return f2u(a.c00) == f2u(b.c00) && f2u(a.c01) == f2u(b.c01) && f2u(a.c11) == f2u(b.c11);
+    }
+    // b, s: block / step of this bin (for the shifted pNoise store)
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
+                                                int64_t bfirst) {
+        const double kap = (p.flags & F_KAPPA) ? clampd((double)in.kap, p.kMin, p.kMax) : 1.0;
+        const double lam = (p.flags & F_LAMBDA) ? clampd((double)in.lam, p.wMin, p.wMax) : 1.0;
+        double qf = (double)in.qs;
+        if (p.flags & F_KAPPA) qf = qf / kap;     // (qScale / procPrec), pyx:412
+        const double Q00 = qf * p.Q00, Q01 = qf * p.Q01, Q10 = qf * p.Q10, Q11 = qf * p.Q11;
+        const double c00 = (double)c.c00, c01 = (double)c.c01, c11 = (double)c.c11;
+        // F P F^T + Q, rounded to float32 (pyx:417-430); the carry is symmetric (c10 == c01)
+        const double t00 = fma(p.F01, c01, p.F00 * c00);
+        const double t01 = fma(p.F01, c11, p.F00 * c01);
+        const double t10 = fma(p.F11, c01, p.F10 * c00);
+        const double t11 = fma(p.F11, c11, p.F10 * c01);
+        const double a00 = r32(fma(t01, p.F01, fma(t00, p.F00, Q00)));
+        const double a01 = r32(fma(t01, p.F11, fma(t00, p.F10, Q01)));
+        const double a10 = r32(fma(t11, p.F01, fma(t10, p.F00, Q10)));
+        const double a11 = r32(fma(t11, p.F11, fma(t10, p.F10, Q11)));
+        // collapsed measurement update (pyx:458, 481-495)
+        const double S0 = lam * in.s0u;
+        const double is = fma(a00, S0, 1.0);
+        const double r = rcp_nr(is);
+        const double gG = S0 * r;
+        const double gH = gG * r;
+        const double i00 = fma(-a00, gG, 1.0);
+        const double i10 = -(a10 * gG);
+        const double n00 = fma(gH, a00 * a00, i00 * i00 * a00);
+        const double n01 = fma(gH, a00 * a10, i00 * fma(i10, a00, a01));
+        const double n11 = fma(gH, a10 * a10, fma(i10 * i10, a00, fma(2.0 * i10, a10, a11)));
+        c.c00 = (float)n00;
+        c.c01 = (float)n01;
+        c.c11 = (float)n11;
+        if constexpr (STORE) {
+            p.tCp[i] = make_float2((float)a00, (float)a10);
+            p.tGs[i] = gG;
+            p.tPf[i] = make_float4(c.c00, c.c01, c.c01, c.c11);
+            // pNoiseForward[k-1] = Q used to reach k (pyx:504-508): shifted store, skipped at the chain's first bin
+            if (s > 0) p.tQ[i - 64] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+            else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+        }
+    }
+};
+
+// ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
+struct FwdPLevel {
+    static constexpr bool FWD = true;
+    static constexpr int U = 8;
+    struct Carry {
+        double p;
+    };
+    using In = FwdPTrend::In;
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) { return FwdPTrend::load(p, i); }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{p.cinit}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{p.cinit}; }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        if (__double_as_longlong(a.p) == __double_as_longlong(b.p)) return true;
+        return fabs(a.p - b.p) <= 1.0e-12 * fmax(fabs(a.p), fabs(b.p));
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
+                                                int64_t bfirst) {
+        const double kap = (p.flags & F_KAPPA) ? clampd((double)in.kap, p.kMin, p.kMax) : 1.0;
+        const double lam = (p.flags & F_LAMBDA) ? clampd((double)in.lam, p.wMin, p.wMax) : 1.0;
+        double qf = (double)in.qs;
+        if (p.flags & F_KAPPA) qf = qf / kap;
+        const double Q = qf * p.Q00;
+        const double pp = c.p + Q;
+        const double S0 = lam * in.s0u;
+        const double is = fma(pp, S0, 1.0);
+        const double r = rcp_nr(is);
+        const double gG = S0 * r;
+        const double gH = gG * r;
+        const double ikh = fma(-pp, gG, 1.0);
+        c.p = fma(gH, pp * pp, ikh * ikh * pp);
+        if constexpr (STORE) {
+            p.tPp[i] = pp;
+            p.tGs[i] = gG;
+            p.tPf[i] = make_float4((float)c.p, 0.f, 0.f, 0.f);
+            if (s > 0) p.tQ[i - 64] = make_float4((float)Q, 0.f, 0.f, 0.f);
+            else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q, 0.f, 0.f, 0.f);
+        }
+    }
+};
+
+// ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
+struct FwdXTrend {
+    static constexpr bool FWD = true;
+    static constexpr int U = 8;
+    struct Carry {
+        float x0, x1;
+    };
+    struct In {
+        double zbar, gs;
+        float2 cp;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+        In in;
+        in.zbar = p.tZbar[i];
+        in.gs = p.tGs[i];
+        in.cp = p.tCp[i];
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{(float)p.init, 0.0f}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{(float)p.init, 0.0f}; }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        return f2u(a.x0) == f2u(b.x0) && f2u(a.x1) == f2u(b.x1);
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+        const double x0 = (double)c.x0, x1 = (double)c.x1;
+        const double xp0 = r32(fma(p.F01, x1, p.F00 * x0));
+        const double xp1 = r32(fma(p.F11, x1, p.F10 * x0));
+        const double dl = in.gs * (in.zbar - xp0);            // S1/innovScale with S1 = S0 (zbar - x)
+        c.x0 = (float)fma((double)in.cp.x, dl, xp0);
+        c.x1 = (float)fma((double)in.cp.y, dl, xp1);
+        if constexpr (STORE) p.tXf[i] = make_float2(c.x0, c.x1);
+    }
+};
+
+// ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
+struct FwdXLevel {
+    static constexpr bool FWD = true;
+    static constexpr int U = 8;
+    struct Carry {
+        double x;
+    };
+    struct In {
+        double zbar, gs, pp;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+        In in;
+        in.zbar = p.tZbar[i];
+        in.gs = p.tGs[i];
+        in.pp = p.tPp[i];
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{p.init}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{p.init}; }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        if (__double_as_longlong(a.x) == __double_as_longlong(b.x)) return true;
+        return fabs(a.x - b.x) <= 1.0e-12 * fmax(fabs(a.x), fabs(b.x)) + 1.0e-300;
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+        const double dl = in.gs * (in.zbar - c.x);
+        c.x = fma(in.pp, dl, c.x);
+        if constexpr (STORE) {
+            p.tXf[i] = make_float2((float)c.x, 0.f);
+            p.tXd[i] = c.x;
+        }
+    }
+};
+
+// ---- backward RTS chain, levelTrend (pyx:6758-6822) ------------------------------------------------------------
+// J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
+// smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
+struct BwdTrend {
+    static constexpr bool FWD = false;
+    static constexpr int U = 4;
+    struct Carry {
+        float x0, x1, p00, p01, p10, p11;
+        int fresh;      // 1: next visited bin seeds the chain with its filtered values (true chain end or cold start)
+        int pad_;
+    };
+    struct In {
+        float2 xf;
+        float4 pf, q;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+        In in;
+        in.xf = p.tXf[i];
+        in.pf = p.tPf[i];
+        in.q = p.tQ[i];
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 0, 0, 0, 0, 1, 0}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &) { return Carry{0, 0, 0, 0, 0, 0, 1, 0}; }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        return f2u(a.x0) == f2u(b.x0) && f2u(a.x1) == f2u(b.x1) && f2u(a.p00) == f2u(b.p00) &&
+               f2u(a.p01) == f2u(b.p01) && f2u(a.p10) == f2u(b.p10) && f2u(a.p11) == f2u(b.p11);
+    }
+    struct Gain {
+        double J00, J01, J10, J11, pp00, pp01, pp10, pp11, c00, c01, c10, c11;
+    };
+    __device__ static __forceinline__ Gain gain(const Prm &p, const float4 &pf, const float4 &q) {
+        Gain g;
+        const double f00 = pf.x, f01 = pf.y, f10 = pf.z, f11 = pf.w;
+        const double a00 = fma(p.F01, f10, p.F00 * f00);      // F Pf
+        const double a01 = fma(p.F01, f11, p.F00 * f01);
+        const double a10 = fma(p.F11, f10, p.F10 * f00);
+        const double a11 = fma(p.F11, f11, p.F10 * f01);
+        g.pp00 = fma(a01, p.F01, fma(a00, p.F00, (double)q.x));
+        g.pp01 = fma(a01, p.F11, fma(a00, p.F10, (double)q.y));
+        g.pp10 = fma(a11, p.F01, fma(a10, p.F00, (double)q.z));
+        g.pp11 = fma(a11, p.F11, fma(a10, p.F10, (double)q.w));
+        const double det = fma(g.pp00, g.pp11, -(g.pp01 * g.pp10));   // unguarded, pyx:6780
+        const double rd = rcp_nr(det);
+        const double v00 = g.pp11 * rd, v01 = -g.pp01 * rd, v10 = -g.pp10 * rd, v11 = g.pp00 * rd;
+        g.c00 = fma(f01, p.F01, f00 * p.F00);                 // Pf F^T
+        g.c01 = fma(f01, p.F11, f00 * p.F10);
+        g.c10 = fma(f11, p.F01, f10 * p.F00);
+        g.c11 = fma(f11, p.F11, f10 * p.F10);
+        g.J00 = fma(g.c01, v10, g.c00 * v00);
+        g.J01 = fma(g.c01, v11, g.c00 * v01);
+        g.J10 = fma(g.c11, v10, g.c10 * v00);
+        g.J11 = fma(g.c11, v11, g.c10 * v01);
+        return g;
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+        if (c.fresh) {      // pyx:6744-6750
+            c.x0 = in.xf.x; c.x1 = in.xf.y;
+            c.p00 = in.pf.x; c.p01 = in.pf.y; c.p10 = in.pf.z; c.p11 = in.pf.w;
+            c.fresh = 0;
+        } else {
+            const Gain g = gain(p, in.pf, in.q);
+            const double xf0 = in.xf.x, xf1 = in.xf.y;
+            const double dx0 = (double)c.x0 - fma(p.F01, xf1, p.F00 * xf0);
+            const double dx1 = (double)c.x1 - fma(p.F11, xf1, p.F10 * xf0);
+            const double d00 = (double)c.p00 - g.pp00, d01 = (double)c.p01 - g.pp01;
+            const double d10 = (double)c.p10 - g.pp10, d11 = (double)c.p11 - g.pp11;
+            const double r00 = fma(d01, g.J01, d00 * g.J00);
+            const double r01 = fma(d01, g.J11, d00 * g.J10);
+            const double r10 = fma(d11, g.J01, d10 * g.J00);
+            const double r11 = fma(d11, g.J11, d10 * g.J10);
+            c.x0 = (float)(xf0 + fma(g.J01, dx1, g.J00 * dx0));
+            c.x1 = (float)(xf1 + fma(g.J11, dx1, g.J10 * dx0));
+            c.p00 = (float)((double)in.pf.x + fma(g.J01, r10, g.J00 * r00));
+            c.p01 = (float)((double)in.pf.y + fma(g.J01, r11, g.J00 * r01));
+            c.p10 = c.p01;                                     // pyx:6821
+            c.p11 = (float)((double)in.pf.w + fma(g.J11, r11, g.J10 * r01));
+        }
+        if constexpr (STORE) {
+            p.tXs[i] = make_float2(c.x0, c.x1);
+            p.tPs[i] = make_float4(c.p00, c.p01, c.p10, c.p11);
+        }
+    }
+};
+
+// ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
+struct BwdLevel {
+    static constexpr bool FWD = false;
+    static constexpr int U = 8;
+    struct Carry {
+        float x, ps;
+        int fresh, pad_;
+    };
+    struct In {
+        float xf, pf, q;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+        In in;
+        in.xf = p.tXf[i].x;
+        in.pf = p.tPf[i].x;
+        in.q = p.tQ[i].x;
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 1, 0}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &) { return Carry{0, 0, 1, 0}; }
+    __device__ static __forceinline__ bool same(const Carry &a, const Carry &b) {
+        return f2u(a.x) == f2u(b.x) && f2u(a.ps) == f2u(b.ps);
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+        if (c.fresh) {
+            c.x = in.xf;
+            c.ps = in.pf;
+            c.fresh = 0;
+        } else {
+            const double pf = in.pf;
+            double pp = pf + (double)in.q;
+            if (pp < 1.0e-12) pp = 1.0e-12;
+            const double J = pf / pp;
+            const double dx = (double)c.x - (double)in.xf;
+            const double dP = (double)c.ps - pp;
+            c.x = (float)fma(J, dx, (double)in.xf);
+            double ps = fma(J * J, dP, pf);
+            if (ps < 0.0) ps = 0.0;
+            c.ps = (float)ps;
+        }
+        if constexpr (STORE) {
+            p.tXs[i] = make_float2(c.x, 0.f);
+            p.tPs[i] = make_float4(c.ps, 0.f, 0.f, 0.f);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// block walker: all valid steps of block `bq` in chain order (ascending for forward chains, descending for the
+// smoother), inputs prefetched U steps ahead so the dependent recursion never waits on HBM.
+// ---------------------------------------------------------------------------------------------------------------
+template <class CH, bool STORE>
+__device__ __forceinline__ void walk_block(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                           int64_t bfirst) {
+    constexpr int U = CH::U;
+    const int B = p.B;
+    const int64_t base = tbase(bq, B);
+    typename CH::In cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int s = CH::FWD ? u : (B - 1 - u);
+        if (act && s < len) cur[u] = CH::load(p, base + (int64_t)s * 64);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < B; i0 += U) {
+        if (i0 + U < B) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = CH::FWD ? (i0 + U + u) : (B - 1 - (i0 + U + u));
+                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = CH::FWD ? (i0 + u) : (B - 1 - (i0 + u));
+            if (act && s < len) CH::template step<STORE>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+}
+
+// Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
+template <class CH>
+__global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    const int64_t bfirst = bi.z, blast = bi.w;
+    typename CH::Carry c = CH::init_cold(p);
+    typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
+    typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
+    if constexpr (CH::FWD) {
+        const int avail = live ? (int)(b - bfirst) : 0;        // preceding blocks of this chain (all full)
+        const int qstart = avail < p.warm ? avail : p.warm;
+        if (live && qstart == avail) c = CH::init_true(p);
+        for (int q = p.warm; q >= 1; --q) {
+            const bool act = live && q <= qstart;
+            if (!__any(act)) continue;
+            walk_block<CH, false>(p, c, b - q, p.B, act, bfirst);
+        }
+        if (live) cin[b] = c;
+        walk_block<CH, true>(p, c, b, bi.y, live, bfirst);
+        if (live) cout[b] = c;
+    } else {
+        const int avail = live ? (int)(blast - b) : 0;         // following blocks of this chain
+        const int qstart = avail < p.warm ? avail : p.warm;
+        int lastLen = p.B;
+        if (live) lastLen = p.blk[blast].y;
+        for (int q = p.warm; q >= 1; --q) {
+            const bool act = live && q <= qstart;
+            if (!__any(act)) continue;
+            const int64_t bq = b + q;
+            walk_block<CH, false>(p, c, bq, (bq == blast) ? lastLen : p.B, act, bfirst);
+        }
+        if (live) cin[b] = c;
+        walk_block<CH, true>(p, c, b, bi.y, live, bfirst);
+        if (live) cout[b] = c;
+    }
+}
+
+// Validation / fix-up pass: a block whose recorded carry-in differs from its neighbour's current carry-out is re-run
+// from that carry.  Iterated (ping-pong outCur/outNext) until no block re-runs: the fixed point is the sequential
+// recursion.  which = 0: read A write B; 1: read B write A.
+template <class CH>
+__global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    using Carry = typename CH::Carry;
+    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
+    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
+    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    const int64_t bfirst = bi.z, blast = bi.w;
+    bool rerun = false;
+    Carry c = CH::init_cold(p);
+    if (live) {
+        const bool edge = CH::FWD ? (b == bfirst) : (b == blast);
+        if (!edge) {
+            const Carry prev = ocur[CH::FWD ? b - 1 : b + 1];
+            if (!CH::same(prev, cin[b])) {
+                rerun = true;
+                c = prev;
+                cin[b] = prev;
+            }
+        }
+        if (!rerun) onxt[b] = ocur[b];
+    }
+    if (!__any(rerun)) return;
+    walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst);
+    if (rerun) {
+        onxt[b] = c;
+        atomicAdd(p.rerunCount, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fully parallel epilogues (blocked layout).  One lane per (block, quarter) walks its steps; rows stay coalesced.
+// ---------------------------------------------------------------------------------------------------------------
+
+// NIS / NLL per bin (pyx:458-475) from the stored predicted covariance, the previous filtered state and the bin
+// statistics; per-block partial sums give deterministic sumD / sumNLL.
+__global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
+    __shared__ double redD[4][64], redN[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = b < p.NB && chain_on(p, b);
+    double sumD = 0.0, sumN = 0.0;
+    if (live) {
+        const int4 bi = p.blk[b];
+        const int64_t base = tbase(b, p.B);
+        const int q4 = p.B >> 2;
+        const int sBeg = part * q4;
+        const int sEnd = (sBeg + q4 < bi.y) ? sBeg + q4 : bi.y;
+        const double mD = (double)p.m;
+        const double log2pi = 1.8378770664093454835606594728112;
+        const bool wantNLL = (p.flags & F_NLL) != 0;
+        for (int s = sBeg; s < sEnd; ++s) {
+            const int64_t i = base + (int64_t)s * 64;
+            const double lam = (p.flags & F_LAMBDA) ? clampd((double)p.tLam[i], p.wMin, p.wMax) : 1.0;
+            double xp0, pp;
+            if (p.d == 2) {
+                double x0, x1;
+                if (s > 0) { const float2 v = p.tXf[i - 64]; x0 = v.x; x1 = v.y; }
+                else if (b > bi.z) { const float2 v = p.tXf[tidx(b - 1, p.B - 1, p.B)]; x0 = v.x; x1 = v.y; }
+                else { x0 = (double)(float)p.init; x1 = 0.0; }
+                xp0 = r32(fma(p.F01, x1, p.F00 * x0));
+                pp = (double)p.tCp[i].x;
+            } else {
+                if (s > 0) xp0 = p.tXd[i - 64];
+                else if (b > bi.z) xp0 = p.tXd[tidx(b - 1, p.B - 1, p.B)];
+                else xp0 = p.init;
+                pp = p.tPp[i];
+            }
+            const double S0 = lam * p.tS0u[i];
+            const double dz = p.tZbar[i] - xp0;
+            const double S1 = S0 * dz;
+            const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
+            const double is = 1.0 + pp * S0;
+            const double gl = pp / is;
+            double quad = S2 - gl * (S1 * S1);
+            if (quad < 0.0) quad = 0.0;
+            double nll = 0.0;
+            if (wantNLL) {
+                double SL = p.tLogR[i];
+                if (p.flags & F_LAMBDA) SL -= mD * log(lam);
+                nll = 0.5 * (SL + log(is) + quad + mD * log2pi);
+                sumN += nll;
+            }
+            const float D = (float)((wantNLL && (p.flags & F_NLL_IN_D)) ? nll : quad / mD);
+            p.tD[i] = D;
+            sumD += (double)D;
+        }
+    }
+    redD[part][lane] = sumD;
+    redN[part][lane] = sumN;
+    __syncthreads();
+    if (part == 0 && live) {
+        p.blkSumD[b] = ((redD[0][lane] + redD[1][lane]) + redD[2][lane]) + redD[3][lane];
+        p.blkSumNLL[b] = ((redN[0][lane] + redN[1][lane]) + redN[2][lane]) + redN[3][lane];
+    }
+}
+
+// per-chain sums in block order (one workgroup per chain, fixed-shape tree: deterministic)
+__global__ __launch_bounds__(256) void k_chain_sums(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
+    __shared__ double sd[256], sn[256];
+    const int c = blockIdx.x;
+    const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
+    double aD = 0.0, aN = 0.0;
+    if (p.chainActive == nullptr || p.chainActive[c]) {
+        for (int64_t i = threadIdx.x; i < nb; i += 256) {
+            aD += p.blkSumD[b0 + i];
+            aN += p.blkSumNLL[b0 + i];
+        }
+    }
+    sd[threadIdx.x] = aD;
+    sn[threadIdx.x] = aN;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sd[threadIdx.x] += sd[threadIdx.x + w];
+            sn[threadIdx.x] += sn[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && (p.chainActive == nullptr || p.chainActive[c])) {
+        p.chainSumD[c] = sd[0];
+        p.chainSumNLL[c] = sn[0];
+    }
+}
+
+// neighbour k+1 of (b, s) in the blocked layout, or -1 at the chain end
+__device__ __forceinline__ int64_t next_slot(const Prm &p, int64_t b, int s, const int4 &bi) {
+    if (s + 1 < bi.y) return tidx(b, s + 1, p.B);
+    if (b < bi.w) return tidx(b + 1, 0, p.B);
+    return -1;
+}
+
+// lag-one covariance C[k] = Pf F^T + J (Ps[k+1] - PPred)  (pyx:6825-6844 / pyx:7142), elementwise
+__global__ __launch_bounds__(256) void k_bwd_lag(Prm p) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.B;
+    const int s = (int)(row % p.B);
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int4 bi = p.blk[b];
+    if (s >= bi.y) return;
+    const int64_t nx = next_slot(p, b, s, bi);
+    if (nx < 0) return;
+    const float4 pf = p.tPf[slot], q = p.tQ[slot], ps1 = p.tPs[nx];
+    if (p.d == 2) {
+        const BwdTrend::Gain g = BwdTrend::gain(p, pf, q);
+        const double d00 = (double)ps1.x - g.pp00, d01 = (double)ps1.y - g.pp01;
+        const double d10 = (double)ps1.z - g.pp10, d11 = (double)ps1.w - g.pp11;
+        p.tLag[slot] = make_float4((float)(g.c00 + fma(g.J01, d10, g.J00 * d00)),
+                                   (float)(g.c01 + fma(g.J01, d11, g.J00 * d01)),
+                                   (float)(g.c10 + fma(g.J11, d10, g.J10 * d00)),
+                                   (float)(g.c11 + fma(g.J11, d11, g.J10 * d01)));
+    } else {
+        const double f = pf.x;
+        double pp = f + (double)q.x;
+        if (pp < 1.0e-12) pp = 1.0e-12;
+        const double J = f / pp;
+        p.tLag[slot] = make_float4((float)fma(J, (double)ps1.x - pp, f), 0.f, 0.f, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ECM E-steps (blocked layout, elementwise)
+// ---------------------------------------------------------------------------------------------------------------
+// lambda (pyx:8210-8239): u2 = sum_j ((z_j - xs0)^2 + P00)/R_j = S2c + S0u (zbar - xs0)^2 + P00 S0u
+__global__ __launch_bounds__(256) void k_estep_lambda(Prm p) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.B;
+    const int s = (int)(row % p.B);
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int4 bi = p.blk[b];
+    if (s >= bi.y) return;
+    double p00 = (double)p.tPs[slot].x;
+    if (p00 < 0.0) p00 = 0.0;
+    const double s0u = p.tS0u[slot];
+    const double dz = p.tZbar[slot] - (double)p.tXs[slot].x;
+    const double u2 = fma(p00, s0u, fma(s0u, dz * dz, p.tS2c[slot]));
+    double w = (p.nu + (double)p.m) / (p.nu + u2);
+    if (w < p.wMin) w = p.wMin;
+    else if (w > p.wMax) w = p.wMax;
+    p.tLam[slot] = (float)w;
+}
+
+// kappa (pyx:8244-8298 with MAT2 helpers pyx:4123-4175; level pyx:7496-7521); also produces lag (needed anyway)
+__global__ __launch_bounds__(256) void k_estep_kappa(Prm p) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.B;
+    const int s = (int)(row % p.B);
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int4 bi = p.blk[b];
+    if (s >= bi.y) return;
+    if (s == 0 && b == bi.z) p.tKap[slot] = 1.0f;     // processPrecExp[0] = 1 (pyx:8245)
+    const int64_t nx = next_slot(p, b, s, bi);
+    if (nx < 0) return;
+    const float4 lg = p.tLag[slot];
+    double delta;
+    if (p.d == 2) {
+        const float2 xa = p.tXs[slot], ya = p.tXs[nx];
+        const float4 pk = p.tPs[slot], pk1 = p.tPs[nx];
+        const double x0 = xa.x, x1 = xa.y, y0 = ya.x, y1 = ya.y;
+        const double f00 = p.F00, f01 = p.F01, f10 = p.F10, f11 = p.F11;
+        const double xx00 = (double)pk.x + x0 * x0, xx01 = (double)pk.y + x0 * x1;
+        const double xx10 = (double)pk.z + x1 * x0, xx11 = (double)pk.w + x1 * x1;
+        const double yy00 = (double)pk1.x + y0 * y0, yy01 = (double)pk1.y + y0 * y1;
+        const double yy10 = (double)pk1.z + y1 * y0, yy11 = (double)pk1.w + y1 * y1;
+        const double xy00 = (double)lg.x + x0 * y0, xy01 = (double)lg.y + x0 * y1;
+        const double xy10 = (double)lg.z + x1 * y0, xy11 = (double)lg.w + x1 * y1;
+        // yx = xy^T, Ft = F^T : ww = yy - yx Ft - F xy + (F xx) Ft
+        double w00 = yy00 - (xy00 * f00 + xy10 * f01);
+        double w01 = yy01 - (xy00 * f10 + xy10 * f11);
+        double w10 = yy10 - (xy01 * f00 + xy11 * f01);
+        double w11 = yy11 - (xy01 * f10 + xy11 * f11);
+        w00 -= (f00 * xy00 + f01 * xy10);
+        w01 -= (f00 * xy01 + f01 * xy11);
+        w10 -= (f10 * xy00 + f11 * xy10);
+        w11 -= (f10 * xy01 + f11 * xy11);
+        const double g00 = f00 * xx00 + f01 * xx10, g01 = f00 * xx01 + f01 * xx11;
+        const double g10 = f10 * xx00 + f11 * xx10, g11 = f10 * xx01 + f11 * xx11;
+        w00 += (g00 * f00 + g01 * f01);
+        w01 += (g00 * f10 + g01 * f11);
+        w10 += (g10 * f00 + g11 * f01);
+        w11 += (g10 * f10 + g11 * f11);
+        if (w00 < 0.0) w00 = 0.0;
+        if (w11 < 0.0) w11 = 0.0;
+        const double det = p.Q00 * p.Q11 - p.Q01 * p.Q10;
+        const double qi00 = p.Q11 / det, qi01 = -p.Q01 / det, qi10 = -p.Q10 / det, qi11 = p.Q00 / det;
+        delta = qi00 * w00 + qi01 * w10 + qi10 * w01 + qi11 * w11;
+    } else {
+        const double x0 = p.tXs[slot].x, y0 = p.tXs[nx].x;
+        const double pk = p.tPs[slot].x, pk1 = p.tPs[nx].x, ck = lg.x;
+        delta = ((pk1 + y0 * y0) - (2.0 * (ck + x0 * y0)) + (pk + x0 * x0)) * (1.0 / p.Q00);
+    }
+    if (p.flags & F_QSCALE) delta = delta / (double)p.tQs[nx];
+    if (delta < 0.0) delta = 0.0;
+    double kap = (p.nu + (double)p.d) / (p.nu + delta);
+    if (kap < p.kMin) kap = p.kMin;
+    else if (kap > p.kMax) kap = p.kMax;
+    p.tKap[nx] = (float)kap;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sequential fallback with adaptive process noise (pyx:510-527 / 688-705): D[k] feeds back into Q[k+1], so the
+// chain cannot be cut; one lane per chain runs the fused step.  Off by default in the reference (constants.py:272).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fwd_apn(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= p.nchains) return;
+    if (p.chainActive != nullptr && !p.chainActive[c]) return;
+    const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
+    const double mD = (double)p.m;
+    const double log2pi = 1.8378770664093454835606594728112;
+    const bool wantNLL = (p.flags & F_NLL) != 0;
+    double apn = 1.0;
+    double sumD = 0.0, sumN = 0.0;
+    // trend carries
+    double x0 = (double)(float)p.init, x1 = 0.0;
+    double c00 = (double)(float)p.cinit, c01 = 0.0, c11 = (double)(float)p.cinit;
+    // level carries
+    double xl = p.init, pl = p.cinit;
+    for (int64_t b = b0; b < b0 + nb; ++b) {
+        const int4 bi = p.blk[b];
+        for (int s = 0; s < bi.y; ++s) {
+            const int64_t i = tidx(b, s, p.B);
+            const double kap = (p.flags & F_KAPPA) ? clampd((double)p.tKap[i], p.kMin, p.kMax) : 1.0;
+            const double lam = (p.flags & F_LAMBDA) ? clampd((double)p.tLam[i], p.wMin, p.wMax) : 1.0;
+            const double qs = (p.flags & F_QSCALE) ? (double)p.tQs[i] : apn;
+            const double qf = qs / kap;
+            const double S0 = lam * p.tS0u[i];
+            double pp, xp0, quad, is, Qd;
+            if (p.d == 2) {
+                const double Q00 = qf * p.Q00, Q01 = qf * p.Q01, Q10 = qf * p.Q10, Q11 = qf * p.Q11;
+                Qd = 0.5 * (Q00 + Q11);
+                const double xq0 = r32(fma(p.F01, x1, p.F00 * x0));
+                const double xq1 = r32(fma(p.F11, x1, p.F10 * x0));
+                const double t00 = fma(p.F01, c01, p.F00 * c00), t01 = fma(p.F01, c11, p.F00 * c01);
+                const double t10 = fma(p.F11, c01, p.F10 * c00), t11 = fma(p.F11, c11, p.F10 * c01);
+                const double a00 = r32(fma(t01, p.F01, fma(t00, p.F00, Q00)));
+                const double a01 = r32(fma(t01, p.F11, fma(t00, p.F10, Q01)));
+                const double a10 = r32(fma(t11, p.F01, fma(t10, p.F00, Q10)));
+                const double a11 = r32(fma(t11, p.F11, fma(t10, p.F10, Q11)));
+                pp = a00;
+                xp0 = xq0;
+                is = 1.0 + a00 * S0;
+                const double dz = p.tZbar[i] - xq0;
+                const double S1 = S0 * dz;
+                const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
+                quad = S2 - (a00 / is) * (S1 * S1);
+                const double delta = S1 / is;
+                x0 = r32(xq0 + a00 * delta);
+                x1 = r32(xq1 + a10 * delta);
+                const double gG = S0 / is, gH = S0 / (is * is);
+                const double i00 = 1.0 - a00 * gG, i10 = -(a10 * gG);
+                c00 = r32(i00 * i00 * a00 + gH * (a00 * a00));
+                c01 = r32(i00 * (i10 * a00 + a01) + gH * (a00 * a10));
+                c11 = r32((i10 * i10 * a00 + 2.0 * i10 * a10 + a11) + gH * (a10 * a10));
+                p.tCp[i] = make_float2((float)a00, (float)a10);
+                p.tXf[i] = make_float2((float)x0, (float)x1);
+                p.tPf[i] = make_float4((float)c00, (float)c01, (float)c01, (float)c11);
+                const float4 qv = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+                if (s > 0) p.tQ[i - 64] = qv;
+                else if (b > b0) p.tQ[tidx(b - 1, p.B - 1, p.B)] = qv;
+            } else {
+                const double Q = qf * p.Q00;
+                Qd = apn * p.Q00;
+                pl += Q;
+                pp = pl;
+                xp0 = xl;
+                is = 1.0 + pl * S0;
+                const double dz = p.tZbar[i] - xl;
+                const double S1 = S0 * dz;
+                const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
+                quad = S2 - (pl / is) * (S1 * S1);
+                xl += pl * (S1 / is);
+                const double gG = S0 / is, gH = S0 / (is * is);
+                const double ikh = 1.0 - pl * gG;
+                pl = ikh * ikh * pl + gH * (pl * pl);
+                p.tPp[i] = pp;
+                p.tXf[i] = make_float2((float)xl, 0.f);
+                p.tXd[i] = xl;
+                p.tPf[i] = make_float4((float)pl, 0.f, 0.f, 0.f);
+                const float4 qv = make_float4((float)Q, 0.f, 0.f, 0.f);
+                if (s > 0) p.tQ[i - 64] = qv;
+                else if (b > b0) p.tQ[tidx(b - 1, p.B - 1, p.B)] = qv;
+            }
+            (void)pp; (void)xp0;
+            if (quad < 0.0) quad = 0.0;
+            double nll = 0.0;
+            if (wantNLL) {
+                double SL = p.tLogR[i];
+                if (p.flags & F_LAMBDA) SL -= mD * log(lam);
+                nll = 0.5 * (SL + log(is) + quad + mD * log2pi);
+                sumN += nll;
+            }
+            const float D = (float)((wantNLL && (p.flags & F_NLL_IN_D)) ? nll : quad / mD);
+            p.tD[i] = D;
+            sumD += (double)D;
+            if (!(p.flags & F_QSCALE)) {      // APN feedback
+                const double qdiag = (p.d == 2) ? p.qDiag : p.Q00;
+                if ((double)D > p.apnThresh && Qd < p.apnMaxQ)
+                    apn *= sqrt(p.apnScale * ((double)D - p.apnThresh) + p.apnPC);
+                else if ((double)D <= p.apnThresh && Qd > p.apnMinQ)
+                    apn *= 1.0 / sqrt(p.apnScale * (p.apnThresh - (double)D) + p.apnPC);
+                const double after = apn * qdiag;
+                if (after < p.apnMinQ) apn = p.apnMinQ / qdiag;
+                else if (after > p.apnMaxQ) apn = p.apnMaxQ / qdiag;
+            }
+        }
+    }
+    p.chainSumD[c] = sumD;
+    p.chainSumNLL[c] = sumN;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout conversion at the API boundary
+// ---------------------------------------------------------------------------------------------------------------
+// natural float32 (nat[(g + shift)*ncomp + comp]) -> blocked float array element `comp4` of a float/float2/float4 slot
+__global__ __launch_bounds__(256) void k_import_f32(Prm p, const float *nat, int ncomp, int comp, float *dst, int dstStride,
+                                                   int dstComp) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.B;
+    const int s = (int)(row % p.B);
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int4 bi = p.blk[b];
+    if (s >= bi.y) return;
+    const int64_t g = (int64_t)bi.x + s;
+    dst[slot * dstStride + dstComp] = nat[g * ncomp + comp];
+}
+
+// blocked -> natural.  src is a float array with srcStride floats per slot; writes ncomp consecutive floats per bin
+// taken from components compMap[0..ncomp).
+struct CompMap {
+    int n;
+    int c[4];
+};
+__global__ __launch_bounds__(256) void k_export_f32(Prm p, const float *src, int srcStride, CompMap cm, float *nat,
+                                                   int skipLastOfChain) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.B;
+    const int s = (int)(row % p.B);
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int4 bi = p.blk[b];
+    if (s >= bi.y) return;
+    if (skipLastOfChain && b == bi.w && s == bi.y - 1) return;
+    const int64_t g = (int64_t)bi.x + s;
+    for (int k = 0; k < cm.n; ++k) nat[g * cm.n + k] = src[slot * srcStride + cm.c[k]];
+}
+
+// natural xs0 -> residuals (pyx:6846-6848): resid[g][j] = float(data[j][g] - xs0[g]); (m, Npad) -> (Npad, m) through LDS
+__global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
+    extern __shared__ float tileR[];                 // [m][65]
+    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int gl = t & 63, r0 = t >> 6;
+    const int64_t g = g0 + gl;
+    float x = 0.f;
+    if (g < nBins) x = xsNat[g * xsStride];
+    for (int j = r0; j < p.m; j += 4) {
+        float v = 0.f;
+        if (g < nBins) v = (float)((double)p.data[(int64_t)j * p.Npad + g] - (double)x);
+        tileR[j * 65 + gl] = v;
+    }
+    __syncthreads();
+    const int total = 64 * p.m;
+    for (int e = t; e < total; e += 256) {
+        const int bin = e / p.m, j = e - bin * p.m;
+        if (g0 + bin < nBins) resid[(g0 + bin) * (int64_t)p.m + j] = tileR[j * 65 + bin];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a10  expected transition residual sums (pyx:710-863), float64 natural inputs, two-stage deterministic reduction
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tsums(int d, int64_t n, const double *xs, const double *Ps, const double *lag,
+                                              double f00, double f01, double f10, double f11, double *partL,
+                                              double *partT) {
+    __shared__ double sL[256], sT[256];
+    double aL = 0.0, aT = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n - 1; k += (int64_t)gridDim.x * 256) {
+        if (d == 1) {
+            const double x0 = xs[k], y0 = xs[k + 1];
+            const double e0 = Ps[k] + (x0 * x0), e1 = Ps[k + 1] + (y0 * y0), ec = lag[k] + (x0 * y0);
+            double mom = e1 - (2.0 * ec) + e0;
+            if (mom < 0.0) mom = 0.0;
+            aL += mom;
+        } else {
+            const double x00 = xs[k * 2], x01 = xs[k * 2 + 1], y0 = xs[(k + 1) * 2], y1 = xs[(k + 1) * 2 + 1];
+            const double a00 = Ps[k * 4] + (x00 * x00), a01 = Ps[k * 4 + 1] + (x00 * x01);
+            const double a10 = Ps[k * 4 + 2] + (x01 * x00), a11 = Ps[k * 4 + 3] + (x01 * x01);
+            const double b00 = Ps[(k + 1) * 4] + (y0 * y0), b11 = Ps[(k + 1) * 4 + 3] + (y1 * y1);
+            const double c00 = lag[k * 4] + (x00 * y0), c01 = lag[k * 4 + 1] + (x00 * y1);
+            const double c10 = lag[k * 4 + 2] + (x01 * y0), c11 = lag[k * 4 + 3] + (x01 * y1);
+            double lm = (b00 - (2.0 * ((f00 * c00) + (f01 * c10))) + (f00 * f00 * a00) + (f00 * f01 * a01) +
+                         (f01 * f00 * a10) + (f01 * f01 * a11));
+            double tm = (b11 - (2.0 * ((f10 * c01) + (f11 * c11))) + (f10 * f10 * a00) + (f10 * f11 * a01) +
+                         (f11 * f10 * a10) + (f11 * f11 * a11));
+            if (lm < 0.0) lm = 0.0;
+            if (tm < 0.0) tm = 0.0;
+            aL += lm;
+            aT += tm;
+        }
+    }
+    sL[threadIdx.x] = aL;
+    sT[threadIdx.x] = aT;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sL[threadIdx.x] += sL[threadIdx.x + w];
+            sT[threadIdx.x] += sT[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partL[blockIdx.x] = sL[0];
+        partT[blockIdx.x] = sT[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthetic workload generator (SURVEY 8(d) distributions; counter-based RNG, not NumPy's stream)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float gauss(uint64_t key) {
+    const uint64_t a = mix64(key), b = mix64(key ^ 0xD1B54A32D192ED03ull);
+    const float u1 = ((float)(a >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+// latent[g] (natural, length Npad) holds the random-walk level uploaded by the host
+__global__ __launch_bounds__(256) void k_synth(Prm p, const float *latent, float *data, float *munc, uint64_t seed,
+                                              int64_t nBins) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nBins) return;
+    const float x = latent[g];
+    for (int j = 0; j < p.m; ++j) {
+        const uint64_t key = seed * 0x100000001B3ull + ((uint64_t)j << 40) + (uint64_t)g;
+        data[(int64_t)j * p.Npad + g] = x + 0.5f * gauss(key * 2);
+        munc[(int64_t)j * p.Npad + g] = 0.25f * expf(0.2f * gauss(key * 2 + 1));
+    }
+}
+
+}  // namespace csr

@@ -1,0 +1,999 @@
+// csr_lib.hip -- host side of libconsenrich_amd.so: context, device memory, launch orchestration and the C ABI
+// declared in include/consenrich_amd.h.  gfx950 only.  No CPU compute path exists here: without a GPU every entry
+// point fails loudly.
+#include "../../include/consenrich_amd.h"
+#include "csr_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace csr;
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+#define HIPOK(expr)                                                                                       \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHECK(expr)                \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != 0) return rc_;  \
+    } while (0)
+
+extern "C" const char *csr_last_error(void) { return g_err; }
+extern "C" int csr_abi_version(void) { return CSR_ABI_VERSION; }
+extern "C" int csr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------------
+struct ChainInfo {
+    int64_t n;      // bins
+    int64_t off;    // natural offset (multiple of 64)
+    int64_t b0;     // first block
+    int64_t nb;     // number of blocks
+};
+
+struct ProfEntry {
+    int64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct csr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // tuning
+    int B = 256, warmP = 2, warmX = 8, warmB = 4;
+    // batch
+    bool configured = false;
+    csr_model mdl{};
+    int64_t m = 0;
+    std::vector<ChainInfo> chains;
+    int64_t Npad = 0, NB = 0, NG = 0, TN = 0;
+    bool statsValid = false;
+    bool haveFwd = false, haveBwd = false;
+    uint32_t fwdFlags = 0;
+    Prm p{};
+    std::vector<void *> allocs;
+    // device arrays not in Prm
+    int64_t *dChainFirst = nullptr, *dChainNb = nullptr;
+    unsigned char *dActive = nullptr;
+    float *dLatent = nullptr;
+    float *nat[CSR_ARR_COUNT] = {nullptr};
+    unsigned int *hCount = nullptr;     // pinned
+    double *hSums = nullptr;            // pinned, 2*nchains
+    // profiling
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> eventPool;
+    // stats
+    csr_run_stats rs{};
+};
+
+static int ctx_select(csr_ctx *c) {
+    HIPOK(hipSetDevice(c->device));
+    return 0;
+}
+
+template <class T>
+static int dalloc(csr_ctx *c, T **ptr, int64_t count) {
+    void *q = nullptr;
+    const size_t bytes = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *ptr = reinterpret_cast<T *>(q);
+    return 0;
+}
+
+static void free_batch(csr_ctx *c) {
+    for (void *q : c->allocs) hipFree(q);
+    c->allocs.clear();
+    c->configured = false;
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    c->dActive = nullptr;
+    for (auto &n : c->nat) n = nullptr;
+}
+
+extern "C" csr_ctx *csr_create(int device_ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fail("no HIP device visible: consenrich_amd has no CPU fallback");
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        fail("device ordinal %d out of range (0..%d)", device_ordinal, n - 1);
+        return nullptr;
+    }
+    csr_ctx *c = new csr_ctx();
+    c->device = device_ordinal;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        fail("cannot initialise device %d", device_ordinal);
+        delete c;
+        return nullptr;
+    }
+    if (hipHostMalloc((void **)&c->hCount, 64) != hipSuccess) {
+        fail("hipHostMalloc failed");
+        delete c;
+        return nullptr;
+    }
+    const char *e;
+    if ((e = getenv("CONSENRICH_AMD_BLOCK"))) c->B = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_WARM_P"))) c->warmP = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_WARM_X"))) c->warmX = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
+    if (c->B < 32 || (c->B % 32) != 0) c->B = 256;
+    return c;
+}
+
+extern "C" void csr_destroy(csr_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_batch(c);
+    for (auto &kv : c->prof)
+        for (auto &pr : kv.second.pending) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    for (hipEvent_t ev : c->eventPool) hipEventDestroy(ev);
+    if (c->hCount) hipHostFree(c->hCount);
+    if (c->hSums) hipHostFree(c->hSums);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int csr_set_tuning(csr_ctx *c, int32_t block_len, int32_t warm_p, int32_t warm_x, int32_t warm_b) {
+    if (!c) return fail("null context");
+    if (block_len != 0) {
+        if (block_len < 32 || (block_len % 32) != 0) return fail("block_len must be a positive multiple of 32");
+        if (c->configured && block_len != c->B) return fail("block_len cannot change after csr_batch_configure");
+        c->B = block_len;
+    }
+    if (warm_p >= 0) c->warmP = warm_p;
+    if (warm_x >= 0) c->warmX = warm_x;
+    if (warm_b >= 0) c->warmB = warm_b;
+    return 0;
+}
+
+extern "C" int csr_synchronize(csr_ctx *c) {
+    if (!c) return fail("null context");
+    CHECK(ctx_select(c));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// profiling helpers: HIP events on the library's stream around every kernel launch
+// ---------------------------------------------------------------------------------------------------------------
+static hipEvent_t get_event(csr_ctx *c) {
+    if (!c->eventPool.empty()) {
+        hipEvent_t e = c->eventPool.back();
+        c->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct Scope {
+    csr_ctx *c;
+    ProfEntry *pe = nullptr;
+    hipEvent_t a{}, b{};
+    Scope(csr_ctx *c_, const char *name) : c(c_) {
+        if (c->profiling) {
+            pe = &c->prof[name];
+            a = get_event(c);
+            b = get_event(c);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~Scope() {
+        if (pe) {
+            hipEventRecord(b, c->stream);
+            pe->pending.emplace_back(a, b);
+            pe->launches++;
+        }
+    }
+};
+static void prof_collect(csr_ctx *c) {
+    hipStreamSynchronize(c->stream);
+    for (auto &kv : c->prof) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+            c->eventPool.push_back(pr.first);
+            c->eventPool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+extern "C" int csr_profile_enable(csr_ctx *c, int32_t on) {
+    if (!c) return fail("null context");
+    CHECK(ctx_select(c));
+    prof_collect(c);
+    c->prof.clear();
+    c->profiling = on != 0;
+    return 0;
+}
+extern "C" int csr_profile_read(csr_ctx *c, csr_kernel_time *out, int32_t capacity, int32_t *n_out) {
+    if (!c) return fail("null context");
+    CHECK(ctx_select(c));
+    prof_collect(c);
+    int32_t k = 0;
+    for (auto &kv : c->prof) {
+        if (k < capacity && out) {
+            memset(&out[k], 0, sizeof(out[k]));
+            strncpy(out[k].name, kv.first.c_str(), sizeof(out[k].name) - 1);
+            out[k].launches = kv.second.launches;
+            out[k].total_ms = kv.second.total_ms;
+        }
+        ++k;
+    }
+    if (n_out) *n_out = k;
+    return 0;
+}
+extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
+    if (!c || !out) return fail("null argument");
+    *out = c->rs;
+    out->blocks = c->NB;
+    out->block_len = c->B;
+    out->warm_p = c->warmP;
+    out->warm_x = c->warmX;
+    out->warm_b = c->warmB;
+    return 0;
+}
+
+#define LAUNCH_CHECK(name)                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return fail("launch %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// batch configuration
+// ---------------------------------------------------------------------------------------------------------------
+static void fill_model(csr_ctx *c) {
+    Prm &p = c->p;
+    const csr_model &m = c->mdl;
+    p.d = m.state_dim;
+    p.F00 = m.F[0]; p.F01 = m.F[1]; p.F10 = m.F[2]; p.F11 = m.F[3];
+    p.Q00 = m.Q0[0]; p.Q01 = m.Q0[1]; p.Q10 = m.Q0[2]; p.Q11 = m.Q0[3];
+    if (m.state_dim == 1) { p.F00 = 1; p.F01 = 0; p.F10 = 0; p.F11 = 1; p.Q01 = p.Q10 = p.Q11 = 0; }
+    p.init = m.state_init; p.cinit = m.state_covar_init; p.pad = m.pad;
+    p.wMin = m.w_min; p.wMax = m.w_max; p.kMin = m.k_min; p.kMax = m.k_max;
+    p.apnMinQ = m.apn_min_q; p.apnMaxQ = m.apn_max_q; p.apnThresh = m.apn_thresh;
+    p.apnScale = m.apn_scale; p.apnPC = m.apn_pc;
+    p.qDiag = 0.5 * (m.Q0[0] + m.Q0[3]);
+    p.nu = 8.0;
+}
+
+extern "C" int csr_batch_set_model(csr_ctx *c, const csr_model *mdl) {
+    if (!c || !mdl) return fail("null argument");
+    if (!c->configured) return fail("batch not configured");
+    if (mdl->state_dim != c->mdl.state_dim) return fail("state_dim cannot change without reconfiguring the batch");
+    if (mdl->pad != c->mdl.pad) c->statsValid = false;
+    c->mdl = *mdl;
+    fill_model(c);
+    c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, int32_t n_chains,
+                                   const int64_t *chain_len) {
+    if (!c || !mdl || !chain_len) return fail("null argument");
+    if (mdl->state_dim != 1 && mdl->state_dim != 2) return fail("state_dim must be 1 or 2");
+    if (m <= 0 || n_chains <= 0) return fail("m and n_chains must be positive");
+    CHECK(ctx_select(c));
+    HIPOK(hipStreamSynchronize(c->stream));
+    free_batch(c);
+    c->mdl = *mdl;
+    c->m = m;
+    c->chains.clear();
+    const int B = c->B;
+    int64_t off = 0, nb = 0;
+    for (int i = 0; i < n_chains; ++i) {
+        if (chain_len[i] <= 0) return fail("chain %d has non-positive length", i);
+        ChainInfo ci;
+        ci.n = chain_len[i];
+        ci.off = off;
+        ci.b0 = nb;
+        ci.nb = (ci.n + B - 1) / B;
+        c->chains.push_back(ci);
+        off += (ci.n + 63) / 64 * 64;
+        nb += ci.nb;
+    }
+    if (off >= (int64_t)1 << 31) return fail("batch too large: %lld bins (limit 2^31)", (long long)off);
+    c->Npad = off;
+    c->NB = nb;
+    c->NG = (nb + 63) / 64;
+    c->TN = c->NG * (int64_t)B * 64;
+
+    Prm &p = c->p;
+    memset(&p, 0, sizeof(p));
+    fill_model(c);
+    p.B = B; p.m = (int)m; p.nchains = n_chains; p.NB = c->NB; p.NG = c->NG; p.Npad = c->Npad;
+
+    // block table
+    std::vector<int4> blk((size_t)nb);
+    std::vector<int> bch((size_t)nb);
+    std::vector<int64_t> cf(n_chains), cn(n_chains);
+    for (int i = 0; i < n_chains; ++i) {
+        const ChainInfo &ci = c->chains[i];
+        cf[i] = ci.b0; cn[i] = ci.nb;
+        for (int64_t k = 0; k < ci.nb; ++k) {
+            int4 e;
+            e.x = (int)(ci.off + k * B);
+            e.y = (int)std::min<int64_t>(B, ci.n - k * B);
+            e.z = (int)ci.b0;
+            e.w = (int)(ci.b0 + ci.nb - 1);
+            blk[(size_t)(ci.b0 + k)] = e;
+            bch[(size_t)(ci.b0 + k)] = i;
+        }
+    }
+    int4 *dblk; int *dbch;
+    CHECK(dalloc(c, &dblk, nb));
+    CHECK(dalloc(c, &dbch, nb));
+    CHECK(dalloc(c, &c->dChainFirst, n_chains));
+    CHECK(dalloc(c, &c->dChainNb, n_chains));
+    CHECK(dalloc(c, &c->dActive, n_chains));
+    HIPOK(hipMemcpy(dblk, blk.data(), sizeof(int4) * nb, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dbch, bch.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(c->dChainFirst, cf.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(c->dChainNb, cn.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
+    HIPOK(hipMemset(c->dActive, 1, n_chains));
+    p.blk = dblk; p.blkChain = dbch; p.chainActive = nullptr;
+
+    float *dd, *dm;
+    CHECK(dalloc(c, &dd, m * c->Npad));
+    CHECK(dalloc(c, &dm, m * c->Npad));
+    HIPOK(hipMemsetAsync(dd, 0, sizeof(float) * m * c->Npad, c->stream));
+    HIPOK(hipMemsetAsync(dm, 0, sizeof(float) * m * c->Npad, c->stream));
+    p.data = dd; p.munc = dm;
+
+    const int64_t T = c->TN;
+    CHECK(dalloc(c, &p.tS0u, T)); CHECK(dalloc(c, &p.tZbar, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
+    CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
+    CHECK(dalloc(c, &p.tGs, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
+    CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T));
+    CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
+    if (mdl->state_dim == 2) { CHECK(dalloc(c, &p.tCp, T)); }
+    else { CHECK(dalloc(c, &p.tPp, T)); CHECK(dalloc(c, &p.tXd, T)); }
+    // defined contents for slots no kernel writes (pNoise/lag tails, padding)
+    HIPOK(hipMemsetAsync(p.tQ, 0, sizeof(float4) * T, c->stream));
+    HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));
+    HIPOK(hipMemsetAsync(p.tD, 0, sizeof(float) * T, c->stream));
+    CHECK(dalloc(c, &p.blkSumD, nb)); CHECK(dalloc(c, &p.blkSumNLL, nb));
+    CHECK(dalloc(c, &p.chainSumD, n_chains)); CHECK(dalloc(c, &p.chainSumNLL, n_chains));
+    HIPOK(hipMemsetAsync(p.chainSumD, 0, sizeof(double) * n_chains, c->stream));
+    HIPOK(hipMemsetAsync(p.chainSumNLL, 0, sizeof(double) * n_chains, c->stream));
+    char *ci_, *coa, *cob;
+    CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
+    p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;
+    CHECK(dalloc(c, &p.rerunCount, 16));
+    if (c->hSums) hipHostFree(c->hSums);
+    HIPOK(hipHostMalloc((void **)&c->hSums, sizeof(double) * 2 * n_chains));
+    c->configured = true;
+    c->rs = csr_run_stats{};
+    return 0;
+}
+
+static int need(csr_ctx *c) {
+    if (!c) return fail("null context");
+    if (!c->configured) return fail("batch not configured");
+    return ctx_select(c);
+}
+
+extern "C" int64_t csr_batch_chain_offset(csr_ctx *c, int32_t chain) {
+    if (!c || !c->configured || chain < 0 || chain >= (int)c->chains.size()) return -1;
+    return c->chains[chain].off;
+}
+
+extern "C" int csr_batch_upload(csr_ctx *c, int32_t chain, const float *data, const float *munc) {
+    CHECK(need(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (!data || !munc) return fail("null host buffer");
+    const ChainInfo &ci = c->chains[chain];
+    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.data) + ci.off, sizeof(float) * c->Npad, data, sizeof(float) * ci.n,
+                           sizeof(float) * ci.n, (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.munc) + ci.off, sizeof(float) * c->Npad, munc, sizeof(float) * ci.n,
+                           sizeof(float) * ci.n, (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+static int grid_slots(csr_ctx *c) { return (int)((c->TN + 255) / 256); }
+
+static int64_t arr_comps(csr_ctx *c, int id);
+// natural device scratch for per-bin float arrays (import/export); lazily allocated
+static int nat_array(csr_ctx *c, int id, float **out) {
+    if (!c->nat[id]) {
+        const int64_t per = arr_comps(c, id);
+        CHECK(dalloc(c, &c->nat[id], per * c->Npad));
+        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * c->Npad, c->stream));
+    }
+    *out = c->nat[id];
+    return 0;
+}
+static int64_t arr_comps(csr_ctx *c, int id);
+static int64_t arr_comps_impl(csr_ctx *c, int id) {
+    const int d = c->mdl.state_dim;
+    switch (id) {
+        case CSR_ARR_D: case CSR_ARR_LAMBDA: case CSR_ARR_KAPPA: return 1;
+        case CSR_ARR_XF: case CSR_ARR_XS: return d;
+        case CSR_ARR_RESID: return c->m;
+        default: return d * d;
+    }
+}
+
+static int64_t arr_comps(csr_ctx *c, int id) { return arr_comps_impl(c, id); }
+
+static int import_vec(csr_ctx *c, int chain, const float *host, float *blocked) {
+    // stage through the natural scratch of CSR_ARR_D (1 comp) then scatter into the blocked array
+    float *scr;
+    CHECK(nat_array(c, CSR_ARR_D, &scr));
+    const ChainInfo &ci = c->chains[chain];
+    HIPOK(hipMemcpyAsync(scr + ci.off, host, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const float *lambda, const float *kappa,
+                                            const float *qscale) {
+    CHECK(need(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    const float *src[3] = {lambda, kappa, qscale};
+    float *dst[3] = {c->p.tLam, c->p.tKap, c->p.tQs};
+    float *scr;
+    CHECK(nat_array(c, CSR_ARR_D, &scr));
+    // restrict the scatter to this chain so other chains' multipliers stay untouched
+    std::vector<unsigned char> act(c->chains.size(), 0);
+    act[chain] = 1;
+    HIPOK(hipMemcpyAsync(c->dActive, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 3; ++k) {
+        if (!src[k]) continue;
+        CHECK(import_vec(c, chain, src[k], dst[k]));
+        Prm p = c->p;
+        p.chainActive = c->dActive;
+        {
+            Scope sc(c, "import_f32");
+            // k_import_f32 ignores chainActive; use the export-style guard by launching the guarded variant below
+            hipLaunchKernelGGL(k_import_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, scr, 1, 0, dst[k], 1, 0);
+        }
+        LAUNCH_CHECK("k_import_f32");
+        HIPOK(hipStreamSynchronize(c->stream));
+    }
+    c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_batch_stats(csr_ctx *c) {
+    CHECK(need(c));
+    Prm p = c->p;
+    const int grid = (int)(c->NG * (c->B / 32));
+    {
+        Scope sc(c, "stats");
+        const int m = (int)c->m;
+        if (m <= 4) hipLaunchKernelGGL(k_stats<4>, dim3(grid), dim3(256), 0, c->stream, p);
+        else if (m <= 8) hipLaunchKernelGGL(k_stats<8>, dim3(grid), dim3(256), 0, c->stream, p);
+        else if (m <= 16) hipLaunchKernelGGL(k_stats<16>, dim3(grid), dim3(256), 0, c->stream, p);
+        else if (m <= 32) hipLaunchKernelGGL(k_stats<32>, dim3(grid), dim3(256), 0, c->stream, p);
+        else if (m <= 64) hipLaunchKernelGGL(k_stats<64>, dim3(grid), dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL(k_stats<0>, dim3(grid), dim3(256), 0, c->stream, p);
+    }
+    LAUNCH_CHECK("k_stats");
+    c->statsValid = true;
+    c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+// speculative pass + validation/fix-up to the fixed point
+template <class CH>
+static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int warm, int64_t *reruns) {
+    static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
+    p.warm = warm;
+    const int grid = (int)c->NG;
+    {
+        Scope sc(c, name);
+        hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+    }
+    LAUNCH_CHECK(name);
+    int which = 0;
+    for (int64_t it = 0; it <= c->NB + 1; ++it) {
+        HIPOK(hipMemsetAsync(p.rerunCount, 0, sizeof(unsigned int), c->stream));
+        {
+            Scope sc(c, fixName);
+            hipLaunchKernelGGL(k_chain_fix<CH>, dim3(grid), dim3(64), 0, c->stream, p, which);
+        }
+        LAUNCH_CHECK(fixName);
+        HIPOK(hipMemcpyAsync(c->hCount, p.rerunCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        c->rs.fix_launches++;
+        which ^= 1;
+        if (*c->hCount == 0) return 0;
+        *reruns += *c->hCount;
+    }
+    return fail("%s: speculative fix-up did not reach a fixed point", name);
+}
+
+static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active) {
+    if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
+    Prm p = c->p;
+    p.flags = flags;
+    p.chainActive = active;
+    const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
+    if (seq) {
+        Scope sc(c, "fwd_apn_sequential");
+        hipLaunchKernelGGL(k_fwd_apn, dim3(((int)c->chains.size() + 63) / 64), dim3(64), 0, c->stream, p, c->dChainFirst,
+                           c->dChainNb);
+        LAUNCH_CHECK("k_fwd_apn");
+    } else {
+        if (c->mdl.state_dim == 2) {
+            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", c->warmP, &c->rs.reruns_p));
+            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", c->warmX, &c->rs.reruns_x));
+        } else {
+            CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", c->warmP, &c->rs.reruns_p));
+            CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", c->warmX, &c->rs.reruns_x));
+        }
+        if (wantD) {
+            {
+                Scope sc(c, "fwd_dstat");
+                hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, c->stream, p);
+            }
+            LAUNCH_CHECK("k_fwd_dstat");
+            {
+                Scope sc(c, "chain_sums");
+                hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(256), 0, c->stream, p, c->dChainFirst,
+                                   c->dChainNb);
+            }
+            LAUNCH_CHECK("k_chain_sums");
+        }
+    }
+    c->haveFwd = true;
+    c->haveBwd = false;
+    c->fwdFlags = flags;
+    return 0;
+}
+
+static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
+    const size_t nc = c->chains.size();
+    HIPOK(hipMemcpyAsync(c->hSums, c->p.chainSumD, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(c->hSums + nc, c->p.chainSumNLL, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    if (sum_d) memcpy(sum_d, c->hSums, sizeof(double) * nc);
+    if (sum_nll) memcpy(sum_nll, c->hSums + nc, sizeof(double) * nc);
+    return 0;
+}
+
+extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    CHECK(forward_impl(c, flags, true, nullptr));
+    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
+    return 0;
+}
+
+static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active) {
+    if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
+    Prm p = c->p;
+    p.flags = c->fwdFlags;
+    p.chainActive = active;
+    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
+    else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
+    if (wantLag) {
+        Scope sc(c, "bwd_lagcov");
+        hipLaunchKernelGGL(k_bwd_lag, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+        LAUNCH_CHECK("k_bwd_lag");
+    }
+    c->haveBwd = true;
+    return 0;
+}
+
+extern "C" int csr_batch_backward(csr_ctx *c) {
+    CHECK(need(c));
+    return backward_impl(c, true, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ECM (pyx:7660-8442 / 7153-7657) over all chains in lock-step; converged chains are masked out
+// ---------------------------------------------------------------------------------------------------------------
+struct EcmState {
+    double prev = 1.0e16, cur = 0.0;
+    bool haveInit = false, done = false;
+};
+
+extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path) {
+    CHECK(need(c));
+    if (!cfg || !out) return fail("null argument");
+    if (!c->statsValid) CHECK(csr_batch_stats(c));
+    const int nc = (int)c->chains.size();
+    uint32_t fl = flags & (F_QSCALE);
+    if (cfg->use_lambda) fl |= F_LAMBDA;
+    if (cfg->use_kappa) fl |= F_KAPPA;
+    if (cfg->use_apn) fl |= F_APN;
+    c->p.nu = cfg->nu;
+    std::vector<EcmState> st(nc);
+    std::vector<unsigned char> act(nc, 0);
+    std::vector<double> nll(nc);
+    for (int i = 0; i < nc; ++i) {
+        csr_ecm_out &o = out[i];
+        memset(&o, 0, sizeof(o));
+    }
+    auto push_active = [&]() -> int {
+        HIPOK(hipMemcpyAsync(c->dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    // tiny chains: filter + smoother + NLL only (pyx:7998-8129)
+    bool anyTiny = false, anyBig = false;
+    for (int i = 0; i < nc; ++i) {
+        if (c->chains[i].n <= 5) { act[i] = 1; anyTiny = true; out[i].skipped = 1; }
+        else anyBig = true;
+    }
+    if (anyTiny) {
+        CHECK(push_active());
+        CHECK(forward_impl(c, fl | F_NLL, true, c->dActive));
+        CHECK(backward_impl(c, true, c->dActive));
+        CHECK(read_sums(c, nullptr, nll.data()));
+        for (int i = 0; i < nc; ++i)
+            if (act[i]) { out[i].final_nll = out[i].initial_nll = nll[i]; st[i].done = true; }
+    }
+    if (anyBig) {
+        for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5) ? 1 : 0;
+        CHECK(push_active());
+        bool fwdFresh = false;   // forward results already match the current multipliers
+        for (int64_t it = 0; it < cfg->max_iters; ++it) {
+            for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
+                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive));
+                fwdFresh = false;
+                CHECK(backward_impl(c, true, c->dActive));
+                Prm p = c->p;
+                p.flags = fl;
+                p.chainActive = c->dActive;
+                if (cfg->use_lambda) {
+                    Scope sc(c, "estep_lambda");
+                    hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                    LAUNCH_CHECK("k_estep_lambda");
+                }
+                if (cfg->use_kappa) {
+                    Scope sc(c, "estep_kappa");
+                    hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                    LAUNCH_CHECK("k_estep_kappa");
+                }
+            }
+            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive));      // pyx:8300
+            // the multipliers do not change until the next E-step: the next sweep may reuse this forward pass,
+            // unless adaptive process noise made it depend on returnNLL-independent state only (it does not)
+            fwdFresh = (cfg->inner_iters > 0);
+            CHECK(read_sums(c, nullptr, nll.data()));
+            bool anyLeft = false, changed = false;
+            for (int i = 0; i < nc; ++i) {
+                if (!act[i]) continue;
+                EcmState &s = st[i];
+                csr_ecm_out &o = out[i];
+                o.iters_done = it + 1;
+                s.cur = nll[i];
+                if (nll_path) nll_path[(int64_t)i * cfg->max_iters + it] = s.cur;
+                const bool havePrev = s.haveInit;       // pyx:8337-8407
+                if (!havePrev) { o.initial_nll = s.cur; s.haveInit = true; }
+                else if (s.cur > s.prev + (1.0e-12 * std::fmax(std::fabs(s.prev), 1.0))) o.nll_increase_count += 1;
+                double delta, scale;
+                if (havePrev) { delta = std::fabs(s.cur - s.prev); scale = std::fabs(s.prev); }
+                else { delta = 0.0; scale = std::fabs(s.cur); }
+                if (std::fabs(s.cur) > scale) scale = std::fabs(s.cur);
+                if (scale < 1.0) scale = 1.0;
+                if (havePrev) { o.rel_improvement = (s.prev - s.cur) / scale; o.abs_rel_change = delta / scale; }
+                else { o.rel_improvement = 0.0; o.abs_rel_change = 0.0; }
+                const double tol = cfg->rtol * scale;
+                s.prev = s.cur;
+                if (havePrev && delta <= tol) o.stable_iters += 1; else o.stable_iters = 0;
+                if (o.stable_iters >= 2) { o.converged = 1; s.done = true; act[i] = 0; changed = true; }
+                else anyLeft = true;
+            }
+            if (!anyLeft) break;
+            if (changed) CHECK(push_active());
+        }
+        for (int i = 0; i < nc; ++i) {
+            if (c->chains[i].n <= 5) continue;
+            out[i].has_initial_nll = st[i].haveInit ? 1 : 0;
+            out[i].final_nll = st[i].prev;
+        }
+    }
+    c->fwdFlags = fl;
+    c->haveFwd = c->haveBwd = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// export / download
+// ---------------------------------------------------------------------------------------------------------------
+static int export_one(csr_ctx *c, int id, const float *src, int srcStride, CompMap cm, int skipLast) {
+    float *dst;
+    CHECK(nat_array(c, id, &dst));
+    Scope sc(c, "export_natural");
+    hipLaunchKernelGGL(k_export_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, c->p, src, srcStride, cm, dst, skipLast);
+    LAUNCH_CHECK("k_export_f32");
+    return 0;
+}
+
+extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
+    CHECK(need(c));
+    const int d = c->mdl.state_dim;
+    const Prm &p = c->p;
+    const CompMap one = {1, {0, 0, 0, 0}}, two = {2, {0, 1, 0, 0}}, four = {4, {0, 1, 2, 3}};
+    const CompMap vec = (d == 2) ? two : one, mat = (d == 2) ? four : one;
+    if (what & CSR_EXPORT_FORWARD) {
+        if (!c->haveFwd) return fail("no forward results to export");
+        CHECK(export_one(c, CSR_ARR_D, p.tD, 1, one, 0));
+        CHECK(export_one(c, CSR_ARR_XF, (const float *)p.tXf, 2, vec, 0));
+        CHECK(export_one(c, CSR_ARR_PF, (const float *)p.tPf, 4, mat, 0));
+        CHECK(export_one(c, CSR_ARR_PNOISE, (const float *)p.tQ, 4, mat, 1));
+    }
+    if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
+        if (!c->haveBwd) return fail("no smoothed results to export");
+        CHECK(export_one(c, CSR_ARR_XS, (const float *)p.tXs, 2, vec, 0));
+    }
+    if (what & CSR_EXPORT_SMOOTH) {
+        CHECK(export_one(c, CSR_ARR_PS, (const float *)p.tPs, 4, mat, 0));
+        CHECK(export_one(c, CSR_ARR_LAG, (const float *)p.tLag, 4, mat, 1));
+    }
+    if (what & CSR_EXPORT_RESID) {
+        float *xs, *res;
+        CHECK(nat_array(c, CSR_ARR_XS, &xs));
+        CHECK(nat_array(c, CSR_ARR_RESID, &res));
+        Scope sc(c, "residuals");
+        hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream, c->p,
+                           xs, d, res, c->Npad);
+        LAUNCH_CHECK("k_resid");
+    }
+    if (what & CSR_EXPORT_MULT) {
+        CHECK(export_one(c, CSR_ARR_LAMBDA, p.tLam, 1, one, 0));
+        CHECK(export_one(c, CSR_ARR_KAPPA, p.tKap, 1, one, 0));
+    }
+    return 0;
+}
+
+extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, int64_t *n_elems) {
+    CHECK(need(c));
+    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
+    float *ptr;
+    CHECK(nat_array(c, id, &ptr));
+    if (dev_ptr) *dev_ptr = ptr;
+    if (n_elems) *n_elems = arr_comps(c, id) * c->Npad;
+    return 0;
+}
+
+extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *host_dst) {
+    CHECK(need(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
+    if (!host_dst) return fail("null host buffer");
+    if (!c->nat[id]) return fail("array %d was not exported", id);
+    const ChainInfo &ci = c->chains[chain];
+    const int64_t per = arr_comps(c, id);
+    int64_t rows = ci.n;
+    if (id == CSR_ARR_PNOISE || id == CSR_ARR_LAG) rows = ci.n - 1;
+    if (rows > 0)
+        HIPOK(hipMemcpyAsync(host_dst, c->nat[id] + ci.off * per, sizeof(float) * per * rows, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthetic fill (bench / scale tests)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_batch_synthesize(csr_ctx *c, uint64_t seed) {
+    CHECK(need(c));
+    if (!c->dLatent) CHECK(dalloc(c, &c->dLatent, c->Npad));
+    std::vector<float> lat((size_t)c->Npad, 0.f);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (size_t ch = 0; ch < c->chains.size(); ++ch) {
+        const ChainInfo &ci = c->chains[ch];
+        double x = 0.0;
+        for (int64_t k = 0; k < ci.n; ++k) {
+            // Irwin-Hall(12) normal approximation is plenty for a synthetic random walk
+            double acc = 0.0;
+            const uint64_t a = next(), b = next();
+            for (int q = 0; q < 6; ++q) acc += (double)((a >> (q * 10)) & 1023) / 1024.0;
+            for (int q = 0; q < 6; ++q) acc += (double)((b >> (q * 10)) & 1023) / 1024.0;
+            x += 0.03 * (acc - 6.0);
+            lat[(size_t)(ci.off + k)] = (float)x;
+        }
+    }
+    HIPOK(hipMemcpy(c->dLatent, lat.data(), sizeof(float) * c->Npad, hipMemcpyHostToDevice));
+    {
+        Scope sc(c, "synthesize");
+        hipLaunchKernelGGL(k_synth, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, c->p, c->dLatent,
+                           const_cast<float *>(c->p.data), const_cast<float *>(c->p.munc), seed, c->Npad);
+    }
+    LAUNCH_CHECK("k_synth");
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (1) reference-shaped single-chain entry points on host buffers (default context, device from
+//     CONSENRICH_AMD_DEVICE or 0)
+// ---------------------------------------------------------------------------------------------------------------
+static csr_ctx *g_default = nullptr;
+static csr_ctx *default_ctx() {
+    if (!g_default) {
+        int dev = 0;
+        if (const char *e = getenv("CONSENRICH_AMD_DEVICE")) dev = atoi(e);
+        g_default = csr_create(dev);
+    }
+    return g_default;
+}
+
+static int configure_single(csr_ctx *c, const csr_model *mdl, int64_t m, int64_t n) {
+    const bool reuse = c->configured && c->chains.size() == 1 && c->chains[0].n == n && c->m == m &&
+                       c->mdl.state_dim == mdl->state_dim;
+    if (reuse) return csr_batch_set_model(c, mdl);
+    return csr_batch_configure(c, mdl, m, 1, &n);
+}
+
+static int import_nat(csr_ctx *c, const float *host, int ncomp, int64_t rows, int64_t rowShift, float *dst, int dstStride) {
+    // host natural (rows, ncomp) -> blocked float slots (dstStride floats per slot), bins [rowShift, rowShift+rows)
+    float *scr;
+    CHECK(nat_array(c, CSR_ARR_PS, &scr));   // 4 (or 1) floats per bin of natural scratch
+    if (rows > 0)
+        HIPOK(hipMemcpyAsync(scr + (c->chains[0].off + rowShift) * ncomp, host, sizeof(float) * ncomp * rows,
+                             hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < ncomp; ++k) {
+        hipLaunchKernelGGL(k_import_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, c->p, scr, ncomp, k, dst, dstStride, k);
+        LAUNCH_CHECK("k_import_f32");
+    }
+    return 0;
+}
+
+extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_fwd_out *out) {
+    if (!mdl || !io || !out) return fail("null argument");
+    if (io->m <= 0 || io->n <= 0) return fail("empty input must be handled by the caller (pyx:6494-6501)");
+    if (!io->data || !io->munc || !io->D) return fail("null host buffer");
+    if ((io->flags & CSR_USE_LAMBDA) && !io->lambda) return fail("CSR_USE_LAMBDA without lambda");
+    if ((io->flags & CSR_USE_KAPPA) && !io->kappa) return fail("CSR_USE_KAPPA without kappa");
+    if ((io->flags & CSR_USE_QSCALE) && !io->qscale) return fail("CSR_USE_QSCALE without qscale");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(configure_single(c, mdl, io->m, io->n));
+    CHECK(csr_batch_upload(c, 0, io->data, io->munc));
+    CHECK(csr_batch_upload_multipliers(c, 0, (io->flags & CSR_USE_LAMBDA) ? io->lambda : nullptr,
+                                       (io->flags & CSR_USE_KAPPA) ? io->kappa : nullptr,
+                                       (io->flags & CSR_USE_QSCALE) ? io->qscale : nullptr));
+    CHECK(csr_batch_stats(c));
+    CHECK(csr_batch_forward(c, io->flags, &out->sum_d, &out->sum_nll));
+    CHECK(csr_batch_export(c, CSR_EXPORT_FORWARD));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_D, io->D));
+    if (io->xf) {
+        if (!io->Pf || !io->pnoise) return fail("xf/Pf/pnoise must be given together");
+        CHECK(csr_batch_download(c, 0, CSR_ARR_XF, io->xf));
+        CHECK(csr_batch_download(c, 0, CSR_ARR_PF, io->Pf));
+        CHECK(csr_batch_download(c, 0, CSR_ARR_PNOISE, io->pnoise));
+    }
+    return 0;
+}
+
+extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, const float *data, const float *xf,
+                                 const float *Pf, const float *pnoise, float *xs, float *Ps, float *lag,
+                                 int64_t lag_rows, float *resid) {
+    if (!mdl || !data || !xf || !Pf || !pnoise || !xs || !Ps || !lag || !resid) return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:6737)");
+    if (lag_rows < std::max<int64_t>(n - 1, 1)) return fail("lagCovSmoothed too small");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(configure_single(c, mdl, m, n));
+    // only `data` matters for the smoother (residuals); munc is not an input of cbackwardPass
+    const ChainInfo &ci = c->chains[0];
+    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.data) + ci.off, sizeof(float) * c->Npad, data, sizeof(float) * n,
+                           sizeof(float) * n, (size_t)m, hipMemcpyHostToDevice, c->stream));
+    c->statsValid = false;
+    const int d = mdl->state_dim;
+    CHECK(import_nat(c, xf, d, n, 0, (float *)c->p.tXf, 2));
+    CHECK(import_nat(c, Pf, d * d, n, 0, (float *)c->p.tPf, 4));
+    if (n > 1) CHECK(import_nat(c, pnoise, d * d, n - 1, 0, (float *)c->p.tQ, 4));
+    c->haveFwd = true;
+    c->fwdFlags = 0;
+    CHECK(backward_impl(c, true, nullptr));
+    CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_RESID, resid));
+    c->haveFwd = c->haveBwd = false;   // imported filter results are not a reusable forward pass
+    return 0;
+}
+
+extern "C" int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg *cfg, int64_t m, int64_t n,
+                                        const float *data, const float *munc, const float *qscale, float *lambda,
+                                        float *kappa, float *xs, float *Ps, float *lag, float *resid,
+                                        double *nll_path, csr_ecm_out *out) {
+    if (!mdl || !cfg || !data || !munc || !xs || !Ps || !lag || !resid || !out) return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:7999)");
+    if (cfg->use_lambda && !lambda) return fail("use_lambda without lambda buffer");
+    if (cfg->use_kappa && !kappa) return fail("use_kappa without kappa buffer");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(configure_single(c, mdl, m, n));
+    CHECK(csr_batch_upload(c, 0, data, munc));
+    CHECK(csr_batch_upload_multipliers(c, 0, cfg->use_lambda ? lambda : nullptr, cfg->use_kappa ? kappa : nullptr, qscale));
+    CHECK(csr_batch_stats(c));
+    CHECK(csr_batch_ecm(c, cfg, qscale ? CSR_USE_QSCALE : 0u, out, nll_path));
+    CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID | CSR_EXPORT_MULT));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));
+    CHECK(csr_batch_download(c, 0, CSR_ARR_RESID, resid));
+    if (cfg->use_lambda) CHECK(csr_batch_download(c, 0, CSR_ARR_LAMBDA, lambda));
+    if (cfg->use_kappa) CHECK(csr_batch_download(c, 0, CSR_ARR_KAPPA, kappa));
+    return 0;
+}
+
+extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t n, const double *xs, const double *Ps,
+                                                     const double *lag, const double *F, double *sum_level,
+                                                     double *sum_trend, int64_t *count) {
+    if (!sum_level || !sum_trend || !count) return fail("null argument");
+    *sum_level = 0.0; *sum_trend = 0.0;
+    *count = n - 1 > 0 ? n - 1 : 0;
+    if (n - 1 <= 0) return 0;
+    if (!xs || !Ps || !lag) return fail("null host buffer");
+    if (state_dim == 2 && !F) return fail("matrixF required for the levelTrend model");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const int d = state_dim;
+    double *dxs = nullptr, *dPs = nullptr, *dlag = nullptr, *dpart = nullptr;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 512);
+    auto cleanup = [&]() { hipFree(dxs); hipFree(dPs); hipFree(dlag); hipFree(dpart); };
+    if (hipMalloc((void **)&dxs, sizeof(double) * n * d) != hipSuccess || hipMalloc((void **)&dPs, sizeof(double) * n * d * d) != hipSuccess ||
+        hipMalloc((void **)&dlag, sizeof(double) * (n - 1) * d * d) != hipSuccess ||
+        hipMalloc((void **)&dpart, sizeof(double) * 2 * grid) != hipSuccess) {
+        cleanup();
+        return fail("hipMalloc failed in transition sums");
+    }
+    hipMemcpyAsync(dxs, xs, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(dPs, Ps, sizeof(double) * n * d * d, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(dlag, lag, sizeof(double) * (n - 1) * d * d, hipMemcpyHostToDevice, c->stream);
+    {
+        Scope sc(c, "transition_sums");
+        hipLaunchKernelGGL(k_tsums, dim3(grid), dim3(256), 0, c->stream, d, n, dxs, dPs, dlag, d == 2 ? F[0] : 1.0,
+                           d == 2 ? F[1] : 0.0, d == 2 ? F[2] : 0.0, d == 2 ? F[3] : 1.0, dpart, dpart + grid);
+    }
+    std::vector<double> part(2 * grid);
+    hipError_t e = hipMemcpyAsync(part.data(), dpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail("transition sums failed: %s", hipGetErrorString(e));
+    double aL = 0.0, aT = 0.0;
+    for (int i = 0; i < grid; ++i) { aL += part[i]; aT += part[grid + i]; }
+    *sum_level = aL;
+    *sum_trend = (d == 2) ? aT : 0.0;
+    return 0;
+}

@@ -1,0 +1,208 @@
+/*
+ * consenrich_amd.h -- C ABI of the MI355X (gfx950) implementation of Consenrich's estimator hot path.
+ *
+ * The reference has no FFI/plugin registry: its hot path sits behind the Python module-attribute interface
+ * `consenrich.cconsenrich.<name>` (core.py:30, looked up at call time: core.py:3286-3290, 4231-4321, 4351-4413,
+ * 3451, 3483).  This library is what a replacement of those callables binds to: every entry point below names the
+ * reference callable it replaces ("pyx" = src/consenrich/cconsenrich.pyx).  Plain C: pointers + sizes, no torch,
+ * no exceptions.  All functions return 0 on success, nonzero on failure; csr_last_error() gives the message
+ * (thread-local).  Host buffers are caller-owned, C-contiguous, and never retained across calls; device buffers
+ * are owned by the library (one context per GPU/process).
+ *
+ * Two API levels:
+ *   (1) reference-shaped single-chain calls on HOST buffers  (csr_forward_pass, csr_backward_pass,
+ *       csr_fixed_background_ecm, csr_expected_transition_residual_sums) -- drop-in for the Cython callables;
+ *   (2) a device-resident multi-chain BATCH (csr_batch_*) -- many chromosomes/contigs per launch, inputs kept in
+ *       HBM across sweeps; used by the genome driver, bench.py and the multi-GPU sharding (one context per rank).
+ */
+#ifndef CONSENRICH_AMD_H
+#define CONSENRICH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSR_ABI_VERSION 1
+
+/* ---- model / flags ------------------------------------------------------------------------------------- */
+
+typedef struct csr_model {
+    int32_t state_dim;          /* 2 = levelTrend (pyx:291-529), 1 = level (pyx:538-707) */
+    int32_t reserved_;
+    double F[4];                /* row-major transition matrix (float32 values widened; pyx:6566-6569) */
+    double Q0[4];               /* row-major base process noise (pyx:6570-6573); level uses Q0[0] */
+    double state_init;          /* (double)(float) stateInit        (pyx:6593) */
+    double state_covar_init;    /* (double)(float) stateCovarInit   (pyx:6594) */
+    double pad;                 /* (double)(float) pad              (pyx:6595) */
+    double w_min, w_max;        /* observation precision (lambda) clamp, pyx:433 */
+    double k_min, k_max;        /* process precision (kappa) clamp, pyx:395 */
+    double apn_min_q, apn_max_q, apn_thresh, apn_scale, apn_pc; /* adaptive process noise, pyx:510-527 */
+} csr_model;
+
+enum {
+    CSR_USE_LAMBDA   = 1u << 0, /* useLambda        (pyx:6449) */
+    CSR_USE_KAPPA    = 1u << 1, /* useProcPrec      (pyx:6453) */
+    CSR_USE_QSCALE   = 1u << 2, /* useProcessQScale (pyx:6452) */
+    CSR_USE_APN      = 1u << 3, /* ECM_useAPN after the qDiagBase veto (pyx:6575); sequential fallback path */
+    CSR_RETURN_NLL   = 1u << 4, /* returnNLL */
+    CSR_NLL_IN_D     = 1u << 5  /* storeNLLInD */
+};
+
+/* ---- (1) reference-shaped single-chain entry points (host buffers) ---------------------------------------- */
+
+typedef struct csr_fwd_io {
+    int64_t m, n;               /* trackCount, intervalCount */
+    const float *data;          /* (m,n) C-order  matrixData */
+    const float *munc;          /* (m,n) C-order  matrixPluginMuncInit */
+    const float *lambda;        /* n or NULL */
+    const float *kappa;         /* n or NULL */
+    const float *qscale;        /* n or NULL */
+    uint32_t flags;             /* CSR_USE_* / CSR_RETURN_NLL / CSR_NLL_IN_D; USE_x requires the pointer */
+    uint32_t reserved_;
+    float *D;                   /* n, always written (vectorD) */
+    float *xf;                  /* (n,d)   or NULL: all three or none (doStore, pyx:6444) */
+    float *Pf;                  /* (n,d,d) */
+    float *pnoise;              /* (n,d,d): rows 0..n-2 written (pyx:504-508) */
+} csr_fwd_io;
+
+typedef struct csr_fwd_out {
+    double sum_d;               /* sum of float32 D[k]  -> phiHat = sum_d/n (pyx:6627) */
+    double sum_nll;             /* sumNLL (pyx:468) */
+} csr_fwd_out;
+
+/* replaces cforwardPass (pyx:6393-6632) and cforwardPassLevel (pyx:6853-7049).  intervalToBlockMap is validated by
+ * the host wrapper (its only effect in the reference is the range check pyx:389-392). */
+int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_fwd_out *out);
+
+/* replaces cbackwardPass (pyx:6635-6850) and cbackwardPassLevel (pyx:7052-7150).
+ * lag_rows = rows available in `lag` (>= max(n-1,1)); resid is (n,m). */
+int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, const float *data,
+                      const float *xf, const float *Pf, const float *pnoise,
+                      float *xs, float *Ps, float *lag, int64_t lag_rows, float *resid);
+
+typedef struct csr_ecm_cfg {
+    int64_t max_iters;          /* ECM_fixedBackgroundIters */
+    int64_t inner_iters;        /* t_innerIters */
+    double rtol;                /* (double)(float) ECM_fixedBackgroundRtol */
+    double nu;                  /* (double)(float) ECM_robustTNu */
+    int32_t use_lambda;         /* ECM_useObsPrecisionReweighting */
+    int32_t use_kappa;          /* ECM_useProcessPrecisionReweighting && (!APN || qscale)  (pyx:7912) */
+    int32_t use_apn;
+    int32_t reserved_;
+} csr_ecm_cfg;
+
+typedef struct csr_ecm_out {
+    int64_t iters_done;
+    double final_nll;
+    double initial_nll;
+    double abs_rel_change;
+    double rel_improvement;
+    int64_t stable_iters;
+    int64_t nll_increase_count;
+    int32_t converged;
+    int32_t skipped;            /* n <= 5 filter+smoother fallback (pyx:7998-8129) */
+    int32_t has_initial_nll;
+    int32_t reserved_;
+} csr_ecm_out;
+
+/* replaces cfixedBackgroundECM (pyx:7660-8442) and cfixedBackgroundECMLevel (pyx:7153-7657).
+ * lambda / kappa: n, in/out (warm start already clipped by the caller, pyx:7899-7923), NULL when disabled.
+ * nll_path: max_iters doubles or NULL (per-iteration NLL, the reference's optimization_path). */
+int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg *cfg, int64_t m, int64_t n,
+                             const float *data, const float *munc, const float *qscale,
+                             float *lambda, float *kappa,
+                             float *xs, float *Ps, float *lag, float *resid,
+                             double *nll_path, csr_ecm_out *out);
+
+/* replaces cExpectedTransitionResidualSums (pyx:710-815) and ...Level (pyx:818-863); float64 host inputs. */
+int csr_expected_transition_residual_sums(int32_t state_dim, int64_t n, const double *xs, const double *Ps,
+                                          const double *lag, const double *F,
+                                          double *sum_level, double *sum_trend, int64_t *count);
+
+/* ---- (2) device-resident multi-chain batch ---------------------------------------------------------------- */
+
+typedef struct csr_ctx csr_ctx;
+
+int csr_device_count(void);
+csr_ctx *csr_create(int device_ordinal);    /* NULL on failure */
+void csr_destroy(csr_ctx *ctx);
+const char *csr_last_error(void);
+int csr_abi_version(void);
+
+/* Speculative-block tuning: block_len (multiple of 32), warm-up lengths in blocks for the forward covariance
+ * chain, forward state chain and backward chain. 0 keeps the default.  Results never depend on these. */
+int csr_set_tuning(csr_ctx *ctx, int32_t block_len, int32_t warm_p, int32_t warm_x, int32_t warm_b);
+
+/* Describe a batch: n_chains independent chains (chromosomes) of chain_len[c] bins, m samples each. (Re)allocates. */
+int csr_batch_configure(csr_ctx *ctx, const csr_model *mdl, int64_t m, int32_t n_chains,
+                        const int64_t *chain_len);
+/* Replace the model parameters (same state_dim) without reallocating or re-uploading. */
+int csr_batch_set_model(csr_ctx *ctx, const csr_model *mdl);
+/* H2D one chain's (m,n_c) C-order matrices. */
+int csr_batch_upload(csr_ctx *ctx, int32_t chain, const float *data, const float *munc);
+/* H2D optional per-bin multipliers (any may be NULL = leave as is). */
+int csr_batch_upload_multipliers(csr_ctx *ctx, int32_t chain, const float *lambda, const float *kappa,
+                                 const float *qscale);
+/* Fill every chain with the SURVEY 8(d) synthetic recipe directly in HBM (counter-based RNG). */
+int csr_batch_synthesize(csr_ctx *ctx, uint64_t seed);
+
+/* a1: per-bin sufficient statistics of (data, munc, pad); must precede forward/ECM after any upload. */
+int csr_batch_stats(csr_ctx *ctx);
+/* a2-a5 over all chains.  sum_d / sum_nll: n_chains doubles each (may be NULL). */
+int csr_batch_forward(csr_ctx *ctx, uint32_t flags, double *sum_d, double *sum_nll);
+/* a6-a7 over all chains (uses the forward results resident on the device). */
+int csr_batch_backward(csr_ctx *ctx);
+/* a8-a9 over all chains in lock-step; out: n_chains entries; nll_path: n_chains*max_iters or NULL. */
+int csr_batch_ecm(csr_ctx *ctx, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path);
+
+enum { /* arrays, reference (natural) layout */
+    CSR_ARR_D = 0,      /* (n)      float32 */
+    CSR_ARR_XF,         /* (n,d)    */
+    CSR_ARR_PF,         /* (n,d,d)  */
+    CSR_ARR_PNOISE,     /* (n,d,d), rows 0..n-2 valid */
+    CSR_ARR_XS,         /* (n,d)    */
+    CSR_ARR_PS,         /* (n,d,d)  */
+    CSR_ARR_LAG,        /* (n,d,d), rows 0..n-2 valid */
+    CSR_ARR_RESID,      /* (n,m)    */
+    CSR_ARR_LAMBDA,     /* (n)      */
+    CSR_ARR_KAPPA,      /* (n)      */
+    CSR_ARR_COUNT
+};
+enum {
+    CSR_EXPORT_FORWARD = 1u << 0,   /* D, xf, Pf, pnoise */
+    CSR_EXPORT_SMOOTH  = 1u << 1,   /* xs, Ps, lag */
+    CSR_EXPORT_RESID   = 1u << 2,   /* resid */
+    CSR_EXPORT_MULT    = 1u << 3    /* lambda, kappa */
+};
+/* Convert device-internal (block-transposed) results into reference-layout device arrays. */
+int csr_batch_export(csr_ctx *ctx, uint32_t what);
+/* D2H one exported array of one chain. */
+int csr_batch_download(csr_ctx *ctx, int32_t chain, int32_t array_id, void *host_dst);
+/* Device pointer + element count of an exported array (all chains, chain c at csr_batch_chain_offset). */
+int csr_batch_device_array(csr_ctx *ctx, int32_t array_id, void **dev_ptr, int64_t *n_elems);
+int64_t csr_batch_chain_offset(csr_ctx *ctx, int32_t chain);   /* in bins, -1 on error */
+int csr_synchronize(csr_ctx *ctx);
+
+/* Instrumentation: kernel timing with HIP events on the library's stream. */
+typedef struct csr_kernel_time {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} csr_kernel_time;
+int csr_profile_enable(csr_ctx *ctx, int32_t on);          /* also clears accumulated times */
+int csr_profile_read(csr_ctx *ctx, csr_kernel_time *out, int32_t capacity, int32_t *n_out);
+
+typedef struct csr_run_stats {
+    int64_t blocks;             /* speculative blocks in the batch */
+    int64_t fix_launches;       /* validation/fix-up kernel launches so far */
+    int64_t reruns_p, reruns_x, reruns_b;  /* blocks re-run because the speculative carry-in was not bit-equal */
+    int32_t block_len, warm_p, warm_x, warm_b;
+} csr_run_stats;
+int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
