@@ -519,13 +519,21 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
     p.warm = warm;
     const int grid = (int)c->NG;
+    if (getenv("CONSENRICH_AMD_POISON")) {
+        HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
+        HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
+        HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
+    }
     {
         Scope sc(c, name);
         hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
     }
     LAUNCH_CHECK(name);
     int which = 0;
+    const char *dbgForce = getenv("CONSENRICH_AMD_FORCE_ITERS");
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
+        p.debugForce = (dbgForce && it < atoi(dbgForce)) ? 1 : 0;
+        if (getenv("CONSENRICH_AMD_FENCE")) p.debugForce |= 2;
         HIPOK(hipMemsetAsync(p.rerunCount, 0, sizeof(unsigned int), c->stream));
         {
             Scope sc(c, fixName);
@@ -536,6 +544,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         HIPOK(hipStreamSynchronize(c->stream));
         c->rs.fix_launches++;
         which ^= 1;
+        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, *c->hCount);
         if (*c->hCount == 0) return 0;
         *reruns += *c->hCount;
     }
@@ -995,5 +1004,47 @@ extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t 
     for (int i = 0; i < grid; ++i) { aL += part[i]; aT += part[grid + i]; }
     *sum_level = aL;
     *sum_trend = (d == 2) ? aT : 0.0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// debugging aids (not part of the public ABI)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uint32_t flags, int force, unsigned int *count) {
+    CHECK(need(c));
+    Prm p = c->p;
+    p.flags = flags;
+    p.debugForce = force;
+    p.warm = kind == 0 ? c->warmP : (kind == 1 ? c->warmX : c->warmB);
+    const int grid = (int)c->NG;
+    HIPOK(hipMemsetAsync(p.rerunCount, 0, sizeof(unsigned int), c->stream));
+    if (op == 0) {
+        if (kind == 0) hipLaunchKernelGGL(k_chain_spec<FwdPTrend>, dim3(grid), dim3(64), 0, c->stream, p);
+        if (kind == 1) hipLaunchKernelGGL(k_chain_spec<FwdXTrend>, dim3(grid), dim3(64), 0, c->stream, p);
+        if (kind == 2) hipLaunchKernelGGL(k_chain_spec<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p);
+    } else {
+        if (kind == 0) hipLaunchKernelGGL(k_chain_fix<FwdPTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
+        if (kind == 1) hipLaunchKernelGGL(k_chain_fix<FwdXTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
+        if (kind == 2) hipLaunchKernelGGL(k_chain_fix<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
+    }
+    LAUNCH_CHECK("debug chain step");
+    HIPOK(hipMemcpyAsync(c->hCount, p.rerunCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    if (count) *count = *c->hCount;
+    c->haveFwd = true;
+    return 0;
+}
+extern "C" int csr_debug_read(csr_ctx *c, int buf, void *dst, int64_t bytes) {
+    CHECK(need(c));
+    const void *src = nullptr;
+    switch (buf) {
+        case 0: src = c->p.carryIn; break;
+        case 1: src = c->p.carryOutA; break;
+        case 2: src = c->p.carryOutB; break;
+        case 3: src = c->p.tPf; break;
+        case 4: src = c->p.tS0u; break;
+        default: return fail("bad debug buffer");
+    }
+    HIPOK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
