@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the Consenrich estimator hot path on MI355X (driver contract: one JSON line on rank 0).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples"):
+22 synthetic chains with the hg38 autosome bin counts at 200 bp (14 375 018 bins), m = 32 samples, levelTrend model,
+SURVEY 8(d) parameters.  One STEP = one full pass of the hot path over every chain the rank owns, inputs already
+resident in HBM:  per-bin sufficient statistics of (data, munc)  ->  forward filter (store, NLL)  ->  RTS smoother
+->  lag-one covariances  ->  export of D, xf, Pf, pNoise, xs, Ps, lagCov to the reference layouts  ->  residuals (n, m).
+With N > 1 the chains are LPT-sharded over the ranks (strong scaling: the genome is fixed); there is no data-path
+collective -- the one RCCL call is the final track gather, done once after the timed region and reported separately.
+torch is used only for the process group / barrier / device-wide synchronize required by the contract.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def b_alg(m: int) -> int:
+    """algorithmic bytes per bin, forward + backward, data read once."""
+    return 12 * m + 100
+
+
+# algorithmic bytes per bin of each kernel (DESIGN.md "Kernels"): only traffic the reference layouts require
+def kernel_alg_bytes(name: str, m: int, d: int) -> float:
+    return {
+        "stats": 8.0 * m,                       # data + munc read once
+        "residuals": 4.0 * m,                   # (n, m) residual write
+        "fwd_cov_chain": 16.0 + 16.0 + 16.0,    # lambda/kappa/qscale/blockMap in, Pf + pNoise out
+        "fwd_state_chain": 8.0,                 # xf out
+        "fwd_dstat": 4.0,                       # D out
+        "bwd_chain": 8.0 + 16.0,                # xs + Ps out
+        "bwd_lagcov": 16.0,                     # lagCov out
+        "export_natural": 0.0,                  # layout conversion: pure overhead
+    }.get(name, 0.0)
+
+
+def cpu_baseline(m: int, max_seconds: float = 30.0):
+    """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases
+    from consenrich_amd.sharding import hg38_chain_lengths
+    from oracle import oracle as orc
+
+    orc.lib()
+    n = hg38_chain_lengths(200)[20]   # chr21-sized chain: 233 550 bins
+    data, munc = cases.synth(n, m, 21)
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    bm = (np.arange(n) // 500).astype(np.int32)
+    xf, Pf, pn = np.empty((n, 2), np.float32), np.empty((n, 2, 2), np.float32), np.empty((n, 2, 2), np.float32)
+    D = np.empty(n, np.float32)
+    xs, Ps = np.empty((n, 2), np.float32), np.empty((n, 2, 2), np.float32)
+    lag, res = np.empty((n - 1, 2, 2), np.float32), np.empty((n, m), np.float32)
+
+    def one():
+        orc.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0, intervalToBlockMap=bm,
+                         blockCount=int(bm.max()) + 1, stateInit=0.0, stateCovarInit=1000.0, stateForward=xf,
+                         stateCovarForward=Pf, pNoiseForward=pn, vectorD=D, returnNLL=True)
+        orc.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                          stateSmoothed=xs, stateCovarSmoothed=Ps, lagCovSmoothed=lag, postFitResiduals=res)
+
+    one()  # warm-up (first-touch page faults)
+    best, spent, reps = float("inf"), 0.0, 0
+    while reps < 400 and spent < min(max_seconds, 12.0):
+        t = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t
+        best = min(best, dt)
+        spent += dt
+        reps += 1
+    return {
+        "value": n / best, "unit": "genomic bins/s", "cores": 1, "kind": "port",
+        "sample": f"oracle C port (forward store+NLL, backward+residuals), 1 thread, chr21-sized chain "
+                  f"({n} bins x {m} samples), best of {reps} passes after warm-up ({spent:.1f} s of CPU work)",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=32)
+    ap.add_argument("--bin-bp", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N > 1 must be launched through torch.distributed.run", file=sys.stderr)
+            return 2
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.sharding import gather_tracks, hg38_chain_lengths, lpt_assign
+
+    m = args.samples
+    lengths = hg38_chain_lengths(args.bin_bp)
+    total_bins = int(sum(lengths))
+    mine = lpt_assign(lengths, world)[rank]
+    my_lens = [lengths[i] for i in mine]
+
+    model = ModelParams(state_dim=2)
+    batch = DeviceBatch(local_rank)
+    batch.configure(model, m, my_lens)
+    batch.synthesize(seed=1234 + rank)
+    flags = L.RETURN_NLL
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+
+    def step():
+        batch.stats()
+        batch.forward(flags, want_sums=True)
+        batch.backward()
+        batch.export(what)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        batch.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    value = total_bins * args.steps / elapsed
+
+    # per-kernel durations: HIP events on the library's stream, separate (untimed) pass of the same steps
+    batch.profile(True)
+    for _ in range(args.steps):
+        step()
+    times = batch.kernel_times()
+    batch.profile(False)
+    rs = batch.run_stats()
+    my_bins = int(sum(my_lens))
+    per_kernel = {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1), "ms_per_step": v[1] / max(args.steps, 1)}
+                  for k, v in times.items()}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else None
+    roofline = None
+    if dom is not None:
+        alg_bytes = kernel_alg_bytes(dom, m, 2) * my_bins
+        avg_s = per_kernel[dom]["avg_ms"] * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as fh:
+                    traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "alg_bytes_per_bin": kernel_alg_bytes(dom, m, 2), "bins_per_launch": my_bins,
+                    "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+
+    gather_ms = None
+    if dist is not None and not args.no_gather:
+        # final track gather (state + uncertainty): once per job, RCCL all_gather over xGMI, not part of `value`
+        xs_tracks = {}
+        for ci, gi in enumerate(mine):
+            xs = batch.download(ci, "xs")[:, :1]
+            ps = np.sqrt(np.maximum(batch.download(ci, "Ps")[:, 0, 0:1], 0.0))
+            xs_tracks[gi] = np.concatenate([xs, ps], axis=1)
+        fence()
+        tg = time.perf_counter()
+        gathered = gather_tracks(xs_tracks, lengths, 2, device=f"cuda:{local_rank}")
+        fence()
+        gather_ms = 1000.0 * (time.perf_counter() - tg)
+        if rank == 0:
+            assert gathered is not None and all(g.shape == (lengths[i], 2) for i, g in enumerate(gathered))
+
+    if rank == 0:
+        out = {
+            "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples",
+            "value": value, "unit": "genomic bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
+                            "stats + forward(store,NLL) + RTS backward + lagCov + export + residuals, levelTrend",
+                "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"],
+                "warm_blocks": [rs["warm_p"], rs["warm_x"], rs["warm_b"]],
+            },
+            "roofline": roofline,
+            "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": value * b_alg(m) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": value * b_alg(m) / 1e9 / HBM_PEAK_GBS},
+            "kernels_rank0": per_kernel,
+            "speculation": {"blocks": rs["blocks"], "reruns_cov": rs["reruns_p"], "reruns_state": rs["reruns_x"],
+                            "reruns_bwd": rs["reruns_b"], "fix_launches": rs["fix_launches"]},
+            "gather_ms": gather_ms,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(m)
+        print(json.dumps(out))
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -67,7 +67,7 @@ class RunStats(C.Structure):
     _fields_ = [
         ("blocks", C.c_int64), ("fix_launches", C.c_int64), ("reruns_p", C.c_int64), ("reruns_x", C.c_int64),
         ("reruns_b", C.c_int64), ("block_len", C.c_int32), ("warm_p", C.c_int32), ("warm_x", C.c_int32),
-        ("warm_b", C.c_int32),
+        ("warm_b", C.c_int32), ("x_tol_ulps", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -79,6 +79,7 @@ SYMBOLS = {
     "csr_create": (C.c_void_p, [C.c_int]),
     "csr_destroy": (None, [C.c_void_p]),
     "csr_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "csr_set_validation": (C.c_int, [C.c_void_p, C.c_int32]),
     "csr_synchronize": (C.c_int, [C.c_void_p]),
     "csr_batch_configure": (C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int64, C.c_int32, I64P]),
     "csr_batch_set_model": (C.c_int, [C.c_void_p, C.POINTER(Model)]),

@@ -48,16 +48,21 @@ _ARR = {"D": L.ARR_D, "xf": L.ARR_XF, "Pf": L.ARR_PF, "pnoise": L.ARR_PNOISE, "x
 class DeviceBatch:
     """One GPU, many chains.  Thin, explicit wrapper: every method is one C-ABI call."""
 
-    def __init__(self, device: int = 0, block_len: int = 0, warm=(-1, -1, -1)):
+    def __init__(self, device: int = 0, block_len: int = 0, warm=(-1, -1, -1), x_tol_ulps=None):
         L.require_gpu()
         self._lib = L.lib()
         self._ctx = self._lib.csr_create(int(device))
         if not self._ctx:
             raise L.ConsenrichAMDError(L.last_error())
         L.check(self._lib.csr_set_tuning(self._ctx, int(block_len), int(warm[0]), int(warm[1]), int(warm[2])))
+        if x_tol_ulps is not None:
+            L.check(self._lib.csr_set_validation(self._ctx, int(x_tol_ulps)))
         self.chain_lens = []
         self.m = 0
         self.d = 2
+
+    def set_validation(self, x_tol_ulps: int):
+        L.check(self._lib.csr_set_validation(self._ctx, int(x_tol_ulps)))
 
     def close(self):
         if self._ctx:

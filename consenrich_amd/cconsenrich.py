@@ -19,6 +19,12 @@ import numpy as np
 
 from . import _lib as L
 
+def set_validation(x_tol_ulps: int) -> None:
+    """Carry validation of the forward state chain for the calls in this module (see csr_set_validation):
+    0 = bit-exact sequential semantics, k > 0 = accept speculative carries within k float32 ulps (default 2)."""
+    L.check(L.lib().csr_set_validation(None, int(x_tol_ulps)))
+
+
 __all__ = [
     "cforwardPass", "cbackwardPass", "cforwardPassLevel", "cbackwardPassLevel", "cfixedBackgroundECM",
     "cfixedBackgroundECMLevel", "cExpectedTransitionResidualSums", "cExpectedTransitionResidualSumsLevel",

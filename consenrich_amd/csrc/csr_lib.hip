@@ -67,6 +67,7 @@ struct csr_ctx {
     hipStream_t stream = nullptr;
     // tuning
     int B = 256, warmP = 2, warmX = 8, warmB = 4;
+    int xTolUlps = 2;
     // batch
     bool configured = false;
     csr_model mdl{};
@@ -145,6 +146,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WARM_P"))) c->warmP = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WARM_X"))) c->warmX = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if (c->B < 32 || (c->B % 32) != 0) c->B = 256;
     return c;
 }
@@ -176,6 +178,15 @@ extern "C" int csr_set_tuning(csr_ctx *c, int32_t block_len, int32_t warm_p, int
     if (warm_p >= 0) c->warmP = warm_p;
     if (warm_x >= 0) c->warmX = warm_x;
     if (warm_b >= 0) c->warmB = warm_b;
+    return 0;
+}
+
+static csr_ctx *default_ctx();
+extern "C" int csr_set_validation(csr_ctx *c, int32_t x_tol_ulps) {
+    if (!c) c = default_ctx();      // NULL addresses the default context of the reference-shaped entry points
+    if (!c) return -1;
+    if (x_tol_ulps < 0 || x_tol_ulps > 64) return fail("x_tol_ulps must be in [0, 64]");
+    c->xTolUlps = x_tol_ulps;
     return 0;
 }
 
@@ -264,6 +275,7 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
     out->warm_p = c->warmP;
     out->warm_x = c->warmX;
     out->warm_b = c->warmB;
+    out->x_tol_ulps = c->xTolUlps;
     return 0;
 }
 
@@ -518,6 +530,7 @@ template <class CH>
 static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int warm, int64_t *reruns) {
     static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
     p.warm = warm;
+    p.xTolUlps = c->xTolUlps;
     const int grid = (int)c->NG;
     if (getenv("CONSENRICH_AMD_POISON")) {
         HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));

@@ -135,6 +135,13 @@ int csr_abi_version(void);
  * chain, forward state chain and backward chain. 0 keeps the default.  Results never depend on these. */
 int csr_set_tuning(csr_ctx *ctx, int32_t block_len, int32_t warm_p, int32_t warm_x, int32_t warm_b);
 
+/* Carry validation of the forward STATE chain.  0: a speculative block is accepted only if its carry-in is bit-equal
+ * to its predecessor's carry-out (results == the sequential recursion, bit for bit).  k > 0 (default 2): also accepted
+ * when |dx0| + |F01||dx1| <= k float32 ulps of the level -- ~1e-7 relative on the state track, far inside the 1e-5
+ * parity budget; needed because exact coalescence of the rounded 2-D recursion can take >10^4 bins.
+ * ctx == NULL addresses the default context used by the reference-shaped single-chain entry points. */
+int csr_set_validation(csr_ctx *ctx, int32_t x_tol_ulps);
+
 /* Describe a batch: n_chains independent chains (chromosomes) of chain_len[c] bins, m samples each. (Re)allocates. */
 int csr_batch_configure(csr_ctx *ctx, const csr_model *mdl, int64_t m, int32_t n_chains,
                         const int64_t *chain_len);
@@ -199,6 +206,7 @@ typedef struct csr_run_stats {
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */
     int64_t reruns_p, reruns_x, reruns_b;  /* blocks re-run because the speculative carry-in was not bit-equal */
     int32_t block_len, warm_p, warm_x, warm_b;
+    int32_t x_tol_ulps, reserved_;
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

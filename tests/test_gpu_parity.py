@@ -39,11 +39,17 @@ def oracle():
 CASES = {c["name"]: c for c in cases.all_cases()}
 
 
+@pytest.mark.parametrize("xtol", [2, 0], ids=["ulp2", "exact"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_product_matches_golden(product, name):
+def test_product_matches_golden(product, name, xtol):
+    """Both carry-validation modes (default: 2-ulp acceptance; 0: bit-exact sequential semantics) must meet parity."""
     case = CASES[name]
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
-    got = cases.run_case(product, case)
+    product.set_validation(xtol)
+    try:
+        got = cases.run_case(product, case)
+    finally:
+        product.set_validation(2)
     cases.compare(case, got, gold, RTOL, ATOL)
 
 
@@ -61,13 +67,13 @@ def test_product_matches_live_oracle(product, oracle, name):
             assert np.asarray(got[k]).item() == pytest.approx(np.asarray(v).item(), rel=RTOL, abs=ATOL), f"{name}:{k}"
 
 
-def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0):
+def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0):
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
 
     mp = ModelParams(state_dim=d, Q0=((1e-3, 0.0), (0.0, 1e-4)) if d == 2 else ((1e-3, 0.0), (0.0, 0.0)))
     out = {}
-    with DeviceBatch(0, block_len=block_len, warm=warm) as b:
+    with DeviceBatch(0, block_len=block_len, warm=warm, x_tol_ulps=xtol) as b:
         b.configure(mp, m, n_list)
         for c, n in enumerate(n_list):
             data, munc = cases.synth(n, m, seed + c, mask_frac=0.02, outlier_frac=0.01)
@@ -104,6 +110,25 @@ def test_speculative_blocks_equal_sequential_recursion(product, d):
                 np.testing.assert_allclose(spec[key], val, rtol=1e-6, atol=1e-7, err_msg=f"{blk} {warm} {key}")
         if warm == (0, 0, 0):
             assert spec["stats"]["reruns_p"] > 0 and spec["stats"]["reruns_b"] > 0   # the fix-up path really ran
+
+
+def test_ulp_tolerant_validation_stays_within_parity_budget(product):
+    """Default mode: speculative carries are accepted within 2 float32 ulps.  Against the exact sequential run the
+    tracks must agree far inside the 1e-5 budget (a few ulps on the level; the trend inherits ulp(level)-sized noise,
+    covered by the absolute tolerance), with large |x| (coarse ulps) to make the test bite."""
+    n_list = [60000, 7000]
+    seq = _run_batch(32 * 2048, (0, 0, 0), 2, n_list, 8, 300, xtol=0)
+    tol = _run_batch(64, (1, 2, 1), 2, n_list, 8, 300, xtol=2)
+    exact = _run_batch(64, (1, 2, 1), 2, n_list, 8, 300, xtol=0)
+    assert tol["stats"]["reruns_x"] < exact["stats"]["reruns_x"]
+    for key, val in seq.items():
+        if key == "stats":
+            continue
+        if not isinstance(key, str):
+            assert np.array_equal(val, exact[key]), key
+        scale = 1.0 if isinstance(key, str) else float(np.abs(val).max())
+        np.testing.assert_allclose(tol[key], val, rtol=2e-6, atol=2e-6 * max(scale, 1e-30) if isinstance(key, str)
+                                   else 1e-6 * scale, err_msg=str(key))
 
 
 def test_batch_chains_are_independent(product):
