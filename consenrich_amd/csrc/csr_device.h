@@ -136,125 +136,108 @@ struct BinStats {
     double s0, zbar, s2c, logr;
 };
 
-template <int MT>
-__device__ __forceinline__ BinStats bin_stats_reg(const float *__restrict__ data, const float *__restrict__ munc,
-                                                  int64_t stride, int64_t g, int m, double pad) {
-    float z[MT], v[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int jj = j < m ? j : m - 1;
-        z[j] = data[(int64_t)jj * stride + g];
-        v[j] = munc[(int64_t)jj * stride + g];
-    }
-    double w[MT];
-    double s0 = 0.0, swz = 0.0, mant = 1.0;
+// One pass over the m samples (register-light, so 8 waves/SIMD hide the HBM latency): weighted sums about the
+// pivot z_0 (first sample), then zbar = z_0 + A/S0 and S2c = B - A^2/S0.  The shift keeps the cancellation in B - A^2/S0
+// at (z_0 - zbar)^2 / var, i.e. a relative error of ~1e-16 * that ratio -- >= 8 digits of headroom to the 1e-5 budget
+// even for a 10^4-sigma pivot.  1/R uses v_rcp_f64 + two Newton steps (<= 1 ulp).
+__device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, const float *__restrict__ munc,
+                                              int64_t stride, int64_t g, int m, double pad) {
+    const double piv = (double)data[g];
+    double s0 = 0.0, A = 0.0, Bq = 0.0, mant = 1.0;
     int ex = 0;
+    const float *dp = data + g, *mp = munc + g;
+    int j = 0;
+    for (; j + 8 <= m; j += 8) {
+        float z[8], v[8];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        double R = (double)v[j] + pad;
-        if (R < 1.0e-12) R = 1.0e-12;
-        const double wj = (j < m) ? 1.0 / R : 0.0;
-        w[j] = wj;
-        s0 += wj;
-        swz = fma(wj, (double)z[j], swz);
-        if (j < m) {
+        for (int u = 0; u < 8; ++u) {
+            z[u] = dp[(int64_t)(j + u) * stride];
+            v[u] = mp[(int64_t)(j + u) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            double R = (double)v[u] + pad;
+            if (R < 1.0e-12) R = 1.0e-12;
+            const double w = rcp_nr(R);
+            const double dz = (double)z[u] - piv;
+            s0 += w;
+            A = fma(w, dz, A);
+            Bq = fma(w * dz, dz, Bq);
             int e;
             mant *= frexp(R, &e);
             ex += e;
         }
-        if ((j & 15) == 15) {
-            int e;
-            mant = frexp(mant, &e);
-            ex += e;
-        }
+        int e2;
+        mant = frexp(mant, &e2);
+        ex += e2;
     }
-    BinStats o;
-    o.s0 = s0;
-    o.zbar = (s0 > 0.0) ? swz / s0 : 0.0;
-    double s2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const double dz = (double)z[j] - o.zbar;
-        s2 = fma(w[j], dz * dz, s2);
-    }
-    o.s2c = s2;
-    o.logr = log(mant) + (double)ex * 0.693147180559945309417232121458;
-    return o;
-}
-
-__device__ __forceinline__ BinStats bin_stats_any(const float *__restrict__ data, const float *__restrict__ munc,
-                                                  int64_t stride, int64_t g, int m, double pad) {
-    double s0 = 0.0, swz = 0.0, mant = 1.0;
-    int ex = 0;
-    for (int j = 0; j < m; ++j) {
-        double R = (double)munc[(int64_t)j * stride + g] + pad;
+    for (; j < m; ++j) {
+        double R = (double)mp[(int64_t)j * stride] + pad;
         if (R < 1.0e-12) R = 1.0e-12;
-        const double wj = 1.0 / R;
-        s0 += wj;
-        swz = fma(wj, (double)data[(int64_t)j * stride + g], swz);
+        const double w = rcp_nr(R);
+        const double dz = (double)dp[(int64_t)j * stride] - piv;
+        s0 += w;
+        A = fma(w, dz, A);
+        Bq = fma(w * dz, dz, Bq);
         int e;
         mant *= frexp(R, &e);
         ex += e;
-        if ((j & 15) == 15) {
-            mant = frexp(mant, &e);
-            ex += e;
-        }
     }
     BinStats o;
     o.s0 = s0;
-    o.zbar = (s0 > 0.0) ? swz / s0 : 0.0;
-    double s2 = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double R = (double)munc[(int64_t)j * stride + g] + pad;
-        if (R < 1.0e-12) R = 1.0e-12;
-        const double dz = (double)data[(int64_t)j * stride + g] - o.zbar;
-        s2 = fma(1.0 / R, dz * dz, s2);
-    }
-    o.s2c = s2;
+    const double shift = (s0 > 0.0) ? A / s0 : 0.0;
+    o.zbar = (s0 > 0.0) ? piv + shift : 0.0;
+    double s2 = Bq - A * shift;
+    o.s2c = s2 > 0.0 ? s2 : 0.0;
     o.logr = log(mant) + (double)ex * 0.693147180559945309417232121458;
     return o;
 }
 
-// One workgroup = one (wave-group G, 32-step) tile: 64 runs of 32 consecutive bins are read with 128-byte coalesced
-// segments, reduced over the m samples in registers, transposed through LDS and written as 32 coalesced rows.
-template <int MT>
+// One workgroup = one tile of TS steps x TL lanes (blocks) of a wave-group: TL runs of TS consecutive bins are read
+// from every sample row (TS*4-byte contiguous segments), reduced over the m samples, transposed through LDS and
+// written as TS rows of TL*8 bytes (a full 128-B line for TL = 16).  TS*TL/256 passes of 256 threads per tile; the tile
+// is kept small (<= 35 KB of LDS) so that >= 4 waves/SIMD are resident to cover the HBM latency.
+template <int TS, int TL>
 __global__ __launch_bounds__(256) void k_stats(Prm p) {
-    __shared__ double tile[4][32][65];
-    const int tilesPerGroup = p.B >> 5;
+    constexpr int RP = 256 / TS;            // runs handled per pass (TS <= 256)
+    constexpr int LT = 64 / TL;             // lane-tiles per wave-group
+    constexpr int NP = TS * TL / 256;       // passes
+    __shared__ double tile[4][TS][TL + 1];
+    const int tilesPerGroup = (p.B / TS) * LT;
     const int64_t G = blockIdx.x / tilesPerGroup;
-    const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
+    const int rem = (int)(blockIdx.x % tilesPerGroup);
+    const int s0 = (rem / LT) * TS;
+    const int l0 = (rem % LT) * TL;
     const int t = threadIdx.x;
-    const int r = t >> 5, si = t & 31;
-    const int s = s0 + si;
+    const int si = t % TS, r = t / TS;
 #pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {
-        const int l = pass * 8 + r;
-        const int64_t b = G * 64 + l;
+    for (int pass = 0; pass < NP; ++pass) {
+        const int ll = pass * RP + r;
+        const int64_t b = G * 64 + l0 + ll;
         BinStats o = {0.0, 0.0, 0.0, 0.0};
         if (b < p.NB) {
             const int4 bi = p.blk[b];
-            if (s < bi.y && chain_on(p, b)) {
-                const int64_t g = (int64_t)bi.x + s;
-                if constexpr (MT > 0) o = bin_stats_reg<MT>(p.data, p.munc, p.Npad, g, p.m, p.pad);
-                else o = bin_stats_any(p.data, p.munc, p.Npad, g, p.m, p.pad);
+            if (s0 + si < bi.y && chain_on(p, b)) {
+                const int64_t g = (int64_t)bi.x + s0 + si;
+                o = bin_stats(p.data, p.munc, p.Npad, g, p.m, p.pad);
             }
         }
-        tile[0][si][l] = o.s0;
-        tile[1][si][l] = o.zbar;
-        tile[2][si][l] = o.s2c;
-        tile[3][si][l] = o.logr;
+        tile[0][si][ll] = o.s0;
+        tile[1][si][ll] = o.zbar;
+        tile[2][si][ll] = o.s2c;
+        tile[3][si][ll] = o.logr;
     }
     __syncthreads();
-    const int lane = t & 63, r0 = t >> 6;
-    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64;
+    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64 + l0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + r0;
-        const int64_t o = rowBase + (int64_t)row * 64 + lane;
-        p.tS0u[o] = tile[0][row][lane];
-        p.tZbar[o] = tile[1][row][lane];
-        p.tS2c[o] = tile[2][row][lane];
-        p.tLogR[o] = tile[3][row][lane];
+    for (int it = 0; it < NP; ++it) {
+        const int idx = it * 256 + t;
+        const int row = idx / TL, ll = idx % TL;
+        const int64_t o = rowBase + (int64_t)row * 64 + ll;
+        p.tS0u[o] = tile[0][row][ll];
+        p.tZbar[o] = tile[1][row][ll];
+        p.tS2c[o] = tile[2][row][ll];
+        p.tLogR[o] = tile[3][row][ll];
     }
 }
 
@@ -264,9 +247,18 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
 // ---------------------------------------------------------------------------------------------------------------
 
 // ---- forward covariance chain, levelTrend (pyx:394-401, 408-435, 458, 481-495) -------------------------------
+#ifndef CSR_U_P
+#define CSR_U_P 8
+#endif
+#ifndef CSR_U_X
+#define CSR_U_X 8
+#endif
+#ifndef CSR_U_B
+#define CSR_U_B 4
+#endif
 struct FwdPTrend {
     static constexpr bool FWD = true;
-    static constexpr int U = 8;
+    static constexpr int U = CSR_U_P;
     struct Carry {
         float c00, c01, c11;   // filtered covariance after the float32 rounding (c10 == c01, pyx:494)
         float pad_;
@@ -342,7 +334,7 @@ struct FwdPTrend {
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
     static constexpr bool FWD = true;
-    static constexpr int U = 8;
+    static constexpr int U = CSR_U_P;
     struct Carry {
         double p;
     };
@@ -384,7 +376,7 @@ struct FwdPLevel {
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
 struct FwdXTrend {
     static constexpr bool FWD = true;
-    static constexpr int U = 8;
+    static constexpr int U = CSR_U_X;
     struct Carry {
         float x0, x1;
     };
@@ -428,7 +420,7 @@ struct FwdXTrend {
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
     static constexpr bool FWD = true;
-    static constexpr int U = 8;
+    static constexpr int U = CSR_U_X;
     struct Carry {
         double x;
     };
@@ -465,7 +457,7 @@ struct FwdXLevel {
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
 struct BwdTrend {
     static constexpr bool FWD = false;
-    static constexpr int U = 4;
+    static constexpr int U = CSR_U_B;
     struct Carry {
         float x0, x1, p00, p01, p10, p11;
         int fresh;      // 1: next visited bin seeds the chain with its filtered values (true chain end or cold start)
@@ -549,7 +541,7 @@ struct BwdTrend {
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
     static constexpr bool FWD = false;
-    static constexpr int U = 8;
+    static constexpr int U = CSR_U_B;
     struct Carry {
         float x, ps;
         int fresh, pad_;
@@ -595,9 +587,11 @@ struct BwdLevel {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// block walker: all valid steps of block `bq` in chain order (ascending for forward chains, descending for the
-// smoother), inputs prefetched U steps ahead so the dependent recursion never waits on HBM.
 // ---------------------------------------------------------------------------------------------------------------
+// block walker: all valid steps of block `bq` in chain order (ascending for forward chains, descending for the
+// smoother).  Inputs of the next U steps are requested before the current U steps are computed.
+// (Measured, profiles/r01_notes.md: hipcc sinks these loads next to their first use, so a wavefront still pays an
+// L2 round trip per batch; a hand-scheduled prefetch ring is the next optimisation of these kernels.)
 template <class CH, bool STORE>
 __device__ __forceinline__ void walk_block(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
                                            int64_t bfirst) {
@@ -1079,6 +1073,72 @@ __global__ __launch_bounds__(256) void k_export_f32(Prm p, const float *src, int
     for (int k = 0; k < cm.n; ++k) nat[g * cm.n + k] = src[slot * srcStride + cm.c[k]];
 }
 
+// blocked -> natural for a list of arrays in ONE launch: a workgroup owns a (wave-group, 32-step) tile, reads 32
+// coalesced rows of every array into LDS and writes, for each of its 64 blocks, 32 consecutive bins (contiguous
+// 128-512 bytes) of the reference layout.  E = floats per blocked slot, n <= E = leading components exported.
+struct ExpDesc {
+    const float *src;
+    float *dst;
+    int E, n, skipLast, pad_;
+};
+struct ExpList {
+    int count;
+    int pad_;
+    ExpDesc d[8];
+};
+template <int E, int N>
+__device__ __forceinline__ void export_tile(const Prm &p, const ExpDesc &d, float *tile, int64_t G, int s0, int t) {
+    typedef float vecE __attribute__((ext_vector_type(E)));
+    typedef float vecN __attribute__((ext_vector_type(N)));
+    constexpr int RS = 65 * E;                // padded row stride in floats
+    const int lane = t & 63, r0 = t >> 6;
+    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + r0;
+        const vecE v = *reinterpret_cast<const vecE *>(d.src + (rowBase + (int64_t)row * 64 + lane) * E);
+        *reinterpret_cast<vecE *>(tile + row * RS + lane * E) = v;
+    }
+    __syncthreads();
+    const int r = t >> 5, si = t & 31;
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int l = pass * 8 + r;
+        const int64_t b = G * 64 + l;
+        if (b < p.NB && chain_on(p, b)) {
+            const int4 bi = p.blk[b];
+            const int s = s0 + si;
+            if (s < bi.y && !(d.skipLast && b == bi.w && s == bi.y - 1)) {
+                const int64_t g = (int64_t)bi.x + s;
+                const float *q = tile + si * RS + l * E;
+                vecN o;
+                if constexpr (N == 1) o = q[0];
+                else {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) o[k] = q[k];
+                }
+                *reinterpret_cast<vecN *>(d.dst + g * N) = o;
+            }
+        }
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_export_tiled(Prm p, ExpList L) {
+    __shared__ __attribute__((aligned(16))) float tile[32 * 65 * 4];
+    const int tilesPerGroup = p.B >> 5;
+    const int64_t G = blockIdx.x / tilesPerGroup;
+    const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
+    const int t = threadIdx.x;
+    for (int a = 0; a < L.count; ++a) {
+        const ExpDesc &d = L.d[a];
+        if (d.E == 1) export_tile<1, 1>(p, d, tile, G, s0, t);
+        else if (d.E == 2 && d.n == 2) export_tile<2, 2>(p, d, tile, G, s0, t);
+        else if (d.E == 2) export_tile<2, 1>(p, d, tile, G, s0, t);
+        else if (d.n == 4) export_tile<4, 4>(p, d, tile, G, s0, t);
+        else export_tile<4, 1>(p, d, tile, G, s0, t);
+    }
+}
+
 // natural xs0 -> residuals (pyx:6846-6848): resid[g][j] = float(data[j][g] - xs0[g]); (m, Npad) -> (Npad, m) through LDS
 __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
     extern __shared__ float tileR[];                 // [m][65]
@@ -1098,6 +1158,41 @@ __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xs
     for (int e = t; e < total; e += 256) {
         const int bin = e / p.m, j = e - bin * p.m;
         if (g0 + bin < nBins) resid[(g0 + bin) * (int64_t)p.m + j] = tileR[j * 65 + bin];
+    }
+}
+
+// vectorised variant for m % 4 == 0: 16-byte loads of four consecutive bins per sample row, 16-byte stores of four
+// consecutive samples of one bin.  One workgroup = 64 bins x m samples.
+__global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
+    extern __shared__ float tileR[];                 // [m][68]: row stride 68 floats keeps float4 rows 16-B aligned
+    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int q = t & 15, r0 = t >> 4;               // q: group of 4 bins, r0: sample row within a sweep of 16
+    const int64_t g = g0 + 4 * q;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+    if (g + 3 < nBins) {
+        x0 = xsNat[(g + 0) * xsStride]; x1 = xsNat[(g + 1) * xsStride];
+        x2 = xsNat[(g + 2) * xsStride]; x3 = xsNat[(g + 3) * xsStride];
+    }
+    for (int j = r0; j < p.m; j += 16) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g + 3 < nBins) {
+            const float4 z = *reinterpret_cast<const float4 *>(p.data + (int64_t)j * p.Npad + g);
+            v.x = (float)((double)z.x - (double)x0); v.y = (float)((double)z.y - (double)x1);
+            v.z = (float)((double)z.z - (double)x2); v.w = (float)((double)z.w - (double)x3);
+        }
+        *reinterpret_cast<float4 *>(tileR + j * 68 + 4 * q) = v;
+    }
+    __syncthreads();
+    const int m4 = p.m >> 2;
+    const int total4 = 64 * m4;
+    for (int e = t; e < total4; e += 256) {
+        const int bin = e / m4, j = (e - bin * m4) << 2;
+        if (g0 + bin < nBins) {
+            const float4 o = make_float4(tileR[(j + 0) * 68 + bin], tileR[(j + 1) * 68 + bin],
+                                         tileR[(j + 2) * 68 + bin], tileR[(j + 3) * 68 + bin]);
+            *reinterpret_cast<float4 *>(resid + (g0 + bin) * (int64_t)p.m + j) = o;
+        }
     }
 }
 

@@ -66,8 +66,9 @@ struct csr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // tuning
-    int B = 256, warmP = 2, warmX = 8, warmB = 4;
+    int B = 256, warmP = 1, warmX = 2, warmB = 1;
     int xTolUlps = 2;
+    int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
     // batch
     bool configured = false;
     csr_model mdl{};
@@ -147,6 +148,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WARM_X"))) c->warmX = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
     if (c->B < 32 || (c->B % 32) != 0) c->B = 256;
     return c;
 }
@@ -505,19 +507,23 @@ extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const flo
 // ---------------------------------------------------------------------------------------------------------------
 // compute
 // ---------------------------------------------------------------------------------------------------------------
+template <int TS, int TL>
+static void launch_stats(csr_ctx *c, const Prm &p) {
+    const int grid = (int)(c->NG * (c->B / TS) * (64 / TL));
+    hipLaunchKernelGGL((k_stats<TS, TL>), dim3(grid), dim3(256), 0, c->stream, p);
+}
+
 extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
     Prm p = c->p;
-    const int grid = (int)(c->NG * (c->B / 32));
     {
         Scope sc(c, "stats");
-        const int m = (int)c->m;
-        if (m <= 4) hipLaunchKernelGGL(k_stats<4>, dim3(grid), dim3(256), 0, c->stream, p);
-        else if (m <= 8) hipLaunchKernelGGL(k_stats<8>, dim3(grid), dim3(256), 0, c->stream, p);
-        else if (m <= 16) hipLaunchKernelGGL(k_stats<16>, dim3(grid), dim3(256), 0, c->stream, p);
-        else if (m <= 32) hipLaunchKernelGGL(k_stats<32>, dim3(grid), dim3(256), 0, c->stream, p);
-        else if (m <= 64) hipLaunchKernelGGL(k_stats<64>, dim3(grid), dim3(256), 0, c->stream, p);
-        else hipLaunchKernelGGL(k_stats<0>, dim3(grid), dim3(256), 0, c->stream, p);
+        int ts = c->statsTile;
+        if (ts == 0) ts = 64;
+        if (c->B % ts != 0) ts = 32;
+        if (ts == 128) launch_stats<128, 16>(c, p);
+        else if (ts == 64) launch_stats<64, 16>(c, p);
+        else launch_stats<32, 16>(c, p);
     }
     LAUNCH_CHECK("k_stats");
     c->statsValid = true;
@@ -754,12 +760,11 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
 // ---------------------------------------------------------------------------------------------------------------
 // export / download
 // ---------------------------------------------------------------------------------------------------------------
-static int export_one(csr_ctx *c, int id, const float *src, int srcStride, CompMap cm, int skipLast) {
+static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, int n, int skipLast) {
     float *dst;
     CHECK(nat_array(c, id, &dst));
-    Scope sc(c, "export_natural");
-    hipLaunchKernelGGL(k_export_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, c->p, src, srcStride, cm, dst, skipLast);
-    LAUNCH_CHECK("k_export_f32");
+    ExpDesc &d = L.d[L.count++];
+    d.src = src; d.dst = dst; d.E = E; d.n = n; d.skipLast = skipLast; d.pad_ = 0;
     return 0;
 }
 
@@ -767,35 +772,46 @@ extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
     CHECK(need(c));
     const int d = c->mdl.state_dim;
     const Prm &p = c->p;
-    const CompMap one = {1, {0, 0, 0, 0}}, two = {2, {0, 1, 0, 0}}, four = {4, {0, 1, 2, 3}};
-    const CompMap vec = (d == 2) ? two : one, mat = (d == 2) ? four : one;
+    const int nv = d, nm = d * d;      // exported components of state vectors / covariance matrices
+    ExpList L;
+    memset(&L, 0, sizeof(L));
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
-        CHECK(export_one(c, CSR_ARR_D, p.tD, 1, one, 0));
-        CHECK(export_one(c, CSR_ARR_XF, (const float *)p.tXf, 2, vec, 0));
-        CHECK(export_one(c, CSR_ARR_PF, (const float *)p.tPf, 4, mat, 0));
-        CHECK(export_one(c, CSR_ARR_PNOISE, (const float *)p.tQ, 4, mat, 1));
+        CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
+        CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
+        CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
+        CHECK(add_export(c, L, CSR_ARR_PNOISE, (const float *)p.tQ, 4, nm, 1));
     }
     if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
         if (!c->haveBwd) return fail("no smoothed results to export");
-        CHECK(export_one(c, CSR_ARR_XS, (const float *)p.tXs, 2, vec, 0));
+        CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
     }
     if (what & CSR_EXPORT_SMOOTH) {
-        CHECK(export_one(c, CSR_ARR_PS, (const float *)p.tPs, 4, mat, 0));
-        CHECK(export_one(c, CSR_ARR_LAG, (const float *)p.tLag, 4, mat, 1));
+        CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
+        CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
+    }
+    if (what & CSR_EXPORT_MULT) {
+        if (L.count + 2 > 8) return fail("too many arrays in one export");
+        CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
+        CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));
+    }
+    if (L.count > 0) {
+        Scope sc(c, "export_natural");
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, c->p, L);
+        LAUNCH_CHECK("k_export_tiled");
     }
     if (what & CSR_EXPORT_RESID) {
         float *xs, *res;
         CHECK(nat_array(c, CSR_ARR_XS, &xs));
         CHECK(nat_array(c, CSR_ARR_RESID, &res));
         Scope sc(c, "residuals");
-        hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream, c->p,
-                           xs, d, res, c->Npad);
+        if ((c->m & 3) == 0)
+            hipLaunchKernelGGL(k_resid_v4, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m, c->stream,
+                               c->p, xs, d, res, c->Npad);
+        else
+            hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
+                               c->p, xs, d, res, c->Npad);
         LAUNCH_CHECK("k_resid");
-    }
-    if (what & CSR_EXPORT_MULT) {
-        CHECK(export_one(c, CSR_ARR_LAMBDA, p.tLam, 1, one, 0));
-        CHECK(export_one(c, CSR_ARR_KAPPA, p.tKap, 1, one, 0));
     }
     return 0;
 }

@@ -1,0 +1,13 @@
+"""Run a few bench steps (for profiling under rocprofv3)."""
+import sys, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+from consenrich_amd import _lib as L
+from consenrich_amd.batch import DeviceBatch, ModelParams
+from consenrich_amd.sharding import hg38_chain_lengths
+m = int(os.environ.get("M", "32"))
+b = DeviceBatch(0)
+b.configure(ModelParams(state_dim=2), m, hg38_chain_lengths(int(os.environ.get("BINBP", "200")))); b.synthesize(1234)
+what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+for _ in range(int(os.environ.get("STEPS", "3"))):
+    b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
+b.synchronize()
