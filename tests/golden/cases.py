@@ -257,9 +257,10 @@ def compare(case, got, gold, rtol, atol, check=None):
                 continue
             np.testing.assert_allclose(np.asarray(g, np.float64), np.asarray(ref, np.float64), rtol=rtol, atol=atol,
                                        err_msg=f"{case['name']}:{k}")
-            den = np.maximum(np.abs(np.asarray(ref, np.float64)), atol / max(rtol, 1e-300))
+            den = np.maximum(np.abs(np.asarray(ref, np.float64)), max(atol / max(rtol, 1e-300), 1e-300))
             if np.size(ref):
-                worst = max(worst, float(np.max(np.abs(np.asarray(g, np.float64) - ref) / den)))
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    worst = max(worst, float(np.nanmax(np.abs(np.asarray(g, np.float64) - ref) / den)))
         else:
             rows = gold[k + "__rows"]
             idx = sample_index(g.shape[0])

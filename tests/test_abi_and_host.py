@@ -1,0 +1,178 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares (no compute without a GPU), the product
+fails loudly when it cannot run, the host-side mirror raises the reference's errors before any launch, and the
+sharding logic is right."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from consenrich_amd import build
+
+    build.build()
+    from consenrich_amd import _lib
+
+    _lib.lib()
+    return _lib
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "consenrich_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(csr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    import ctypes
+
+    handle = ctypes.CDLL(L.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/consenrich_amd.h but not exported"
+    assert set(declared) == set(L.SYMBOLS), "ctypes binding and header disagree"
+    assert L.lib().csr_abi_version() == 1
+
+
+def test_struct_layouts_match_header(L):
+    import ctypes as C
+
+    assert C.sizeof(L.Model) == 8 + 8 * (4 + 4 + 3 + 4 + 5)
+    assert C.sizeof(L.FwdIO) == 8 * 2 + 8 * 5 + 8 + 8 * 4
+    assert C.sizeof(L.EcmCfg) == 8 * 4 + 4 * 4
+    assert C.sizeof(L.EcmOut) == 8 * 7 + 4 * 4
+    assert C.sizeof(L.RunStats) == 8 * 5 + 4 * 6
+
+
+def _has_gpu(L):
+    return L.device_count() > 0
+
+
+def test_product_fails_loudly_without_gpu(L):
+    if _has_gpu(L):
+        pytest.skip("a GPU is present")
+    from consenrich_amd import cconsenrich
+    from consenrich_amd.batch import DeviceBatch
+
+    assert L.lib().csr_create(0) is None and "no HIP device" in L.last_error()
+    with pytest.raises(L.ConsenrichAMDError):
+        DeviceBatch(0)
+    n, m = 16, 2
+    with pytest.raises(L.ConsenrichAMDError):
+        cconsenrich.cforwardPass(matrixData=np.zeros((m, n), np.float32), matrixPluginMuncInit=np.ones((m, n), np.float32),
+                                 matrixF=np.eye(2, dtype=np.float32), matrixQ0=np.eye(2, dtype=np.float32),
+                                 intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                 stateCovarInit=1.0)
+
+
+def test_product_sources_never_touch_the_oracle():
+    pkg = os.path.join(ROOT, "consenrich_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "libconsenrich_oracle" not in text, f
+
+
+def _kw(n=12, m=2):
+    return dict(matrixData=np.zeros((m, n), np.float32), matrixPluginMuncInit=np.full((m, n), 0.2, np.float32),
+                matrixF=np.asarray([[1, 1], [0, 1]], np.float32), matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+                intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0, stateCovarInit=1.0)
+
+
+def test_reference_error_contract_is_enforced_before_any_launch(L):
+    """Messages of pyx:6503-6561, 6624, 125-130, 143-151; all raised on the host, so they work without a GPU."""
+    from consenrich_amd import cconsenrich as cc
+
+    kw = _kw()
+    with pytest.raises(ValueError, match="blockCount must be positive"):
+        cc.cforwardPass(**{**kw, "blockCount": 0})
+    with pytest.raises(ValueError, match="must match matrixData shape"):
+        cc.cforwardPass(**{**kw, "matrixPluginMuncInit": np.ones((2, 5), np.float32)})
+    with pytest.raises(ValueError, match="at least shape"):
+        cc.cforwardPass(**{**kw, "matrixF": np.ones((1, 2), np.float32)})
+    with pytest.raises(ValueError, match="observation precision multiplier bounds"):
+        cc.cforwardPass(**kw, obsPrecisionMultiplierMin=0.0)
+    with pytest.raises(ValueError, match="process precision multiplier bounds"):
+        cc.cforwardPass(**kw, procPrecisionMultiplierMin=2.0, procPrecisionMultiplierMax=1.0)
+    with pytest.raises(ValueError, match="intervalToBlockMap length"):
+        cc.cforwardPass(**{**kw, "intervalToBlockMap": np.zeros(3, np.int32)})
+    with pytest.raises(ValueError, match="out-of-range block id"):
+        cc.cforwardPass(**{**kw, "intervalToBlockMap": np.full(12, 4, np.int32)})
+    with pytest.raises(ValueError, match="lambdaExp length"):
+        cc.cforwardPass(**kw, lambdaExp=np.ones(3, np.float32))
+    with pytest.raises(ValueError, match="wrong number of dimensions"):
+        cc.cforwardPass(**kw, lambdaExp=np.ones((2, 12), np.float32))
+    with pytest.raises(ValueError, match="processQScale\\[0\\] must be 1.0"):
+        cc.cforwardPass(**kw, processQScale=np.full(12, 2.0, np.float32))
+    with pytest.raises(ValueError, match="positive finite"):
+        cc.cforwardPass(**kw, processQScale=np.asarray([1.0] + [-1.0] * 11, np.float32))
+    with pytest.raises(ValueError, match="vectorD length"):
+        cc.cforwardPass(**kw, vectorD=np.empty(3, np.float32))
+    with pytest.raises(ValueError, match="stateForward shape"):
+        cc.cforwardPass(**kw, stateForward=np.empty((3, 2), np.float32), stateCovarForward=np.empty((12, 2, 2), np.float32),
+                        pNoiseForward=np.empty((12, 2, 2), np.float32))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        cc.cforwardPass(**{**kw, "matrixData": np.zeros((2, 12), np.float64)})
+    with pytest.raises(ValueError, match="not C-contiguous"):
+        cc.cforwardPass(**{**kw, "matrixData": np.zeros((12, 2), np.float32).T})
+    lv = {k: v for k, v in kw.items() if k != "matrixF"}
+    with pytest.raises(ValueError, match=r"matrixQ0\[0, 0\] must be positive"):
+        cc.cforwardPassLevel(**{**lv, "matrixQ0": np.zeros((1, 1), np.float32)})
+    with pytest.raises(ValueError, match="matrixQ0 is singular"):
+        cc.cfixedBackgroundECM(**{**kw, "matrixQ0": np.ones((2, 2), np.float32)}, logIterations=False)
+    with pytest.raises(ValueError, match="lambdaExpInit length"):
+        cc.cfixedBackgroundECM(**kw, lambdaExpInit=np.ones(3, np.float32), logIterations=False)
+    with pytest.raises(ValueError, match="only finite values"):
+        cc.cfixedBackgroundECM(**kw, processPrecExpInit=np.full(12, np.nan, np.float32), logIterations=False)
+    with pytest.raises(ValueError, match=r"stateSmoothed must have shape \(n, 2\)"):
+        cc.cExpectedTransitionResidualSums(np.zeros((4, 1)), np.zeros((4, 2, 2)), np.zeros((3, 2, 2)), np.eye(2))
+    with pytest.raises(ValueError, match="lagCovSmoothed must have shape"):
+        cc.cExpectedTransitionResidualSums(np.zeros((4, 2)), np.zeros((4, 2, 2)), np.zeros((1, 2, 2)), np.eye(2))
+
+
+def test_empty_and_degenerate_inputs_follow_the_reference(L):
+    from consenrich_amd import cconsenrich as cc
+
+    kw = _kw(n=0)
+    r = cc.cforwardPass(**kw, returnNLL=True)
+    assert r[0] == 0.0 and r[1] == 0 and r[2].shape == (0,) and r[3] == 0.0
+    assert cc.cExpectedTransitionResidualSums(np.zeros((1, 2)), np.zeros((1, 2, 2)), np.zeros((0, 2, 2)), np.eye(2)) == (0.0, 0.0, 0)
+    assert cc.cExpectedTransitionResidualSumsLevel(np.zeros((1, 1)), np.zeros((1, 1, 1)), np.zeros((0, 1, 1))) == (0.0, 0.0, 0)
+    out = cc.cfixedBackgroundECM(**kw, returnIntermediates=True, returnDiagnostics=True, logIterations=False)
+    assert out[0] == 0 and out[1] == 0.0 and out[8]["skipped"] is True and out[8]["skip_reason"] == "empty_input"
+    xs, Ps, lag, res = cc.cbackwardPass(matrixData=np.empty((2, 0), np.float32), matrixF=kw["matrixF"],
+                                        stateForward=np.empty((0, 2), np.float32),
+                                        stateCovarForward=np.empty((0, 2, 2), np.float32),
+                                        pNoiseForward=np.empty((0, 2, 2), np.float32))
+    assert xs.shape == (0, 2) and Ps.shape == (0, 2, 2) and lag.shape == (1, 2, 2) and res.shape == (0, 2)
+
+
+def test_convergence_replay_matches_reference_bookkeeping():
+    from consenrich_amd.cconsenrich import _replay_path
+
+    rec = _replay_path("t", [100.0, 90.0, 89.99999, 89.99998, 89.9], 1e-6, False)
+    assert [r["stable_iters"] for r in rec] == [0, 0, 1, 2, 0]
+    assert rec[0]["reset_iteration"] and rec[0]["change"] is None
+    assert rec[3]["converged"] and not rec[4]["converged"]
+    assert rec[1]["relative_improvement"] == pytest.approx(10.0 / 100.0)
+
+
+def test_lpt_sharding_of_hg38():
+    from consenrich_amd.sharding import hg38_chain_lengths, lpt_assign, shard_bound
+
+    lens = hg38_chain_lengths(200)
+    assert len(lens) == 22 and sum(lens) == 14375018 and lens[0] == 1244783
+    for w in (1, 2, 4, 8):
+        owned = lpt_assign(lens, w)
+        assert sorted(i for v in owned for i in v) == list(range(22))
+    assert shard_bound(lens, 8) == pytest.approx(7.67, abs=0.01)
+    assert shard_bound(lens, 4) == pytest.approx(3.89, abs=0.02)
+    assert shard_bound(lens, 2) == pytest.approx(2.0, abs=0.01)
+    assert sum(hg38_chain_lengths(50)) == 57500042
