@@ -99,6 +99,8 @@ def main() -> int:
     ap.add_argument("--bin-bp", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +108,8 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             print("bench.py: --gpus N > 1 must be launched through torch.distributed.run", file=sys.stderr)
@@ -117,8 +121,11 @@ def main() -> int:
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -160,7 +167,8 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
@@ -205,7 +213,8 @@ def main() -> int:
             xs_tracks[gi] = np.concatenate([xs, ps], axis=1)
         fence()
         tg = time.perf_counter()
-        gathered = gather_tracks(xs_tracks, lengths, 2, device=f"cuda:{local_rank}")
+        gathered = gather_tracks(xs_tracks, lengths, 2,
+                                 device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         fence()
         gather_ms = 1000.0 * (time.perf_counter() - tg)
         if rank == 0:
