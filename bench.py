@@ -230,7 +230,7 @@ def main() -> int:
                 "workload": f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
                             "stats + forward(store,NLL) + RTS backward + lagCov + export + residuals, levelTrend",
                 "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"],
-                "warm_blocks": [rs["warm_p"], rs["warm_x"], rs["warm_b"]],
+                "warm_bins": [rs["warm_p"], rs["warm_x"], rs["warm_b"]], "x_tol_ulps": rs["x_tol_ulps"],
             },
             "roofline": roofline,
             "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": value * b_alg(m) / 1e9, "peak": HBM_PEAK_GBS,

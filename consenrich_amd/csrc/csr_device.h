@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
 #endif
 struct FwdPTrend {
     static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = false;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_P;
     struct Carry {
         float c00, c01, c11;   // filtered covariance after the float32 rounding (c10 == c01, pyx:494)
@@ -334,6 +335,7 @@ struct FwdPTrend {
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
     static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = false;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_P;
     struct Carry {
         double p;
@@ -376,6 +378,7 @@ struct FwdPLevel {
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
 struct FwdXTrend {
     static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = true;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_X;
     struct Carry {
         float x0, x1;
@@ -420,6 +423,7 @@ struct FwdXTrend {
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
     static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = true;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_X;
     struct Carry {
         double x;
@@ -457,6 +461,7 @@ struct FwdXLevel {
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
 struct BwdTrend {
     static constexpr bool FWD = false;
+    static constexpr bool PINGPONG = false;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_B;
     struct Carry {
         float x0, x1, p00, p01, p10, p11;
@@ -541,6 +546,7 @@ struct BwdTrend {
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
     static constexpr bool FWD = false;
+    static constexpr bool PINGPONG = false;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_B;
     struct Carry {
         float x, ps;
@@ -592,34 +598,85 @@ struct BwdLevel {
 // smoother).  Inputs of the next U steps are requested before the current U steps are computed.
 // (Measured, profiles/r01_notes.md: hipcc sinks these loads next to their first use, so a wavefront still pays an
 // L2 round trip per batch; a hand-scheduled prefetch ring is the next optimisation of these kernels.)
-template <class CH, bool STORE>
-__device__ __forceinline__ void walk_block(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
-                                           int64_t bfirst) {
+template <class CH, bool STORE, bool FAST>
+__device__ __forceinline__ void walk_impl(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                          int64_t bfirst, int sLo, int sHi) {
+    // steps [sLo, sHi) of block bq (both multiples of 2U), ascending for forward chains, descending for the smoother.
+    // Two register buffers in ping-pong: while the recursion consumes one batch of U steps the loads of the next
+    // batch are in flight; no buffer is ever copied, so no wait is needed until a value is really consumed.
     constexpr int U = CH::U;
     const int B = p.B;
     const int64_t base = tbase(bq, B);
+    const int cnt = sHi - sLo;
+    typename CH::In bufA[U], bufB[U];
+#define CSR_LOAD(buf, off)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+        const int s_ = CH::FWD ? (sLo + (off) + u) : (sHi - 1 - ((off) + u));                    \
+        if (FAST || (act && s_ < len)) buf[u] = CH::load(p, base + (int64_t)s_ * 64);           \
+    }
+#define CSR_STEP(buf, off)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+        const int s_ = CH::FWD ? (sLo + (off) + u) : (sHi - 1 - ((off) + u));                    \
+        if (FAST || (act && s_ < len))                                                           \
+            CH::template step<STORE>(p, c, buf[u], bq, s_, base + (int64_t)s_ * 64, bfirst);     \
+    }
+    CSR_LOAD(bufA, 0)
+#pragma unroll 1
+    for (int i0 = 0; i0 < cnt; i0 += 2 * U) {
+        CSR_LOAD(bufB, i0 + U)
+        asm volatile("" ::: "memory");
+        CSR_STEP(bufA, i0)
+        if (i0 + 2 * U < cnt) { CSR_LOAD(bufA, i0 + 2 * U) }
+        asm volatile("" ::: "memory");
+        CSR_STEP(bufB, i0 + U)
+    }
+#undef CSR_LOAD
+#undef CSR_STEP
+}
+
+// FAST: every lane of the wavefront walks the whole range -> no per-step predicates, one straight-line loop body,
+// so the compiler's s_waitcnt accounting stays exact (counted vmcnt) and the next batch really is in flight while the
+// dependent recursion runs.  Wavefronts at chain ends / starts take the predicated variant.
+template <class CH, bool STORE>
+__device__ __forceinline__ void walk_simple(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                            int64_t bfirst, int sLo, int sHi) {
+    // one register buffer copied forward per batch: smallest code, best when the kernel is bandwidth-bound anyway
+    constexpr int U = CH::U;
+    const int64_t base = tbase(bq, p.B);
+    const int cnt = sHi - sLo;
     typename CH::In cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int s = CH::FWD ? u : (B - 1 - u);
+        const int s = CH::FWD ? (sLo + u) : (sHi - 1 - u);
         if (act && s < len) cur[u] = CH::load(p, base + (int64_t)s * 64);
     }
 #pragma unroll 1
-    for (int i0 = 0; i0 < B; i0 += U) {
-        if (i0 + U < B) {
+    for (int i0 = 0; i0 < cnt; i0 += U) {
+        if (i0 + U < cnt) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int s = CH::FWD ? (i0 + U + u) : (B - 1 - (i0 + U + u));
+                const int s = CH::FWD ? (sLo + i0 + U + u) : (sHi - 1 - (i0 + U + u));
                 if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = CH::FWD ? (i0 + u) : (B - 1 - (i0 + u));
+            const int s = CH::FWD ? (sLo + i0 + u) : (sHi - 1 - (i0 + u));
             if (act && s < len) CH::template step<STORE>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+}
+
+template <class CH, bool STORE>
+__device__ __forceinline__ void walk_block(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                           int64_t bfirst, int sLo, int sHi) {
+    if constexpr (CH::PINGPONG) {
+        if (__all(act && len >= sHi)) walk_impl<CH, STORE, true>(p, c, bq, len, act, bfirst, sLo, sHi);
+        else walk_impl<CH, STORE, false>(p, c, bq, len, act, bfirst, sLo, sHi);
+    } else {
+        walk_simple<CH, STORE>(p, c, bq, len, act, bfirst, sLo, sHi);
     }
 }
 
@@ -634,31 +691,47 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
     typename CH::Carry c = CH::init_cold(p);
     typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
     typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
+    // p.warm = warm-up length in bins (multiple of 8): qmax blocks are visited, the farthest one only partially
+    const int B = p.B;
+    const int qmax = (p.warm + B - 1) / B;
+    const int rem = p.warm - (qmax - 1) * B;           // bins taken from the farthest block, in (0, B]
     if constexpr (CH::FWD) {
         const int avail = live ? (int)(b - bfirst) : 0;        // preceding blocks of this chain (all full)
-        const int qstart = avail < p.warm ? avail : p.warm;
+        const int qstart = avail < qmax ? avail : qmax;
         if (live && qstart == avail) c = CH::init_true(p);
-        for (int q = p.warm; q >= 1; --q) {
+        for (int q = qmax; q >= 1; --q) {
             const bool act = live && q <= qstart;
             if (!__any(act)) continue;
-            walk_block<CH, false>(p, c, b - q, p.B, act, bfirst);
+            // a lane whose chain starts inside the window walks its first block in full (from the true prior)
+            const int lo = (q == qmax) ? (B - rem) : 0;
+            if (q == qmax && __any(act && avail == qmax && rem < B)) {
+                // mixed wave: lanes at their chain start need the whole block, the others only the tail
+                walk_block<CH, false>(p, c, b - q, B, act && avail == qmax, bfirst, 0, lo);
+            }
+            walk_block<CH, false>(p, c, b - q, B, act, bfirst, lo, B);
         }
         if (live) cin[b] = c;
-        walk_block<CH, true>(p, c, b, bi.y, live, bfirst);
+        walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         if (live) cout[b] = c;
     } else {
         const int avail = live ? (int)(blast - b) : 0;         // following blocks of this chain
-        const int qstart = avail < p.warm ? avail : p.warm;
-        int lastLen = p.B;
+        const int qstart = avail < qmax ? avail : qmax;
+        int lastLen = B;
         if (live) lastLen = p.blk[blast].y;
-        for (int q = p.warm; q >= 1; --q) {
+        for (int q = qmax; q >= 1; --q) {
             const bool act = live && q <= qstart;
             if (!__any(act)) continue;
             const int64_t bq = b + q;
-            walk_block<CH, false>(p, c, bq, (bq == blast) ? lastLen : p.B, act, bfirst);
+            const int len = (bq == blast) ? lastLen : B;
+            const int hi = (q == qmax) ? rem : B;
+            if (q == qmax && __any(act && avail == qmax && rem < B)) {
+                // lanes whose chain ends in this block start from the true end (seeded by the first visited bin)
+                walk_block<CH, false>(p, c, bq, len, act && avail == qmax, bfirst, hi, B);
+            }
+            walk_block<CH, false>(p, c, bq, len, act, bfirst, 0, hi);
         }
         if (live) cin[b] = c;
-        walk_block<CH, true>(p, c, b, bi.y, live, bfirst);
+        walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         if (live) cout[b] = c;
     }
 }
@@ -695,7 +768,7 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     if (rerun) cin[b] = prev;
     if (live && !rerun) onxt[b] = keep;
     if (!__any(rerun)) return;
-    walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst);
+    walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
     if (rerun) {
         onxt[b] = c;
         atomicAdd(p.rerunCount, 1u);

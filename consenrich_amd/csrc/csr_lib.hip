@@ -66,7 +66,9 @@ struct csr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // tuning
-    int B = 256, warmP = 1, warmX = 2, warmB = 1;
+    int B = 0;                 // block length; 0 = chosen from the batch size at configure time
+    int warmP = 256, warmX = 256, warmB = 256;   // speculative warm-up in bins (rounded up to a multiple of 8)
+    bool Bfixed = false;
     int xTolUlps = 2;
     int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
     // batch
@@ -143,13 +145,13 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         return nullptr;
     }
     const char *e;
-    if ((e = getenv("CONSENRICH_AMD_BLOCK"))) c->B = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_BLOCK"))) { c->B = atoi(e); c->Bfixed = c->B != 0; }
     if ((e = getenv("CONSENRICH_AMD_WARM_P"))) c->warmP = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WARM_X"))) c->warmX = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
-    if (c->B < 32 || (c->B % 32) != 0) c->B = 256;
+    if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
     return c;
 }
 
@@ -176,10 +178,11 @@ extern "C" int csr_set_tuning(csr_ctx *c, int32_t block_len, int32_t warm_p, int
         if (block_len < 32 || (block_len % 32) != 0) return fail("block_len must be a positive multiple of 32");
         if (c->configured && block_len != c->B) return fail("block_len cannot change after csr_batch_configure");
         c->B = block_len;
+        c->Bfixed = true;
     }
-    if (warm_p >= 0) c->warmP = warm_p;
-    if (warm_x >= 0) c->warmX = warm_x;
-    if (warm_b >= 0) c->warmB = warm_b;
+    if (warm_p >= 0) c->warmP = (warm_p + 15) / 16 * 16;
+    if (warm_x >= 0) c->warmX = (warm_x + 15) / 16 * 16;
+    if (warm_b >= 0) c->warmB = (warm_b + 15) / 16 * 16;
     return 0;
 }
 
@@ -327,6 +330,12 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     c->mdl = *mdl;
     c->m = m;
     c->chains.clear();
+    if (!c->Bfixed || c->B == 0) {
+        // enough blocks to occupy the chip (>= ~16k lanes) without inflating the warm-up share more than needed
+        int64_t total = 0;
+        for (int i = 0; i < n_chains; ++i) total += chain_len[i];
+        c->B = total >= (int64_t)6000000 ? 256 : (total >= (int64_t)2000000 ? 128 : 64);
+    }
     const int B = c->B;
     int64_t off = 0, nb = 0;
     for (int i = 0; i < n_chains; ++i) {

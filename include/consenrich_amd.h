@@ -131,8 +131,9 @@ void csr_destroy(csr_ctx *ctx);
 const char *csr_last_error(void);
 int csr_abi_version(void);
 
-/* Speculative-block tuning: block_len (multiple of 32), warm-up lengths in blocks for the forward covariance
- * chain, forward state chain and backward chain. 0 keeps the default.  Results never depend on these. */
+/* Speculative-block tuning: block_len (multiple of 32; 0 = keep / choose from the batch size) and warm-up lengths in
+ * BINS (rounded up to a multiple of 16; negative = keep) for the forward covariance chain, the forward state chain and
+ * the backward chain.  Results never depend on these beyond the documented validation tolerance. */
 int csr_set_tuning(csr_ctx *ctx, int32_t block_len, int32_t warm_p, int32_t warm_x, int32_t warm_b);
 
 /* Carry validation of the forward STATE chain.  0: a speculative block is accepted only if its carry-in is bit-equal

@@ -5,14 +5,14 @@ import numpy as np
 from consenrich_amd import _lib as L
 from consenrich_amd.batch import DeviceBatch, ModelParams
 from consenrich_amd.sharding import hg38_chain_lengths
-m = int(os.environ.get("M", "32")); B = int(os.environ.get("B", "256"))
+m = int(os.environ.get("M", "32")); B = int(os.environ.get("B", "0"))
 lengths = hg38_chain_lengths(int(os.environ.get("BINBP", "200")))
 b = DeviceBatch(0, block_len=B)
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
     b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
-for cfg in [(1,2,1)]:
+for cfg in [(256,256,256),(256,1024,256),(256,4096,256)]:
     b.set_tuning(0, *cfg)
     for _ in range(2): step()
     b.synchronize(); r0 = b.run_stats()
