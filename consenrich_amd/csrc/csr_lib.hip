@@ -405,6 +405,10 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
     if (mdl->state_dim == 2) { CHECK(dalloc(c, &p.tCp, T)); }
     else { CHECK(dalloc(c, &p.tPp, T)); CHECK(dalloc(c, &p.tXd, T)); }
+    // multipliers default to 1 (the reference's cold start, pyx:7901/7914) until csr_batch_upload_multipliers
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tLam, 0x3f800000, (size_t)T, c->stream));
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tKap, 0x3f800000, (size_t)T, c->stream));
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tQs, 0x3f800000, (size_t)T, c->stream));
     // defined contents for slots no kernel writes (pNoise/lag tails, padding)
     HIPOK(hipMemsetAsync(p.tQ, 0, sizeof(float4) * T, c->stream));
     HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));

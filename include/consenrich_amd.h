@@ -150,7 +150,7 @@ int csr_batch_configure(csr_ctx *ctx, const csr_model *mdl, int64_t m, int32_t n
 int csr_batch_set_model(csr_ctx *ctx, const csr_model *mdl);
 /* H2D one chain's (m,n_c) C-order matrices. */
 int csr_batch_upload(csr_ctx *ctx, int32_t chain, const float *data, const float *munc);
-/* H2D optional per-bin multipliers (any may be NULL = leave as is). */
+/* H2D optional per-bin multipliers (any may be NULL = leave as is).  After csr_batch_configure all multipliers are 1. */
 int csr_batch_upload_multipliers(csr_ctx *ctx, int32_t chain, const float *lambda, const float *kappa,
                                  const float *qscale);
 /* Fill every chain with the SURVEY 8(d) synthetic recipe directly in HBM (counter-based RNG). */
