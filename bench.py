@@ -43,8 +43,7 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
         "fwd_cov_chain": 16.0 + 16.0 + 16.0,    # lambda/kappa/qscale/blockMap in, Pf + pNoise out
         "fwd_state_chain": 8.0,                 # xf out
         "fwd_dstat": 4.0,                       # D out
-        "bwd_chain": 8.0 + 16.0,                # xs + Ps out
-        "bwd_lagcov": 16.0,                     # lagCov out
+        "bwd_chain": 8.0 + 16.0 + 16.0,         # xs + Ps + lagCov out
         "export_natural": 0.0,                  # layout conversion: pure overhead
     }.get(name, 0.0)
 

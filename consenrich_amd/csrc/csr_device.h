@@ -50,6 +50,8 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
+    int qFromMult;      // smoother: 1 = process noise is the constant float32(Q0) (internal forward pass without
+                        //           kappa / qScale / APN), 0 = read the stored / imported pNoise array tQ
     int xTolUlps;       // forward state chain validation: 0 = bitwise, k = accept a carry-in within k float32 ulps
 
     // block table: x = natural index of first bin, y = length, z = first block of chain, w = last block of chain
@@ -268,7 +270,7 @@ struct FwdPTrend {
         double s0u;
         float lam, kap, qs;
     };
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
         in.s0u = p.tS0u[i];
         in.lam = (p.flags & F_LAMBDA) ? p.tLam[i] : 1.0f;
@@ -341,7 +343,9 @@ struct FwdPLevel {
         double p;
     };
     using In = FwdPTrend::In;
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) { return FwdPTrend::load(p, i); }
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
+        return FwdPTrend::load(p, i, bq, s, len);
+    }
     __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{p.cinit}; }
     __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{p.cinit}; }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
@@ -387,7 +391,7 @@ struct FwdXTrend {
         double zbar, gs;
         float2 cp;
     };
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
         in.zbar = p.tZbar[i];
         in.gs = p.tGs[i];
@@ -431,7 +435,7 @@ struct FwdXLevel {
     struct In {
         double zbar, gs, pp;
     };
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
         in.zbar = p.tZbar[i];
         in.gs = p.tGs[i];
@@ -456,6 +460,8 @@ struct FwdXLevel {
     }
 };
 
+
+
 // ---- backward RTS chain, levelTrend (pyx:6758-6822) ------------------------------------------------------------
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
@@ -472,11 +478,13 @@ struct BwdTrend {
         float2 xf;
         float4 pf, q;
     };
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
         in.xf = p.tXf[i];
         in.pf = p.tPf[i];
-        in.q = p.tQ[i];
+        // without multipliers the stored process noise is the constant float32(Q0): nothing to read
+        if (p.qFromMult) in.q = make_float4((float)p.Q00, (float)p.Q01, (float)p.Q10, (float)p.Q11);
+        else in.q = p.tQ[i];
         return in;
     }
     __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 0, 0, 0, 0, 1, 0}; }
@@ -535,6 +543,13 @@ struct BwdTrend {
             c.p01 = (float)((double)in.pf.y + fma(g.J01, r11, g.J00 * r01));
             c.p10 = c.p01;                                     // pyx:6821
             c.p11 = (float)((double)in.pf.w + fma(g.J11, r11, g.J10 * r01));
+            if constexpr (STORE) {
+                // lag-one covariance C[k] = Pf F^T + J (Ps[k+1] - PPred), pyx:6825-6844 (dP uses the incoming carry)
+                p.tLag[i] = make_float4((float)(g.c00 + fma(g.J01, d10, g.J00 * d00)),
+                                        (float)(g.c01 + fma(g.J01, d11, g.J00 * d01)),
+                                        (float)(g.c10 + fma(g.J11, d10, g.J10 * d00)),
+                                        (float)(g.c11 + fma(g.J11, d11, g.J10 * d01)));
+            }
         }
         if constexpr (STORE) {
             p.tXs[i] = make_float2(c.x0, c.x1);
@@ -555,11 +570,12 @@ struct BwdLevel {
     struct In {
         float xf, pf, q;
     };
-    __device__ static __forceinline__ In load(const Prm &p, int64_t i) {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
         in.xf = p.tXf[i].x;
         in.pf = p.tPf[i].x;
-        in.q = p.tQ[i].x;
+        if (p.qFromMult) in.q = (float)p.Q00;
+        else in.q = p.tQ[i].x;
         return in;
     }
     __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 1, 0}; }
@@ -584,6 +600,7 @@ struct BwdLevel {
             double ps = fma(J * J, dP, pf);
             if (ps < 0.0) ps = 0.0;
             c.ps = (float)ps;
+            if constexpr (STORE) p.tLag[i] = make_float4((float)fma(J, dP, pf), 0.f, 0.f, 0.f);   // pyx:7142
         }
         if constexpr (STORE) {
             p.tXs[i] = make_float2(c.x, 0.f);
@@ -612,7 +629,7 @@ __device__ __forceinline__ void walk_impl(const Prm &p, typename CH::Carry &c, i
 #define CSR_LOAD(buf, off)                                                                       \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
         const int s_ = CH::FWD ? (sLo + (off) + u) : (sHi - 1 - ((off) + u));                    \
-        if (FAST || (act && s_ < len)) buf[u] = CH::load(p, base + (int64_t)s_ * 64);           \
+        if (FAST || (act && s_ < len)) buf[u] = CH::load(p, base + (int64_t)s_ * 64, bq, s_, len);           \
     }
 #define CSR_STEP(buf, off)                                                                       \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
@@ -648,7 +665,7 @@ __device__ __forceinline__ void walk_simple(const Prm &p, typename CH::Carry &c,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = CH::FWD ? (sLo + u) : (sHi - 1 - u);
-        if (act && s < len) cur[u] = CH::load(p, base + (int64_t)s * 64);
+        if (act && s < len) cur[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
     }
 #pragma unroll 1
     for (int i0 = 0; i0 < cnt; i0 += U) {
@@ -656,7 +673,7 @@ __device__ __forceinline__ void walk_simple(const Prm &p, typename CH::Carry &c,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = CH::FWD ? (sLo + i0 + U + u) : (sHi - 1 - (i0 + U + u));
-                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64);
+                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
             }
         }
 #pragma unroll

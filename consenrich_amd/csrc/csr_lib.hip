@@ -67,8 +67,9 @@ struct csr_ctx {
     hipStream_t stream = nullptr;
     // tuning
     int B = 0;                 // block length; 0 = chosen from the batch size at configure time
-    int warmP = 256, warmX = 256, warmB = 256;   // speculative warm-up in bins (rounded up to a multiple of 8)
+    int warmP = 256, warmX = 256, warmB = 128;   // speculative warm-up in bins (rounded up to a multiple of 8)
     bool Bfixed = false;
+    bool adaptWarm = true;
     int xTolUlps = 2;
     int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
     // batch
@@ -79,6 +80,7 @@ struct csr_ctx {
     int64_t Npad = 0, NB = 0, NG = 0, TN = 0;
     bool statsValid = false;
     bool haveFwd = false, haveBwd = false;
+    bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
     uint32_t fwdFlags = 0;
     Prm p{};
     std::vector<void *> allocs;
@@ -180,6 +182,7 @@ extern "C" int csr_set_tuning(csr_ctx *c, int32_t block_len, int32_t warm_p, int
         c->B = block_len;
         c->Bfixed = true;
     }
+    if (warm_p >= 0 || warm_x >= 0 || warm_b >= 0) c->adaptWarm = false;   // explicit tuning pins the windows
     if (warm_p >= 0) c->warmP = (warm_p + 15) / 16 * 16;
     if (warm_x >= 0) c->warmX = (warm_x + 15) / 16 * 16;
     if (warm_b >= 0) c->warmB = (warm_b + 15) / 16 * 16;
@@ -546,7 +549,8 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
 
 // speculative pass + validation/fix-up to the fixed point
 template <class CH>
-static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int warm, int64_t *reruns) {
+static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int &warmRef, int64_t *reruns) {
+    const int warm = warmRef;
     static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
     p.warm = warm;
     p.xTolUlps = c->xTolUlps;
@@ -579,6 +583,10 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, *c->hCount);
         if (*c->hCount == 0) return 0;
         *reruns += *c->hCount;
+        // adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data
+        // (longer filter memory); lengthen it for the following sweeps.  Results do not depend on it.
+        if (it == 0 && c->adaptWarm && (int64_t)*c->hCount > std::max<int64_t>(8, c->NB / 100) && warmRef < 8192)
+            warmRef = std::min(8192, warmRef * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
@@ -618,6 +626,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     }
     c->haveFwd = true;
     c->haveBwd = false;
+    c->fwdInternal = true;
     c->fwdFlags = flags;
     return 0;
 }
@@ -644,13 +653,11 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active) 
     Prm p = c->p;
     p.flags = c->fwdFlags;
     p.chainActive = active;
+    // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
+    p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
+    (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
     if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
     else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
-    if (wantLag) {
-        Scope sc(c, "bwd_lagcov");
-        hipLaunchKernelGGL(k_bwd_lag, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
-        LAUNCH_CHECK("k_bwd_lag");
-    }
     c->haveBwd = true;
     return 0;
 }
@@ -900,6 +907,8 @@ static csr_ctx *default_ctx() {
         int dev = 0;
         if (const char *e = getenv("CONSENRICH_AMD_DEVICE")) dev = atoi(e);
         g_default = csr_create(dev);
+        // the drop-in single-chain callables favour parity: bit-exact sequential semantics unless told otherwise
+        if (g_default && !getenv("CONSENRICH_AMD_XTOL_ULPS")) g_default->xTolUlps = 0;
     }
     return g_default;
 }
@@ -971,6 +980,7 @@ extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, con
     CHECK(import_nat(c, Pf, d * d, n, 0, (float *)c->p.tPf, 4));
     if (n > 1) CHECK(import_nat(c, pnoise, d * d, n - 1, 0, (float *)c->p.tQ, 4));
     c->haveFwd = true;
+    c->fwdInternal = false;
     c->fwdFlags = 0;
     CHECK(backward_impl(c, true, nullptr));
     CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));

@@ -12,7 +12,7 @@ b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
     b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
-for cfg in [(256,256,256),(256,1024,256),(256,4096,256)]:
+for cfg in [(256,256,256),(256,256,128)]:
     b.set_tuning(0, *cfg)
     for _ in range(2): step()
     b.synchronize(); r0 = b.run_stats()

@@ -51,14 +51,15 @@ def close_mostly(got, ref, frac=1e-3, cap=2e-3, msg=""):
 @pytest.mark.parametrize("xtol", [2, 0], ids=["ulp2", "exact"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_product_matches_golden(product, name, xtol):
-    """Both carry-validation modes (default: 2-ulp acceptance; 0: bit-exact sequential semantics) must meet parity."""
+    """Both carry-validation modes (2-ulp acceptance = batch/bench default; 0 = bit-exact sequential semantics = default
+    of the drop-in callables) must meet parity."""
     case = CASES[name]
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
     product.set_validation(xtol)
     try:
         got = cases.run_case(product, case)
     finally:
-        product.set_validation(2)
+        product.set_validation(0)
     cases.compare(case, got, gold, RTOL, ATOL)
 
 
@@ -165,8 +166,13 @@ def _full_chain(mod, d, n, m, seed=4242):
 @pytest.mark.parametrize("d,n,m", [(2, 1000000, 4), (2, 1244783, 8), (1, 1000000, 4)])
 def test_full_size_chain_matches_oracle(product, oracle, d, n, m):
     """BASELINE config sizes (1e6 x 4; chr1 @200bp x 8): the whole chain, every bin, against the CPU oracle in the
-    DEFAULT (2-ulp carry validation) mode.  |x| reaches ~30 here, so one float32 ulp of the level is 2e-6."""
-    g, o = _full_chain(product, d, n, m), _full_chain(oracle, d, n, m)
+    THROUGHPUT (2-ulp carry validation) mode.  |x| reaches ~30 here, so one float32 ulp of the level is 2e-6."""
+    product.set_validation(2)
+    try:
+        g = _full_chain(product, d, n, m)
+    finally:
+        product.set_validation(0)
+    o = _full_chain(oracle, d, n, m)
     assert g["phi"] == pytest.approx(o["phi"], rel=1e-6)
     assert g["nll"] == pytest.approx(o["nll"], rel=1e-8)          # sumNLL drives the ECM stop rule
     for name in ("xf", "Pf", "pn", "D", "xs", "Ps", "lag", "resid"):
@@ -199,10 +205,7 @@ def test_exact_mode_is_bit_identical_to_the_oracle_at_full_size(product, oracle)
     float32 rounding boundary ~once per 10^7 values; measured: 1 of 2e6 filtered-state values, 3 covariance rows at
     the P = 1000 start-up); the fp64 NLL agrees to 1e-12."""
     product.set_validation(0)
-    try:
-        g = _full_chain(product, 2, 1000000, 4)
-    finally:
-        product.set_validation(2)
+    g = _full_chain(product, 2, 1000000, 4)
     o = _full_chain(oracle, 2, 1000000, 4)
     for name in ("xf", "Pf", "pn", "D", "xs", "Ps", "lag", "resid"):
         diff = g[name] != o[name]
@@ -280,7 +283,6 @@ def test_batch_ecm_lockstep_equals_per_chain_calls(product):
         np.testing.assert_allclose(got[c][3], r[6], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(got[c][4], r[7], rtol=RTOL, atol=ATOL)
         iters.add(r[0])
-    product.set_validation(2)
     assert len(iters) >= 2      # the chains really stop at different iterations
 
 
