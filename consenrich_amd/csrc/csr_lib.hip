@@ -70,6 +70,7 @@ struct csr_ctx {
     int warmP = 256, warmX = 256, warmB = 128;   // speculative warm-up in bins (rounded up to a multiple of 8)
     bool Bfixed = false;
     bool adaptWarm = true;
+    bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
     int xTolUlps = 2;
     int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
     // batch
@@ -90,6 +91,7 @@ struct csr_ctx {
     float *dLatent = nullptr;
     float *nat[CSR_ARR_COUNT] = {nullptr};
     unsigned int *hCount = nullptr;     // pinned
+    unsigned int lastCount = 0;         // value of the (monotonic) device rerun counter at the last read
     double *hSums = nullptr;            // pinned, 2*nchains
     // profiling
     bool profiling = false;
@@ -153,6 +155,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
     if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
     return c;
 }
@@ -403,11 +406,10 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     const int64_t T = c->TN;
     CHECK(dalloc(c, &p.tS0u, T)); CHECK(dalloc(c, &p.tZbar, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
     CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
-    CHECK(dalloc(c, &p.tGs, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
+    CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
     CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T));
     CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
-    if (mdl->state_dim == 2) { CHECK(dalloc(c, &p.tCp, T)); }
-    else { CHECK(dalloc(c, &p.tPp, T)); CHECK(dalloc(c, &p.tXd, T)); }
+    if (mdl->state_dim == 1) { CHECK(dalloc(c, &p.tXd, T)); }
     // multipliers default to 1 (the reference's cold start, pyx:7901/7914) until csr_batch_upload_multipliers
     HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tLam, 0x3f800000, (size_t)T, c->stream));
     HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tKap, 0x3f800000, (size_t)T, c->stream));
@@ -424,6 +426,8 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
     p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;
     CHECK(dalloc(c, &p.rerunCount, 16));
+    HIPOK(hipMemsetAsync(p.rerunCount, 0, 16 * sizeof(unsigned int), c->stream));
+    c->lastCount = 0;
     if (c->hSums) hipHostFree(c->hSums);
     HIPOK(hipHostMalloc((void **)&c->hSums, sizeof(double) * 2 * n_chains));
     c->configured = true;
@@ -562,7 +566,14 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     }
     {
         Scope sc(c, name);
-        hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+        if constexpr (CH::DMA) {
+            if (c->useDma)
+                hipLaunchKernelGGL(k_chain_spec_dma<CH>, dim3(grid), dim3(64), sizeof(unsigned) * DMA_R * CH::NW * 64,
+                                   c->stream, p);
+            else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+        } else {
+            hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+        }
     }
     LAUNCH_CHECK(name);
     int which = 0;
@@ -570,7 +581,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
         p.debugForce = (dbgForce && it < atoi(dbgForce)) ? 1 : 0;
         if (getenv("CONSENRICH_AMD_FENCE")) p.debugForce |= 2;
-        HIPOK(hipMemsetAsync(p.rerunCount, 0, sizeof(unsigned int), c->stream));
+        // the device counter only ever grows (no per-launch memset: that costs a fill kernel); compare deltas
         {
             Scope sc(c, fixName);
             hipLaunchKernelGGL(k_chain_fix<CH>, dim3(grid), dim3(64), 0, c->stream, p, which);
@@ -580,12 +591,14 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         HIPOK(hipStreamSynchronize(c->stream));
         c->rs.fix_launches++;
         which ^= 1;
-        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, *c->hCount);
-        if (*c->hCount == 0) return 0;
-        *reruns += *c->hCount;
+        const unsigned int fresh = *c->hCount - c->lastCount;
+        c->lastCount = *c->hCount;
+        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
+        if (fresh == 0) return 0;
+        *reruns += fresh;
         // adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data
         // (longer filter memory); lengthen it for the following sweeps.  Results do not depend on it.
-        if (it == 0 && c->adaptWarm && (int64_t)*c->hCount > std::max<int64_t>(8, c->NB / 100) && warmRef < 8192)
+        if (it == 0 && c->adaptWarm && (int64_t)fresh > std::max<int64_t>(8, c->NB / 100) && warmRef < 8192)
             warmRef = std::min(8192, warmRef * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
@@ -1083,6 +1096,7 @@ extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uin
     HIPOK(hipMemcpyAsync(c->hCount, p.rerunCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
     if (count) *count = *c->hCount;
+    c->lastCount = *c->hCount;
     c->haveFwd = true;
     return 0;
 }

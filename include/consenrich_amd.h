@@ -138,7 +138,7 @@ int csr_set_tuning(csr_ctx *ctx, int32_t block_len, int32_t warm_p, int32_t warm
 
 /* Carry validation of the forward STATE chain.  0: a speculative block is accepted only if its carry-in is bit-equal
  * to its predecessor's carry-out (results == the sequential recursion, bit for bit).  k > 0 (default 2): also accepted
- * when |dx0| + |F01||dx1| <= k float32 ulps of the level -- ~1e-7 relative on the state track, far inside the 1e-5
+ * when |dx0| <= k and |F01||dx1| <= k float32 ulps of max(|level|, 1) -- ~1e-7 relative on the state track, far inside the 1e-5
  * parity budget; needed because exact coalescence of the rounded 2-D recursion can take >10^4 bins.
  * ctx == NULL addresses the default context used by the reference-shaped single-chain entry points, whose default is
  * k = 0 (parity first: results are then reproducible and independent of block length / warm-up); contexts made by
