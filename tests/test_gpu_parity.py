@@ -297,6 +297,46 @@ def test_exact_mode_on_a_chromosome_sized_chain(product):
     assert spec["stats"]["blocks"] > 1000
 
 
+def test_many_ragged_chains_in_one_batch(product, oracle):
+    """200 contigs of ragged length (1 .. 3000 bins, like the unplaced scaffolds of a real assembly) in one batch:
+    block tables, wave-groups straddling chain boundaries, partial last blocks.  Every chain is checked against the
+    oracle (forward + smoother), in exact mode and with deliberately short warm-up."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    rng = np.random.default_rng(5)
+    n_list = [int(v) for v in np.concatenate([[1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257],
+                                              rng.integers(1, 3000, 185)])]
+    m = 3
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    with DeviceBatch(0, block_len=64, warm=(32, 48, 32), x_tol_ulps=0) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        sets = []
+        for c, n in enumerate(n_list):
+            d_, v_ = cases.synth(n, m, 7000 + c, mask_frac=0.03)
+            sets.append((d_, v_))
+            b.upload(c, d_, v_)
+        b.stats()
+        sd, sn = b.forward(L.RETURN_NLL)
+        b.backward()
+        b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        for c in list(range(20)) + list(range(20, 200, 9)):
+            n = n_list[c]
+            d_, v_ = sets[c]
+            xf, Pf, pn = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+            D = np.zeros(n, np.float32)
+            r = oracle.cforwardPass(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=Q0,
+                                    intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                    stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                                    vectorD=D, returnNLL=True)
+            bw = oracle.cbackwardPass(matrixData=d_, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+            assert sn[c] == pytest.approx(r[3], rel=1e-9, abs=1e-9), c
+            for name, ref in (("D", D), ("xf", xf), ("Pf", Pf), ("pnoise", pn[: n - 1]), ("xs", bw[0]), ("Ps", bw[1]),
+                              ("lag", bw[2][: n - 1]), ("resid", bw[3])):
+                np.testing.assert_allclose(b.download(c, name), ref, rtol=RTOL, atol=ATOL, err_msg=f"chain {c} {name}")
+
+
 def test_batch_chains_are_independent(product):
     """A chain's result must not depend on which other chains share the batch (contig sharding relies on it)."""
     a = _run_batch(64, (128, 256, 128), 2, [3000, 777], 3, 7)
