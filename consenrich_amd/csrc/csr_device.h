@@ -497,8 +497,14 @@ struct FwdXTrend {
 
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
-    static constexpr bool DMA = false;
-    static constexpr int NW = 1, ND = 1;
+    static constexpr bool DMA = true;
+    static constexpr int NW = 6, ND = 3;
+    __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
+        const char *z = reinterpret_cast<const char *>(p.tZbar + i);
+        dma16(p.tXin + i, slot);
+        dma4(z, slot + 256);
+        dma4(z + 4, slot + 320);
+    }
     static constexpr bool FWD = true;
     static constexpr bool PINGPONG = true;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_X;
@@ -514,6 +520,16 @@ struct FwdXLevel {
         const float4 r = p.tXin[i];
         in.gs = unpack_d(r.x, r.y);
         in.pp = unpack_d(r.z, r.w);
+        return in;
+    }
+    __device__ static __forceinline__ In dma_read(const unsigned *slot, int lane) {
+        const uint4 r = lds_rd128(slot + lane * 4);
+        const unsigned w0 = lds_rd32(slot + 256 + lane), w1 = lds_rd32(slot + 320 + lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        In in;
+        in.zbar = words2double(w0, w1);
+        in.gs = words2double(r.x, r.y);
+        in.pp = words2double(r.z, r.w);
         return in;
     }
     __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{p.init}; }
@@ -842,51 +858,63 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
 // The lane walks its whole trajectory (warm-up blocks + own block) as one stream, so the pipeline is filled once.
 // Chain policies opt in with DMA = true and provide dma_issue() / dma_read().
 // ---------------------------------------------------------------------------------------------------------------
-// cursor over a lane's trajectory: FWD visits (k = -Q .. 0, s ascending), BWD visits (k = Q .. 0, s descending)
+// Position of a wavefront on its lanes' trajectories.  (k, s) is wave-uniform: block offset relative to the lane's own
+// block and step inside it; FWD visits k = -Q .. 0 with s ascending, BWD visits k = Q .. 0 with s descending.  The
+// per-lane state (blocked slot, valid length, membership of block b+k in the lane's chain) is refreshed only when the
+// position wraps into the next block, so a step costs one 64-bit add.
 template <bool FWD>
-struct Cursor {
+struct LaneCursor {
     int k, s;
-    __device__ __forceinline__ void init(int W, int B) {
-        const int qmax = (W + B - 1) / B, rem = W - (qmax - 1) * B;
+    int64_t idx;
+    int len;
+    bool ok;
+    __device__ __forceinline__ void locate(const Prm &p, int64_t b, bool live, const int4 &bi, int lastLen) {
+        const int64_t bq = b + k;
+        ok = live && (FWD ? bq >= (int64_t)bi.z : bq <= (int64_t)bi.w);
+        len = !ok ? 0 : (k == 0 ? bi.y : ((!FWD && bq == (int64_t)bi.w) ? lastLen : p.B));
+        const int64_t bs = ok ? bq : (live ? b : 0);           // inactive lanes fetch a harmless in-bounds slot
+        idx = tbase(bs, p.B) + (int64_t)(ok ? s : 0) * 64;
+    }
+    __device__ __forceinline__ void init(const Prm &p, int W, int64_t b, bool live, const int4 &bi, int lastLen) {
+        const int B = p.B, qmax = (W + B - 1) / B, rem = W - (qmax - 1) * B;
         if (W == 0) { k = 0; s = FWD ? 0 : B - 1; }
         else if (FWD) { k = -qmax; s = B - rem; }
         else { k = qmax; s = rem - 1; }
+        locate(p, b, live, bi, lastLen);
     }
-    __device__ __forceinline__ void next(int B) {
-        if (FWD) { if (++s == B) { s = 0; ++k; } }
-        else { if (--s < 0) { s = B - 1; --k; } }
+    __device__ __forceinline__ void next(const Prm &p, int64_t b, bool live, const int4 &bi, int lastLen) {
+        if (FWD) {
+            ++s;
+            idx += ok ? 64 : 0;
+            if (s == p.B) { s = 0; ++k; locate(p, b, live, bi, lastLen); }
+        } else {
+            --s;
+            idx -= ok ? 64 : 0;
+            if (s < 0) { s = p.B - 1; --k; locate(p, b, live, bi, lastLen); }
+        }
     }
 };
 
 template <class CH, bool STORE>
 __device__ __forceinline__ void dma_phase(const Prm &p, typename CH::Carry &c, unsigned *ring, int64_t b, bool live,
-                                          const int4 &bi, int lastLen, Cursor<CH::FWD> &cons, Cursor<CH::FWD> &iss,
-                                          int &t, int tEnd, int T) {
+                                          const int4 &bi, int lastLen, LaneCursor<CH::FWD> &cons,
+                                          LaneCursor<CH::FWD> &iss, int &t, int tEnd, int T) {
     constexpr int ND = CH::ND;
     const int lane = threadIdx.x;
-    const int64_t bfirst = bi.z, blast = bi.w;
-    const int64_t bsafe = live ? b : 0;
+    const int64_t bfirst = bi.z;
 #pragma unroll 1
     for (; t < tEnd; ++t) {
         if (t + DMA_L <= T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_L - 1) * ND) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         typename CH::In in = CH::dma_read(ring + (t % DMA_R) * (CH::NW * 64), lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (t + DMA_L < T) {
-            int64_t bq = b + iss.k;
-            const bool ok = live && (CH::FWD ? bq >= bfirst : bq <= blast);
-            if (!ok) bq = bsafe;
-            CH::dma_issue(p, tidx(bq, ok ? iss.s : 0, p.B), ring + ((t + DMA_L) % DMA_R) * (CH::NW * 64));
-            iss.next(p.B);
+            CH::dma_issue(p, iss.idx, ring + ((t + DMA_L) % DMA_R) * (CH::NW * 64));
+            iss.next(p, b, live, bi, lastLen);
         }
-        {
-            const int64_t bq = b + cons.k;
-            const int len = CH::FWD ? (cons.k == 0 ? bi.y : p.B) : (bq == blast ? lastLen : (cons.k == 0 ? bi.y : p.B));
-            const bool act = live && (CH::FWD ? bq >= bfirst : bq <= blast) && cons.s < len;
-            if (act) CH::template step<STORE>(p, c, in, bq, cons.s, tidx(bq, cons.s, p.B), bfirst);
-            cons.next(p.B);
-        }
+        if (cons.ok && cons.s < cons.len)
+            CH::template step<STORE>(p, c, in, b + cons.k, cons.s, cons.idx, bfirst);
+        cons.next(p, b, live, bi, lastLen);
     }
 }
 
@@ -897,24 +925,19 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {
     const bool live = b < p.NB && chain_on(p, b);
     int4 bi = make_int4(0, 0, 0, 0);
     if (b < p.NB) bi = p.blk[b];
-    const int64_t bfirst = bi.z, blast = bi.w;
     int lastLen = p.B;
-    if (!CH::FWD && live) lastLen = p.blk[blast].y;
+    if (!CH::FWD && live) lastLen = p.blk[bi.w].y;
     typename CH::Carry c = CH::init_cold(p);
     typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
     typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
     const int W = p.warm, T = W + p.B;
-    Cursor<CH::FWD> cons, iss;
-    cons.init(W, p.B);
-    iss.init(W, p.B);
-    const int64_t bsafe = live ? b : 0;
+    LaneCursor<CH::FWD> cons, iss;
+    cons.init(p, W, b, live, bi, lastLen);
+    iss.init(p, W, b, live, bi, lastLen);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // block-table loads retired before the ring starts
     for (int t0 = 0; t0 < DMA_L && t0 < T; ++t0) {
-        int64_t bq = b + iss.k;
-        const bool ok = live && (CH::FWD ? bq >= bfirst : bq <= blast);
-        if (!ok) bq = bsafe;
-        CH::dma_issue(p, tidx(bq, ok ? iss.s : 0, p.B), ringMem + (t0 % DMA_R) * (CH::NW * 64));
-        iss.next(p.B);
+        CH::dma_issue(p, iss.idx, ringMem + (t0 % DMA_R) * (CH::NW * 64));
+        iss.next(p, b, live, bi, lastLen);
     }
     int t = 0;
     dma_phase<CH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, T);
