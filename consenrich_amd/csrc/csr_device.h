@@ -295,6 +295,13 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
 //   Carry, In, U (prefetch depth), FWD, load(), step<STORE>(), init_true(), init_cold(), same()
 // ---------------------------------------------------------------------------------------------------------------
 
+// k-ulp (float32) proximity tests used by the tolerant validation mode (Prm::xTolUlps = k > 0); k = 0 never matches.
+__device__ __forceinline__ float ulp_of(float mag) { return __uint_as_float(f2u(mag) & 0x7f800000u) * 1.1920929e-07f; }
+__device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) {
+    return fabsf(a - b) <= (float)k * ulp_of(fmaxf(fmaxf(fabsf(a), fabsf(b)), scale));
+}
+
+
 // ---- forward covariance chain, levelTrend (pyx:394-401, 408-435, 458, 481-495) -------------------------------
 #ifndef CSR_U_P
 #define CSR_U_P 8
@@ -337,7 +344,14 @@ struct FwdPTrend {
     }
     __device__ static __forceinline__ Carry init_cold(const Prm &p) { return init_true(p); }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
-        return ((f2u(a.c00) ^ f2u(b.c00)) | (f2u(a.c01) ^ f2u(b.c01)) | (f2u(a.c11) ^ f2u(b.c11))) == 0u;
+        const bool bits = ((f2u(a.c00) ^ f2u(b.c00)) | (f2u(a.c01) ^ f2u(b.c01)) | (f2u(a.c11) ^ f2u(b.c11))) == 0u;
+        // Tolerant mode: two float32-rounded Riccati trajectories contract to within an ulp quickly but may then sit one
+        // ulp apart for a long time (the contraction of a 1-ulp difference rounds back to 0 or 1 ulp); accept k ulps
+        // per entry, the cross term measured against sqrt(c00 c11).
+        const int k = p.xTolUlps;
+        const bool near = (k > 0) & near_ulps(a.c00, b.c00, 0.f, k) & near_ulps(a.c11, b.c11, 0.f, k) &
+                          near_ulps(a.c01, b.c01, sqrtf(fabsf(a.c00 * a.c11)), k);
+        return bits | near;
     }
     // b, s: block / step of this bin (for the shifted pNoise store)
     template <bool STORE>
@@ -400,7 +414,9 @@ struct FwdPLevel {
     __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{p.cinit}; }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
         const bool bits = __double_as_longlong(a.p) == __double_as_longlong(b.p);
-        const bool tol = fabs(a.p - b.p) <= 1.0e-12 * fmax(fabs(a.p), fabs(b.p));
+        // double carries (pyx:579-580) never coalesce bitwise: 1e-12 relative in exact mode, k float32 ulps otherwise
+        const double rel = p.xTolUlps > 0 ? 5.9604644775390625e-8 * (double)p.xTolUlps : 1.0e-12;
+        const bool tol = fabs(a.p - b.p) <= rel * fmax(fabs(a.p), fabs(b.p));
         return bits | tol;
     }
     template <bool STORE>
@@ -536,7 +552,9 @@ struct FwdXLevel {
     __device__ static __forceinline__ Carry init_cold(const Prm &p) { return Carry{p.init}; }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
         const bool bits = __double_as_longlong(a.x) == __double_as_longlong(b.x);
-        const bool tol = fabs(a.x - b.x) <= 1.0e-12 * fmax(fabs(a.x), fabs(b.x)) + 1.0e-300;
+        const double rel = p.xTolUlps > 0 ? 5.9604644775390625e-8 * (double)p.xTolUlps : 1.0e-12;
+        const double mag = fmax(fabs(a.x), fabs(b.x));
+        const bool tol = fabs(a.x - b.x) <= rel * (p.xTolUlps > 0 ? fmax(mag, 1.0) : mag) + 1.0e-300;
         return bits | tol;
     }
     template <bool STORE>
@@ -582,8 +600,17 @@ struct BwdTrend {
     __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 0, 0, 0, 0, 1, 0}; }
     __device__ static __forceinline__ Carry init_cold(const Prm &) { return Carry{0, 0, 0, 0, 0, 0, 1, 0}; }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
-        return ((f2u(a.x0) ^ f2u(b.x0)) | (f2u(a.x1) ^ f2u(b.x1)) | (f2u(a.p00) ^ f2u(b.p00)) |
-                (f2u(a.p01) ^ f2u(b.p01)) | (f2u(a.p10) ^ f2u(b.p10)) | (f2u(a.p11) ^ f2u(b.p11))) == 0u;
+        const bool bits = ((f2u(a.x0) ^ f2u(b.x0)) | (f2u(a.x1) ^ f2u(b.x1)) | (f2u(a.p00) ^ f2u(b.p00)) |
+                           (f2u(a.p01) ^ f2u(b.p01)) | (f2u(a.p10) ^ f2u(b.p10)) | (f2u(a.p11) ^ f2u(b.p11))) == 0u;
+        // tolerant mode: same criterion as the forward chains (level / trend against the level's ulp, covariance entries
+        // against their own ulp, cross terms against sqrt(p00 p11))
+        const int k = p.xTolUlps;
+        const float lim = (float)k * ulp_of(fmaxf(fmaxf(fabsf(a.x0), fabsf(b.x0)), 1.0f));
+        const float ps = sqrtf(fabsf(a.p00 * a.p11));
+        const bool near = (k > 0) & (fabsf(a.x0 - b.x0) <= lim) & ((float)fabs(p.F01) * fabsf(a.x1 - b.x1) <= lim) &
+                          near_ulps(a.p00, b.p00, 0.f, k) & near_ulps(a.p11, b.p11, 0.f, k) &
+                          near_ulps(a.p01, b.p01, ps, k) & near_ulps(a.p10, b.p10, ps, k);
+        return bits | near;
     }
     struct Gain {
         double J00, J01, J10, J11, pp00, pp01, pp10, pp11, c00, c01, c10, c11;
@@ -675,7 +702,10 @@ struct BwdLevel {
     __device__ static __forceinline__ Carry init_true(const Prm &) { return Carry{0, 0, 1, 0}; }
     __device__ static __forceinline__ Carry init_cold(const Prm &) { return Carry{0, 0, 1, 0}; }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
-        return ((f2u(a.x) ^ f2u(b.x)) | (f2u(a.ps) ^ f2u(b.ps))) == 0u;
+        const bool bits = ((f2u(a.x) ^ f2u(b.x)) | (f2u(a.ps) ^ f2u(b.ps))) == 0u;
+        const int k = p.xTolUlps;
+        const bool near = (k > 0) & near_ulps(a.x, b.x, 1.0f, k) & near_ulps(a.ps, b.ps, 0.f, k);
+        return bits | near;
     }
     template <bool STORE>
     __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {

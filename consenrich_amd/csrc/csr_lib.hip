@@ -67,7 +67,10 @@ struct csr_ctx {
     hipStream_t stream = nullptr;
     // tuning
     int B = 0;                 // block length; 0 = chosen from the batch size at configure time
-    int warmP = 256, warmX = 256, warmB = 128;   // speculative warm-up in bins (rounded up to a multiple of 8)
+    // speculative warm-up in bins (multiples of 16).  Defaults follow the validation mode (mode_warm_defaults): bitwise
+    // coalescence of float32-rounded trajectories needs ~4x the window that k-ulp agreement does.
+    int warmP = 256, warmX = 256, warmB = 128;
+    bool pinP = false, pinX = false, pinB = false;
     bool Bfixed = false;
     bool adaptWarm = true;
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
@@ -126,6 +129,16 @@ static void free_batch(csr_ctx *c) {
     for (auto &n : c->nat) n = nullptr;
 }
 
+// Warm-up windows that gave zero re-runs on the bench workload with margin (hg38 x 32 synthetic: the state chain needs
+// 64 bins at k = 2, the covariance chain 64, the smoother 48; exact mode 256 / 256 / 128).  run_chain lengthens them
+// when the data has a longer filter memory; results never depend on them.
+static void mode_warm_defaults(csr_ctx *c) {
+    const bool tol = c->xTolUlps > 0;
+    if (!c->pinP) c->warmP = tol ? 80 : 256;
+    if (!c->pinX) c->warmX = tol ? 80 : 256;
+    if (!c->pinB) c->warmB = tol ? 64 : 128;
+}
+
 extern "C" csr_ctx *csr_create(int device_ordinal) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -150,10 +163,12 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     }
     const char *e;
     if ((e = getenv("CONSENRICH_AMD_BLOCK"))) { c->B = atoi(e); c->Bfixed = c->B != 0; }
-    if ((e = getenv("CONSENRICH_AMD_WARM_P"))) c->warmP = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_WARM_X"))) c->warmX = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_WARM_B"))) c->warmB = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_WARM_P"))) { c->warmP = atoi(e); c->pinP = true; }
+    if ((e = getenv("CONSENRICH_AMD_WARM_X"))) { c->warmX = atoi(e); c->pinX = true; }
+    if ((e = getenv("CONSENRICH_AMD_WARM_B"))) { c->warmB = atoi(e); c->pinB = true; }
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_ADAPT"))) c->adaptWarm = atoi(e) != 0;
+    mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
     if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
@@ -186,9 +201,9 @@ extern "C" int csr_set_tuning(csr_ctx *c, int32_t block_len, int32_t warm_p, int
         c->Bfixed = true;
     }
     if (warm_p >= 0 || warm_x >= 0 || warm_b >= 0) c->adaptWarm = false;   // explicit tuning pins the windows
-    if (warm_p >= 0) c->warmP = (warm_p + 15) / 16 * 16;
-    if (warm_x >= 0) c->warmX = (warm_x + 15) / 16 * 16;
-    if (warm_b >= 0) c->warmB = (warm_b + 15) / 16 * 16;
+    if (warm_p >= 0) { c->warmP = (warm_p + 15) / 16 * 16; c->pinP = true; }
+    if (warm_x >= 0) { c->warmX = (warm_x + 15) / 16 * 16; c->pinX = true; }
+    if (warm_b >= 0) { c->warmB = (warm_b + 15) / 16 * 16; c->pinB = true; }
     return 0;
 }
 
@@ -198,6 +213,7 @@ extern "C" int csr_set_validation(csr_ctx *c, int32_t x_tol_ulps) {
     if (!c) return -1;
     if (x_tol_ulps < 0 || x_tol_ulps > 64) return fail("x_tol_ulps must be in [0, 64]");
     c->xTolUlps = x_tol_ulps;
+    mode_warm_defaults(c);
     return 0;
 }
 
@@ -598,7 +614,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         *reruns += fresh;
         // adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data
         // (longer filter memory); lengthen it for the following sweeps.  Results do not depend on it.
-        if (it == 0 && c->adaptWarm && (int64_t)fresh > std::max<int64_t>(8, c->NB / 100) && warmRef < 8192)
+        if (it == 0 && c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
             warmRef = std::min(8192, warmRef * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
@@ -921,7 +937,10 @@ static csr_ctx *default_ctx() {
         if (const char *e = getenv("CONSENRICH_AMD_DEVICE")) dev = atoi(e);
         g_default = csr_create(dev);
         // the drop-in single-chain callables favour parity: bit-exact sequential semantics unless told otherwise
-        if (g_default && !getenv("CONSENRICH_AMD_XTOL_ULPS")) g_default->xTolUlps = 0;
+        if (g_default && !getenv("CONSENRICH_AMD_XTOL_ULPS")) {
+            g_default->xTolUlps = 0;
+            mode_warm_defaults(g_default);
+        }
     }
     return g_default;
 }

@@ -6,7 +6,11 @@ from consenrich_amd.batch import DeviceBatch, ModelParams
 from consenrich_amd.sharding import hg38_chain_lengths
 m = int(os.environ.get("M", "32"))
 b = DeviceBatch(0)
-b.configure(ModelParams(state_dim=2), m, hg38_chain_lengths(int(os.environ.get("BINBP", "200")))); b.synthesize(1234)
+lengths = hg38_chain_lengths(int(os.environ.get("BINBP", "200")))
+if os.environ.get("SHARD"):
+    from consenrich_amd.sharding import lpt_assign
+    w, r = map(int, os.environ["SHARD"].split(":")); lengths = [lengths[i] for i in lpt_assign(lengths, w)[r]]
+b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 for _ in range(int(os.environ.get("STEPS", "3"))):
     b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)

@@ -7,12 +7,16 @@ from consenrich_amd.batch import DeviceBatch, ModelParams
 from consenrich_amd.sharding import hg38_chain_lengths
 m = int(os.environ.get("M", "32")); B = int(os.environ.get("B", "0"))
 lengths = hg38_chain_lengths(int(os.environ.get("BINBP", "200")))
+if os.environ.get("SHARD"):      # "8:0" = the contigs rank 0 of 8 would own
+    from consenrich_amd.sharding import lpt_assign
+    w, r = map(int, os.environ["SHARD"].split(":")); lengths = [lengths[i] for i in lpt_assign(lengths, w)[r]]
 b = DeviceBatch(0, block_len=B)
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
     b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
-for cfg in [(256,256,256),(256,256,128)]:
+cfgs = [tuple(map(int, c.split(','))) for c in os.environ.get('CFGS', '256,256,128').split(';')]
+for cfg in cfgs:
     b.set_tuning(0, *cfg)
     for _ in range(2): step()
     b.synchronize(); r0 = b.run_stats()
