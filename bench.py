@@ -147,9 +147,9 @@ def main() -> int:
 
     def step():
         batch.stats()
-        batch.forward(flags, want_sums=True)
-        batch.backward()
+        batch.forward_backward(flags, want_sums=False)
         batch.export(what)
+        batch.sums()                    # phiHat / NLL per chain: the step's one host synchronisation
 
     def fence():
         if dist is not None:

@@ -67,7 +67,7 @@ class RunStats(C.Structure):
     _fields_ = [
         ("blocks", C.c_int64), ("fix_launches", C.c_int64), ("reruns_p", C.c_int64), ("reruns_x", C.c_int64),
         ("reruns_b", C.c_int64), ("block_len", C.c_int32), ("warm_p", C.c_int32), ("warm_x", C.c_int32),
-        ("warm_b", C.c_int32), ("x_tol_ulps", C.c_int32), ("reserved_", C.c_int32),
+        ("warm_b", C.c_int32), ("x_tol_ulps", C.c_int32), ("pipeline_redos", C.c_int32),
     ]
 
 
@@ -89,6 +89,8 @@ SYMBOLS = {
     "csr_batch_stats": (C.c_int, [C.c_void_p]),
     "csr_batch_forward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
     "csr_batch_backward": (C.c_int, [C.c_void_p]),
+    "csr_batch_forward_backward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
+    "csr_batch_sums": (C.c_int, [C.c_void_p, DP, DP]),
     "csr_batch_ecm": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.POINTER(EcmOut), DP]),
     "csr_batch_export": (C.c_int, [C.c_void_p, C.c_uint32]),
     "csr_batch_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

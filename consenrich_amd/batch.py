@@ -130,6 +130,23 @@ class DeviceBatch:
     def backward(self):
         L.check(self._lib.csr_batch_backward(self._ctx))
 
+    def forward_backward(self, flags: int = L.RETURN_NLL, want_sums: bool = True):
+        """forward() + backward() as one pipeline (one host synchronisation; `_runForwardBackward`, core.py:4207)."""
+        nc = len(self.chain_lens)
+        if not want_sums:
+            L.check(self._lib.csr_batch_forward_backward(self._ctx, int(flags), None, None))
+            return None, None
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        L.check(self._lib.csr_batch_forward_backward(self._ctx, int(flags), L.dp(sd), L.dp(sn)))
+        return sd, sn
+
+    def sums(self):
+        """Per-chain (sumD, sumNLL) of the resident forward pass; synchronises (and validates) everything queued."""
+        nc = len(self.chain_lens)
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        L.check(self._lib.csr_batch_sums(self._ctx, L.dp(sd), L.dp(sn)))
+        return sd, sn
+
     def ecm(self, max_iters=50, inner_iters=5, rtol=1.0e-6, nu=8.0, use_lambda=False, use_kappa=True,
             use_apn=False, use_qscale=False):
         nc = len(self.chain_lens)

@@ -977,6 +977,12 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {
     if (live) cout[b] = c;
 }
 
+// diagnostic: a near-empty kernel (used to attribute kernel-boundary costs when profiling)
+__global__ __launch_bounds__(64) void k_probe(Prm p) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b < p.NB && p.blk[b].y < 0) p.rerunCount[3] = 1u;
+}
+
 // Validation / fix-up pass: a block whose recorded carry-in differs from its neighbour's current carry-out is re-run
 // from that carry.  Iterated (ping-pong outCur/outNext) until no block re-runs: the fixed point is the sequential
 // recursion.  which = 0: read A write B; 1: read B write A.
@@ -1003,11 +1009,12 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     const int64_t self = live ? b : 0;
     const Carry prev = ocur[nbr];
     const Carry mine = cin[self];
-    const Carry keep = ocur[self];
     const bool rerun = check && (((p.debugForce & 1) != 0) | !CH::same(p, prev, mine));
     Carry c = prev;
     if (rerun) cin[b] = prev;
-    if (live && !rerun) onxt[b] = keep;
+    // (loaded here rather than held across the comparison: a held copy becomes an alloca that hipcc promotes to LDS,
+    // and the LDS allocation alone made this kernel's dispatch ~6x slower)
+    if (live && !rerun) onxt[b] = ocur[self];
     if (!__any(rerun)) return;
     walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
     if (rerun) {
@@ -1083,29 +1090,37 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
     }
 }
 
-// per-chain sums in block order (one workgroup per chain, fixed-shape tree: deterministic)
-__global__ __launch_bounds__(256) void k_chain_sums(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
-    __shared__ double sd[256], sn[256];
+// per-chain sums in block order (one workgroup per chain; fixed partition and fixed-shape tree: deterministic).
+// Four independent accumulators per thread keep the loads of a long chain (10^4 blocks) in flight together.
+__global__ __launch_bounds__(1024) void k_chain_sums(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
+    __shared__ double sd[1024], sn[1024];
     const int c = blockIdx.x;
     const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
-    double aD = 0.0, aN = 0.0;
-    if (p.chainActive == nullptr || p.chainActive[c]) {
-        for (int64_t i = threadIdx.x; i < nb; i += 256) {
-            aD += p.blkSumD[b0 + i];
-            aN += p.blkSumNLL[b0 + i];
+    const bool on = p.chainActive == nullptr || p.chainActive[c];
+    double aD[4] = {0.0, 0.0, 0.0, 0.0}, aN[4] = {0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        for (int64_t i = threadIdx.x; i < nb; i += 4096) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = i + (int64_t)u * 1024;
+                if (j < nb) {
+                    aD[u] += p.blkSumD[b0 + j];
+                    aN[u] += p.blkSumNLL[b0 + j];
+                }
+            }
         }
     }
-    sd[threadIdx.x] = aD;
-    sn[threadIdx.x] = aN;
+    sd[threadIdx.x] = (aD[0] + aD[1]) + (aD[2] + aD[3]);
+    sn[threadIdx.x] = (aN[0] + aN[1]) + (aN[2] + aN[3]);
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {
             sd[threadIdx.x] += sd[threadIdx.x + w];
             sn[threadIdx.x] += sn[threadIdx.x + w];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && (p.chainActive == nullptr || p.chainActive[c])) {
+    if (threadIdx.x == 0 && on) {
         p.chainSumD[c] = sd[0];
         p.chainSumNLL[c] = sn[0];
     }

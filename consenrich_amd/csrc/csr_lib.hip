@@ -93,9 +93,23 @@ struct csr_ctx {
     unsigned char *dActive = nullptr;
     float *dLatent = nullptr;
     float *nat[CSR_ARR_COUNT] = {nullptr};
-    unsigned int *hCount = nullptr;     // pinned
-    unsigned int lastCount = 0;         // value of the (monotonic) device rerun counter at the last read
-    double *hSums = nullptr;            // pinned, 2*nchains
+    // mailbox: [4 x u32 monotonic re-run counters (covariance, state, smoother, debug) | sumD[nchains] | sumNLL[nchains]]
+    // in device memory, mirrored into pinned host memory with ONE copy per settle point
+    char *dMail = nullptr, *hMail = nullptr;
+    size_t mailBytes = 0;
+    unsigned int lastCnt[4] = {0, 0, 0, 0};
+    // deferred validation: a stage whose last synchronous run needed no re-run is launched optimistically (speculative
+    // pass + one validation pass, no host round trip); the counters are checked at the next settle point and the
+    // pipeline is re-run synchronously from the first stage that did re-run blocks.
+    bool deferEnabled = true;
+    bool spinWait = true;
+    bool optimistic[3] = {true, true, true};
+    bool pendFwd = false, pendBwd = false, sidePending = false;
+    uint32_t pendFlags = 0, pendExport = 0;
+    bool pendWantD = false;
+    const unsigned char *pendActiveF = nullptr, *pendActiveB = nullptr;
+    hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -103,6 +117,9 @@ struct csr_ctx {
     // stats
     csr_run_stats rs{};
 };
+
+static int settle(csr_ctx *c);
+static int export_impl(csr_ctx *c, uint32_t what);
 
 static int ctx_select(csr_ctx *c) {
     HIPOK(hipSetDevice(c->device));
@@ -125,6 +142,9 @@ static void free_batch(csr_ctx *c) {
     c->allocs.clear();
     c->configured = false;
     c->statsValid = c->haveFwd = c->haveBwd = false;
+    c->pendFwd = c->pendBwd = c->sidePending = false;
+    c->pendExport = 0;
+    c->dMail = nullptr;
     c->dActive = nullptr;
     for (auto &n : c->nat) n = nullptr;
 }
@@ -134,6 +154,7 @@ static void free_batch(csr_ctx *c) {
 // when the data has a longer filter memory; results never depend on them.
 static void mode_warm_defaults(csr_ctx *c) {
     const bool tol = c->xTolUlps > 0;
+    c->optimistic[1] = tol;     // bit-exact state chains re-run blocks on most calls: validate them synchronously
     if (!c->pinP) c->warmP = tol ? 80 : 256;
     if (!c->pinX) c->warmX = tol ? 80 : 256;
     if (!c->pinB) c->warmB = tol ? 64 : 128;
@@ -156,8 +177,10 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         delete c;
         return nullptr;
     }
-    if (hipHostMalloc((void **)&c->hCount, 64) != hipSuccess) {
-        fail("hipHostMalloc failed");
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) {
+        fail("cannot create the side stream of device %d", device_ordinal);
         delete c;
         return nullptr;
     }
@@ -168,6 +191,9 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) { c->warmB = atoi(e); c->pinB = true; }
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_ADAPT"))) c->adaptWarm = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
+    if (getenv("CONSENRICH_AMD_FORCE_ITERS")) c->deferEnabled = false;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
@@ -179,6 +205,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
     free_batch(c);
     for (auto &kv : c->prof)
         for (auto &pr : kv.second.pending) {
@@ -186,8 +213,10 @@ extern "C" void csr_destroy(csr_ctx *c) {
             hipEventDestroy(pr.second);
         }
     for (hipEvent_t ev : c->eventPool) hipEventDestroy(ev);
-    if (c->hCount) hipHostFree(c->hCount);
-    if (c->hSums) hipHostFree(c->hSums);
+    if (c->hMail) hipHostFree(c->hMail);
+    if (c->evFork) hipEventDestroy(c->evFork);
+    if (c->evJoin) hipEventDestroy(c->evJoin);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -220,6 +249,7 @@ extern "C" int csr_set_validation(csr_ctx *c, int32_t x_tol_ulps) {
 extern "C" int csr_synchronize(csr_ctx *c) {
     if (!c) return fail("null context");
     CHECK(ctx_select(c));
+    if (c->configured) CHECK(settle(c));
     HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -241,17 +271,18 @@ struct Scope {
     csr_ctx *c;
     ProfEntry *pe = nullptr;
     hipEvent_t a{}, b{};
-    Scope(csr_ctx *c_, const char *name) : c(c_) {
+    hipStream_t st;
+    Scope(csr_ctx *c_, const char *name, hipStream_t st_ = nullptr) : c(c_), st(st_ ? st_ : c_->stream) {
         if (c->profiling) {
             pe = &c->prof[name];
             a = get_event(c);
             b = get_event(c);
-            hipEventRecord(a, c->stream);
+            hipEventRecord(a, st);
         }
     }
     ~Scope() {
         if (pe) {
-            hipEventRecord(b, c->stream);
+            hipEventRecord(b, st);
             pe->pending.emplace_back(a, b);
             pe->launches++;
         }
@@ -259,6 +290,7 @@ struct Scope {
 };
 static void prof_collect(csr_ctx *c) {
     hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
     for (auto &kv : c->prof) {
         for (auto &pr : kv.second.pending) {
             float ms = 0.f;
@@ -334,6 +366,8 @@ extern "C" int csr_batch_set_model(csr_ctx *c, const csr_model *mdl) {
     if (!c || !mdl) return fail("null argument");
     if (!c->configured) return fail("batch not configured");
     if (mdl->state_dim != c->mdl.state_dim) return fail("state_dim cannot change without reconfiguring the batch");
+    CHECK(ctx_select(c));
+    CHECK(settle(c));
     if (mdl->pad != c->mdl.pad) c->statsValid = false;
     c->mdl = *mdl;
     fill_model(c);
@@ -435,17 +469,20 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));
     HIPOK(hipMemsetAsync(p.tD, 0, sizeof(float) * T, c->stream));
     CHECK(dalloc(c, &p.blkSumD, nb)); CHECK(dalloc(c, &p.blkSumNLL, nb));
-    CHECK(dalloc(c, &p.chainSumD, n_chains)); CHECK(dalloc(c, &p.chainSumNLL, n_chains));
-    HIPOK(hipMemsetAsync(p.chainSumD, 0, sizeof(double) * n_chains, c->stream));
-    HIPOK(hipMemsetAsync(p.chainSumNLL, 0, sizeof(double) * n_chains, c->stream));
+    c->mailBytes = 16 + sizeof(double) * 2 * (size_t)n_chains;
+    CHECK(dalloc(c, &c->dMail, (int64_t)c->mailBytes));
+    HIPOK(hipMemsetAsync(c->dMail, 0, c->mailBytes, c->stream));
+    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail);
+    p.chainSumD = reinterpret_cast<double *>(c->dMail + 16);
+    p.chainSumNLL = p.chainSumD + n_chains;
+    for (unsigned int &v : c->lastCnt) v = 0;
+    if (c->hMail) hipHostFree(c->hMail);
+    c->hMail = nullptr;
+    HIPOK(hipHostMalloc((void **)&c->hMail, c->mailBytes));
+    memset(c->hMail, 0, c->mailBytes);
     char *ci_, *coa, *cob;
     CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
     p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;
-    CHECK(dalloc(c, &p.rerunCount, 16));
-    HIPOK(hipMemsetAsync(p.rerunCount, 0, 16 * sizeof(unsigned int), c->stream));
-    c->lastCount = 0;
-    if (c->hSums) hipHostFree(c->hSums);
-    HIPOK(hipHostMalloc((void **)&c->hSums, sizeof(double) * 2 * n_chains));
     c->configured = true;
     c->rs = csr_run_stats{};
     return 0;
@@ -464,6 +501,7 @@ extern "C" int64_t csr_batch_chain_offset(csr_ctx *c, int32_t chain) {
 
 extern "C" int csr_batch_upload(csr_ctx *c, int32_t chain, const float *data, const float *munc) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
     if (!data || !munc) return fail("null host buffer");
     const ChainInfo &ci = c->chains[chain];
@@ -514,6 +552,7 @@ static int import_vec(csr_ctx *c, int chain, const float *host, float *blocked) 
 extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const float *lambda, const float *kappa,
                                             const float *qscale) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
     const float *src[3] = {lambda, kappa, qscale};
     float *dst[3] = {c->p.tLam, c->p.tKap, c->p.tQs};
@@ -551,6 +590,7 @@ static void launch_stats(csr_ctx *c, const Prm &p) {
 
 extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
+    CHECK(settle(c));
     Prm p = c->p;
     {
         Scope sc(c, "stats");
@@ -567,13 +607,53 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
     return 0;
 }
 
-// speculative pass + validation/fix-up to the fixed point
+enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
+
+// Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
+// 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
+// step: poll first, block only if the stream is still busy after ~200 us.
+static hipError_t wait_stream(csr_ctx *c) {
+    if (c->spinWait) {
+        for (int i = 0; i < 20000; ++i) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+static int read_mail(csr_ctx *c, size_t bytes) {
+    HIPOK(hipMemcpyAsync(c->hMail, c->dMail, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    return 0;
+}
+static unsigned int take_fresh(csr_ctx *c, int stage) {
+    const unsigned int now = reinterpret_cast<const unsigned int *>(c->hMail)[stage];
+    const unsigned int fresh = now - c->lastCnt[stage];
+    c->lastCnt[stage] = now;
+    return fresh;
+}
+// adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data (longer filter
+// memory); lengthen it for the following sweeps.  Results do not depend on it.
+static void grow_warm(csr_ctx *c, int &warmRef, unsigned int fresh) {
+    if (c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
+        warmRef = std::min(8192, warmRef * 2);
+}
+static int &stage_warm(csr_ctx *c, int stage) { return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB); }
+static int64_t &stage_reruns(csr_ctx *c, int stage) {
+    return stage == ST_P ? c->rs.reruns_p : (stage == ST_X ? c->rs.reruns_x : c->rs.reruns_b);
+}
+
+// Speculative pass + validation/fix-up.  defer = true: launch the speculative pass and ONE validation pass and return
+// without a host round trip (the stage's monotonic counter is checked at the next settle point); otherwise iterate
+// validation passes to the fixed point here.
 template <class CH>
-static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int &warmRef, int64_t *reruns) {
-    const int warm = warmRef;
+static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int stage, bool defer) {
     static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
-    p.warm = warm;
+    int &warmRef = stage_warm(c, stage);
+    p.warm = warmRef;
     p.xTolUlps = c->xTolUlps;
+    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + stage;
     const int grid = (int)c->NG;
     if (getenv("CONSENRICH_AMD_POISON")) {
         HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
@@ -592,39 +672,74 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         }
     }
     LAUNCH_CHECK(name);
+    if (getenv("CONSENRICH_AMD_PROBE")) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
     int which = 0;
     const char *dbgForce = getenv("CONSENRICH_AMD_FORCE_ITERS");
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
         p.debugForce = (dbgForce && it < atoi(dbgForce)) ? 1 : 0;
         if (getenv("CONSENRICH_AMD_FENCE")) p.debugForce |= 2;
-        // the device counter only ever grows (no per-launch memset: that costs a fill kernel); compare deltas
         {
             Scope sc(c, fixName);
             hipLaunchKernelGGL(k_chain_fix<CH>, dim3(grid), dim3(64), 0, c->stream, p, which);
         }
         LAUNCH_CHECK(fixName);
-        HIPOK(hipMemcpyAsync(c->hCount, p.rerunCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipStreamSynchronize(c->stream));
         c->rs.fix_launches++;
         which ^= 1;
-        const unsigned int fresh = *c->hCount - c->lastCount;
-        c->lastCount = *c->hCount;
+        if (defer) return 0;
+        CHECK(read_mail(c, 16));
+        const unsigned int fresh = take_fresh(c, stage);
         if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
-        if (fresh == 0) return 0;
-        *reruns += fresh;
-        // adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data
-        // (longer filter memory); lengthen it for the following sweeps.  Results do not depend on it.
-        if (it == 0 && c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
-            warmRef = std::min(8192, warmRef * 2);
+        if (fresh == 0) {
+            if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) c->optimistic[stage] = true;
+            return 0;
+        }
+        stage_reruns(c, stage) += fresh;
+        if (it == 0) grow_warm(c, warmRef, fresh);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
 
-static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active) {
+static void join_side(csr_ctx *c) {
+    if (c->sidePending) {
+        hipStreamWaitEvent(c->stream, c->evJoin, 0);
+        c->sidePending = false;
+    }
+}
+
+// NIS/NLL epilogue; side = true runs it on the side stream (forked after the state chain) so that it overlaps the
+// latency-bound smoother chain.
+static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
+    hipStream_t st = c->stream;
+    if (side) {
+        join_side(c);
+        HIPOK(hipEventRecord(c->evFork, c->stream));
+        HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+        st = c->side;
+    }
+    {
+        Scope sc(c, "fwd_dstat", st);
+        hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, st, p);
+    }
+    LAUNCH_CHECK("k_fwd_dstat");
+    {
+        Scope sc(c, "chain_sums", st);
+        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, st, p, c->dChainFirst, c->dChainNb);
+    }
+    LAUNCH_CHECK("k_chain_sums");
+    if (side) {
+        HIPOK(hipEventRecord(c->evJoin, c->side));
+        c->sidePending = true;
+    }
+    return 0;
+}
+
+static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
+                        bool side = false) {
     if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
+    defer = defer && c->deferEnabled;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
         Scope sc(c, "fwd_apn_sequential");
@@ -632,25 +747,20 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                            c->dChainNb);
         LAUNCH_CHECK("k_fwd_apn");
     } else {
+        const bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
         if (c->mdl.state_dim == 2) {
-            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", c->warmP, &c->rs.reruns_p));
-            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", c->warmX, &c->rs.reruns_x));
+            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         } else {
-            CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", c->warmP, &c->rs.reruns_p));
-            CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", c->warmX, &c->rs.reruns_x));
+            CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         }
-        if (wantD) {
-            {
-                Scope sc(c, "fwd_dstat");
-                hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, c->stream, p);
-            }
-            LAUNCH_CHECK("k_fwd_dstat");
-            {
-                Scope sc(c, "chain_sums");
-                hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(256), 0, c->stream, p, c->dChainFirst,
-                                   c->dChainNb);
-            }
-            LAUNCH_CHECK("k_chain_sums");
+        if (wantD) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
+        if (dP || dX) {
+            c->pendFwd = true;
+            c->pendFlags = flags;
+            c->pendWantD = wantD;
+            c->pendActiveF = active;
         }
     }
     c->haveFwd = true;
@@ -660,24 +770,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     return 0;
 }
 
-static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
-    const size_t nc = c->chains.size();
-    HIPOK(hipMemcpyAsync(c->hSums, c->p.chainSumD, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(c->hSums + nc, c->p.chainSumNLL, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    if (sum_d) memcpy(sum_d, c->hSums, sizeof(double) * nc);
-    if (sum_nll) memcpy(sum_nll, c->hSums + nc, sizeof(double) * nc);
-    return 0;
-}
-
-extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
-    CHECK(need(c));
-    CHECK(forward_impl(c, flags, true, nullptr));
-    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
-    return 0;
-}
-
-static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active) {
+static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false) {
     if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
     Prm p = c->p;
     p.flags = c->fwdFlags;
@@ -685,15 +778,88 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active) 
     // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
     p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
-    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
-    else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", c->warmB, &c->rs.reruns_b));
+    const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
+    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    if (dB) {
+        c->pendBwd = true;
+        c->pendActiveB = active;
+    }
     c->haveBwd = true;
+    return 0;
+}
+
+// Settle point: every optimistically launched stage is checked (one mailbox copy, one host sync).  If a stage re-ran
+// blocks in its single validation pass, its results -- and everything computed from them -- are not yet the fixed
+// point: the pipeline is re-run synchronously from that stage and the stage goes back to synchronous validation
+// until a clean pass re-arms it.  After settle() the mailbox mirror holds the current per-chain sums.
+static int settle(csr_ctx *c) {
+    join_side(c);
+    if (!c->pendFwd && !c->pendBwd) return 0;
+    CHECK(read_mail(c, c->mailBytes));
+    const bool pf = c->pendFwd, pb = c->pendBwd;
+    const uint32_t pe = c->pendExport;
+    c->pendFwd = c->pendBwd = false;
+    c->pendExport = 0;
+    int firstFail = -1;
+    for (int stg = ST_P; stg <= ST_B; ++stg) {
+        const unsigned int fresh = take_fresh(c, stg);
+        if (fresh == 0) continue;
+        stage_reruns(c, stg) += fresh;
+        c->optimistic[stg] = false;
+        grow_warm(c, stage_warm(c, stg), fresh);
+        if (firstFail < 0) firstFail = stg;
+        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
+    }
+    if (firstFail < 0) return 0;
+    c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation
+    if (firstFail <= ST_X && pf) {
+        const bool bwdToo = pb || c->haveBwd;
+        CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false));
+        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false));
+    } else if (pb) {
+        CHECK(backward_impl(c, true, c->pendActiveB, false));
+    }
+    if (pe) CHECK(export_impl(c, pe));      // arrays exported from the unvalidated results
+    CHECK(read_mail(c, c->mailBytes));
+    for (int stg = ST_P; stg <= ST_B; ++stg) (void)take_fresh(c, stg);
+    return 0;
+}
+
+static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
+    const size_t nc = c->chains.size();
+    const bool pending = c->pendFwd || c->pendBwd;
+    CHECK(settle(c));
+    if (!pending) CHECK(read_mail(c, c->mailBytes));
+    const double *hs = reinterpret_cast<const double *>(c->hMail + 16);
+    if (sum_d) memcpy(sum_d, hs, sizeof(double) * nc);
+    if (sum_nll) memcpy(sum_nll, hs + nc, sizeof(double) * nc);
+    return 0;
+}
+
+extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, false));
+    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
     return 0;
 }
 
 extern "C" int csr_batch_backward(csr_ctx *c) {
     CHECK(need(c));
-    return backward_impl(c, true, nullptr);
+    CHECK(backward_impl(c, true, nullptr, true));
+    return 0;       // validated at the next settle point
+}
+
+// forward (NIS, optional NLL) + backward as one pipeline: one host synchronisation, the NIS/NLL epilogue overlapped
+// with the smoother chain.  Equivalent to csr_batch_forward followed by csr_batch_backward.
+extern "C" int csr_batch_forward_backward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, true));
+    CHECK(backward_impl(c, true, nullptr, true));
+    if (sum_d || sum_nll) return read_sums(c, sum_d, sum_nll);
+    return 0;       // validation stays pending until the next settle point (sums, download, synchronize, new inputs)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -706,6 +872,7 @@ struct EcmState {
 
 extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (!cfg || !out) return fail("null argument");
     if (!c->statsValid) CHECK(csr_batch_stats(c));
     const int nc = (int)c->chains.size();
@@ -734,8 +901,8 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
     }
     if (anyTiny) {
         CHECK(push_active());
-        CHECK(forward_impl(c, fl | F_NLL, true, c->dActive));
-        CHECK(backward_impl(c, true, c->dActive));
+        CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));
+        CHECK(backward_impl(c, true, c->dActive, true));
         CHECK(read_sums(c, nullptr, nll.data()));
         for (int i = 0; i < nc; ++i)
             if (act[i]) { out[i].final_nll = out[i].initial_nll = nll[i]; st[i].done = true; }
@@ -746,9 +913,10 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
         bool fwdFresh = false;   // forward results already match the current multipliers
         for (int64_t it = 0; it < cfg->max_iters; ++it) {
             for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
-                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive));
+                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
                 fwdFresh = false;
-                CHECK(backward_impl(c, true, c->dActive));
+                CHECK(backward_impl(c, true, c->dActive, true));
+                CHECK(settle(c));          // the E-steps consume validated smoothed moments
                 Prm p = c->p;
                 p.flags = fl;
                 p.chainActive = c->dActive;
@@ -763,7 +931,7 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
                     LAUNCH_CHECK("k_estep_kappa");
                 }
             }
-            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive));      // pyx:8300
+            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));      // pyx:8300
             // the multipliers do not change until the next E-step: the next sweep may reuse this forward pass,
             // unless adaptive process noise made it depend on returnNLL-independent state only (it does not)
             fwdFresh = (cfg->inner_iters > 0);
@@ -817,8 +985,21 @@ static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, i
     return 0;
 }
 
+// Exports may be queued behind an optimistically validated pipeline: they are re-issued by settle() if it fails.
 extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
     CHECK(need(c));
+    join_side(c);
+    if (c->pendFwd || c->pendBwd) c->pendExport |= what;
+    return export_impl(c, what);
+}
+
+extern "C" int csr_batch_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    if (!c->haveFwd) return fail("no forward results");
+    return read_sums(c, sum_d, sum_nll);
+}
+
+static int export_impl(csr_ctx *c, uint32_t what) {
     const int d = c->mdl.state_dim;
     const Prm &p = c->p;
     const int nv = d, nm = d * d;      // exported components of state vectors / covariance matrices
@@ -867,6 +1048,7 @@ extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
 
 extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, int64_t *n_elems) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
     float *ptr;
     CHECK(nat_array(c, id, &ptr));
@@ -877,6 +1059,7 @@ extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, in
 
 extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *host_dst) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
     if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
     if (!host_dst) return fail("null host buffer");
@@ -897,6 +1080,7 @@ extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *h
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int csr_batch_synthesize(csr_ctx *c, uint64_t seed) {
     CHECK(need(c));
+    CHECK(settle(c));
     if (!c->dLatent) CHECK(dalloc(c, &c->dLatent, c->Npad));
     std::vector<float> lat((size_t)c->Npad, 0.f);
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
@@ -1101,7 +1285,8 @@ extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uin
     p.debugForce = force;
     p.warm = kind == 0 ? c->warmP : (kind == 1 ? c->warmX : c->warmB);
     const int grid = (int)c->NG;
-    HIPOK(hipMemsetAsync(p.rerunCount, 0, sizeof(unsigned int), c->stream));
+    CHECK(settle(c));
+    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + ST_DEBUG;
     if (op == 0) {
         if (kind == 0) hipLaunchKernelGGL(k_chain_spec<FwdPTrend>, dim3(grid), dim3(64), 0, c->stream, p);
         if (kind == 1) hipLaunchKernelGGL(k_chain_spec<FwdXTrend>, dim3(grid), dim3(64), 0, c->stream, p);
@@ -1112,10 +1297,9 @@ extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uin
         if (kind == 2) hipLaunchKernelGGL(k_chain_fix<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
     }
     LAUNCH_CHECK("debug chain step");
-    HIPOK(hipMemcpyAsync(c->hCount, p.rerunCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    if (count) *count = *c->hCount;
-    c->lastCount = *c->hCount;
+    CHECK(read_mail(c, 16));
+    const unsigned int fresh = take_fresh(c, ST_DEBUG);
+    if (count) *count = fresh;
     c->haveFwd = true;
     return 0;
 }

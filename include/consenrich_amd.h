@@ -164,6 +164,12 @@ int csr_batch_stats(csr_ctx *ctx);
 int csr_batch_forward(csr_ctx *ctx, uint32_t flags, double *sum_d, double *sum_nll);
 /* a6-a7 over all chains (uses the forward results resident on the device). */
 int csr_batch_backward(csr_ctx *ctx);
+/* csr_batch_forward + csr_batch_backward as ONE pipeline (core.py:4207 `_runForwardBackward` calls the two back to back):
+ * a single host synchronisation; the NIS/NLL epilogue runs on a side stream concurrently with the smoother chain. */
+int csr_batch_forward_backward(csr_ctx *ctx, uint32_t flags, double *sum_d, double *sum_nll);
+/* Per-chain sumD / sumNLL of the resident forward pass (n_chains doubles each, either may be NULL).  Lets a caller
+ * queue csr_batch_export behind csr_batch_forward_backward(…, NULL, NULL) and synchronise once, here. */
+int csr_batch_sums(csr_ctx *ctx, double *sum_d, double *sum_nll);
 /* a8-a9 over all chains in lock-step; out: n_chains entries; nll_path: n_chains*max_iters or NULL. */
 int csr_batch_ecm(csr_ctx *ctx, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path);
 
@@ -209,7 +215,8 @@ typedef struct csr_run_stats {
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */
     int64_t reruns_p, reruns_x, reruns_b;  /* blocks re-run because the speculative carry-in was not bit-equal */
     int32_t block_len, warm_p, warm_x, warm_b;
-    int32_t x_tol_ulps, reserved_;
+    int32_t x_tol_ulps;
+    int32_t pipeline_redos;     /* optimistic (deferred) validations that failed and re-ran their pipeline synchronously */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

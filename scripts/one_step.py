@@ -13,5 +13,5 @@ if os.environ.get("SHARD"):
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 for _ in range(int(os.environ.get("STEPS", "3"))):
-    b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
+    b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
 b.synchronize()

@@ -14,15 +14,18 @@ b = DeviceBatch(0, block_len=B)
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
-    b.stats(); b.forward(L.RETURN_NLL, True); b.backward(); b.export(what)
+    b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
 cfgs = [tuple(map(int, c.split(','))) for c in os.environ.get('CFGS', '256,256,128').split(';')]
 for cfg in cfgs:
     b.set_tuning(0, *cfg)
     for _ in range(2): step()
-    b.synchronize(); r0 = b.run_stats()
+    b.synchronize(); t=time.perf_counter()
+    for _ in range(20): step()
+    b.synchronize(); clean=(time.perf_counter()-t)/20
+    r0 = b.run_stats()
     b.profile(True); t=time.perf_counter()
     for _ in range(5): step()
     b.synchronize(); dt=(time.perf_counter()-t)/5
     kt = b.kernel_times(); b.profile(False); r1=b.run_stats()
     sel = {k: round(v[1]/5,3) for k,v in kt.items() if k in ("fwd_cov_chain","fwd_state_chain","bwd_chain","fwd_state_fix","fwd_cov_fix","bwd_fix","stats","residuals","export_natural")}
-    print("warm",cfg,"ms/step %.2f"%(dt*1e3), "reruns/step p,x,b", [(r1[k]-r0[k])/5 for k in ("reruns_p","reruns_x","reruns_b")], "fixl", (r1["fix_launches"]-r0["fix_launches"])/5, sel, flush=True)
+    print("warm",cfg,"ms/step %.3f (profiled %.2f)"%(clean*1e3, dt*1e3), "reruns/step p,x,b", [(r1[k]-r0[k])/5 for k in ("reruns_p","reruns_x","reruns_b")], "fixl", (r1["fix_launches"]-r0["fix_launches"])/5, sel, flush=True)

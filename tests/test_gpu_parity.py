@@ -77,7 +77,7 @@ def test_product_matches_live_oracle(product, oracle, name):
             assert np.asarray(got[k]).item() == pytest.approx(np.asarray(v).item(), rel=RTOL, abs=ATOL), f"{name}:{k}"
 
 
-def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0):
+def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0, fused=False):
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
 
@@ -91,9 +91,15 @@ def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0):
             b.upload(c, data, munc)
             b.upload_multipliers(c, lam, kap, qs)
         b.stats()
-        sd, sn = b.forward(L.RETURN_NLL | L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE | flags_extra)
-        b.backward()
-        b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        fl = L.RETURN_NLL | L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE | flags_extra
+        if fused:       # everything queued behind the optimistic pipeline, one synchronisation in sums()
+            b.forward_backward(fl, want_sums=False)
+            b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+            sd, sn = b.sums()
+        else:
+            sd, sn = b.forward(fl)
+            b.backward()
+            b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
         out["sd"], out["sn"] = sd, sn
         for c in range(len(n_list)):
             for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
@@ -120,6 +126,28 @@ def test_speculative_blocks_equal_sequential_recursion(product, d):
                 np.testing.assert_allclose(spec[key], val, rtol=1e-6, atol=1e-7, err_msg=f"{blk} {warm} {key}")
         if warm == (0, 0, 0):
             assert spec["stats"]["reruns_p"] > 0 and spec["stats"]["reruns_b"] > 0   # the fix-up path really ran
+
+
+@pytest.mark.parametrize("d", [2, 1])
+def test_fused_pipeline_and_failed_optimistic_validation(product, d):
+    """csr_batch_forward_backward (one host sync, NIS/NLL epilogue on the side stream, validation counters checked
+    at the end) must equal forward() + backward(), also when the optimistic validation FAILS: with a deliberately
+    short warm-up every stage re-runs blocks, the deferred check notices and the pipeline is redone synchronously."""
+    n_list = [5000, 37, 1, 12345, 64, 65]
+    seq = _run_batch(32 * 512, (0, 0, 0), d, n_list, 4, 100)
+    for blk, warm in ((64, (512, 512, 512)), (32, (0, 16, 0))):
+        fused = _run_batch(blk, warm, d, n_list, 4, 100, fused=True)
+        for key, val in seq.items():
+            if key == "stats":
+                continue
+            if d == 2 and not isinstance(key, str):
+                assert np.array_equal(val, fused[key]), f"block={blk} warm={warm} {key}"
+            else:
+                np.testing.assert_allclose(fused[key], val, rtol=1e-6, atol=1e-7, err_msg=f"{blk} {warm} {key}")
+        if warm == (0, 16, 0):
+            assert fused["stats"]["pipeline_redos"] >= 1 and fused["stats"]["reruns_b"] > 0
+        else:
+            assert fused["stats"]["pipeline_redos"] == 0
 
 
 def test_ulp_tolerant_validation_stays_within_parity_budget(product):
