@@ -390,8 +390,10 @@ struct FwdPTrend {
             p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
             p.tPf[i] = make_float4(c.c00, c.c01, c.c01, c.c11);
             // pNoiseForward[k-1] = Q used to reach k (pyx:504-508): shifted store, skipped at the chain's first bin
-            if (s > 0) p.tQ[i - 64] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
-            else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+            if (!p.qFromMult) {     // constant float32(Q0) otherwise: neither stored nor read back (smoother, export)
+                if (s > 0) p.tQ[i - 64] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+                else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
+            }
         }
     }
 };
@@ -438,8 +440,10 @@ struct FwdPLevel {
         if constexpr (STORE) {
             p.tXin[i] = pack_gain_level(gG, pp);
             p.tPf[i] = make_float4((float)c.p, 0.f, 0.f, 0.f);
-            if (s > 0) p.tQ[i - 64] = make_float4((float)Q, 0.f, 0.f, 0.f);
-            else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q, 0.f, 0.f, 0.f);
+            if (!p.qFromMult) {
+                if (s > 0) p.tQ[i - 64] = make_float4((float)Q, 0.f, 0.f, 0.f);
+                else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q, 0.f, 0.f, 0.f);
+            }
         }
     }
 };
@@ -1353,9 +1357,10 @@ __global__ __launch_bounds__(256) void k_import_f32(Prm p, const float *nat, int
 // coalesced rows of every array into LDS and writes, for each of its 64 blocks, 32 consecutive bins (contiguous
 // 128-512 bytes) of the reference layout.  E = floats per blocked slot, n <= E = leading components exported.
 struct ExpDesc {
-    const float *src;
+    const float *src;       // blocked source, or nullptr: fill with the constant row cval[0..n)
     float *dst;
     int E, n, skipLast, pad_;
+    float cval[4];
 };
 struct ExpList {
     int count;
@@ -1369,11 +1374,14 @@ __device__ __forceinline__ void export_tile(const Prm &p, const ExpDesc &d, floa
     constexpr int RS = 65 * E;                // padded row stride in floats
     const int lane = t & 63, r0 = t >> 6;
     const int64_t rowBase = (G * (int64_t)p.B + s0) * 64;
+    const bool fill = d.src == nullptr;
+    if (!fill) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + r0;
-        const vecE v = *reinterpret_cast<const vecE *>(d.src + (rowBase + (int64_t)row * 64 + lane) * E);
-        *reinterpret_cast<vecE *>(tile + row * RS + lane * E) = v;
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + r0;
+            const vecE v = *reinterpret_cast<const vecE *>(d.src + (rowBase + (int64_t)row * 64 + lane) * E);
+            *reinterpret_cast<vecE *>(tile + row * RS + lane * E) = v;
+        }
     }
     __syncthreads();
     const int r = t >> 5, si = t & 31;
@@ -1388,10 +1396,10 @@ __device__ __forceinline__ void export_tile(const Prm &p, const ExpDesc &d, floa
                 const int64_t g = (int64_t)bi.x + s;
                 const float *q = tile + si * RS + l * E;
                 vecN o;
-                if constexpr (N == 1) o = q[0];
+                if constexpr (N == 1) o = fill ? d.cval[0] : q[0];
                 else {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) o[k] = q[k];
+                    for (int k = 0; k < N; ++k) o[k] = fill ? d.cval[k] : q[k];
                 }
                 *reinterpret_cast<vecN *>(d.dst + g * N) = o;
             }

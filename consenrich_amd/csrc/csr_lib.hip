@@ -739,6 +739,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
+    p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
     defer = defer && c->deferEnabled;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
@@ -1010,7 +1011,15 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
         CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
         CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
-        CHECK(add_export(c, L, CSR_ARR_PNOISE, (const float *)p.tQ, 4, nm, 1));
+        const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
+        CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
+        if (constQ) {
+            ExpDesc &e = L.d[L.count - 1];
+            e.cval[0] = (float)p.Q00;
+            e.cval[1] = d == 2 ? (float)p.Q01 : 0.f;
+            e.cval[2] = d == 2 ? (float)p.Q10 : 0.f;
+            e.cval[3] = d == 2 ? (float)p.Q11 : 0.f;
+        }
     }
     if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
         if (!c->haveBwd) return fail("no smoothed results to export");
