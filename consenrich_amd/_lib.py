@@ -17,7 +17,8 @@ I64P = C.POINTER(C.c_int64)
 
 # flag bits (include/consenrich_amd.h)
 USE_LAMBDA, USE_KAPPA, USE_QSCALE, USE_APN, RETURN_NLL, NLL_IN_D = (1 << i for i in range(6))
-(ARR_D, ARR_XF, ARR_PF, ARR_PNOISE, ARR_XS, ARR_PS, ARR_LAG, ARR_RESID, ARR_LAMBDA, ARR_KAPPA, ARR_COUNT) = range(11)
+(ARR_D, ARR_XF, ARR_PF, ARR_PNOISE, ARR_XS, ARR_PS, ARR_LAG, ARR_RESID, ARR_LAMBDA, ARR_KAPPA, ARR_QSCALE,
+ ARR_SUMGAIN0, ARR_SUMGAIN1, ARR_EFFQ_LEVEL, ARR_EFFQ_TREND, ARR_MUNCTRACE, ARR_COUNT) = range(17)
 EXPORT_FORWARD, EXPORT_SMOOTH, EXPORT_RESID, EXPORT_MULT = 1, 2, 4, 8
 
 
@@ -91,6 +92,9 @@ SYMBOLS = {
     "csr_batch_backward": (C.c_int, [C.c_void_p]),
     "csr_batch_forward_backward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
     "csr_batch_sums": (C.c_int, [C.c_void_p, DP, DP]),
+    "csr_batch_diagnostics": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "csr_output_diagnostics": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, FP, FP, FP,
+                                         FP]),
     "csr_batch_ecm": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.POINTER(EcmOut), DP]),
     "csr_batch_export": (C.c_int, [C.c_void_p, C.c_uint32]),
     "csr_batch_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

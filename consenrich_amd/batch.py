@@ -42,7 +42,9 @@ class ModelParams:
 
 
 _ARR = {"D": L.ARR_D, "xf": L.ARR_XF, "Pf": L.ARR_PF, "pnoise": L.ARR_PNOISE, "xs": L.ARR_XS, "Ps": L.ARR_PS,
-        "lag": L.ARR_LAG, "resid": L.ARR_RESID, "lambda": L.ARR_LAMBDA, "kappa": L.ARR_KAPPA}
+        "lag": L.ARR_LAG, "resid": L.ARR_RESID, "lambda": L.ARR_LAMBDA, "kappa": L.ARR_KAPPA, "qscale": L.ARR_QSCALE,
+        "sumGain0": L.ARR_SUMGAIN0, "sumGain1": L.ARR_SUMGAIN1, "effectiveQLevel": L.ARR_EFFQ_LEVEL,
+        "effectiveQTrend": L.ARR_EFFQ_TREND, "muncTrace": L.ARR_MUNCTRACE}
 
 
 class DeviceBatch:
@@ -157,6 +159,12 @@ class DeviceBatch:
         L.check(self._lib.csr_batch_ecm(self._ctx, C.byref(cfg), L.USE_QSCALE if use_qscale else 0, outs, L.dp(path)))
         return list(outs), path.reshape(nc, -1)
 
+    def diagnostics(self, flags: int = 0):
+        """Per-interval output diagnostics (core.py:7734-7878) of the resident forward pass; results are the arrays
+        sumGain0, sumGain1, effectiveQLevel, effectiveQTrend, muncTrace (download()).  flags: USE_LAMBDA / USE_KAPPA /
+        USE_QSCALE = which resident multipliers enter (None in the reference call otherwise)."""
+        L.check(self._lib.csr_batch_diagnostics(self._ctx, int(flags)))
+
     def export(self, what: int):
         L.check(self._lib.csr_batch_export(self._ctx, int(what)))
 
@@ -167,7 +175,7 @@ class DeviceBatch:
     def download(self, chain: int, name: str) -> np.ndarray:
         n, d, m = self.chain_lens[chain], self.d, self.m
         shape = {"D": (n,), "xf": (n, d), "Pf": (n, d, d), "pnoise": (max(n - 1, 0), d, d), "xs": (n, d),
-                 "Ps": (n, d, d), "lag": (max(n - 1, 0), d, d), "resid": (n, m), "lambda": (n,), "kappa": (n,)}[name]
+                 "Ps": (n, d, d), "lag": (max(n - 1, 0), d, d), "resid": (n, m)}.get(name, (n,))
         out = np.empty(shape, np.float32)
         L.check(self._lib.csr_batch_download(self._ctx, chain, _ARR[name], out.ctypes.data_as(C.c_void_p)))
         return out

@@ -1556,4 +1556,90 @@ __global__ __launch_bounds__(256) void k_synth(Prm p, const float *latent, float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-interval output diagnostics (core.py:7734-7878).  Natural layout, one thread per bin: the
+// reference's per-bin Python loop carries no state (bin k uses the STORED float32 filtered covariance of bin k-1).
+// ---------------------------------------------------------------------------------------------------------------
+struct DiagArgs {
+    const float *Pf;        // natural (Npad, d*d) filtered covariance
+    const float *pn;        // natural (Npad, d*d) process noise, row k-1 entering bin k; nullptr = not used
+    const float *lam, *kap, *qs;        // natural (Npad) multipliers or nullptr
+    float *g0, *g1, *eql, *eqt, *trace;
+    const int64_t *chainOff, *chainLen;
+    int nchains, pad_;
+};
+__global__ __launch_bounds__(256) void k_diag_natural(Prm p, DiagArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.Npad) return;
+    int lo = 0, hi = a.nchains - 1;          // chain whose [off, off + padded len) holds g
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.chainOff[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int64_t k = g - a.chainOff[lo];
+    if (k >= a.chainLen[lo]) return;
+    if (p.chainActive != nullptr && !p.chainActive[lo]) return;
+    const double tiny = 2.2250738585072014e-308;
+    const int d = p.d, dd = d * d;
+    double lam = 1.0;
+    if (a.lam) lam = fmax(clampd((double)a.lam[g], p.wMin, p.wMax), tiny);
+    // R / lambda and lambda / R through one Newton-refined reciprocal per cell (<= 1 ulp from the IEEE quotient; the
+    // two fp64 divisions per cell otherwise make this HBM-streaming kernel compute-bound)
+    const double invLam = rcp_nr(lam);
+    double tr = 0.0, sInv = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < p.m; ++j) {
+        const double R = fmax((double)p.munc[(int64_t)j * p.Npad + g] + p.pad, 1.0e-12);
+        const double e = R * invLam, w = lam * rcp_nr(R);
+        if (isfinite(e)) tr += e;
+        if (isfinite(w)) sInv += w;
+    }
+    double qs = 1.0;
+    if (a.qs && k > 0) qs = fmax((double)a.qs[g], tiny);
+    double Q00 = p.Q00 * qs, Q01 = p.Q01 * qs, Q10 = p.Q10 * qs, Q11 = p.Q11 * qs;
+    if (a.kap) {
+        const double kp = fmax(clampd((double)a.kap[g], p.kMin, p.kMax), tiny);
+        Q00 /= kp; Q01 /= kp; Q10 /= kp; Q11 /= kp;
+    } else if (a.pn && k > 0) {
+        const float *q = a.pn + (g - 1) * dd;
+        if (d == 2) {
+            const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3)) { Q00 = q0; Q01 = q1; Q10 = q2; Q11 = q3; }
+        } else {
+            const double q0 = q[0];
+            if (isfinite(q0)) Q00 = q0;
+        }
+    }
+    double c00 = p.cinit, c01 = 0.0, c10 = 0.0, c11 = p.cinit;
+    if (k > 0) {
+        const float *c = a.Pf + (g - 1) * dd;
+        c00 = c[0];
+        if (d == 2) { c01 = c[1]; c10 = c[2]; c11 = c[3]; }
+    }
+    double pred00, pred10 = 0.0;
+    if (d == 2) {
+        // F P F^T + Q in float64 (core.py:7850)
+        const double t00 = p.F00 * c00 + p.F01 * c10, t01 = p.F00 * c01 + p.F01 * c11;
+        const double t10 = p.F10 * c00 + p.F11 * c10, t11 = p.F10 * c01 + p.F11 * c11;
+        pred00 = (t00 * p.F00 + t01 * p.F01) + Q00;
+        pred10 = (t10 * p.F00 + t11 * p.F01) + Q10;
+    } else {
+        pred00 = c00 + Q00;
+    }
+    pred00 = fmax(pred00, 0.0);
+    const double den = 1.0 + pred00 * sInv;
+    double g0 = 0.0, g1 = 0.0;
+    if (isfinite(den) && den > 0.0) {
+        const double sc = sInv / den;
+        g0 = pred00 * sc;
+        g1 = pred10 * sc;
+    }
+    a.g0[g] = (float)g0;
+    a.g1[g] = (float)g1;
+    a.eql[g] = (float)Q00;
+    a.eqt[g] = d == 2 ? (float)Q11 : 0.f;
+    a.trace[g] = (float)tr;
+}
+
 }  // namespace csr

@@ -90,6 +90,7 @@ struct csr_ctx {
     std::vector<void *> allocs;
     // device arrays not in Prm
     int64_t *dChainFirst = nullptr, *dChainNb = nullptr;
+    int64_t *dChainOff = nullptr, *dChainLen = nullptr;     // natural offset / length of every chain (bins)
     unsigned char *dActive = nullptr;
     float *dLatent = nullptr;
     float *nat[CSR_ARR_COUNT] = {nullptr};
@@ -443,6 +444,14 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     HIPOK(hipMemcpy(dbch, bch.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(c->dChainFirst, cf.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(c->dChainNb, cn.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
+    {
+        std::vector<int64_t> co(n_chains), cl(n_chains);
+        for (int i = 0; i < n_chains; ++i) { co[i] = c->chains[i].off; cl[i] = c->chains[i].n; }
+        CHECK(dalloc(c, &c->dChainOff, n_chains));
+        CHECK(dalloc(c, &c->dChainLen, n_chains));
+        HIPOK(hipMemcpy(c->dChainOff, co.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(c->dChainLen, cl.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
+    }
     HIPOK(hipMemset(c->dActive, 1, n_chains));
     p.blk = dblk; p.blkChain = dbch; p.chainActive = nullptr;
 
@@ -531,7 +540,8 @@ static int64_t arr_comps(csr_ctx *c, int id);
 static int64_t arr_comps_impl(csr_ctx *c, int id) {
     const int d = c->mdl.state_dim;
     switch (id) {
-        case CSR_ARR_D: case CSR_ARR_LAMBDA: case CSR_ARR_KAPPA: return 1;
+        case CSR_ARR_D: case CSR_ARR_LAMBDA: case CSR_ARR_KAPPA: case CSR_ARR_QSCALE: case CSR_ARR_SUMGAIN0:
+        case CSR_ARR_SUMGAIN1: case CSR_ARR_EFFQ_LEVEL: case CSR_ARR_EFFQ_TREND: case CSR_ARR_MUNCTRACE: return 1;
         case CSR_ARR_XF: case CSR_ARR_XS: return d;
         case CSR_ARR_RESID: return c->m;
         default: return d * d;
@@ -978,13 +988,6 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
 // ---------------------------------------------------------------------------------------------------------------
 // export / download
 // ---------------------------------------------------------------------------------------------------------------
-static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, int n, int skipLast) {
-    float *dst;
-    CHECK(nat_array(c, id, &dst));
-    ExpDesc &d = L.d[L.count++];
-    d.src = src; d.dst = dst; d.E = E; d.n = n; d.skipLast = skipLast; d.pad_ = 0;
-    return 0;
-}
 
 // Exports may be queued behind an optimistically validated pipeline: they are re-issued by settle() if it fails.
 extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
@@ -998,6 +1001,26 @@ extern "C" int csr_batch_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
     CHECK(need(c));
     if (!c->haveFwd) return fail("no forward results");
     return read_sums(c, sum_d, sum_nll);
+}
+
+static int flush_export(csr_ctx *c, ExpList &L) {
+    if (L.count == 0) return 0;
+    {
+        Scope sc(c, "export_natural");
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, c->p, L);
+    }
+    LAUNCH_CHECK("k_export_tiled");
+    L.count = 0;
+    return 0;
+}
+static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, int n, int skipLast) {
+    if (L.count == 8) CHECK(flush_export(c, L));       // one launch converts up to eight arrays
+    float *dst;
+    CHECK(nat_array(c, id, &dst));
+    ExpDesc &d = L.d[L.count++];
+    memset(&d, 0, sizeof(d));
+    d.src = src; d.dst = dst; d.E = E; d.n = n; d.skipLast = skipLast;
+    return 0;
 }
 
 static int export_impl(csr_ctx *c, uint32_t what) {
@@ -1030,15 +1053,11 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
     }
     if (what & CSR_EXPORT_MULT) {
-        if (L.count + 2 > 8) return fail("too many arrays in one export");
         CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
         CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));
+        CHECK(add_export(c, L, CSR_ARR_QSCALE, p.tQs, 1, 1, 0));
     }
-    if (L.count > 0) {
-        Scope sc(c, "export_natural");
-        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, c->p, L);
-        LAUNCH_CHECK("k_export_tiled");
-    }
+    CHECK(flush_export(c, L));
     if (what & CSR_EXPORT_RESID) {
         float *xs, *res;
         CHECK(nat_array(c, CSR_ARR_XS, &xs));
@@ -1281,6 +1300,83 @@ extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t 
     for (int i = 0; i < grid; ++i) { aL += part[i]; aT += part[grid + i]; }
     *sum_level = aL;
     *sum_trend = (d == 2) ? aT : 0.0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-interval output diagnostics (core.py:7734-7878)
+// ---------------------------------------------------------------------------------------------------------------
+static int launch_diag(csr_ctx *c, uint32_t flags, bool usePnoise) {
+    DiagArgs a;
+    memset(&a, 0, sizeof(a));
+    float *q;
+    CHECK(nat_array(c, CSR_ARR_PF, &q)); a.Pf = q;
+    if (usePnoise) { CHECK(nat_array(c, CSR_ARR_PNOISE, &q)); a.pn = q; }
+    if (flags & CSR_USE_LAMBDA) { CHECK(nat_array(c, CSR_ARR_LAMBDA, &q)); a.lam = q; }
+    if (flags & CSR_USE_KAPPA) { CHECK(nat_array(c, CSR_ARR_KAPPA, &q)); a.kap = q; }
+    if (flags & CSR_USE_QSCALE) { CHECK(nat_array(c, CSR_ARR_QSCALE, &q)); a.qs = q; }
+    CHECK(nat_array(c, CSR_ARR_SUMGAIN0, &a.g0));
+    CHECK(nat_array(c, CSR_ARR_SUMGAIN1, &a.g1));
+    CHECK(nat_array(c, CSR_ARR_EFFQ_LEVEL, &a.eql));
+    CHECK(nat_array(c, CSR_ARR_EFFQ_TREND, &a.eqt));
+    CHECK(nat_array(c, CSR_ARR_MUNCTRACE, &a.trace));
+    a.chainOff = c->dChainOff;
+    a.chainLen = c->dChainLen;
+    a.nchains = (int)c->chains.size();
+    Prm p = c->p;
+    p.chainActive = nullptr;
+    {
+        Scope sc(c, "diagnostics");
+        hipLaunchKernelGGL(k_diag_natural, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, p, a);
+    }
+    LAUNCH_CHECK("k_diag_natural");
+    return 0;
+}
+
+extern "C" int csr_batch_diagnostics(csr_ctx *c, uint32_t flags) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!c->haveFwd) return fail("no forward results: run csr_batch_forward / csr_batch_ecm first");
+    const uint32_t mult = flags & (CSR_USE_LAMBDA | CSR_USE_KAPPA | CSR_USE_QSCALE);
+    CHECK(export_impl(c, CSR_EXPORT_FORWARD | (mult ? CSR_EXPORT_MULT : 0u)));
+    return launch_diag(c, flags, !(flags & CSR_USE_KAPPA));
+}
+
+extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n, const float *Pf, const float *munc,
+                                      const float *lambda, const float *kappa, const float *qscale,
+                                      const float *pnoise, float *sum_gain0, float *sum_gain1, float *effq_level,
+                                      float *effq_trend, float *munc_trace) {
+    if (!mdl || !Pf || !munc || !sum_gain0 || !sum_gain1 || !effq_level || !effq_trend || !munc_trace)
+        return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(configure_single(c, mdl, m, n));
+    CHECK(settle(c));
+    const ChainInfo &ci = c->chains[0];
+    const int dd = mdl->state_dim * mdl->state_dim;
+    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.munc) + ci.off, sizeof(float) * c->Npad, munc, sizeof(float) * n,
+                           sizeof(float) * n, (size_t)m, hipMemcpyHostToDevice, c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    uint32_t flags = 0;
+    struct { const float *src; int id; int64_t comps, rows; uint32_t flag; } in[5] = {
+        {Pf, CSR_ARR_PF, dd, n, 0u}, {pnoise, CSR_ARR_PNOISE, dd, n - 1, 0u}, {lambda, CSR_ARR_LAMBDA, 1, n, CSR_USE_LAMBDA},
+        {kappa, CSR_ARR_KAPPA, 1, n, CSR_USE_KAPPA}, {qscale, CSR_ARR_QSCALE, 1, n, CSR_USE_QSCALE}};
+    for (auto &e : in) {
+        if (!e.src) continue;
+        flags |= e.flag;
+        float *dst;
+        CHECK(nat_array(c, e.id, &dst));
+        if (e.rows > 0)
+            HIPOK(hipMemcpyAsync(dst + ci.off * e.comps, e.src, sizeof(float) * e.comps * e.rows, hipMemcpyHostToDevice,
+                                 c->stream));
+    }
+    CHECK(launch_diag(c, flags, pnoise != nullptr && kappa == nullptr));
+    float *outs[5] = {sum_gain0, sum_gain1, effq_level, effq_trend, munc_trace};
+    const int ids[5] = {CSR_ARR_SUMGAIN0, CSR_ARR_SUMGAIN1, CSR_ARR_EFFQ_LEVEL, CSR_ARR_EFFQ_TREND, CSR_ARR_MUNCTRACE};
+    for (int k = 0; k < 5; ++k)
+        HIPOK(hipMemcpyAsync(outs[k], c->nat[ids[k]] + ci.off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -184,13 +184,19 @@ enum { /* arrays, reference (natural) layout */
     CSR_ARR_RESID,      /* (n,m)    */
     CSR_ARR_LAMBDA,     /* (n)      */
     CSR_ARR_KAPPA,      /* (n)      */
+    CSR_ARR_QSCALE,     /* (n)      process-noise scale (exported with CSR_EXPORT_MULT) */
+    CSR_ARR_SUMGAIN0,   /* (n)      diagnostics, see csr_batch_diagnostics */
+    CSR_ARR_SUMGAIN1,   /* (n)      */
+    CSR_ARR_EFFQ_LEVEL, /* (n)      */
+    CSR_ARR_EFFQ_TREND, /* (n)      */
+    CSR_ARR_MUNCTRACE,  /* (n)      */
     CSR_ARR_COUNT
 };
 enum {
     CSR_EXPORT_FORWARD = 1u << 0,   /* D, xf, Pf, pnoise */
     CSR_EXPORT_SMOOTH  = 1u << 1,   /* xs, Ps, lag */
     CSR_EXPORT_RESID   = 1u << 2,   /* resid */
-    CSR_EXPORT_MULT    = 1u << 3    /* lambda, kappa */
+    CSR_EXPORT_MULT    = 1u << 3    /* lambda, kappa, qscale */
 };
 /* Convert device-internal (block-transposed) results into reference-layout device arrays. */
 int csr_batch_export(csr_ctx *ctx, uint32_t what);
@@ -209,6 +215,23 @@ typedef struct csr_kernel_time {
 } csr_kernel_time;
 int csr_profile_enable(csr_ctx *ctx, int32_t on);          /* also clears accumulated times */
 int csr_profile_read(csr_ctx *ctx, csr_kernel_time *out, int32_t capacity, int32_t *n_out);
+
+/* ---- per-interval output diagnostics (core.py:7734-7878 `_perIntervalOutputDiagnosticTracks`,
+ * a per-bin Python loop in the reference) ---------------------------------------------------------------------------
+ * From the resident forward pass of every chain: sumGain0/1 (total Kalman gain on level / trend, re-derived from the
+ * STORED float32 filtered covariance of the previous bin exactly as the reference does), effectiveQLevel/Trend and
+ * muncTrace = sum_j max(v_j+pad,1e-12)/lambda.  flags: CSR_USE_LAMBDA / CSR_USE_KAPPA / CSR_USE_QSCALE select the
+ * resident multipliers (absent = None in the reference call); without CSR_USE_KAPPA the forward pass's own pNoise is
+ * the effective process noise (core.py:7826-7848).  Results: CSR_ARR_SUMGAIN0.. arrays (download / device_array).
+ * The five remaining reference tracks (baseQ*, preKappaQ*, processQScale) are O(1)-per-bin functions of Q0 and qScale
+ * and are formed by the host mirror. */
+int csr_batch_diagnostics(csr_ctx *ctx, uint32_t flags);
+/* Same on host buffers, shaped like the reference call (drop-in for core._perIntervalOutputDiagnosticTracks):
+ * Pf (n,d,d), munc (m,n); lambda / kappa / qscale / pnoise may be NULL (pnoise: (>=n-1,d,d)); outputs (n) float32. */
+int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n, const float *Pf, const float *munc,
+                           const float *lambda, const float *kappa, const float *qscale, const float *pnoise,
+                           float *sum_gain0, float *sum_gain1, float *effq_level, float *effq_trend,
+                           float *munc_trace);
 
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */

@@ -417,3 +417,107 @@ def test_ecm_is_silent_unless_logging(product, capfd):
                                 stateCovarInit=1.0, ECM_fixedBackgroundIters=2, logIterations=False)
     cap = capfd.readouterr()
     assert cap.out == "" and cap.err == ""
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# per-interval output diagnostics (core.py:7734-7878)
+# ---------------------------------------------------------------------------------------------------------------
+DIAG_KEYS = ("baseQLevel", "baseQTrend", "preKappaQLevel", "preKappaQTrend", "effectiveQLevel", "effectiveQTrend",
+             "processQScale", "muncTrace", "sumGain0", "sumGain1")
+
+
+def _diag_inputs(d, n, m, mode, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, d, d))
+    covar = (A @ A.transpose(0, 2, 1) * 0.01 + np.eye(d) * 0.02).astype(np.float32)
+    munc = (0.25 * np.exp(rng.normal(0, 0.4, (m, n)))).astype(np.float32)
+    munc[1 % m, 17 % n] = 1e30
+    munc[:, 40 % n] = 1e30
+    kw = dict(stateCovarForward=covar, matrixMunc=munc, matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+              matrixF=np.asarray([[1, 1], [0, 1]], np.float32), stateCovarInit=1000.0,
+              lambdaExp=np.exp(rng.normal(0, 1.0, n)).astype(np.float32),
+              processPrecExp=np.exp(rng.normal(0, 3.0, n)).astype(np.float32) if mode == "kappa" else None,
+              processQScale=np.exp(rng.normal(0, 0.3, n)).astype(np.float32) if mode != "plain" else None,
+              pNoiseForward=None, pad=1e-4, obsPrecisionMultiplierMin=0.25, obsPrecisionMultiplierMax=4.0,
+              procPrecisionMultiplierMin=5e-3, procPrecisionMultiplierMax=5e3)
+    if mode == "pnoise":
+        pn = np.zeros((n - 1, d, d), np.float32)
+        pn[:, 0, 0] = 1e-3 * np.exp(rng.normal(0, 0.5, n - 1))
+        if d == 2:
+            pn[:, 1, 1] = 1e-4
+        pn[5 % (n - 1), 0, 0] = np.nan
+        kw["pNoiseForward"] = pn
+    if mode == "plain":
+        kw["lambdaExp"] = None
+    return kw
+
+
+@pytest.mark.parametrize("d", [2, 1])
+@pytest.mark.parametrize("mode", ["kappa", "pnoise", "plain"])
+@pytest.mark.parametrize("n,m", [(3, 2), (257, 5), (100003, 8)])
+def test_output_diagnostics_match_oracle(d, mode, n, m):
+    from consenrich_amd import diagnostics as amd
+    from oracle import diagnostics as orc
+
+    kw = _diag_inputs(d, n, m, mode, 11 * d + n)
+    got = amd.perIntervalOutputDiagnosticTracks(stateModel="levelTrend" if d == 2 else "level", **kw)
+    ref = orc.output_diagnostic_tracks(state_dim=d, **kw)
+    assert set(got) == set(DIAG_KEYS)
+    for k in DIAG_KEYS:
+        assert got[k].dtype == np.float32 and got[k].shape == (n,)
+        np.testing.assert_allclose(got[k], ref[k], rtol=RTOL, atol=0, err_msg=k)
+
+
+def test_output_diagnostics_reference_known_answers():
+    """the literal case of the reference's tests/test_core.py:2632-2698 through the HIP path"""
+    from consenrich_amd import diagnostics as amd
+    from test_oracle_diagnostics import _known_answer_inputs
+
+    kw = _known_answer_inputs()
+    kw.pop("state_dim")
+    t = amd.perIntervalOutputDiagnosticTracks(stateModel="levelTrend", **kw)
+    np.testing.assert_allclose(t["effectiveQLevel"], [0.2, 0.2, 0.15], rtol=1e-6)
+    np.testing.assert_allclose(t["effectiveQTrend"], [0.05, 0.05, 0.0375], rtol=1e-6)
+    np.testing.assert_allclose(t["processQScale"], [1.0, 2.0, 3.0])
+    s0 = 1.0 + 1.0 / 1.2
+    assert t["sumGain0"][0] == pytest.approx(1.21 * s0 / (1.0 + 1.21 * s0), rel=1e-6)
+    assert t["sumGain1"][0] == pytest.approx(0.1 * s0 / (1.0 + 1.21 * s0), rel=1e-6)
+    with pytest.raises(ValueError, match="stateModel"):
+        amd.perIntervalOutputDiagnosticTracks(stateModel="bogus", **kw)
+
+
+def test_batch_diagnostics_from_resident_forward_pass(product):
+    """csr_batch_diagnostics on a ragged batch (multipliers resident, forward pass with kappa and without) equals the
+    oracle evaluated on the downloaded filter outputs."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from oracle import diagnostics as orc
+
+    n_list, m = [4097, 130, 64, 1, 999], 6
+    mp = ModelParams(state_dim=2, Q0=((1e-3, 0.0), (0.0, 1e-4)))
+    for flags in (L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE, 0):
+        with DeviceBatch(0) as b:
+            b.configure(mp, m, n_list)
+            ins = []
+            for c, n in enumerate(n_list):
+                data, munc = cases.synth(n, m, 900 + c, mask_frac=0.02, outlier_frac=0.01)
+                lam, kap, qs = cases.multipliers(n, 900 + c)
+                b.upload(c, data, munc)
+                b.upload_multipliers(c, lam, kap, qs)
+                ins.append((munc, lam, kap, qs))
+            b.stats()
+            b.forward(L.RETURN_NLL | flags)
+            b.diagnostics(flags)
+            for c, n in enumerate(n_list):
+                munc, lam, kap, qs = ins[c]
+                Pf, pn = b.download(c, "Pf"), b.download(c, "pnoise")
+                use = flags != 0
+                ref = orc.output_diagnostic_tracks(
+                    stateCovarForward=Pf, matrixMunc=munc, matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+                    matrixF=np.asarray(cases.F_TREND, np.float32), stateCovarInit=mp.state_covar_init, state_dim=2,
+                    lambdaExp=lam if use else None, processPrecExp=kap if use else None,
+                    processQScale=qs if use else None, pNoiseForward=None if use else pn, pad=mp.pad,
+                    obsPrecisionMultiplierMin=mp.lambda_bounds[0], obsPrecisionMultiplierMax=mp.lambda_bounds[1],
+                    procPrecisionMultiplierMin=mp.kappa_bounds[0], procPrecisionMultiplierMax=mp.kappa_bounds[1])
+                for k in ("sumGain0", "sumGain1", "effectiveQLevel", "effectiveQTrend", "muncTrace"):
+                    np.testing.assert_allclose(b.download(c, k), ref[k], rtol=RTOL, atol=0, err_msg=f"{flags} {c} {k}")
