@@ -93,6 +93,9 @@ SYMBOLS = {
     "csr_batch_forward_backward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
     "csr_batch_sums": (C.c_int, [C.c_void_p, DP, DP]),
     "csr_batch_diagnostics": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "csr_solve_background": (C.c_int, [C.c_int32, I64P, DP, DP, C.c_double, C.c_double, C.c_int32, C.c_int32, DP, I64P,
+                                       DP]),
+    "csr_background_weighted_stats": (C.c_int, [C.c_int64, C.c_int64, FP, FP, DP, DP, I64P]),
     "csr_output_diagnostics": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, FP, FP, FP,
                                          FP]),
     "csr_batch_ecm": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.POINTER(EcmOut), DP]),

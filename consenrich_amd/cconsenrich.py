@@ -531,3 +531,74 @@ def cExpectedTransitionResidualSums(stateSmoothed, stateCovarSmoothed, lagCovSmo
 def cExpectedTransitionResidualSumsLevel(stateSmoothed, stateCovarSmoothed, lagCovSmoothed):
     """Scalar level-model variant (pyx:818-863) on the GPU."""
     return _tsums(1, stateSmoothed, stateCovarSmoothed, lagCovSmoothed, None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 1: natives of the background update (pyx:944-1096, pyx:9700-9724)
+# ------------------------------------------------------------------------------------------------------------------
+def _bad_pivot(index, value):
+    return RuntimeError("roughness-penalized LDL factorization required pivot "
+                        f"modification at index {int(index)} (pivot={float(value):.6g}, floor={1.0e-12:.6g}).")
+
+
+def solveBackgroundBatch(weightTracks, rhsTracks, lam, zeroCenter=True, lamFirst=0.0, blockLen=0):
+    """Many independent chains (chromosomes) in ONE device pass: lists of float64 vectors -> list of solutions.
+    Same system and error behaviour per chain as `csolveZeroCenteredBackground`."""
+    ws = [np.ascontiguousarray(w, dtype=np.float64).reshape(-1) for w in weightTracks]
+    rs = [np.ascontiguousarray(r, dtype=np.float64).reshape(-1) for r in rhsTracks]
+    if len(ws) != len(rs) or any(w.shape != r.shape for w, r in zip(ws, rs)):
+        raise ValueError("weightTrack and rhsTrack must have the same length")
+    if not np.isfinite(lamFirst) or lamFirst < 0.0:
+        raise ValueError("lamFirst must be finite and nonnegative")
+    if not np.isfinite(lam) or lam < 0.0:
+        raise ValueError("lam must be finite and nonnegative")
+    outs = [np.zeros(w.shape[0]) for w in ws]
+    live = [i for i, w in enumerate(ws) if w.shape[0] > 0]
+    if not live:
+        return outs
+    L.require_gpu()
+    n = np.asarray([ws[i].shape[0] for i in live], np.int64)
+    wcat, rcat = np.concatenate([ws[i] for i in live]), np.concatenate([rs[i] for i in live])
+    out = np.zeros(wcat.shape[0])
+    bad_i, bad_v = np.full(len(live), -1, np.int64), np.zeros(len(live))
+    L.check(L.lib().csr_solve_background(len(live), n.ctypes.data_as(L.I64P), L.dp(wcat), L.dp(rcat), float(lam),
+                                         float(lamFirst), int(bool(zeroCenter)), int(blockLen), L.dp(out),
+                                         bad_i.ctypes.data_as(L.I64P), L.dp(bad_v)))
+    for k in range(len(live)):
+        if bad_i[k] >= 0:
+            raise _bad_pivot(bad_i[k], bad_v[k])
+    pos = 0
+    for k, i in enumerate(live):
+        outs[i] = out[pos: pos + n[k]].copy()
+        pos += int(n[k])
+    return outs
+
+
+def csolveZeroCenteredBackground(weightTrack, rhsTrack, lam, zeroCenter=True, lamFirst=0.0):
+    """pyx:944-1096.  float64 vectors in, float64 solution out; RuntimeError when a pivot had to be raised to 1e-12."""
+    w = np.asarray(weightTrack)
+    r = np.asarray(rhsTrack)
+    for a, name in ((w, "weightTrack"), (r, "rhsTrack")):
+        if a.dtype != np.float64 or a.ndim != 1:
+            raise ValueError(f"Buffer dtype mismatch or wrong number of dimensions for {name} (expected 1-D float64)")
+    if r.shape[0] != w.shape[0]:
+        raise ValueError("weightTrack and rhsTrack must have the same length")
+    return solveBackgroundBatch([w], [r], lam, zeroCenter, lamFirst)[0]
+
+
+def cbackgroundWeightedStatsWithSupport(residualMatrix, invVarMatrix):
+    """pyx:9700-9724: (weightTrack, rhsTrack, supportCount)."""
+    res = np.ascontiguousarray(residualMatrix, dtype=np.float32)
+    inv = np.ascontiguousarray(invVarMatrix, dtype=np.float32)
+    if res.ndim != 2 or inv.ndim != 2 or inv.shape[0] != res.shape[0] or inv.shape[1] != res.shape[1]:
+        raise ValueError("residualMatrix and invVarMatrix must have identical 2D shapes")
+    m, n = res.shape
+    w, r = np.empty(n), np.empty(n)
+    if n == 0 or m == 0:
+        w[:] = 0.0
+        r[:] = 0.0
+        return w, r, 0
+    L.require_gpu()
+    sup = C.c_int64(0)
+    L.check(L.lib().csr_background_weighted_stats(m, n, L.fp(res), L.fp(inv), L.dp(w), L.dp(r), C.byref(sup)))
+    return w, r, int(sup.value)

@@ -1,0 +1,346 @@
+// csr_background.h -- SURVEY 8(f) rank 1: the native pieces of the background update between ECM phases
+// (reference: cconsenrich.pyx:944-1096 `csolveZeroCenteredBackground`, pyx:9700-9724
+// `cbackgroundWeightedStatsWithSupport`; callers core.py:5064-5137, 7531-7589, 8085-8378).
+//
+// The reference factorises the pentadiagonal SPD system  (diag(w) + lamF D1'D1 + lam D2'D2) x = r  of one chromosome
+// with a sequential LDL' (1.2 M dependent steps).  Its Green's function decays over thousands of bins for the default
+// penalties (span 750 bins: an overlap of 8000 bins still leaves 5e-4), so windowed / speculative variants do not
+// pay.  Here the system is solved EXACTLY by a two-level partition (domain decomposition with 2-bin separators):
+//
+//   * every chain is cut into blocks of Bp bins; the last two bins of a block (all but the chain's last block) form a
+//     separator S_k, the rest is the interior I_k.  Bandwidth 2 => interiors are mutually decoupled given the
+//     separators.
+//   * k_bg_local (one lane per interior, 64 interiors per wavefront, blocked-transposed storage => coalesced rows):
+//     LDL' of A[I_k,I_k] with the reference's own recurrence and pivot floor, forward/back substitution of the data
+//     column(s) and of the four coupling columns A[I_k, S_{k-1} u S_k]; emits the 4x4 Schur contribution
+//     T_k = C_k' A_II^-1 C_k, t_k = C_k' A_II^-1 r and keeps the solution columns.
+//   * k_bg_reduced (one lane per chain): block-tridiagonal (2x2 blocks) elimination over the separators.
+//   * k_bg_combine (one thread per bin): x_I = A_II^-1 r - (A_II^-1 C) x_S, written in natural order.
+//   * k_bg_center (zero-sum Lagrange correction, pyx:1086-1096) when requested.
+//
+// All arithmetic is fp64 with IEEE division.  A single-block chain (n < 2 Bp) degenerates to the reference's own
+// recurrence on one lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csr {
+
+struct BgPrm {
+    int nchains, Bp, SB, NR;            // SB: rows allocated per 64-block group (>= longest block); NR: 1 or 2 columns
+    int64_t NBk, NGk;                   // blocks, groups of 64 blocks
+    double lam, lamF;
+    const int64_t *chainOff, *chainLen, *chainFirstBlk, *chainNumBlk;
+    const int4 *blk;                    // x: natural index of the block's first bin, y: length, z: chain, w: 1 = has separator
+    const double *w, *rhs;              // natural, concatenated chains
+    double *invd, *l1;                  // blocked (NGk*SB*64)
+    double *X[6];                       // blocked solution columns: data [, ones], L0, L1, R0, R1 (slots NR..NR+3)
+    double *T, *t;                      // per block: 16, 4*NR
+    double *sepMinv, *sepG;             // per block (its separator): 3, 2*NR  (sepG becomes x_S)
+    int64_t *badIdx;                    // per block: first modified pivot (chain-local index) or -1
+    double *badVal;
+    int64_t *chainBadIdx;               // per chain
+    double *chainBadVal;
+    double *out0, *out1;                // natural solutions (data, ones)
+    double *chainMu;
+};
+
+__device__ __forceinline__ int64_t bgidx(const BgPrm &p, int64_t kb, int s) {
+    return (((kb >> 6) * (int64_t)p.SB + s) << 6) + (kb & 63);
+}
+// stencil of A for a chain of n bins (pyx:905-941)
+__device__ __forceinline__ double bg_pen_diag(int64_t n, int64_t i, double lam, double lamF) {
+    double v = 0.0;
+    if (n >= 2 && lamF > 0.0) v += (i == 0 || i == n - 1) ? lamF : 2.0 * lamF;
+    if (n >= 3 && lam > 0.0) {
+        if (n == 3) v += (i == 1) ? 4.0 * lam : lam;
+        else if (i == 0 || i == n - 1) v += lam;
+        else if (i == 1 || i == n - 2) v += 5.0 * lam;
+        else v += 6.0 * lam;
+    }
+    return v;
+}
+__device__ __forceinline__ double bg_off1(int64_t n, int64_t i, double lam, double lamF) {   // A[i, i+1]
+    double v = (n >= 2 && lamF > 0.0) ? -lamF : 0.0;
+    if (n >= 3 && lam > 0.0) v += (n == 3 || i == 0 || i == n - 2) ? -2.0 * lam : -4.0 * lam;
+    return v;
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
+    const int64_t kb = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (kb >= p.NBk) return;
+    const int4 bi = p.blk[kb];
+    const int64_t off = p.chainOff[bi.z], n = p.chainLen[bi.z];
+    const int64_t a = (int64_t)bi.x - off;             // chain-local index of the first interior bin
+    const int L = bi.y - (bi.w ? 2 : 0);               // interior length (>= 2 unless the chain itself is shorter)
+    const bool hasL = a > 0, hasR = bi.w != 0;
+    const double lam = p.lam, lamF = p.lamF, floor_ = 1.0e-12;
+    const double *w = p.w + off, *r = p.rhs + off;
+    int64_t bad = -1;
+    double badv = 0.0;
+    constexpr int NC = NR + 2;                         // dense columns of the forward pass: data[, ones], L0, L1
+    double y1[NC], y2[NC];                             // y_{s-1}, y_{s-2} (before the division by d)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) { y1[j] = 0.0; y2[j] = 0.0; }
+    double d1 = 1.0, d2 = 1.0, l1p = 0.0;              // d_{s-1}, d_{s-2}, l1_{s-1}
+    const double cL0_0 = hasL ? lam : 0.0;                                   // A[a, a-2]
+    const double cL1_0 = hasL ? bg_off1(n, a - 1, lam, lamF) : 0.0;          // A[a, a-1]
+    const double cL1_1 = hasL ? lam : 0.0;                                   // A[a+1, a-1]
+    for (int s = 0; s < L; ++s) {
+        const int64_t i = a + s;
+        double dg = w[i] + bg_pen_diag(n, i, lam, lamF);
+        if (dg < floor_) { if (bad < 0) { bad = i; badv = dg; } dg = floor_; }      // pyx:1031-1035
+        double c[NC];
+        c[0] = r[i];
+        if (NR == 2) c[1] = 1.0;
+        c[NR] = s == 0 ? cL0_0 : 0.0;
+        c[NR + 1] = s == 0 ? cL1_0 : (s == 1 ? cL1_1 : 0.0);
+        double l1 = 0.0, d = dg;
+        if (s == 1) {
+            l1 = bg_off1(n, i - 1, lam, lamF) / d1;                                 // pyx:1042-1043
+            d = dg - l1 * l1 * d1;
+        } else if (s >= 2) {
+            l1 = (bg_off1(n, i - 1, lam, lamF) - lam * l1p) / d1;                   // pyx:1052-1058
+            d = dg - l1 * l1 * d1 - (lam * lam) / d2;
+        }
+        if (s >= 1 && d < floor_) { if (bad < 0) { bad = i; badv = d; } d = floor_; }
+        const double l2 = s >= 2 ? lam / d2 : 0.0;
+        const int64_t q = bgidx(p, kb, s);
+        p.invd[q] = 1.0 / d;
+        p.l1[q] = l1;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            double y = c[j];
+            if (s >= 1) y -= l1 * y1[j];
+            if (s >= 2) y -= l2 * y2[j];
+            y2[j] = y1[j];
+            y1[j] = y;
+            p.X[j][q] = y / d;                                                       // pyx:1074-1076
+        }
+        d2 = d1; d1 = d; l1p = l1;
+    }
+    // right coupling columns: nonzero only in the last two interior rows
+    //   R0 (bin a+L):   A[a+L-2, a+L] = lam, A[a+L-1, a+L] = off1(a+L-1);   R1 (bin a+L+1): A[a+L-1, a+L+1] = lam
+    const double offR = hasR ? bg_off1(n, a + L - 1, lam, lamF) : 0.0;
+    const double lamR = hasR ? lam : 0.0;
+    // ---- back substitution (pyx:1079-1084) of all columns; z = y/d is stored, x overwrites it
+    constexpr int NX = NR + 4;
+    double x1[NX], x2[NX];                             // x_{s+1}, x_{s+2}
+    double xe[NX], xe1[NX];                            // x_{L-1}, x_{L-2}
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { x1[j] = 0.0; x2[j] = 0.0; xe[j] = 0.0; xe1[j] = 0.0; }
+    double l1n = 0.0;                                  // l1_{s+1}
+    for (int s = L - 1; s >= 0; --s) {
+        const int64_t q = bgidx(p, kb, s);
+        const double invd = p.invd[q];
+        const double l2n = lam * invd;                 // l2_{s+2} = lam / d_s
+        double z[NX];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) z[j] = p.X[j][q];
+        // forward-substituted right columns: y_{L-2} = c_{L-2}, y_{L-1} = c_{L-1} - l1_{L-1} y_{L-2}
+        z[NR + 2] = 0.0; z[NR + 3] = 0.0;
+        if (L >= 2) {
+            if (s == L - 2) z[NR + 2] = lamR * invd;
+            if (s == L - 1) { z[NR + 2] = (offR - p.l1[q] * lamR) * invd; z[NR + 3] = lamR * invd; }
+        } else if (s == L - 1) {                       // one-bin interior (only in chains shorter than a block)
+            z[NR + 2] = offR * invd; z[NR + 3] = lamR * invd;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double x = z[j];
+            if (s + 1 < L) x -= l1n * x1[j];
+            if (s + 2 < L) x -= l2n * x2[j];
+            x2[j] = x1[j];
+            x1[j] = x;
+            p.X[j][q] = x;
+            if (s == L - 1) xe[j] = x;
+            if (s == L - 2) xe1[j] = x;
+        }
+        l1n = p.l1[q];
+    }
+    // x1 = x_0, x2 = x_1 (if L >= 2).  Schur contributions: rows of C' = [L0, L1, R0, R1]
+    double *T = p.T + kb * 16, *t = p.t + kb * 4 * NR;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const double X0 = x1[j], X1 = L >= 2 ? x2[j] : 0.0, Xe = xe[j], Xe1 = L >= 2 ? xe1[j] : 0.0;
+        const double rowL0 = cL0_0 * X0;
+        const double rowL1 = cL1_0 * X0 + cL1_1 * X1;
+        const double rowR0 = lamR * Xe1 + offR * Xe;
+        const double rowR1 = lamR * Xe;
+        if (j < NR) {
+            t[j * 4 + 0] = rowL0; t[j * 4 + 1] = rowL1; t[j * 4 + 2] = rowR0; t[j * 4 + 3] = rowR1;
+        } else {
+            const int cidx = j - NR;
+            T[0 * 4 + cidx] = rowL0; T[1 * 4 + cidx] = rowL1; T[2 * 4 + cidx] = rowR0; T[3 * 4 + cidx] = rowR1;
+        }
+    }
+    p.badIdx[kb] = bad;
+    p.badVal[kb] = badv;
+}
+
+// Block-tridiagonal elimination over the separators of one chain (2x2 blocks), one lane per chain.
+template <int NR>
+__global__ __launch_bounds__(64) void k_bg_reduced(BgPrm p) {
+    const int c = blockIdx.x;
+    if (threadIdx.x != 0 || c >= p.nchains) return;
+    const int64_t kb0 = p.chainFirstBlk[c], K = p.chainNumBlk[c];
+    const int64_t off = p.chainOff[c], n = p.chainLen[c];
+    const double lam = p.lam, lamF = p.lamF, floor_ = 1.0e-12;
+    int64_t bad = -1;
+    double badv = 0.0;
+    for (int64_t k = 0; k < K; ++k)
+        if (p.badIdx[kb0 + k] >= 0) { bad = p.badIdx[kb0 + k]; badv = p.badVal[kb0 + k]; break; }
+    const double *w = p.w + off, *r = p.rhs + off;
+    double Mi00 = 0, Mi01 = 0, Mi11 = 0;               // inverse of the previous pivot block
+    double gp[2 * NR];
+    double U[4] = {0, 0, 0, 0};                        // coupling S_{s-1} (rows) -- S_s (cols)
+    for (int64_t s = 0; s + 1 < K; ++s) {
+        const int64_t kb = kb0 + s;
+        const int4 bi = p.blk[kb];
+        const int64_t b = (int64_t)bi.x - off + bi.y - 2;       // chain-local index of the separator's first bin
+        const double *Tk = p.T + kb * 16, *Tn = p.T + (kb + 1) * 16;
+        double dg0 = w[b] + bg_pen_diag(n, b, lam, lamF), dg1 = w[b + 1] + bg_pen_diag(n, b + 1, lam, lamF);
+        if (dg0 < floor_) { if (bad < 0 || b < bad) { bad = b; badv = dg0; } dg0 = floor_; }
+        if (dg1 < floor_) { if (bad < 0 || b + 1 < bad) { bad = b + 1; badv = dg1; } dg1 = floor_; }
+        double M00 = dg0 - Tk[2 * 4 + 2] - Tn[0 * 4 + 0];
+        double M01 = bg_off1(n, b, lam, lamF) - Tk[2 * 4 + 3] - Tn[0 * 4 + 1];
+        double M11 = dg1 - Tk[3 * 4 + 3] - Tn[1 * 4 + 1];
+        double g[2 * NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const double *tk = p.t + kb * 4 * NR + j * 4, *tn = p.t + (kb + 1) * 4 * NR + j * 4;
+            g[2 * j] = (j == 0 ? r[b] : 1.0) - tk[2] - tn[0];
+            g[2 * j + 1] = (j == 0 ? r[b + 1] : 1.0) - tk[3] - tn[1];
+        }
+        if (s > 0) {
+            // M -= U' Minv U ;  g -= U' Minv g_prev
+            const double a00 = Mi00 * U[0] + Mi01 * U[2], a01 = Mi00 * U[1] + Mi01 * U[3];
+            const double a10 = Mi01 * U[0] + Mi11 * U[2], a11 = Mi01 * U[1] + Mi11 * U[3];
+            M00 -= U[0] * a00 + U[2] * a10;
+            M01 -= U[0] * a01 + U[2] * a11;
+            M11 -= U[1] * a01 + U[3] * a11;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const double h0 = Mi00 * gp[2 * j] + Mi01 * gp[2 * j + 1], h1 = Mi01 * gp[2 * j] + Mi11 * gp[2 * j + 1];
+                g[2 * j] -= U[0] * h0 + U[2] * h1;
+                g[2 * j + 1] -= U[1] * h0 + U[3] * h1;
+            }
+        }
+        // 2x2 LDL' pivots with the reference's floor
+        double p0 = M00;
+        if (p0 < floor_) { if (bad < 0 || b < bad) { bad = b; badv = p0; } p0 = floor_; }
+        const double l = M01 / p0;
+        double p1 = M11 - l * l * p0;
+        if (p1 < floor_) { if (bad < 0 || b + 1 < bad) { bad = b + 1; badv = p1; } p1 = floor_; }
+        Mi11 = 1.0 / p1;
+        Mi01 = -l * Mi11;
+        Mi00 = 1.0 / p0 + l * l * Mi11;
+        p.sepMinv[kb * 3 + 0] = Mi00; p.sepMinv[kb * 3 + 1] = Mi01; p.sepMinv[kb * 3 + 2] = Mi11;
+#pragma unroll
+        for (int j = 0; j < 2 * NR; ++j) { p.sepG[kb * 2 * NR + j] = g[j]; gp[j] = g[j]; }
+        // coupling to the next separator through interior k+1:  U = -T_{k+1}[L, R]
+        U[0] = -Tn[0 * 4 + 2]; U[1] = -Tn[0 * 4 + 3]; U[2] = -Tn[1 * 4 + 2]; U[3] = -Tn[1 * 4 + 3];
+    }
+    // back substitution: x_s = Minv_s (g_s - U_s x_{s+1})
+    double xn[2 * NR];
+#pragma unroll
+    for (int j = 0; j < 2 * NR; ++j) xn[j] = 0.0;
+    for (int64_t s = K - 2; s >= 0; --s) {
+        const int64_t kb = kb0 + s;
+        const double *Tn = p.T + (kb + 1) * 16;
+        const double u0 = -Tn[0 * 4 + 2], u1 = -Tn[0 * 4 + 3], u2 = -Tn[1 * 4 + 2], u3 = -Tn[1 * 4 + 3];
+        const double m00 = p.sepMinv[kb * 3], m01 = p.sepMinv[kb * 3 + 1], m11 = p.sepMinv[kb * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double g0 = p.sepG[kb * 2 * NR + 2 * j], g1 = p.sepG[kb * 2 * NR + 2 * j + 1];
+            if (s + 2 < K) {
+                g0 -= u0 * xn[2 * j] + u1 * xn[2 * j + 1];
+                g1 -= u2 * xn[2 * j] + u3 * xn[2 * j + 1];
+            }
+            const double x0 = m00 * g0 + m01 * g1, x1 = m01 * g0 + m11 * g1;
+            p.sepG[kb * 2 * NR + 2 * j] = x0;
+            p.sepG[kb * 2 * NR + 2 * j + 1] = x1;
+            xn[2 * j] = x0; xn[2 * j + 1] = x1;
+        }
+    }
+    p.chainBadIdx[c] = bad;
+    p.chainBadVal[c] = badv;
+}
+
+// x_I = A_II^-1 r - (A_II^-1 C) x_S ; separators copy their own solution.  One thread per blocked slot.
+template <int NR>
+__global__ __launch_bounds__(256) void k_bg_combine(BgPrm p) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / p.SB;
+    const int s = (int)(row - G * p.SB);
+    const int64_t kb = G * 64 + lane;
+    if (G >= p.NGk || kb >= p.NBk) return;
+    const int4 bi = p.blk[kb];
+    if (s >= bi.y) return;
+    const int L = bi.y - (bi.w ? 2 : 0);
+    const int64_t g = (int64_t)bi.x + s;
+    const bool hasL = (int64_t)bi.x > p.chainOff[bi.z];
+    double *outs[2] = {p.out0, p.out1};
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        double x;
+        if (s < L) {
+            const int64_t q = bgidx(p, kb, s);
+            x = p.X[j][q];
+            if (hasL) {
+                const double *xs = p.sepG + (kb - 1) * 2 * NR + 2 * j;
+                x -= p.X[NR][q] * xs[0] + p.X[NR + 1][q] * xs[1];
+            }
+            if (bi.w) {
+                const double *xs = p.sepG + kb * 2 * NR + 2 * j;
+                x -= p.X[NR + 2][q] * xs[0] + p.X[NR + 3][q] * xs[1];
+            }
+        } else {
+            x = p.sepG[kb * 2 * NR + 2 * j + (s - L)];
+        }
+        outs[j][g] = x;
+    }
+}
+
+// zero-sum Lagrange correction (pyx:1086-1096): one workgroup per chain, fixed-shape reduction
+__global__ __launch_bounds__(1024) void k_bg_center(BgPrm p) {
+    __shared__ double sr[1024], sc[1024];
+    const int c = blockIdx.x;
+    const int64_t off = p.chainOff[c], n = p.chainLen[c];
+    double ar = 0.0, ac = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { ar += p.out0[off + i]; ac += p.out1[off + i]; }
+    sr[threadIdx.x] = ar; sc[threadIdx.x] = ac;
+    __syncthreads();
+    for (int wd = 512; wd > 0; wd >>= 1) {
+        if ((int)threadIdx.x < wd) { sr[threadIdx.x] += sr[threadIdx.x + wd]; sc[threadIdx.x] += sc[threadIdx.x + wd]; }
+        __syncthreads();
+    }
+    const double mu = fabs(sc[0]) > 1.0e-12 ? sr[0] / sc[0] : sr[0] / (double)n;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) p.out0[off + i] -= mu * p.out1[off + i];
+    if (threadIdx.x == 0) p.chainMu[c] = mu;
+}
+
+// pyx:9700-9724: weight = sum_j invVar, rhs = sum_j invVar * resid (fp64 over float32 matrices), natural (m, n)
+__global__ __launch_bounds__(256) void k_bg_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv,
+                                                           double *weight, double *rhs, unsigned long long *support) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool pos = false;
+    if (i < n) {
+        double ws = 0.0, rs = 0.0;
+        for (int64_t j = 0; j < m; ++j) {
+            const double w = (double)inv[j * n + i];
+            ws += w;
+            rs += w * (double)resid[j * n + i];
+        }
+        weight[i] = ws;
+        rhs[i] = rs;
+        pos = ws > 0.0;
+    }
+    const unsigned long long bal = __ballot(pos);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(support, (unsigned long long)__popcll(bal));
+}
+
+}  // namespace csr

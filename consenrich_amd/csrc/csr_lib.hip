@@ -3,6 +3,7 @@
 // point fails loudly.
 #include "../../include/consenrich_amd.h"
 #include "csr_device.h"
+#include "csr_background.h"
 
 #include <algorithm>
 #include <cmath>
@@ -303,7 +304,8 @@ static void prof_collect(csr_ctx *c) {
     }
 }
 extern "C" int csr_profile_enable(csr_ctx *c, int32_t on) {
-    if (!c) return fail("null context");
+    if (!c) c = default_ctx();      // NULL addresses the default context of the host-buffer entry points
+    if (!c) return -1;
     CHECK(ctx_select(c));
     prof_collect(c);
     c->prof.clear();
@@ -311,7 +313,8 @@ extern "C" int csr_profile_enable(csr_ctx *c, int32_t on) {
     return 0;
 }
 extern "C" int csr_profile_read(csr_ctx *c, csr_kernel_time *out, int32_t capacity, int32_t *n_out) {
-    if (!c) return fail("null context");
+    if (!c) c = default_ctx();
+    if (!c) return -1;
     CHECK(ctx_select(c));
     prof_collect(c);
     int32_t k = 0;
@@ -1377,6 +1380,176 @@ extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n
     for (int k = 0; k < 5; ++k)
         HIPOK(hipMemcpyAsync(outs[k], c->nat[ids[k]] + ci.off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// background update natives (pyx:944-1096, 9700-9724)
+// ---------------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (ptr) hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+};
+static DevBuf g_bgBuf;      // work space of the background solver (default context's device), grown on demand
+
+template <int NR>
+static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
+    {
+        Scope sc(c, "bg_local");
+        hipLaunchKernelGGL(k_bg_local<NR>, dim3((int)p.NGk), dim3(64), 0, c->stream, p);
+    }
+    {
+        Scope sc(c, "bg_reduced");
+        hipLaunchKernelGGL(k_bg_reduced<NR>, dim3(p.nchains), dim3(64), 0, c->stream, p);
+    }
+    {
+        Scope sc(c, "bg_combine");
+        hipLaunchKernelGGL(k_bg_combine<NR>, dim3((int)((p.NGk * p.SB * 64 + 255) / 256)), dim3(256), 0, c->stream, p);
+    }
+    if (center) {
+        Scope sc(c, "bg_center");
+        hipLaunchKernelGGL(k_bg_center, dim3(p.nchains), dim3(1024), 0, c->stream, p);
+    }
+}
+
+extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weight, const double *rhs,
+                                    double lam, double lam_first, int32_t zero_center, int32_t block_len, double *out,
+                                    int64_t *bad_index, double *bad_value) {
+    if (n_chains <= 0 || !n || !weight || !rhs || !out) return fail("null / empty argument");
+    if (!std::isfinite(lam_first) || lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
+    if (!std::isfinite(lam) || lam < 0.0) return fail("lam must be finite and nonnegative");
+    int Bp = block_len > 0 ? block_len : 1024;
+    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
+    if (Bp < 8) return fail("block_len must be at least 8");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    // partition
+    std::vector<int64_t> off(n_chains), first(n_chains), nblk(n_chains), len(n, n + n_chains);
+    std::vector<int4> blk;
+    int64_t N = 0;
+    for (int i = 0; i < n_chains; ++i) {
+        if (n[i] <= 0) return fail("chain %d is empty", i);
+        off[i] = N;
+        int64_t K = (n[i] + Bp - 1) / Bp;
+        if (K > 1 && n[i] - (K - 1) * Bp < 4) K -= 1;         // the last block absorbs a remainder shorter than 4 bins
+        first[i] = (int64_t)blk.size();
+        nblk[i] = K;
+        for (int64_t k = 0; k < K; ++k) {
+            int4 b;
+            b.x = (int)(N + k * Bp);
+            b.y = (int)(k + 1 < K ? Bp : n[i] - (K - 1) * Bp);
+            b.z = i;
+            b.w = k + 1 < K ? 1 : 0;
+            blk.push_back(b);
+        }
+        N += n[i];
+        if (N >= ((int64_t)1 << 31)) return fail("batch too large");
+    }
+    const int NR = zero_center ? 2 : 1;
+    BgPrm p;
+    memset(&p, 0, sizeof(p));
+    p.nchains = n_chains; p.Bp = Bp; p.SB = Bp + 4; p.NR = NR;
+    p.NBk = (int64_t)blk.size();
+    p.NGk = (p.NBk + 63) / 64;
+    p.lam = lam; p.lamF = lam_first;
+    // carve the work buffer
+    const size_t TN = (size_t)p.NGk * p.SB * 64;
+    size_t need_ = 0;
+    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
+    const size_t oOff = take(8 * n_chains), oLen = take(8 * n_chains), oFirst = take(8 * n_chains), oNum = take(8 * n_chains);
+    const size_t oBlk = take(sizeof(int4) * blk.size());
+    const size_t oW = take(8 * N), oR = take(8 * N), oO0 = take(8 * N), oO1 = take(8 * N);
+    const size_t oInvd = take(8 * TN), oL1 = take(8 * TN);
+    size_t oX[6];
+    for (int j = 0; j < NR + 4; ++j) oX[j] = take(8 * TN);
+    const size_t oT = take(8 * 16 * blk.size()), ot = take(8 * 4 * NR * blk.size());
+    const size_t oMi = take(8 * 3 * blk.size()), oG = take(8 * 2 * NR * blk.size());
+    const size_t oBI = take(8 * blk.size()), oBV = take(8 * blk.size());
+    const size_t oCBI = take(8 * n_chains), oCBV = take(8 * n_chains), oMu = take(8 * n_chains);
+    CHECK(g_bgBuf.reserve(need_));
+    char *base = (char *)g_bgBuf.ptr;
+    p.chainOff = (const int64_t *)(base + oOff); p.chainLen = (const int64_t *)(base + oLen);
+    p.chainFirstBlk = (const int64_t *)(base + oFirst); p.chainNumBlk = (const int64_t *)(base + oNum);
+    p.blk = (const int4 *)(base + oBlk);
+    p.w = (const double *)(base + oW); p.rhs = (const double *)(base + oR);
+    p.out0 = (double *)(base + oO0); p.out1 = (double *)(base + oO1);
+    p.invd = (double *)(base + oInvd); p.l1 = (double *)(base + oL1);
+    for (int j = 0; j < NR + 4; ++j) p.X[j] = (double *)(base + oX[j]);
+    p.T = (double *)(base + oT); p.t = (double *)(base + ot);
+    p.sepMinv = (double *)(base + oMi); p.sepG = (double *)(base + oG);
+    p.badIdx = (int64_t *)(base + oBI); p.badVal = (double *)(base + oBV);
+    p.chainBadIdx = (int64_t *)(base + oCBI); p.chainBadVal = (double *)(base + oCBV); p.chainMu = (double *)(base + oMu);
+    HIPOK(hipMemcpyAsync(base + oOff, off.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oLen, len.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oFirst, first.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oNum, nblk.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oW, weight, 8 * N, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oR, rhs, 8 * N, hipMemcpyHostToDevice, c->stream));
+    if (NR == 2) launch_bg<2>(c, p, true);
+    else launch_bg<1>(c, p, false);
+    LAUNCH_CHECK("background solve");
+    std::vector<int64_t> cbi(n_chains);
+    std::vector<double> cbv(n_chains);
+    HIPOK(hipMemcpyAsync(out, p.out0, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(cbi.data(), p.chainBadIdx, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(cbv.data(), p.chainBadVal, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_chains; ++i) {
+        if (n[i] == 1) {                                   // pyx:1001-1011
+            out[off[i]] = 0.0;
+            cbi[i] = -1;
+            if (!zero_center) {
+                if (weight[off[i]] < 1.0e-12) { cbi[i] = 0; cbv[i] = weight[off[i]]; }
+                else out[off[i]] = rhs[off[i]] / weight[off[i]];
+            }
+        }
+        if (bad_index) bad_index[i] = cbi[i];
+        if (bad_value) bad_value[i] = cbi[i] >= 0 ? cbv[i] : 0.0;
+    }
+    return 0;
+}
+
+extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var,
+                                             double *weight, double *rhs, int64_t *support) {
+    if (!resid || !inv_var || !weight || !rhs || !support) return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const size_t mat = sizeof(float) * (size_t)m * n, vec = 8 * (size_t)n;
+    const size_t matA = (mat + 255) / 256 * 256, vecA = (vec + 255) / 256 * 256;
+    CHECK(g_bgBuf.reserve(2 * matA + 2 * vecA + 256));
+    char *base = (char *)g_bgBuf.ptr;
+    float *dr = (float *)base, *di = (float *)(base + matA);
+    double *dw = (double *)(base + 2 * matA), *dh = (double *)(base + 2 * matA + vecA);
+    unsigned long long *ds = (unsigned long long *)(base + 2 * matA + 2 * vecA);
+    HIPOK(hipMemcpyAsync(dr, resid, mat, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(di, inv_var, mat, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(ds, 0, 8, c->stream));
+    {
+        Scope sc(c, "bg_weighted_stats");
+        hipLaunchKernelGGL(k_bg_weighted_stats, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, m, n, dr, di, dw, dh, ds);
+    }
+    LAUNCH_CHECK("k_bg_weighted_stats");
+    unsigned long long sup = 0;
+    HIPOK(hipMemcpyAsync(weight, dw, vec, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(rhs, dh, vec, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(&sup, ds, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    *support = (int64_t)sup;
     return 0;
 }
 

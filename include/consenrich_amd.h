@@ -233,6 +233,21 @@ int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n, const flo
                            float *sum_gain0, float *sum_gain1, float *effq_level, float *effq_trend,
                            float *munc_trace);
 
+/* ---- natives of the background update between ECM phases ------------------------------------
+ * csr_solve_background replaces cconsenrich.csolveZeroCenteredBackground (pyx:944-1096) for a BATCH of independent
+ * chains: solves (diag(w) + lam_first D1'D1 + lam D2'D2) x = rhs per chain (pentadiagonal SPD, fp64), optionally with
+ * the zero-sum Lagrange correction.  weight / rhs / out: the chains' vectors concatenated (chain c has n[c] entries).
+ * The reference's sequential LDL' is replaced by an exact two-level partition (see csrc/csr_background.h);
+ * block_len = 0 picks the default partition size.  bad_index[c] (chain-local) / bad_value[c]: first pivot that had to be
+ * raised to the 1e-12 floor, or -1 -- the reference raises RuntimeError in that case; `out` is filled regardless. */
+int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weight, const double *rhs, double lam,
+                         double lam_first, int32_t zero_center, int32_t block_len, double *out, int64_t *bad_index,
+                         double *bad_value);
+/* cconsenrich.cbackgroundWeightedStatsWithSupport (pyx:9700-9724): weight[i] = sum_j inv_var[j,i],
+ * rhs[i] = sum_j inv_var[j,i]*resid[j,i] in fp64 over float32 (m,n) C-order matrices; *support = #{weight > 0}. */
+int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var, double *weight,
+                                  double *rhs, int64_t *support);
+
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */

@@ -9,6 +9,7 @@
 
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #define R32(x) ((double)(float)(x)) /* round-trip through float32: the reference's <double><float32_t> casts */
 
@@ -600,4 +601,118 @@ void cor_transition_sums(int32_t state_dim, int64_t n, const double *xs, const d
     }
     *sum_level = accL;
     *sum_trend = accT;
+}
+
+
+/* ================================================================================================================
+ * background update natives
+ * ================================================================================================================ */
+int64_t cor_background_stats(int64_t m, int64_t n, const float *resid, const float *inv_var, double *weight,
+                             double *rhs) { /* pyx:9712-9724 */
+    int64_t support = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double ws = 0.0, rs = 0.0;
+        for (int64_t j = 0; j < m; ++j) {
+            const double w = (double)inv_var[j * n + i];
+            ws += w;
+            rs += w * (double)resid[j * n + i];
+        }
+        weight[i] = ws;
+        rhs[i] = rs;
+        if (ws > 0.0) ++support;
+    }
+    return support;
+}
+
+/* penalty stencils: pyx:905-941 */
+static double pen2_diag(int64_t n, int64_t i, double lam) {
+    if (n < 3 || lam <= 0.0) return 0.0;
+    if (n == 3) return i == 1 ? 4.0 * lam : lam;
+    if (i == 0 || i == n - 1) return lam;
+    if (i == 1 || i == n - 2) return 5.0 * lam;
+    return 6.0 * lam;
+}
+static double pen2_off1(int64_t n, int64_t i, double lam) {
+    if (n < 3 || lam <= 0.0) return 0.0;
+    if (n == 3) return -2.0 * lam;
+    return (i == 0 || i == n - 2) ? -2.0 * lam : -4.0 * lam;
+}
+static double pen1_diag(int64_t n, int64_t i, double lam) {
+    if (n < 2 || lam <= 0.0) return 0.0;
+    return (i == 0 || i == n - 1) ? lam : 2.0 * lam;
+}
+static double pen1_off1(int64_t n, double lam) { return (n < 2 || lam <= 0.0) ? 0.0 : -lam; }
+
+int64_t cor_solve_background(int64_t n, const double *weight, const double *rhs_in, double lam, int zero_center,
+                             double lam_first, double *out, double *bad_value) {
+    const double floor_ = 1.0e-12;
+    int64_t bad = -1;
+    double badv = 0.0;
+    for (int64_t i = 0; i < n; ++i) out[i] = 0.0;
+    if (n <= 0) return -1;
+    if (n == 1) { /* pyx:1001-1011 */
+        if (!zero_center) {
+            const double den = weight[0];
+            if (den < floor_) {
+                if (bad_value) *bad_value = den;
+                return 0;
+            }
+            out[0] = rhs_in[0] / den;
+        }
+        return -1;
+    }
+    double *d = (double *)malloc(sizeof(double) * (size_t)n * 4);
+    double *r = d + n, *c = r + n, *l1 = c + n;
+#define CSR_FLOOR(i)                     \
+    if (d[i] < floor_) {                 \
+        if (bad < 0) { bad = (i); badv = d[i]; } \
+        d[i] = floor_;                   \
+    }
+    for (int64_t i = 0; i < n; ++i) { /* pyx:1026-1036 */
+        d[i] = weight[i] + pen1_diag(n, i, lam_first) + pen2_diag(n, i, lam);
+        r[i] = rhs_in[i];
+        c[i] = 1.0;
+        l1[i] = 0.0;
+        CSR_FLOOR(i)
+    }
+    /* factorisation, pyx:1041-1063: the second sub-diagonal of L is lam / d[i-2] */
+    double off = pen1_off1(n, lam_first) + pen2_off1(n, 0, lam);
+    l1[1] = off / d[0];
+    d[1] = d[1] - l1[1] * l1[1] * d[0];
+    CSR_FLOOR(1)
+    for (int64_t i = 2; i < n; ++i) {
+        off = pen1_off1(n, lam_first) + pen2_off1(n, i - 1, lam);
+        l1[i] = (off - lam * l1[i - 1]) / d[i - 1];
+        d[i] = d[i] - l1[i] * l1[i] * d[i - 1] - (lam * lam) / d[i - 2];
+        CSR_FLOOR(i)
+    }
+#undef CSR_FLOOR
+    /* forward substitution for the data right-hand side and for A^-1 1, pyx:1067-1072 */
+    r[1] = r[1] - l1[1] * r[0];
+    c[1] = c[1] - l1[1] * c[0];
+    for (int64_t i = 2; i < n; ++i) {
+        const double l2 = lam / d[i - 2];
+        r[i] = r[i] - l1[i] * r[i - 1] - l2 * r[i - 2];
+        c[i] = c[i] - l1[i] * c[i - 1] - l2 * c[i - 2];
+    }
+    for (int64_t i = 0; i < n; ++i) { r[i] = r[i] / d[i]; c[i] = c[i] / d[i]; } /* pyx:1074-1076 */
+    /* back substitution, pyx:1079-1084 */
+    r[n - 2] = r[n - 2] - l1[n - 1] * r[n - 1];
+    c[n - 2] = c[n - 2] - l1[n - 1] * c[n - 1];
+    for (int64_t i = n - 3; i >= 0; --i) {
+        const double l2 = lam / d[i];
+        r[i] = r[i] - l1[i + 1] * r[i + 1] - l2 * r[i + 2];
+        c[i] = c[i] - l1[i + 1] * c[i + 1] - l2 * c[i + 2];
+    }
+    if (zero_center) { /* pyx:1086-1096 */
+        double sr = 0.0, sc = 0.0;
+        for (int64_t i = 0; i < n; ++i) { sr += r[i]; sc += c[i]; }
+        const double mu = fabs(sc) > floor_ ? sr / sc : sr / (double)n;
+        for (int64_t i = 0; i < n; ++i) out[i] = r[i] - mu * c[i];
+    } else {
+        for (int64_t i = 0; i < n; ++i) out[i] = r[i];
+    }
+    free(d);
+    if (bad >= 0 && bad_value) *bad_value = badv;
+    return bad;
 }

@@ -105,6 +105,17 @@ void cor_transition_sums(int32_t state_dim, int64_t n, const double *xs, const d
                          const double *lag, const double *F, double *sum_level, double *sum_trend,
                          int64_t *count);
 
+/* ---- background update natives -------------------------------------------------------------- */
+/* pyx:9700-9724 `cbackgroundWeightedStatsWithSupport`: per-interval weight = sum_j invVar[j,i] and
+ * rhs = sum_j invVar[j,i]*resid[j,i] in fp64 over float32 (m,n) C-order matrices; returns the count of weight > 0. */
+int64_t cor_background_stats(int64_t m, int64_t n, const float *resid, const float *inv_var, double *weight,
+                             double *rhs);
+/* pyx:944-1096 `csolveZeroCenteredBackground`: (diag(w) + lam_first D1'D1 + lam D2'D2) x = rhs by pentadiagonal LDL'
+ * with pivot floor 1e-12, optional zero-sum Lagrange correction.  Returns -1 if no pivot was modified, otherwise the
+ * index of the first modified pivot (its value in *bad_value); `out` is filled in both cases (the reference raises). */
+int64_t cor_solve_background(int64_t n, const double *weight, const double *rhs, double lam, int zero_center,
+                             double lam_first, double *out, double *bad_value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,3 +456,46 @@ def cExpectedTransitionResidualSums(stateSmoothed, stateCovarSmoothed, lagCovSmo
 
 def cExpectedTransitionResidualSumsLevel(stateSmoothed, stateCovarSmoothed, lagCovSmoothed):
     return _sums(1, stateSmoothed, stateCovarSmoothed, lagCovSmoothed, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# background update natives (pyx:9700-9724, pyx:944-1096)
+# ---------------------------------------------------------------------------------------------------------------------
+_DP = C.POINTER(C.c_double)
+
+
+def cbackgroundWeightedStatsWithSupport(residualMatrix, invVarMatrix):
+    res = np.ascontiguousarray(residualMatrix, dtype=np.float32)
+    inv = np.ascontiguousarray(invVarMatrix, dtype=np.float32)
+    if res.ndim != 2 or inv.shape != res.shape:
+        raise ValueError("residualMatrix and invVarMatrix must have identical 2D shapes")
+    m, n = res.shape
+    w, r = np.empty(n), np.empty(n)
+    f = lib().cor_background_stats
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int64, C.c_int64, _FP, _FP, _DP, _DP]
+    support = f(m, n, _fp(res), _fp(inv), w.ctypes.data_as(_DP), r.ctypes.data_as(_DP))
+    return w, r, int(support)
+
+
+def csolveZeroCenteredBackground(weightTrack, rhsTrack, lam, zeroCenter=True, lamFirst=0.0):
+    w = np.ascontiguousarray(weightTrack, dtype=np.float64)
+    r = np.ascontiguousarray(rhsTrack, dtype=np.float64)
+    n = w.shape[0]
+    if r.shape[0] != n:
+        raise ValueError("weightTrack and rhsTrack must have the same length")
+    if not np.isfinite(lamFirst) or lamFirst < 0.0:
+        raise ValueError("lamFirst must be finite and nonnegative")
+    if not np.isfinite(lam) or lam < 0.0:
+        raise ValueError("lam must be finite and nonnegative")
+    out = np.zeros(n)
+    f = lib().cor_solve_background
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int64, _DP, _DP, C.c_double, C.c_int, C.c_double, _DP, _DP]
+    badv = C.c_double(0.0)
+    bad = f(n, w.ctypes.data_as(_DP), r.ctypes.data_as(_DP), float(lam), int(bool(zeroCenter)), float(lamFirst),
+            out.ctypes.data_as(_DP), C.byref(badv))
+    if bad >= 0:
+        raise RuntimeError("roughness-penalized LDL factorization required pivot "
+                           f"modification at index {bad} (pivot={badv.value:.6g}, floor={1.0e-12:.6g}).")
+    return out

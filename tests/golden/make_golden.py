@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
+import bg_cases  # noqa: E402
 import cases  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from oracle import ref_loader  # noqa: E402
@@ -50,6 +51,24 @@ def main() -> int:
         np.savez_compressed(path, **cases.compact(case, out_ref))
         n_written += 1
         print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)} B)")
+    # background-update natives (same rule: the oracle must equal the reference bit for bit)
+    for case in bg_cases.solve_cases():
+        out_ref = bg_cases.run_solve(ref, case)
+        out_orc = bg_cases.run_solve(orc, case)
+        for key, val in out_ref.items():
+            if not np.array_equal(val, out_orc[key]):
+                raise SystemExit(f"oracle != reference for case {case['name']} key {key}")
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **out_ref)
+        n_written += 1
+        print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)} B)")
+    res, inv = bg_cases.stats_inputs()
+    w_ref, r_ref, s_ref = ref.cbackgroundWeightedStatsWithSupport(res, inv)
+    w_orc, r_orc, s_orc = orc.cbackgroundWeightedStatsWithSupport(res, inv)
+    if not (np.array_equal(w_ref, w_orc) and np.array_equal(r_ref, r_orc) and s_ref == s_orc):
+        raise SystemExit("oracle != reference for cbackgroundWeightedStatsWithSupport")
+    np.savez_compressed(os.path.join(HERE, "bg_stats.npz"), weight=w_ref, rhs=r_ref, support=np.int64(s_ref))
+    n_written += 1
     print(f"{n_written} fixtures written; oracle == reference on all of them")
     return 0
 

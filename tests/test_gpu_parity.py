@@ -521,3 +521,93 @@ def test_batch_diagnostics_from_resident_forward_pass(product):
                     procPrecisionMultiplierMin=mp.kappa_bounds[0], procPrecisionMultiplierMax=mp.kappa_bounds[1])
                 for k in ("sumGain0", "sumGain1", "effectiveQLevel", "effectiveQTrend", "muncTrace"):
                     np.testing.assert_allclose(b.download(c, k), ref[k], rtol=RTOL, atol=0, err_msg=f"{flags} {c} {k}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# background-update natives (pyx:944-1096, 9700-9724)
+# ---------------------------------------------------------------------------------------------------------------
+import bg_cases  # noqa: E402
+
+BG_CASES = {c["name"]: c for c in bg_cases.solve_cases()}
+
+
+def _bg_tol(case, w):
+    """The pentadiagonal system is ill-conditioned by design: the reference itself guards it with
+    roundoffIndex = eps * (1 + (4 lamF + 16 lam) / mean(w > 0)) (core.py:8160-8187), and an equally stable elimination in
+    another order moves the solution by up to about that much times max|x| (the reference's LDL' vs LAPACK's banded
+    Cholesky: 1e-6..7e-6 at the default span of 750 bins, roundoffIndex 7e-5).  Tolerance relative to max|x|: the
+    roundoff index, at least 1e-10, never more than north_star's 1e-5."""
+    lam_first, lam = bg_cases.solve_lams(case)
+    pos = w[w > 0]
+    idx = np.finfo(np.float64).eps * (1.0 + (4.0 * lam_first + 16.0 * lam) / float(pos.mean())) if pos.size else 0.0
+    return min(1e-5, max(1e-10, idx))
+
+
+@pytest.mark.parametrize("block_len", [0, 8, 64])
+@pytest.mark.parametrize("name", sorted(BG_CASES))
+def test_background_solve_matches_golden(product, name, block_len):
+    case = BG_CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    w, r = bg_cases.solve_inputs(case)
+    lam_first, lam = bg_cases.solve_lams(case)
+    for zc, key in ((False, "plain"), (True, "zc")):
+        if key + "_error" in gold.files:
+            with pytest.raises(RuntimeError, match="required pivot modification at index"):
+                product.solveBackgroundBatch([w], [r], lam, zc, lam_first, blockLen=block_len)
+            continue
+        got = product.solveBackgroundBatch([w], [r], lam, zc, lam_first, blockLen=block_len)[0]
+        ref = gold[key]
+        scale = max(float(np.abs(ref).max()), 1e-300)
+        assert got.dtype == np.float64 and got.shape == ref.shape
+        assert float(np.abs(got - ref).max()) <= _bg_tol(case, w) * scale, (name, key, float(np.abs(got - ref).max()) / scale)
+
+
+def test_background_solve_reference_contract(product):
+    with pytest.raises(RuntimeError, match=r"required pivot modification at index 0 \(pivot=0, floor=1e-12\)"):
+        product.csolveZeroCenteredBackground(np.zeros(3), np.zeros(3), 0.0, False, lamFirst=0.0)  # test_core.py:94-101
+    one = product.csolveZeroCenteredBackground(np.asarray([2.0]), np.asarray([8.0]), 9.0, False, lamFirst=6.0)
+    np.testing.assert_allclose(one, [4.0])                                                         # test_core.py:103-110
+    assert product.csolveZeroCenteredBackground(np.asarray([2.0]), np.asarray([8.0]), 9.0, True, lamFirst=6.0)[0] == 0.0
+    assert product.csolveZeroCenteredBackground(np.zeros(0), np.zeros(0), 1.0).shape == (0,)
+    with pytest.raises(ValueError, match="same length"):
+        product.csolveZeroCenteredBackground(np.zeros(3), np.zeros(4), 1.0)
+    with pytest.raises(ValueError, match="lamFirst must be finite"):
+        product.csolveZeroCenteredBackground(np.ones(3), np.ones(3), 1.0, lamFirst=-1.0)
+    with pytest.raises(ValueError, match="lam must be finite"):
+        product.csolveZeroCenteredBackground(np.ones(3), np.ones(3), np.nan)
+
+
+def test_background_solve_chromosome_sized_batch(product, oracle):
+    """Three chromosome-sized chains in one device pass (default span / smoothness) against the CPU oracle, plus
+    independence of the partition size; zero-sum variant sums to zero."""
+    rng = np.random.default_rng(99)
+    lam_first, lam = bg_cases.penalties(750, 128.0)
+    ws, rs = [], []
+    for n in (1244783, 233550, 4100):
+        w = 128.0 * np.exp(rng.normal(0, 0.3, n))
+        w[rng.random(n) < 0.02] = 0.0
+        w[n // 2: n // 2 + 3000] = 0.0
+        ws.append(w)
+        rs.append(w * (0.4 * np.sin(np.arange(n) / 40000.0) + rng.normal(0, 0.09, n)))
+    got = product.solveBackgroundBatch(ws, rs, lam, False, lam_first)
+    got2 = product.solveBackgroundBatch(ws, rs, lam, False, lam_first, blockLen=4096)
+    gotz = product.solveBackgroundBatch(ws, rs, lam, True, lam_first)
+    for w, r, g, g2, gz in zip(ws, rs, got, got2, gotz):
+        ref = oracle.csolveZeroCenteredBackground(w, r, lam, False, lamFirst=lam_first)
+        refz = oracle.csolveZeroCenteredBackground(w, r, lam, True, lamFirst=lam_first)
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(g - ref).max()) <= 1e-5 * scale
+        assert float(np.abs(g2 - ref).max()) <= 1e-5 * scale
+        assert float(np.abs(gz - refz).max()) <= 1e-5 * max(float(np.abs(refz).max()), scale)
+        assert abs(float(gz.sum())) <= 1e-6 * scale * len(gz)
+
+
+def test_background_weighted_stats(product):
+    res, inv = bg_cases.stats_inputs()
+    w, r, s = product.cbackgroundWeightedStatsWithSupport(res, inv)
+    gold = np.load(os.path.join(GOLDEN, "bg_stats.npz"))
+    assert np.array_equal(w, gold["weight"]) and np.array_equal(r, gold["rhs"]) and s == int(gold["support"])
+    w0, r0, s0 = product.cbackgroundWeightedStatsWithSupport(res, np.zeros_like(inv))      # test_core.py:2563-2572
+    assert s0 == 0 and not w0.any() and not r0.any()
+    with pytest.raises(ValueError, match="identical 2D shapes"):
+        product.cbackgroundWeightedStatsWithSupport(res, inv[:, :-1])

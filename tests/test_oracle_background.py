@@ -1,0 +1,96 @@
+"""CPU tests pinning the oracle's background-update natives (oracle/consenrich_oracle.c
+`cor_solve_background`, `cor_background_stats`) to the REAL reference: committed golden vectors (bit for bit,
+including the pivot-modification error text), the live reference build when present, the reference's own literal test
+values (tests/test_core.py:95-110) and an independent dense specification."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import bg_cases  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+
+GOLDEN = os.path.join(HERE, "golden")
+CASES = {c["name"]: c for c in bg_cases.solve_cases()}
+
+
+def dense_system(w, lam_first, lam):
+    """diag(w) + lam_first D1'D1 + lam D2'D2 from explicit difference operators"""
+    n = len(w)
+    A = np.diag(np.asarray(w, np.float64))
+    if n >= 2:
+        D1 = np.zeros((n - 1, n))
+        D1[np.arange(n - 1), np.arange(n - 1)] = -1.0
+        D1[np.arange(n - 1), np.arange(1, n)] = 1.0
+        A = A + lam_first * D1.T @ D1
+    if n >= 3:
+        D2 = np.zeros((n - 2, n))
+        for i in range(n - 2):
+            D2[i, i:i + 3] = [1.0, -2.0, 1.0]
+        A = A + lam * D2.T @ D2
+    return A
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_golden(name):
+    got = bg_cases.run_solve(orc, CASES[name])
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert set(got) == set(gold.files)
+    for k in gold.files:
+        if k.endswith("_error"):
+            assert str(got[k]) == str(gold[k])
+        else:
+            assert np.array_equal(got[k], gold[k]), k
+
+
+def test_oracle_stats_match_golden():
+    res, inv = bg_cases.stats_inputs()
+    w, r, s = orc.cbackgroundWeightedStatsWithSupport(res, inv)
+    gold = np.load(os.path.join(GOLDEN, "bg_stats.npz"))
+    assert np.array_equal(w, gold["weight"]) and np.array_equal(r, gold["rhs"]) and s == int(gold["support"])
+    # the reference test's own expectation (tests/test_core.py:2527-2541)
+    np.testing.assert_allclose(w, np.sum(inv.astype(np.float64), axis=0), rtol=1e-7)
+    np.testing.assert_allclose(r, np.sum(inv.astype(np.float64) * res.astype(np.float64), axis=0), rtol=1e-7)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference build only exists in the build container")
+def test_oracle_matches_live_reference():
+    ref = ref_loader.load()
+    rng = np.random.default_rng(3)
+    for n in (6, 131, 4099):
+        w = np.abs(rng.normal(50, 20, n))
+        r = rng.normal(0, 10, n)
+        for lam_first, lam in ((0.0, 0.0), (3.0, 0.0), (0.0, 40.0), (1e3, 1e7)):
+            for zc in (False, True):
+                assert np.array_equal(ref.csolveZeroCenteredBackground(w, r, lam, zc, lamFirst=lam_first),
+                                      orc.csolveZeroCenteredBackground(w, r, lam, zc, lamFirst=lam_first))
+
+
+def test_reference_literals_and_dense_specification():
+    with pytest.raises(RuntimeError, match="required pivot modification"):        # tests/test_core.py:94-101
+        orc.csolveZeroCenteredBackground(np.zeros(3), np.zeros(3), 0.0, False, lamFirst=0.0)
+    one = orc.csolveZeroCenteredBackground(np.asarray([2.0]), np.asarray([8.0]), 9.0, False, lamFirst=6.0)
+    np.testing.assert_allclose(one, [4.0])                                          # tests/test_core.py:103-110
+    w, r = np.asarray(bg_cases.LIT_W), np.asarray(bg_cases.LIT_R)
+    lam_first, lam = bg_cases.penalties(3, 2.0)
+    assert (lam_first, lam) == (pytest.approx(2.0 * 9 / 4), pytest.approx(2.0 * 81 / 16))
+    A = dense_system(w, lam_first, lam)
+    np.testing.assert_allclose(orc.csolveZeroCenteredBackground(w, r, lam, False, lamFirst=lam_first),
+                               np.linalg.solve(A, r), rtol=1e-11)
+    # zero-sum variant: KKT system [A 1; 1' 0]
+    n = len(w)
+    K = np.zeros((n + 1, n + 1))
+    K[:n, :n] = A
+    K[:n, n] = 1.0
+    K[n, :n] = 1.0
+    xz = np.linalg.solve(K, np.concatenate([r, [0.0]]))[:n]
+    np.testing.assert_allclose(orc.csolveZeroCenteredBackground(w, r, lam, True, lamFirst=lam_first), xz, rtol=1e-10,
+                               atol=1e-13)
+    for bad in (dict(lam=-1.0), dict(lamFirst=np.inf)):
+        with pytest.raises(ValueError):
+            orc.csolveZeroCenteredBackground(w, r, bad.get("lam", 1.0), False, lamFirst=bad.get("lamFirst", 0.0))
