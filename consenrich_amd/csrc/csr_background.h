@@ -36,7 +36,8 @@ struct BgPrm {
     double *invd, *l1;                  // blocked (NGk*SB*64)
     double *X[6];                       // blocked solution columns: data [, ones], L0, L1, R0, R1 (slots NR..NR+3)
     double *T, *t;                      // per block: 16, 4*NR
-    double *sepMinv, *sepG;             // per block (its separator): 3, 2*NR  (sepG becomes x_S)
+    double *sepIn, *sepOut;             // reduced system, struct-of-arrays planes of NBk doubles (7+2NR in, 3+2NR out)
+    double *sepG;                       // per block (its separator): x_S, 2*NR
     int64_t *badIdx;                    // per block: first modified pivot (chain-local index) or -1
     double *badVal;
     int64_t *chainBadIdx;               // per chain
@@ -83,31 +84,52 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
     double y1[NC], y2[NC];                             // y_{s-1}, y_{s-2} (before the division by d)
 #pragma unroll
     for (int j = 0; j < NC; ++j) { y1[j] = 0.0; y2[j] = 0.0; }
-    double d1 = 1.0, d2 = 1.0, l1p = 0.0;              // d_{s-1}, d_{s-2}, l1_{s-1}
+    double d1 = 1.0, id1 = 1.0, id2 = 1.0, l1p = 0.0;  // d_{s-1}, 1/d_{s-1}, 1/d_{s-2}, l1_{s-1}
     const double cL0_0 = hasL ? lam : 0.0;                                   // A[a, a-2]
     const double cL1_0 = hasL ? bg_off1(n, a - 1, lam, lamF) : 0.0;          // A[a, a-1]
     const double cL1_1 = hasL ? lam : 0.0;                                   // A[a+1, a-1]
-    for (int s = 0; s < L; ++s) {
+    // inputs are fetched PF steps ahead of the dependent recurrence (natural layout: a lane's reads are sequential)
+    constexpr int PF = 8;
+    double wq[PF], rq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { wq[u] = u < L ? w[a + u] : 0.0; rq[u] = u < L ? r[a + u] : 0.0; }
+    for (int s0 = 0; s0 < L; s0 += PF) {
+        double wc[PF], rc[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { wc[u] = wq[u]; rc[u] = rq[u]; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int sn = s0 + PF + u;
+            wq[u] = sn < L ? w[a + sn] : 0.0;
+            rq[u] = sn < L ? r[a + sn] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int s = s0 + u;
+        if (s >= L) break;
         const int64_t i = a + s;
-        double dg = w[i] + bg_pen_diag(n, i, lam, lamF);
+        double dg = wc[u] + bg_pen_diag(n, i, lam, lamF);
         if (dg < floor_) { if (bad < 0) { bad = i; badv = dg; } dg = floor_; }      // pyx:1031-1035
         double c[NC];
-        c[0] = r[i];
+        c[0] = rc[u];
         if (NR == 2) c[1] = 1.0;
         c[NR] = s == 0 ? cL0_0 : 0.0;
         c[NR + 1] = s == 0 ? cL1_0 : (s == 1 ? cL1_1 : 0.0);
+        // one IEEE division per step: the reciprocals of the two previous pivots are carried (the reference divides
+        // four times per step; the difference is rounding-level and far below the system's own roundoff index)
         double l1 = 0.0, d = dg;
         if (s == 1) {
-            l1 = bg_off1(n, i - 1, lam, lamF) / d1;                                 // pyx:1042-1043
+            l1 = bg_off1(n, i - 1, lam, lamF) * id1;                                // pyx:1042-1043
             d = dg - l1 * l1 * d1;
         } else if (s >= 2) {
-            l1 = (bg_off1(n, i - 1, lam, lamF) - lam * l1p) / d1;                   // pyx:1052-1058
-            d = dg - l1 * l1 * d1 - (lam * lam) / d2;
+            l1 = (bg_off1(n, i - 1, lam, lamF) - lam * l1p) * id1;                  // pyx:1052-1058
+            d = dg - l1 * l1 * d1 - (lam * lam) * id2;
         }
         if (s >= 1 && d < floor_) { if (bad < 0) { bad = i; badv = d; } d = floor_; }
-        const double l2 = s >= 2 ? lam / d2 : 0.0;
+        const double l2 = s >= 2 ? lam * id2 : 0.0;
+        const double id = 1.0 / d;
         const int64_t q = bgidx(p, kb, s);
-        p.invd[q] = 1.0 / d;
+        p.invd[q] = id;
         p.l1[q] = l1;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
@@ -116,9 +138,10 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
             if (s >= 2) y -= l2 * y2[j];
             y2[j] = y1[j];
             y1[j] = y;
-            p.X[j][q] = y / d;                                                       // pyx:1074-1076
+            p.X[j][q] = y * id;                                                      // pyx:1074-1076
         }
-        d2 = d1; d1 = d; l1p = l1;
+        d1 = d; id2 = id1; id1 = id; l1p = l1;
+      }
     }
     // right coupling columns: nonzero only in the last two interior rows
     //   R0 (bin a+L):   A[a+L-2, a+L] = lam, A[a+L-1, a+L] = off1(a+L-1);   R1 (bin a+L+1): A[a+L-1, a+L+1] = lam
@@ -131,18 +154,32 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
 #pragma unroll
     for (int j = 0; j < NX; ++j) { x1[j] = 0.0; x2[j] = 0.0; xe[j] = 0.0; xe1[j] = 0.0; }
     double l1n = 0.0;                                  // l1_{s+1}
+    // row s-1 is fetched before row s is overwritten (the stores may alias the loads as far as the compiler knows)
+    double nInvd = 0.0, nL1 = 0.0, nz[NC];
+    if (L > 0) {
+        const int64_t q0 = bgidx(p, kb, L - 1);
+        nInvd = p.invd[q0]; nL1 = p.l1[q0];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) nz[j] = p.X[j][q0];
+    }
     for (int s = L - 1; s >= 0; --s) {
         const int64_t q = bgidx(p, kb, s);
-        const double invd = p.invd[q];
+        const double invd = nInvd, l1s = nL1;
         const double l2n = lam * invd;                 // l2_{s+2} = lam / d_s
         double z[NX];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) z[j] = p.X[j][q];
+        for (int j = 0; j < NC; ++j) z[j] = nz[j];
+        if (s > 0) {
+            const int64_t qm = q - 64;
+            nInvd = p.invd[qm]; nL1 = p.l1[qm];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) nz[j] = p.X[j][qm];
+        }
         // forward-substituted right columns: y_{L-2} = c_{L-2}, y_{L-1} = c_{L-1} - l1_{L-1} y_{L-2}
         z[NR + 2] = 0.0; z[NR + 3] = 0.0;
         if (L >= 2) {
             if (s == L - 2) z[NR + 2] = lamR * invd;
-            if (s == L - 1) { z[NR + 2] = (offR - p.l1[q] * lamR) * invd; z[NR + 3] = lamR * invd; }
+            if (s == L - 1) { z[NR + 2] = (offR - l1s * lamR) * invd; z[NR + 3] = lamR * invd; }
         } else if (s == L - 1) {                       // one-bin interior (only in chains shorter than a block)
             z[NR + 2] = offR * invd; z[NR + 3] = lamR * invd;
         }
@@ -157,7 +194,7 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
             if (s == L - 1) xe[j] = x;
             if (s == L - 2) xe1[j] = x;
         }
-        l1n = p.l1[q];
+        l1n = l1s;
     }
     // x1 = x_0, x2 = x_1 (if L >= 2).  Schur contributions: rows of C' = [L0, L1, R0, R1]
     double *T = p.T + kb * 16, *t = p.t + kb * 4 * NR;
@@ -179,93 +216,170 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
     p.badVal[kb] = badv;
 }
 
-// Block-tridiagonal elimination over the separators of one chain (2x2 blocks), one lane per chain.
+// Reduced system, step 1 (parallel, one thread per separator): assemble the 2x2 diagonal block D_s, the coupling
+// U_{s-1} to the previous separator (through interior s) and the right-hand side f_s into struct-of-array form.
+//   D_s = A[S_s,S_s] - T_s[R,R] - T_{s+1}[L,L];  U_{s-1} = -T_s[L,R];  f_s = r[S_s] - t_s[R] - t_{s+1}[L]
+template <int NR>
+__global__ __launch_bounds__(256) void k_bg_sep_assemble(BgPrm p) {
+    const int64_t kb = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kb >= p.NBk) return;
+    const int4 bi = p.blk[kb];
+    if (!bi.w) return;                                  // the chain's last block has no separator
+    const int64_t off = p.chainOff[bi.z], n = p.chainLen[bi.z];
+    const int64_t b = (int64_t)bi.x - off + bi.y - 2;   // chain-local index of the separator's first bin
+    const double lam = p.lam, lamF = p.lamF, floor_ = 1.0e-12;
+    const double *w = p.w + off, *r = p.rhs + off;
+    const double *Tk = p.T + kb * 16, *Tn = p.T + (kb + 1) * 16;
+    double dg0 = w[b] + bg_pen_diag(n, b, lam, lamF), dg1 = w[b + 1] + bg_pen_diag(n, b + 1, lam, lamF);
+    int64_t bad = p.badIdx[kb];
+    double badv = p.badVal[kb];
+    if (dg0 < floor_) { if (bad < 0) { bad = b; badv = dg0; } dg0 = floor_; }
+    if (dg1 < floor_) { if (bad < 0) { bad = b + 1; badv = dg1; } dg1 = floor_; }
+    p.badIdx[kb] = bad;
+    p.badVal[kb] = badv;
+    const int64_t NB = p.NBk;
+    double *S = p.sepIn;                                // SoA: 7 + 2 NR planes of NBk doubles
+    S[0 * NB + kb] = dg0 - Tk[2 * 4 + 2] - Tn[0 * 4 + 0];
+    S[1 * NB + kb] = bg_off1(n, b, lam, lamF) - Tk[2 * 4 + 3] - Tn[0 * 4 + 1];
+    S[2 * NB + kb] = dg1 - Tk[3 * 4 + 3] - Tn[1 * 4 + 1];
+    S[3 * NB + kb] = -Tk[0 * 4 + 2]; S[4 * NB + kb] = -Tk[0 * 4 + 3];
+    S[5 * NB + kb] = -Tk[1 * 4 + 2]; S[6 * NB + kb] = -Tk[1 * 4 + 3];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const double *tk = p.t + kb * 4 * NR + j * 4, *tn = p.t + (kb + 1) * 4 * NR + j * 4;
+        S[(7 + 2 * j) * NB + kb] = (j == 0 ? r[b] : 1.0) - tk[2] - tn[0];
+        S[(8 + 2 * j) * NB + kb] = (j == 0 ? r[b + 1] : 1.0) - tk[3] - tn[1];
+    }
+}
+
+// Reduced system, step 2: block-tridiagonal (2x2 blocks) elimination over the separators of one chain.  One wavefront
+// per chain: the lanes stage 64 separators at a time through LDS (coalesced loads / stores), every lane then runs the
+// same dependent recurrence on broadcast LDS reads, so the serial chain never waits on global memory.
 template <int NR>
 __global__ __launch_bounds__(64) void k_bg_reduced(BgPrm p) {
-    const int c = blockIdx.x;
-    if (threadIdx.x != 0 || c >= p.nchains) return;
-    const int64_t kb0 = p.chainFirstBlk[c], K = p.chainNumBlk[c];
-    const int64_t off = p.chainOff[c], n = p.chainLen[c];
-    const double lam = p.lam, lamF = p.lamF, floor_ = 1.0e-12;
+    constexpr int NI = 7 + 2 * NR, NO = 3 + 2 * NR;
+    __shared__ double sin_[NI][64];
+    __shared__ double sout[NO][64];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t kb0 = p.chainFirstBlk[c], K = p.chainNumBlk[c], nsep = K - 1, NB = p.NBk;
+    const double floor_ = 1.0e-12;
+    // first modified pivot of the local factorisations / separator diagonals (chain order)
     int64_t bad = -1;
     double badv = 0.0;
-    for (int64_t k = 0; k < K; ++k)
-        if (p.badIdx[kb0 + k] >= 0) { bad = p.badIdx[kb0 + k]; badv = p.badVal[kb0 + k]; break; }
-    const double *w = p.w + off, *r = p.rhs + off;
-    double Mi00 = 0, Mi01 = 0, Mi11 = 0;               // inverse of the previous pivot block
-    double gp[2 * NR];
-    double U[4] = {0, 0, 0, 0};                        // coupling S_{s-1} (rows) -- S_s (cols)
-    for (int64_t s = 0; s + 1 < K; ++s) {
-        const int64_t kb = kb0 + s;
-        const int4 bi = p.blk[kb];
-        const int64_t b = (int64_t)bi.x - off + bi.y - 2;       // chain-local index of the separator's first bin
-        const double *Tk = p.T + kb * 16, *Tn = p.T + (kb + 1) * 16;
-        double dg0 = w[b] + bg_pen_diag(n, b, lam, lamF), dg1 = w[b + 1] + bg_pen_diag(n, b + 1, lam, lamF);
-        if (dg0 < floor_) { if (bad < 0 || b < bad) { bad = b; badv = dg0; } dg0 = floor_; }
-        if (dg1 < floor_) { if (bad < 0 || b + 1 < bad) { bad = b + 1; badv = dg1; } dg1 = floor_; }
-        double M00 = dg0 - Tk[2 * 4 + 2] - Tn[0 * 4 + 0];
-        double M01 = bg_off1(n, b, lam, lamF) - Tk[2 * 4 + 3] - Tn[0 * 4 + 1];
-        double M11 = dg1 - Tk[3 * 4 + 3] - Tn[1 * 4 + 1];
-        double g[2 * NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const double *tk = p.t + kb * 4 * NR + j * 4, *tn = p.t + (kb + 1) * 4 * NR + j * 4;
-            g[2 * j] = (j == 0 ? r[b] : 1.0) - tk[2] - tn[0];
-            g[2 * j + 1] = (j == 0 ? r[b + 1] : 1.0) - tk[3] - tn[1];
+    for (int64_t k0 = 0; k0 < K && bad < 0; k0 += 64) {
+        const int64_t k = k0 + lane;
+        const int64_t bi_ = k < K ? p.badIdx[kb0 + k] : -1;
+        const unsigned long long m = __ballot(bi_ >= 0);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            bad = __shfl(bi_, first);
+            badv = __shfl(k < K ? p.badVal[kb0 + k] : 0.0, first);
         }
-        if (s > 0) {
-            // M -= U' Minv U ;  g -= U' Minv g_prev
-            const double a00 = Mi00 * U[0] + Mi01 * U[2], a01 = Mi00 * U[1] + Mi01 * U[3];
-            const double a10 = Mi01 * U[0] + Mi11 * U[2], a11 = Mi01 * U[1] + Mi11 * U[3];
-            M00 -= U[0] * a00 + U[2] * a10;
-            M01 -= U[0] * a01 + U[2] * a11;
-            M11 -= U[1] * a01 + U[3] * a11;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const double h0 = Mi00 * gp[2 * j] + Mi01 * gp[2 * j + 1], h1 = Mi01 * gp[2 * j] + Mi11 * gp[2 * j + 1];
-                g[2 * j] -= U[0] * h0 + U[2] * h1;
-                g[2 * j + 1] -= U[1] * h0 + U[3] * h1;
-            }
-        }
-        // 2x2 LDL' pivots with the reference's floor
-        double p0 = M00;
-        if (p0 < floor_) { if (bad < 0 || b < bad) { bad = b; badv = p0; } p0 = floor_; }
-        const double l = M01 / p0;
-        double p1 = M11 - l * l * p0;
-        if (p1 < floor_) { if (bad < 0 || b + 1 < bad) { bad = b + 1; badv = p1; } p1 = floor_; }
-        Mi11 = 1.0 / p1;
-        Mi01 = -l * Mi11;
-        Mi00 = 1.0 / p0 + l * l * Mi11;
-        p.sepMinv[kb * 3 + 0] = Mi00; p.sepMinv[kb * 3 + 1] = Mi01; p.sepMinv[kb * 3 + 2] = Mi11;
-#pragma unroll
-        for (int j = 0; j < 2 * NR; ++j) { p.sepG[kb * 2 * NR + j] = g[j]; gp[j] = g[j]; }
-        // coupling to the next separator through interior k+1:  U = -T_{k+1}[L, R]
-        U[0] = -Tn[0 * 4 + 2]; U[1] = -Tn[0 * 4 + 3]; U[2] = -Tn[1 * 4 + 2]; U[3] = -Tn[1 * 4 + 3];
     }
-    // back substitution: x_s = Minv_s (g_s - U_s x_{s+1})
+    double Mi00 = 0, Mi01 = 0, Mi11 = 0, gp[2 * NR];
+#pragma unroll
+    for (int j = 0; j < 2 * NR; ++j) gp[j] = 0.0;
+    const double *S = p.sepIn;
+    double *O = p.sepOut;                               // SoA: Minv (3) + g (2 NR) planes
+    for (int64_t base = 0; base < nsep; base += 64) {
+        const int cnt = (int)(nsep - base < 64 ? nsep - base : 64);
+        if (lane < cnt) {
+#pragma unroll
+            for (int q = 0; q < NI; ++q) sin_[q][lane] = S[q * NB + kb0 + base + lane];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            double M00 = sin_[0][j], M01 = sin_[1][j], M11 = sin_[2][j];
+            double g[2 * NR];
+#pragma unroll
+            for (int q = 0; q < 2 * NR; ++q) g[q] = sin_[7 + q][j];
+            if (base + j > 0) {
+                const double U0 = sin_[3][j], U1 = sin_[4][j], U2 = sin_[5][j], U3 = sin_[6][j];
+                const double a00 = Mi00 * U0 + Mi01 * U2, a01 = Mi00 * U1 + Mi01 * U3;
+                const double a10 = Mi01 * U0 + Mi11 * U2, a11 = Mi01 * U1 + Mi11 * U3;
+                M00 -= U0 * a00 + U2 * a10;
+                M01 -= U0 * a01 + U2 * a11;
+                M11 -= U1 * a01 + U3 * a11;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const double h0 = Mi00 * gp[2 * q] + Mi01 * gp[2 * q + 1], h1 = Mi01 * gp[2 * q] + Mi11 * gp[2 * q + 1];
+                    g[2 * q] -= U0 * h0 + U2 * h1;
+                    g[2 * q + 1] -= U1 * h0 + U3 * h1;
+                }
+            }
+            double p0 = M00;                            // 2x2 LDL' pivots with the reference's floor
+            if (p0 < floor_) { if (bad < 0) { bad = -2 - (base + j) * 2; badv = p0; } p0 = floor_; }
+            const double l = M01 / p0;
+            double p1 = M11 - l * l * p0;
+            if (p1 < floor_) { if (bad < 0) { bad = -2 - ((base + j) * 2 + 1); badv = p1; } p1 = floor_; }
+            Mi11 = 1.0 / p1;
+            Mi01 = -l * Mi11;
+            Mi00 = 1.0 / p0 + l * l * Mi11;
+            if (lane == j) {
+                sout[0][j] = Mi00; sout[1][j] = Mi01; sout[2][j] = Mi11;
+#pragma unroll
+                for (int q = 0; q < 2 * NR; ++q) sout[3 + q][j] = g[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * NR; ++q) gp[q] = g[q];
+        }
+        __syncthreads();
+        if (lane < cnt) {
+#pragma unroll
+            for (int q = 0; q < NO; ++q) O[q * NB + kb0 + base + lane] = sout[q][lane];
+        }
+        __syncthreads();
+    }
+    // back substitution: x_s = Minv_s (g_s - U_s x_{s+1}),  U_s = coupling stored with separator s+1
     double xn[2 * NR];
 #pragma unroll
     for (int j = 0; j < 2 * NR; ++j) xn[j] = 0.0;
-    for (int64_t s = K - 2; s >= 0; --s) {
-        const int64_t kb = kb0 + s;
-        const double *Tn = p.T + (kb + 1) * 16;
-        const double u0 = -Tn[0 * 4 + 2], u1 = -Tn[0 * 4 + 3], u2 = -Tn[1 * 4 + 2], u3 = -Tn[1 * 4 + 3];
-        const double m00 = p.sepMinv[kb * 3], m01 = p.sepMinv[kb * 3 + 1], m11 = p.sepMinv[kb * 3 + 2];
+    for (int64_t hi = nsep; hi > 0; hi -= 64) {
+        const int64_t base = hi >= 64 ? hi - 64 : 0;
+        const int cnt = (int)(hi - base);
+        if (lane < cnt) {
+            const int64_t sI = kb0 + base + lane;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            double g0 = p.sepG[kb * 2 * NR + 2 * j], g1 = p.sepG[kb * 2 * NR + 2 * j + 1];
-            if (s + 2 < K) {
-                g0 -= u0 * xn[2 * j] + u1 * xn[2 * j + 1];
-                g1 -= u2 * xn[2 * j] + u3 * xn[2 * j + 1];
-            }
-            const double x0 = m00 * g0 + m01 * g1, x1 = m01 * g0 + m11 * g1;
-            p.sepG[kb * 2 * NR + 2 * j] = x0;
-            p.sepG[kb * 2 * NR + 2 * j + 1] = x1;
-            xn[2 * j] = x0; xn[2 * j + 1] = x1;
+            for (int q = 0; q < NO; ++q) sout[q][lane] = O[q * NB + sI];
+            const bool hasNext = base + lane + 1 < nsep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sin_[q][lane] = hasNext ? S[(3 + q) * NB + sI + 1] : 0.0;
         }
+        __syncthreads();
+        for (int j = cnt - 1; j >= 0; --j) {
+            const double m00 = sout[0][j], m01 = sout[1][j], m11 = sout[2][j];
+            const double u0 = sin_[0][j], u1 = sin_[1][j], u2 = sin_[2][j], u3 = sin_[3][j];
+            double xs[2 * NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double g0 = sout[3 + 2 * q][j] - (u0 * xn[2 * q] + u1 * xn[2 * q + 1]);
+                const double g1 = sout[4 + 2 * q][j] - (u2 * xn[2 * q] + u3 * xn[2 * q + 1]);
+                xs[2 * q] = m00 * g0 + m01 * g1;
+                xs[2 * q + 1] = m01 * g0 + m11 * g1;
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * NR; ++q) xn[q] = xs[q];
+            if (lane == j) {
+#pragma unroll
+                for (int q = 0; q < 2 * NR; ++q) sin_[4 + q][j] = xs[q];
+            }
+        }
+        __syncthreads();
+        if (lane < cnt) {
+#pragma unroll
+            for (int q = 0; q < 2 * NR; ++q) p.sepG[(kb0 + base + lane) * 2 * NR + q] = sin_[4 + q][lane];
+        }
+        __syncthreads();
     }
-    p.chainBadIdx[c] = bad;
-    p.chainBadVal[c] = badv;
+    if (lane == 0) {
+        if (bad <= -2) {                                // a Schur pivot: report the separator bin it belongs to
+            const int64_t e = -2 - bad, sidx = e >> 1;
+            const int4 bi = p.blk[kb0 + sidx];
+            bad = (int64_t)bi.x - p.chainOff[c] + bi.y - 2 + (e & 1);
+        }
+        p.chainBadIdx[c] = bad;
+        p.chainBadVal[c] = badv;
+    }
 }
 
 // x_I = A_II^-1 r - (A_II^-1 C) x_S ; separators copy their own solution.  One thread per blocked slot.

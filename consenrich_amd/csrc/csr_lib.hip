@@ -1410,6 +1410,10 @@ static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
         hipLaunchKernelGGL(k_bg_local<NR>, dim3((int)p.NGk), dim3(64), 0, c->stream, p);
     }
     {
+        Scope sc(c, "bg_sep_assemble");
+        hipLaunchKernelGGL(k_bg_sep_assemble<NR>, dim3((int)((p.NBk + 255) / 256)), dim3(256), 0, c->stream, p);
+    }
+    {
         Scope sc(c, "bg_reduced");
         hipLaunchKernelGGL(k_bg_reduced<NR>, dim3(p.nchains), dim3(64), 0, c->stream, p);
     }
@@ -1475,7 +1479,8 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
     size_t oX[6];
     for (int j = 0; j < NR + 4; ++j) oX[j] = take(8 * TN);
     const size_t oT = take(8 * 16 * blk.size()), ot = take(8 * 4 * NR * blk.size());
-    const size_t oMi = take(8 * 3 * blk.size()), oG = take(8 * 2 * NR * blk.size());
+    const size_t oSI = take(8 * (7 + 2 * NR) * blk.size()), oSO = take(8 * (3 + 2 * NR) * blk.size());
+    const size_t oG = take(8 * 2 * NR * blk.size());
     const size_t oBI = take(8 * blk.size()), oBV = take(8 * blk.size());
     const size_t oCBI = take(8 * n_chains), oCBV = take(8 * n_chains), oMu = take(8 * n_chains);
     CHECK(g_bgBuf.reserve(need_));
@@ -1488,7 +1493,7 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
     p.invd = (double *)(base + oInvd); p.l1 = (double *)(base + oL1);
     for (int j = 0; j < NR + 4; ++j) p.X[j] = (double *)(base + oX[j]);
     p.T = (double *)(base + oT); p.t = (double *)(base + ot);
-    p.sepMinv = (double *)(base + oMi); p.sepG = (double *)(base + oG);
+    p.sepIn = (double *)(base + oSI); p.sepOut = (double *)(base + oSO); p.sepG = (double *)(base + oG);
     p.badIdx = (int64_t *)(base + oBI); p.badVal = (double *)(base + oBV);
     p.chainBadIdx = (int64_t *)(base + oCBI); p.chainBadVal = (double *)(base + oCBV); p.chainMu = (double *)(base + oMu);
     HIPOK(hipMemcpyAsync(base + oOff, off.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
