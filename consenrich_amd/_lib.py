@@ -18,7 +18,9 @@ I64P = C.POINTER(C.c_int64)
 # flag bits (include/consenrich_amd.h)
 USE_LAMBDA, USE_KAPPA, USE_QSCALE, USE_APN, RETURN_NLL, NLL_IN_D = (1 << i for i in range(6))
 (ARR_D, ARR_XF, ARR_PF, ARR_PNOISE, ARR_XS, ARR_PS, ARR_LAG, ARR_RESID, ARR_LAMBDA, ARR_KAPPA, ARR_QSCALE,
- ARR_SUMGAIN0, ARR_SUMGAIN1, ARR_EFFQ_LEVEL, ARR_EFFQ_TREND, ARR_MUNCTRACE, ARR_COUNT) = range(17)
+ ARR_SUMGAIN0, ARR_SUMGAIN1, ARR_EFFQ_LEVEL, ARR_EFFQ_TREND, ARR_MUNCTRACE, ARR_BACKGROUND, ARR_BACKGROUND_NEXT,
+ ARR_COUNT) = range(19)
+BG_OK, BG_NO_SUPPORT, BG_BAD_PIVOT, BG_UNRELIABLE, BG_NONFINITE = range(5)
 EXPORT_FORWARD, EXPORT_SMOOTH, EXPORT_RESID, EXPORT_MULT = 1, 2, 4, 8
 
 
@@ -60,6 +62,22 @@ class EcmOut(C.Structure):
     ]
 
 
+class BgCfg(C.Structure):
+    _fields_ = [
+        ("lam_first", C.c_double), ("lam", C.c_double), ("negative_penalty_multiplier", C.c_double),
+        ("zero_center", C.c_int32), ("use_nonnegative", C.c_int32), ("use_lambda", C.c_int32),
+        ("use_initial", C.c_int32), ("max_passes", C.c_int32), ("block_len", C.c_int32),
+    ]
+
+
+class BgOut(C.Structure):
+    _fields_ = [
+        ("support", C.c_int64), ("weight_sum", C.c_double), ("weight_scale", C.c_double),
+        ("roundoff_index", C.c_double), ("shift_rms", C.c_double), ("bad_index", C.c_int64),
+        ("bad_value", C.c_double), ("passes", C.c_int32), ("status", C.c_int32),
+    ]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -93,6 +111,9 @@ SYMBOLS = {
     "csr_batch_forward_backward": (C.c_int, [C.c_void_p, C.c_uint32, DP, DP]),
     "csr_batch_sums": (C.c_int, [C.c_void_p, DP, DP]),
     "csr_batch_diagnostics": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "csr_batch_background_update": (C.c_int, [C.c_void_p, C.POINTER(BgCfg), C.POINTER(BgOut)]),
+    "csr_batch_background_apply": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "csr_batch_set_background": (C.c_int, [C.c_void_p, C.c_int32, FP]),
     "csr_solve_background": (C.c_int, [C.c_int32, I64P, DP, DP, C.c_double, C.c_double, C.c_int32, C.c_int32, DP, I64P,
                                        DP]),
     "csr_background_weighted_stats": (C.c_int, [C.c_int64, C.c_int64, FP, FP, DP, DP, I64P]),

@@ -44,7 +44,8 @@ class ModelParams:
 _ARR = {"D": L.ARR_D, "xf": L.ARR_XF, "Pf": L.ARR_PF, "pnoise": L.ARR_PNOISE, "xs": L.ARR_XS, "Ps": L.ARR_PS,
         "lag": L.ARR_LAG, "resid": L.ARR_RESID, "lambda": L.ARR_LAMBDA, "kappa": L.ARR_KAPPA, "qscale": L.ARR_QSCALE,
         "sumGain0": L.ARR_SUMGAIN0, "sumGain1": L.ARR_SUMGAIN1, "effectiveQLevel": L.ARR_EFFQ_LEVEL,
-        "effectiveQTrend": L.ARR_EFFQ_TREND, "muncTrace": L.ARR_MUNCTRACE}
+        "effectiveQTrend": L.ARR_EFFQ_TREND, "muncTrace": L.ARR_MUNCTRACE, "background": L.ARR_BACKGROUND,
+        "background_next": L.ARR_BACKGROUND_NEXT}
 
 
 class DeviceBatch:
@@ -164,6 +165,46 @@ class DeviceBatch:
         sumGain0, sumGain1, effectiveQLevel, effectiveQTrend, muncTrace (download()).  flags: USE_LAMBDA / USE_KAPPA /
         USE_QSCALE = which resident multipliers enter (None in the reference call otherwise)."""
         L.check(self._lib.csr_batch_diagnostics(self._ctx, int(flags)))
+
+    # -- background update between ECM phases (SURVEY 8(f) rank 1) -----------------------------------------------------
+    def background_update(self, lam_first: float, lam: float, zero_center=False, use_nonnegative=True,
+                          negative_penalty_multiplier=1.0, use_lambda=False, use_initial=True, max_passes=5,
+                          block_len=0, raise_on_error=True):
+        """core.py:5064-5137 + 8085-8378 for every chain, device-resident: weight / rhs tracks from the original data,
+        munc and the smoothed level, conditioning guard, pentadiagonal solve with the asymmetric-IRLS wrapper.  The
+        proposal is the array "background_next"; returns one dict per chain.  Errors the reference raises
+        (pivot modification, float64 reliability, non-finite solution) raise RuntimeError here unless
+        raise_on_error=False."""
+        nc = len(self.chain_lens)
+        cfg = L.BgCfg(float(lam_first), float(lam),
+                      float("nan") if negative_penalty_multiplier is None else float(negative_penalty_multiplier),
+                      int(bool(zero_center)), int(bool(use_nonnegative)), int(bool(use_lambda)), int(bool(use_initial)),
+                      int(max_passes), int(block_len))
+        outs = (L.BgOut * nc)()
+        L.check(self._lib.csr_batch_background_update(self._ctx, C.byref(cfg), outs))
+        res = [{k: getattr(o, k) for k, _ in L.BgOut._fields_} for o in outs]
+        if raise_on_error:
+            for c, o in enumerate(res):
+                if o["status"] == L.BG_BAD_PIVOT:
+                    raise RuntimeError("roughness-penalized LDL factorization required pivot modification at index "
+                                       f"{o['bad_index']} (pivot={o['bad_value']:.6g}, floor={1.0e-12:.6g}). [chain {c}]")
+                if o["status"] == L.BG_UNRELIABLE:
+                    raise RuntimeError("roughness-penalized LDL system exceeds float64 reliability: "
+                                       f"roundoffIndex={o['roundoff_index']:.6g} threshold=1 [chain {c}]")
+                if o["status"] == L.BG_NONFINITE:
+                    raise RuntimeError(f"solver returned non-finite values [chain {c}]")
+        return res
+
+    def background_apply(self, take=None):
+        """current background := last proposal (for the chains with take[c] true; default all)."""
+        buf = None if take is None else bytes(bytearray(int(bool(t)) for t in take))
+        L.check(self._lib.csr_batch_background_apply(self._ctx, buf))
+
+    def set_background(self, chain: int, background=None):
+        a = None if background is None else np.ascontiguousarray(background, np.float32)
+        if a is not None and a.shape != (self.chain_lens[chain],):
+            raise ValueError("background must have shape (chain_len,)")
+        L.check(self._lib.csr_batch_set_background(self._ctx, chain, L.fp(a)))
 
     def export(self, what: int):
         L.check(self._lib.csr_batch_export(self._ctx, int(what)))

@@ -44,6 +44,7 @@ struct BgPrm {
     double *chainBadVal;
     double *out0, *out1;                // natural solutions (data, ones)
     double *chainMu;
+    const unsigned char *active;        // per chain: 0 = leave this chain's solution untouched (IRLS lock-step); null = all
 };
 
 __device__ __forceinline__ int64_t bgidx(const BgPrm &p, int64_t kb, int s) {
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(64) void k_bg_local(BgPrm p) {
     const int64_t kb = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (kb >= p.NBk) return;
     const int4 bi = p.blk[kb];
+    if (p.active && !p.active[bi.z]) return;
     const int64_t off = p.chainOff[bi.z], n = p.chainLen[bi.z];
     const int64_t a = (int64_t)bi.x - off;             // chain-local index of the first interior bin
     const int L = bi.y - (bi.w ? 2 : 0);               // interior length (>= 2 unless the chain itself is shorter)
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void k_bg_sep_assemble(BgPrm p) {
     if (kb >= p.NBk) return;
     const int4 bi = p.blk[kb];
     if (!bi.w) return;                                  // the chain's last block has no separator
+    if (p.active && !p.active[bi.z]) return;
     const int64_t off = p.chainOff[bi.z], n = p.chainLen[bi.z];
     const int64_t b = (int64_t)bi.x - off + bi.y - 2;   // chain-local index of the separator's first bin
     const double lam = p.lam, lamF = p.lamF, floor_ = 1.0e-12;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(64) void k_bg_reduced(BgPrm p) {
     __shared__ double sin_[NI][64];
     __shared__ double sout[NO][64];
     const int c = blockIdx.x, lane = threadIdx.x;
+    if (p.active && !p.active[c]) return;
     const int64_t kb0 = p.chainFirstBlk[c], K = p.chainNumBlk[c], nsep = K - 1, NB = p.NBk;
     const double floor_ = 1.0e-12;
     // first modified pivot of the local factorisations / separator diagonals (chain order)
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256) void k_bg_combine(BgPrm p) {
     if (G >= p.NGk || kb >= p.NBk) return;
     const int4 bi = p.blk[kb];
     if (s >= bi.y) return;
+    if (p.active && !p.active[bi.z]) return;
     const int L = bi.y - (bi.w ? 2 : 0);
     const int64_t g = (int64_t)bi.x + s;
     const bool hasL = (int64_t)bi.x > p.chainOff[bi.z];
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(256) void k_bg_combine(BgPrm p) {
 __global__ __launch_bounds__(1024) void k_bg_center(BgPrm p) {
     __shared__ double sr[1024], sc[1024];
     const int c = blockIdx.x;
+    if (p.active && !p.active[c]) return;
     const int64_t off = p.chainOff[c], n = p.chainLen[c];
     double ar = 0.0, ac = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 1024) { ar += p.out0[off + i]; ac += p.out1[off + i]; }
@@ -455,6 +461,133 @@ __global__ __launch_bounds__(256) void k_bg_weighted_stats(int64_t m, int64_t n,
     }
     const unsigned long long bal = __ballot(pos);
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(support, (unsigned long long)__popcll(bal));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident background update (core.py:5064-5083, 8085-8378) on a csr batch: inputs never leave HBM
+// ---------------------------------------------------------------------------------------------------------------
+struct BgBatch {
+    const int *groupChain;              // chain of every 64-bin group of the natural layout
+    const int64_t *chainOff, *chainLen;
+    int nchains, useLambda;
+    float padf, wMinf, wMaxf;
+    const float *lamNat;                // natural lambda (exported) or null
+    const float *xsNat;                 // natural smoothed state (Npad, d), level = component 0
+    int xsStride;
+    double *w, *rhs, *wAdj, *keys, *sol;
+    unsigned char *maskPrev, *maskNew;
+    const float *bgCur;
+    float *bgNext;
+    const unsigned char *active;        // chains still iterating
+    const double *pen;                  // per chain negative-penalty weight
+    unsigned int *flags;                // per chain: bit0 any negative, bit1 mask changed, bit2 non-finite solution
+    double *chainSum;                   // per chain: [sumW, support, shiftNum]
+};
+
+// weight / rhs per bin exactly as the reference forms them (core.py:5064-5083): float32 invVar = 1/max(munc+pad,1e-8)
+// (* clip(lambda)), float32 residual = data - xs0 (ORIGINAL data: the residual contains the background), fp64 sums.
+__global__ __launch_bounds__(256) void k_bg_batch_stats(Prm p, BgBatch a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.Npad) return;
+    const int c = a.groupChain[g >> 6];
+    double ws = 0.0, rs = 0.0;
+    if (c >= 0 && g - a.chainOff[c] < a.chainLen[c]) {
+        float lam = 1.f;
+        if (a.useLambda) lam = fminf(fmaxf(a.lamNat[g], a.wMinf), a.wMaxf);
+        const float xs0 = a.xsNat[g * a.xsStride];
+        for (int j = 0; j < p.m; ++j) {
+            float iv = __fdiv_rn(1.0f, fmaxf(p.munc[(int64_t)j * p.Npad + g] + a.padf, 1.0e-8f));
+            if (a.useLambda) iv *= lam;
+            const float res = p.data[(int64_t)j * p.Npad + g] - xs0;
+            ws += (double)iv;
+            rs += (double)iv * (double)res;
+        }
+    }
+    a.w[g] = ws;
+    a.rhs[g] = rs;
+    a.keys[g] = (ws > 0.0 && isfinite(ws)) ? ws : __longlong_as_double(0x7ff0000000000000LL);   // +inf sorts last
+}
+
+// per chain: sum of weights and count of positive weights (fixed-shape reduction)
+__global__ __launch_bounds__(1024) void k_bg_chain_reduce(BgBatch a) {
+    __shared__ double s0[1024], s1[1024];
+    const int c = blockIdx.x;
+    const int64_t off = a.chainOff[c], n = a.chainLen[c];
+    double sw = 0.0, sp = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double w = a.w[off + i];
+        sw += w;
+        sp += w > 0.0 ? 1.0 : 0.0;
+    }
+    s0[threadIdx.x] = sw; s1[threadIdx.x] = sp;
+    __syncthreads();
+    for (int wd = 512; wd > 0; wd >>= 1) {
+        if ((int)threadIdx.x < wd) { s0[threadIdx.x] += s0[threadIdx.x + wd]; s1[threadIdx.x] += s1[threadIdx.x + wd]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { a.chainSum[c * 3 + 0] = s0[0]; a.chainSum[c * 3 + 1] = s1[0]; }
+}
+
+// mode 0: maskPrev = (current background < 0)  (initialBackground, core.py:8306-8316)
+// mode 1: maskNew = (solution < 0) with per-chain flags (core.py:8331-8340)
+// mode 2: maskPrev = maskNew for the chains that iterate on
+__global__ __launch_bounds__(256) void k_bg_mask(Prm p, BgBatch a, int mode) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;      // Npad is a multiple of 64: whole wavefronts only
+    if (g >= p.Npad) return;
+    const int c = a.groupChain[g >> 6];                             // wave-uniform (64-bin groups never straddle chains)
+    if (c < 0) return;
+    const bool inChain = g - a.chainOff[c] < a.chainLen[c];
+    if (mode == 0) {
+        if (inChain) a.maskPrev[g] = (a.bgCur != nullptr && (double)a.bgCur[g] < 0.0) ? 1 : 0;
+        return;
+    }
+    if (!a.active[c]) return;
+    if (mode == 2) {
+        if (inChain) a.maskPrev[g] = a.maskNew[g];
+        return;
+    }
+    unsigned int f = 0u;
+    if (inChain) {
+        const double x = a.sol[g];
+        const unsigned char neg = x < 0.0 ? 1 : 0;
+        a.maskNew[g] = neg;
+        f = (neg ? 1u : 0u) | ((neg != a.maskPrev[g]) ? 2u : 0u) | (isfinite(x) ? 0u : 4u);
+    }
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);         // one atomic per wavefront
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(a.flags + c, f);
+}
+
+// adjusted weights of the asymmetric IRLS (core.py:8312-8313, 8342-8343)
+__global__ __launch_bounds__(256) void k_bg_adjust(Prm p, BgBatch a, int useMask) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.Npad) return;
+    const int c = a.groupChain[g >> 6];
+    if (c < 0 || !a.active[c]) { if (c < 0) a.wAdj[g] = 0.0; return; }
+    double w = a.w[g];
+    if (useMask && a.maskPrev[g]) w += a.pen[c];
+    a.wAdj[g] = w;
+}
+
+// next background = float32(solution) (zero for chains without support); shift numerator sum w (next - current)^2
+__global__ __launch_bounds__(1024) void k_bg_finish(BgBatch a, const unsigned char *hasSupport) {
+    __shared__ double s0[1024];
+    const int c = blockIdx.x;
+    const int64_t off = a.chainOff[c], n = a.chainLen[c];
+    double num = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float nx = hasSupport[c] ? (float)a.sol[off + i] : 0.f;
+        a.bgNext[off + i] = nx;
+        const double dlt = (double)nx - (a.bgCur ? (double)a.bgCur[off + i] : 0.0);
+        num += a.w[off + i] * dlt * dlt;
+    }
+    s0[threadIdx.x] = num;
+    __syncthreads();
+    for (int wd = 512; wd > 0; wd >>= 1) {
+        if ((int)threadIdx.x < wd) s0[threadIdx.x] += s0[threadIdx.x + wd];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.chainSum[c * 3 + 2] = s0[0];
 }
 
 }  // namespace csr

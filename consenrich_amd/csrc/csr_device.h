@@ -50,6 +50,7 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
+    const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
     int qFromMult;      // smoother: 1 = process noise is the constant float32(Q0) (internal forward pass without
                         //           kappa / qScale / APN), 0 = read the stored / imported pNoise array tQ
     int xTolUlps;       // forward state chain validation: 0 = bitwise, k = accept a carry-in within k float32 ulps
@@ -190,8 +191,9 @@ struct BinStats {
 // at (z_0 - zbar)^2 / var, i.e. a relative error of ~1e-16 * that ratio -- >= 8 digits of headroom to the 1e-5 budget
 // even for a 10^4-sigma pivot.  1/R uses v_rcp_f64 + two Newton steps (<= 1 ulp).
 __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, const float *__restrict__ munc,
-                                              int64_t stride, int64_t g, int m, double pad) {
-    const double piv = (double)data[g];
+                                              int64_t stride, int64_t g, int m, double pad, float bgv) {
+    // bgv: background of this bin; z = data - background is formed in float32 like the reference's dataAdjusted
+    const double piv = (double)(data[g] - bgv);
     double s0 = 0.0, A = 0.0, Bq = 0.0, mant = 1.0;
     int ex = 0;
     const float *dp = data + g, *mp = munc + g;
@@ -200,7 +202,7 @@ __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, co
         float z[8], v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            z[u] = dp[(int64_t)(j + u) * stride];
+            z[u] = dp[(int64_t)(j + u) * stride] - bgv;
             v[u] = mp[(int64_t)(j + u) * stride];
         }
 #pragma unroll
@@ -224,7 +226,7 @@ __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, co
         double R = (double)mp[(int64_t)j * stride] + pad;
         if (R < 1.0e-12) R = 1.0e-12;
         const double w = rcp_nr(R);
-        const double dz = (double)dp[(int64_t)j * stride] - piv;
+        const double dz = (double)(dp[(int64_t)j * stride] - bgv) - piv;
         s0 += w;
         A = fma(w, dz, A);
         Bq = fma(w * dz, dz, Bq);
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
             const int4 bi = p.blk[b];
             if (s0 + si < bi.y && chain_on(p, b)) {
                 const int64_t g = (int64_t)bi.x + s0 + si;
-                o = bin_stats(p.data, p.munc, p.Npad, g, p.m, p.pad);
+                o = bin_stats(p.data, p.munc, p.Npad, g, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
             }
         }
         tile[0][si][ll] = o.s0;
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xs
     if (g < nBins) x = xsNat[g * xsStride];
     for (int j = r0; j < p.m; j += 4) {
         float v = 0.f;
-        if (g < nBins) v = (float)((double)p.data[(int64_t)j * p.Npad + g] - (double)x);
+        if (g < nBins) v = (float)((double)(p.data[(int64_t)j * p.Npad + g] - (p.bg ? p.bg[g] : 0.f)) - (double)x);
         tileR[j * 65 + gl] = v;
     }
     __syncthreads();
@@ -1454,16 +1456,18 @@ __global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int
     const int q = t & 15, r0 = t >> 4;               // q: group of 4 bins, r0: sample row within a sweep of 16
     const int64_t g = g0 + 4 * q;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+    float4 bg4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g + 3 < nBins) {
         x0 = xsNat[(g + 0) * xsStride]; x1 = xsNat[(g + 1) * xsStride];
         x2 = xsNat[(g + 2) * xsStride]; x3 = xsNat[(g + 3) * xsStride];
+        if (p.bg) bg4 = *reinterpret_cast<const float4 *>(p.bg + g);
     }
     for (int j = r0; j < p.m; j += 16) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g + 3 < nBins) {
             const float4 z = *reinterpret_cast<const float4 *>(p.data + (int64_t)j * p.Npad + g);
-            v.x = (float)((double)z.x - (double)x0); v.y = (float)((double)z.y - (double)x1);
-            v.z = (float)((double)z.z - (double)x2); v.w = (float)((double)z.w - (double)x3);
+            v.x = (float)((double)(z.x - bg4.x) - (double)x0); v.y = (float)((double)(z.y - bg4.y) - (double)x1);
+            v.z = (float)((double)(z.z - bg4.z) - (double)x2); v.w = (float)((double)(z.w - bg4.w) - (double)x3);
         }
         *reinterpret_cast<float4 *>(tileR + j * 68 + 4 * q) = v;
     }

@@ -5,6 +5,8 @@
 #include "csr_device.h"
 #include "csr_background.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -110,6 +112,20 @@ struct csr_ctx {
     uint32_t pendFlags = 0, pendExport = 0;
     bool pendWantD = false;
     const unsigned char *pendActiveF = nullptr, *pendActiveB = nullptr;
+    // device-resident background update (allocated on first use, freed with the batch)
+    struct BgState {
+        bool ready = false, haveCur = false;
+        int Bp = 0;
+        BgPrm prm{};
+        BgBatch bat{};
+        int *dGroupChain = nullptr;
+        double *keysSorted = nullptr, *out1 = nullptr;
+        unsigned char *dActive = nullptr, *dHasSup = nullptr;
+        double *dPen = nullptr;
+        void *sortTemp = nullptr;
+        size_t sortBytes = 0;
+        int64_t *segEnd = nullptr;
+    } bg;
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // profiling
@@ -147,6 +163,7 @@ static void free_batch(csr_ctx *c) {
     c->pendFwd = c->pendBwd = c->sidePending = false;
     c->pendExport = 0;
     c->dMail = nullptr;
+    c->bg = csr_ctx::BgState{};
     c->dActive = nullptr;
     for (auto &n : c->nat) n = nullptr;
 }
@@ -456,7 +473,7 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
         HIPOK(hipMemcpy(c->dChainLen, cl.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
     }
     HIPOK(hipMemset(c->dActive, 1, n_chains));
-    p.blk = dblk; p.blkChain = dbch; p.chainActive = nullptr;
+    p.blk = dblk; p.blkChain = dbch; p.chainActive = nullptr; p.bg = nullptr;
 
     float *dd, *dm;
     CHECK(dalloc(c, &dd, m * c->Npad));
@@ -544,7 +561,8 @@ static int64_t arr_comps_impl(csr_ctx *c, int id) {
     const int d = c->mdl.state_dim;
     switch (id) {
         case CSR_ARR_D: case CSR_ARR_LAMBDA: case CSR_ARR_KAPPA: case CSR_ARR_QSCALE: case CSR_ARR_SUMGAIN0:
-        case CSR_ARR_SUMGAIN1: case CSR_ARR_EFFQ_LEVEL: case CSR_ARR_EFFQ_TREND: case CSR_ARR_MUNCTRACE: return 1;
+        case CSR_ARR_SUMGAIN1: case CSR_ARR_EFFQ_LEVEL: case CSR_ARR_EFFQ_TREND: case CSR_ARR_MUNCTRACE:
+        case CSR_ARR_BACKGROUND: case CSR_ARR_BACKGROUND_NEXT: return 1;
         case CSR_ARR_XF: case CSR_ARR_XS: return d;
         case CSR_ARR_RESID: return c->m;
         default: return d * d;
@@ -1094,6 +1112,10 @@ extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *h
     if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
     if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
     if (!host_dst) return fail("null host buffer");
+    if (id == CSR_ARR_BACKGROUND && !c->nat[id]) {       // no background set yet: it is identically zero
+        float *q;
+        CHECK(nat_array(c, id, &q));
+    }
     if (!c->nat[id]) return fail("array %d was not exported", id);
     const ChainInfo &ci = c->chains[chain];
     const int64_t per = arr_comps(c, id);
@@ -1403,6 +1425,29 @@ struct DevBuf {
 };
 static DevBuf g_bgBuf;      // work space of the background solver (default context's device), grown on demand
 
+// blocks of Bp bins per chain; the last block absorbs a remainder shorter than 4 bins (interiors need >= 2 bins)
+static void bg_partition(const std::vector<int64_t> &off, const std::vector<int64_t> &len, int Bp, std::vector<int4> &blk,
+                         std::vector<int64_t> &first, std::vector<int64_t> &nblk) {
+    const size_t nc = off.size();
+    first.assign(nc, 0);
+    nblk.assign(nc, 0);
+    blk.clear();
+    for (size_t i = 0; i < nc; ++i) {
+        int64_t K = (len[i] + Bp - 1) / Bp;
+        if (K > 1 && len[i] - (K - 1) * Bp < 4) K -= 1;
+        first[i] = (int64_t)blk.size();
+        nblk[i] = K;
+        for (int64_t k = 0; k < K; ++k) {
+            int4 b;
+            b.x = (int)(off[i] + k * Bp);
+            b.y = (int)(k + 1 < K ? Bp : len[i] - (K - 1) * Bp);
+            b.z = (int)i;
+            b.w = k + 1 < K ? 1 : 0;
+            blk.push_back(b);
+        }
+    }
+}
+
 template <int NR>
 static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
     {
@@ -1440,27 +1485,16 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
     if (!c) return -1;
     CHECK(ctx_select(c));
     // partition
-    std::vector<int64_t> off(n_chains), first(n_chains), nblk(n_chains), len(n, n + n_chains);
+    std::vector<int64_t> off(n_chains), first, nblk, len(n, n + n_chains);
     std::vector<int4> blk;
     int64_t N = 0;
     for (int i = 0; i < n_chains; ++i) {
         if (n[i] <= 0) return fail("chain %d is empty", i);
         off[i] = N;
-        int64_t K = (n[i] + Bp - 1) / Bp;
-        if (K > 1 && n[i] - (K - 1) * Bp < 4) K -= 1;         // the last block absorbs a remainder shorter than 4 bins
-        first[i] = (int64_t)blk.size();
-        nblk[i] = K;
-        for (int64_t k = 0; k < K; ++k) {
-            int4 b;
-            b.x = (int)(N + k * Bp);
-            b.y = (int)(k + 1 < K ? Bp : n[i] - (K - 1) * Bp);
-            b.z = i;
-            b.w = k + 1 < K ? 1 : 0;
-            blk.push_back(b);
-        }
         N += n[i];
         if (N >= ((int64_t)1 << 31)) return fail("batch too large");
     }
+    bg_partition(off, len, Bp, blk, first, nblk);
     const int NR = zero_center ? 2 : 1;
     BgPrm p;
     memset(&p, 0, sizeof(p));
@@ -1555,6 +1589,287 @@ extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *
     HIPOK(hipMemcpyAsync(&sup, ds, 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
     *support = (int64_t)sup;
+    return 0;
+}
+
+// ---- device-resident background update of a batch (core.py:5064-5137, 8085-8378) ---------------------------------
+static int bg_setup(csr_ctx *c, int Bp) {
+    csr_ctx::BgState &S = c->bg;
+    if (S.ready && S.Bp == Bp) return 0;
+    if (S.ready) return fail("the background partition size cannot change after its first use in a batch");
+    const int nc = (int)c->chains.size();
+    std::vector<int64_t> off(nc), len(nc), first, nblk;
+    for (int i = 0; i < nc; ++i) { off[i] = c->chains[i].off; len[i] = c->chains[i].n; }
+    std::vector<int4> blk;
+    bg_partition(off, len, Bp, blk, first, nblk);
+    BgPrm &p = S.prm;
+    memset(&p, 0, sizeof(p));
+    p.nchains = nc; p.Bp = Bp; p.SB = Bp + 4;
+    p.NBk = (int64_t)blk.size();
+    p.NGk = (p.NBk + 63) / 64;
+    const int64_t TN = p.NGk * p.SB * 64, N = c->Npad;
+    int64_t *dFirst, *dNum;
+    int4 *dBlk;
+    CHECK(dalloc(c, &dFirst, nc)); CHECK(dalloc(c, &dNum, nc)); CHECK(dalloc(c, &dBlk, p.NBk));
+    HIPOK(hipMemcpy(dFirst, first.data(), 8 * nc, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dNum, nblk.data(), 8 * nc, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice));
+    p.chainOff = c->dChainOff; p.chainLen = c->dChainLen; p.chainFirstBlk = dFirst; p.chainNumBlk = dNum; p.blk = dBlk;
+    CHECK(dalloc(c, &p.invd, TN)); CHECK(dalloc(c, &p.l1, TN));
+    for (int j = 0; j < 6; ++j) CHECK(dalloc(c, &p.X[j], TN));
+    CHECK(dalloc(c, &p.T, 16 * p.NBk)); CHECK(dalloc(c, &p.t, 8 * p.NBk));
+    CHECK(dalloc(c, &p.sepIn, 11 * p.NBk)); CHECK(dalloc(c, &p.sepOut, 7 * p.NBk)); CHECK(dalloc(c, &p.sepG, 4 * p.NBk));
+    CHECK(dalloc(c, &p.badIdx, p.NBk)); CHECK(dalloc(c, &p.badVal, p.NBk));
+    CHECK(dalloc(c, &p.chainBadIdx, nc)); CHECK(dalloc(c, &p.chainBadVal, nc)); CHECK(dalloc(c, &p.chainMu, nc));
+    BgBatch &a = S.bat;
+    memset(&a, 0, sizeof(a));
+    std::vector<int> gc((size_t)(N / 64), -1);
+    for (int i = 0; i < nc; ++i)
+        for (int64_t g = off[i] / 64; g < (off[i] + len[i] + 63) / 64; ++g) gc[(size_t)g] = i;
+    CHECK(dalloc(c, &S.dGroupChain, N / 64));
+    HIPOK(hipMemcpy(S.dGroupChain, gc.data(), sizeof(int) * gc.size(), hipMemcpyHostToDevice));
+    a.groupChain = S.dGroupChain; a.chainOff = c->dChainOff; a.chainLen = c->dChainLen; a.nchains = nc;
+    CHECK(dalloc(c, &a.w, N)); CHECK(dalloc(c, &a.rhs, N)); CHECK(dalloc(c, &a.wAdj, N)); CHECK(dalloc(c, &a.keys, N));
+    CHECK(dalloc(c, &a.sol, N)); CHECK(dalloc(c, &S.keysSorted, N)); CHECK(dalloc(c, &S.out1, N));
+    CHECK(dalloc(c, &a.maskPrev, N)); CHECK(dalloc(c, &a.maskNew, N));
+    CHECK(dalloc(c, &S.dActive, nc)); CHECK(dalloc(c, &S.dHasSup, nc)); CHECK(dalloc(c, &S.dPen, nc));
+    CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 3 * nc));
+    HIPOK(hipMemsetAsync(a.sol, 0, 8 * N, c->stream));
+    HIPOK(hipMemsetAsync(S.out1, 0, 8 * N, c->stream));
+    HIPOK(hipMemsetAsync(a.wAdj, 0, 8 * N, c->stream));
+    a.active = S.dActive; a.pen = S.dPen;
+    std::vector<int64_t> segEnd(nc);
+    for (int i = 0; i < nc; ++i) segEnd[i] = off[i] + len[i];
+    CHECK(dalloc(c, &S.segEnd, nc));
+    HIPOK(hipMemcpy(S.segEnd, segEnd.data(), 8 * nc, hipMemcpyHostToDevice));
+    S.sortBytes = 0;
+    if (hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, S.sortBytes, a.keys, S.keysSorted, (int)N, nc, c->dChainOff,
+                                                  S.segEnd, 0, 64, c->stream) != hipSuccess)
+        return fail("segmented sort sizing failed");
+    char *tmp;
+    CHECK(dalloc(c, &tmp, (int64_t)S.sortBytes + 256));
+    S.sortTemp = tmp;
+    float *q;
+    CHECK(nat_array(c, CSR_ARR_BACKGROUND_NEXT, &q)); a.bgNext = q;
+    S.Bp = Bp;
+    S.ready = true;
+    return 0;
+}
+
+static int bg_solve_active(csr_ctx *c, const csr_bg_cfg *cfg) {
+    csr_ctx::BgState &S = c->bg;
+    BgPrm p = S.prm;
+    p.NR = cfg->zero_center ? 2 : 1;
+    p.lam = cfg->lam; p.lamF = cfg->lam_first;
+    p.w = S.bat.wAdj; p.rhs = S.bat.rhs;
+    p.out0 = S.bat.sol; p.out1 = S.out1;
+    p.active = S.dActive;
+    if (p.NR == 2) launch_bg<2>(c, p, true);
+    else launch_bg<1>(c, p, false);
+    LAUNCH_CHECK("background solve");
+    return 0;
+}
+
+extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, csr_bg_out *out) {
+    CHECK(need(c));
+    if (!cfg || !out) return fail("null argument");
+    CHECK(settle(c));
+    if (!c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
+    if (!std::isfinite(cfg->lam_first) || cfg->lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
+    if (!std::isfinite(cfg->lam) || cfg->lam < 0.0) return fail("lam must be finite and nonnegative");
+    int Bp = cfg->block_len > 0 ? cfg->block_len : 1024;
+    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
+    if (Bp < 8) return fail("block_len must be at least 8");
+    CHECK(bg_setup(c, Bp));
+    csr_ctx::BgState &S = c->bg;
+    BgBatch &a = S.bat;
+    const int nc = (int)c->chains.size();
+    const int gridN = (int)((c->Npad + 255) / 256);
+    // natural smoothed level (+ lambda)
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+        if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        CHECK(flush_export(c, L));
+    }
+    a.xsNat = c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
+    a.useLambda = cfg->use_lambda ? 1 : 0;
+    a.lamNat = cfg->use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr;
+    a.padf = (float)c->mdl.pad; a.wMinf = (float)c->mdl.w_min; a.wMaxf = (float)c->mdl.w_max;
+    a.bgCur = S.haveCur ? c->nat[CSR_ARR_BACKGROUND] : nullptr;
+    Prm p = c->p;
+    {
+        Scope sc(c, "bg_batch_stats");
+        hipLaunchKernelGGL(k_bg_batch_stats, dim3(gridN), dim3(256), 0, c->stream, p, a);
+    }
+    hipLaunchKernelGGL(k_bg_chain_reduce, dim3(nc), dim3(1024), 0, c->stream, a);
+    {
+        Scope sc(c, "bg_median_sort");
+        if (hipcub::DeviceSegmentedRadixSort::SortKeys(S.sortTemp, S.sortBytes, a.keys, S.keysSorted, (int)c->Npad, nc,
+                                                      c->dChainOff, S.segEnd, 0, 64, c->stream) != hipSuccess)
+            return fail("segmented sort failed");
+    }
+    LAUNCH_CHECK("background statistics");
+    std::vector<double> cs(3 * (size_t)nc);
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    std::vector<unsigned char> act(nc, 0), sup(nc, 0);
+    std::vector<double> pen(nc, 0.0);
+    std::vector<int> prevValid(nc, 0);
+    const double mult = cfg->negative_penalty_multiplier;
+    bool irls = cfg->use_nonnegative && std::isfinite(mult) && mult > 0.0;
+    for (int i = 0; i < nc; ++i) {
+        csr_bg_out &o = out[i];
+        memset(&o, 0, sizeof(o));
+        o.bad_index = -1;
+        o.weight_sum = cs[3 * i];
+        o.support = (int64_t)cs[3 * i + 1];
+        if (o.support <= 0) { o.status = CSR_BG_NO_SUPPORT; continue; }       // core.py:8148-8149
+        sup[i] = 1;
+        const double meanPos = o.weight_sum / (double)o.support;              // core.py:8157-8166
+        const double ratio = 1.0 + (4.0 * cfg->lam_first + 16.0 * cfg->lam) / meanPos;
+        o.roundoff_index = 2.220446049250313e-16 * ratio;
+        if (!std::isfinite(meanPos) || meanPos <= 0.0 || !std::isfinite(ratio) || ratio <= 0.0 || o.roundoff_index >= 1.0) {
+            o.status = CSR_BG_UNRELIABLE;
+            sup[i] = 0;
+            continue;
+        }
+        act[i] = 1;
+    }
+    // median of the positive weights = scale of the negative-part penalty (core.py:8287-8296)
+    if (irls) {
+        std::vector<double> mid(2 * (size_t)nc, 0.0);
+        for (int i = 0; i < nc; ++i) {
+            if (!act[i]) continue;
+            const int64_t P = out[i].support, o0 = c->chains[i].off;
+            HIPOK(hipMemcpyAsync(&mid[2 * i], S.keysSorted + o0 + (P - 1) / 2, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(hipMemcpyAsync(&mid[2 * i + 1], S.keysSorted + o0 + P / 2, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i) {
+            if (!act[i]) continue;
+            double scale = 0.5 * (mid[2 * i] + mid[2 * i + 1]);
+            if (!std::isfinite(scale) || scale <= 0.0) scale = 1.0;
+            out[i].weight_scale = scale;
+            pen[i] = mult * scale;
+            if (!std::isfinite(pen[i]) || pen[i] <= 0.0) pen[i] = 0.0;          // that chain: plain solve
+        }
+    }
+    HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(S.dPen, pen.data(), 8 * nc, hipMemcpyHostToDevice, c->stream));
+    // first solve (core.py:8306-8324)
+    const bool useInit = irls && cfg->use_initial;
+    if (useInit) {
+        hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 0);
+        for (int i = 0; i < nc; ++i) prevValid[i] = 1;
+    }
+    hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, useInit ? 1 : 0);
+    CHECK(bg_solve_active(c, cfg));
+    auto harvest_bad = [&]() -> int {
+        std::vector<int64_t> bi(nc);
+        std::vector<double> bv(nc);
+        HIPOK(hipMemcpyAsync(bi.data(), S.prm.chainBadIdx, 8 * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipMemcpyAsync(bv.data(), S.prm.chainBadVal, 8 * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i)
+            if (act[i] && bi[i] >= 0 && out[i].status == CSR_BG_OK) {
+                out[i].status = CSR_BG_BAD_PIVOT;
+                out[i].bad_index = bi[i];
+                out[i].bad_value = bv[i];
+                act[i] = 0;
+            }
+        return 0;
+    };
+    const int maxPasses = cfg->max_passes > 0 ? cfg->max_passes : 5;
+    if (irls) {
+        for (int pass = 0; pass < maxPasses; ++pass) {
+            CHECK(harvest_bad());
+            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemsetAsync(a.flags, 0, sizeof(unsigned int) * nc, c->stream));
+            hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+            std::vector<unsigned int> fl(nc);
+            HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(wait_stream(c));
+            bool any = false;
+            for (int i = 0; i < nc; ++i) {
+                if (!act[i]) continue;
+                if (fl[i] & 4u) { out[i].status = CSR_BG_NONFINITE; act[i] = 0; continue; }
+                if (pen[i] <= 0.0) { act[i] = 0; continue; }
+                if (prevValid[i] && !(fl[i] & 2u)) { act[i] = 0; continue; }       // same negative set: done
+                if (!(fl[i] & 1u)) { act[i] = 0; continue; }                       // nothing negative: done
+                prevValid[i] = 1;
+                out[i].passes = pass + 1;
+                any = true;
+            }
+            if (!any) break;
+            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 2);
+            hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+            CHECK(bg_solve_active(c, cfg));
+        }
+    }
+    CHECK(harvest_bad());
+    // finite check of the final solutions of chains that never went through the mask kernel is covered by k_bg_mask
+    // in the IRLS path; the plain path checks here
+    if (!irls) {
+        std::vector<unsigned char> all(nc);
+        for (int i = 0; i < nc; ++i) all[i] = sup[i];
+        HIPOK(hipMemcpyAsync(S.dActive, all.data(), nc, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipMemsetAsync(a.flags, 0, sizeof(unsigned int) * nc, c->stream));
+        hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+        std::vector<unsigned int> fl(nc);
+        HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i)
+            if (sup[i] && (fl[i] & 4u) && out[i].status == CSR_BG_OK) out[i].status = CSR_BG_NONFINITE;
+    }
+    for (int i = 0; i < nc; ++i) sup[i] = (out[i].status == CSR_BG_OK) ? 1 : 0;
+    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bg_finish, dim3(nc), dim3(1024), 0, c->stream, a, S.dHasSup);
+    LAUNCH_CHECK("k_bg_finish");
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    for (int i = 0; i < nc; ++i)
+        out[i].shift_rms = out[i].weight_sum > 0.0 ? std::sqrt(cs[3 * i + 2] / out[i].weight_sum) : 0.0;
+    return 0;
+}
+
+static int bg_current(csr_ctx *c, float **cur) {
+    CHECK(nat_array(c, CSR_ARR_BACKGROUND, cur));       // zero-initialised on first use
+    c->bg.haveCur = true;
+    c->p.bg = *cur;
+    return 0;
+}
+
+extern "C" int csr_batch_background_apply(csr_ctx *c, const unsigned char *take) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!c->bg.ready) return fail("no background proposal: run csr_batch_background_update first");
+    float *cur;
+    CHECK(bg_current(c, &cur));
+    const float *nxt = c->nat[CSR_ARR_BACKGROUND_NEXT];
+    for (size_t i = 0; i < c->chains.size(); ++i) {
+        if (take && !take[i]) continue;
+        const ChainInfo &ci = c->chains[i];
+        HIPOK(hipMemcpyAsync(cur + ci.off, nxt + ci.off, sizeof(float) * ci.n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+extern "C" int csr_batch_set_background(csr_ctx *c, int32_t chain, const float *background) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    float *cur;
+    CHECK(bg_current(c, &cur));
+    const ChainInfo &ci = c->chains[chain];
+    if (background) HIPOK(hipMemcpyAsync(cur + ci.off, background, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
+    else HIPOK(hipMemsetAsync(cur + ci.off, 0, sizeof(float) * ci.n, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
     return 0;
 }
 

@@ -190,6 +190,8 @@ enum { /* arrays, reference (natural) layout */
     CSR_ARR_EFFQ_LEVEL, /* (n)      */
     CSR_ARR_EFFQ_TREND, /* (n)      */
     CSR_ARR_MUNCTRACE,  /* (n)      */
+    CSR_ARR_BACKGROUND,       /* (n) current background (subtracted from the data), see csr_batch_background_* */
+    CSR_ARR_BACKGROUND_NEXT,  /* (n) proposal of the last csr_batch_background_update */
     CSR_ARR_COUNT
 };
 enum {
@@ -247,6 +249,39 @@ int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weigh
  * rhs[i] = sum_j inv_var[j,i]*resid[j,i] in fp64 over float32 (m,n) C-order matrices; *support = #{weight > 0}. */
 int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var, double *weight,
                                   double *rhs, int64_t *support);
+
+/* Device-resident background update for a whole batch (core.py:5064-5137 + 8085-8378): weight / rhs tracks from the
+ * resident ORIGINAL data, munc, smoothed level (and lambda), conditioning guard, the pentadiagonal solve and the
+ * asymmetric-IRLS wrapper (<= max_passes re-solves with the negative-part penalty), all chains in lock-step.  Nothing
+ * crosses PCIe but a few scalars per chain.  The proposal lands in CSR_ARR_BACKGROUND_NEXT; csr_batch_background_apply
+ * makes it the current background, which csr_batch_stats / the residuals then subtract from the data in float32 exactly
+ * like the reference's `dataAdjusted` (core.py:3253). */
+typedef struct csr_bg_cfg {
+    double lam_first, lam;              /* core.py:7478-7491 `_backgroundPenaltyWeightsFromSpan` */
+    double negative_penalty_multiplier; /* fitParams.backgroundNegativePenaltyMultiplier; <= 0 / non-finite: plain solve */
+    int32_t zero_center;                /* fitParams.ECM_zeroCenterBackground */
+    int32_t use_nonnegative;            /* fitParams.useNonnegativeBackground */
+    int32_t use_lambda;                 /* multiply 1/max(munc+pad,1e-8) by clip(lambda) (core.py:5065-5074) */
+    int32_t use_initial;                /* seed the first solve with the current background's negative mask */
+    int32_t max_passes;                 /* reference: 5 */
+    int32_t block_len;                  /* partition size of the solver, 0 = default */
+} csr_bg_cfg;
+enum { CSR_BG_OK = 0, CSR_BG_NO_SUPPORT = 1, CSR_BG_BAD_PIVOT = 2, CSR_BG_UNRELIABLE = 3, CSR_BG_NONFINITE = 4 };
+typedef struct csr_bg_out {
+    int64_t support;                    /* bins with positive weight */
+    double weight_sum, weight_scale;    /* sum of weights; median of the positive weights (IRLS penalty scale) */
+    double roundoff_index;              /* eps * (1 + (4 lam_first + 16 lam) / mean positive weight), core.py:8160-8187 */
+    double shift_rms;                   /* sqrt(sum w (next - current)^2 / sum w), core.py:5199-5215 */
+    int64_t bad_index;                  /* first modified pivot (CSR_BG_BAD_PIVOT) */
+    double bad_value;
+    int32_t passes;                     /* IRLS re-solves performed */
+    int32_t status;                     /* CSR_BG_*: the reference raises for 2, 3, 4 and returns zeros for 1 */
+} csr_bg_out;
+int csr_batch_background_update(csr_ctx *ctx, const csr_bg_cfg *cfg, csr_bg_out *out /* n_chains */);
+/* current background := last proposal for the chains with take[c] != 0 (NULL: all).  Invalidates the statistics. */
+int csr_batch_background_apply(csr_ctx *ctx, const unsigned char *take);
+/* H2D a background track for one chain (NULL: zeros). */
+int csr_batch_set_background(csr_ctx *ctx, int32_t chain, const float *background);
 
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */

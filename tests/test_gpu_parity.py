@@ -611,3 +611,101 @@ def test_background_weighted_stats(product):
     assert s0 == 0 and not w0.any() and not r0.any()
     with pytest.raises(ValueError, match="identical 2D shapes"):
         product.cbackgroundWeightedStatsWithSupport(res, inv[:, :-1])
+
+
+def _bg_batch_fixture(n_list, m, seed, bg_amp=0.3):
+    """synthetic chains with a smooth additive background; returns (batch inputs per chain)"""
+    ins = []
+    for c, n in enumerate(n_list):
+        data, munc = cases.synth(n, m, seed + c, mask_frac=0.02, outlier_frac=0.0)
+        bg = (bg_amp * np.sin(np.arange(n) / max(n / 5.0, 8.0)) - 0.1).astype(np.float32)
+        ins.append(((data + bg[None, :]).astype(np.float32), munc))
+    return ins
+
+
+@pytest.mark.parametrize("mode", ["irls", "plain", "zero_center", "lambda"])
+def test_batch_background_update_matches_oracle(product, oracle, mode):
+    """Device-resident background update (weights / rhs from the resident data, guard, solve, asymmetric IRLS) against
+    the oracle's restatement of core.py:5064-5137 + 8085-8378 evaluated on the downloaded smoothed level; then the
+    proposal is applied and the next fit must equal a fit of (data - background) uploaded from the host."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from oracle import background as bgo
+
+    n_list, m = [6000, 777, 64, 20000], 5
+    mp = ModelParams(state_dim=2)
+    ins = _bg_batch_fixture(n_list, m, 4100)
+    lam_first, lam = bgo.penalties(60, 2.0)
+    use_lambda = mode == "lambda"
+    fl = L.RETURN_NLL | (L.USE_LAMBDA if use_lambda else 0)
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, n_list)
+        lams = []
+        for c, (data, munc) in enumerate(ins):
+            b.upload(c, data, munc)
+            lam_c = cases.multipliers(n_list[c], 50 + c)[0]
+            lams.append(lam_c)
+            if use_lambda:
+                b.upload_multipliers(c, lam_c, None, None)
+        b.stats()
+        b.forward_backward(fl)
+        b.export(L.EXPORT_SMOOTH)
+        xs = [b.download(c, "xs") for c in range(len(n_list))]
+        kw = dict(zero_center=mode == "zero_center", use_nonnegative=mode != "plain", negative_penalty_multiplier=2.0,
+                  use_lambda=use_lambda, use_initial=True)
+        info = b.background_update(lam_first, lam, **kw)
+        nxt = [b.download(c, "background_next") for c in range(len(n_list))]
+        for c, (data, munc) in enumerate(ins):
+            w, r, _, _ = bgo.weight_rhs_tracks(data, munc, xs[c][:, 0], np.float32(mp.pad),
+                                               lams[c] if use_lambda else None, mp.lambda_bounds)
+            ref, rinfo = bgo.solve_background(w, r, 0, zero_center=kw["zero_center"], use_nonnegative=kw["use_nonnegative"],
+                                              multiplier=2.0, initial=np.zeros(n_list[c], np.float32),
+                                              penalties_override=(lam_first, lam), return_info=True)
+            scale = max(float(np.abs(ref).max()), 1e-6)
+            assert info[c]["status"] == L.BG_OK and info[c]["support"] == int(np.count_nonzero(w > 0))
+            assert info[c]["weight_sum"] == pytest.approx(float(w.sum()), rel=1e-12)
+            assert info[c]["passes"] == rinfo["passes"], (mode, c)
+            assert info[c]["roundoff_index"] == pytest.approx(rinfo["roundoff_index"], rel=1e-9)
+            assert float(np.abs(nxt[c] - ref).max()) <= max(1e-5, 10 * rinfo["roundoff_index"]) * scale + 1e-7, (mode, c)
+            shift = np.sqrt(np.dot(w, ref.astype(np.float64) ** 2) / w.sum())
+            assert info[c]["shift_rms"] == pytest.approx(shift, rel=1e-4)
+        # apply and refit: identical to fitting (data - background) uploaded from the host (float32 subtraction)
+        b.background_apply()
+        b.stats()
+        sd, sn = b.forward_backward(fl)
+        b.export(L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        got = [(b.download(c, "xs"), b.download(c, "resid")) for c in range(len(n_list))]
+    with DeviceBatch(0) as b2:
+        b2.configure(mp, m, n_list)
+        for c, (data, munc) in enumerate(ins):
+            b2.upload(c, (data - nxt[c][None, :]).astype(np.float32), munc)
+            if use_lambda:
+                b2.upload_multipliers(c, lams[c], None, None)
+        b2.stats()
+        sd2, sn2 = b2.forward_backward(fl)
+        b2.export(L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        for c in range(len(n_list)):
+            assert np.array_equal(got[c][0], b2.download(c, "xs")) and np.array_equal(got[c][1], b2.download(c, "resid"))
+        assert np.array_equal(sn, sn2)
+
+
+def test_batch_background_error_statuses(product):
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [3000, 500], 3
+    ins = _bg_batch_fixture(n_list, m, 4200)
+    with DeviceBatch(0) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        for c, (data, munc) in enumerate(ins):
+            b.upload(c, data, munc)
+        b.stats()
+        b.forward_backward(L.RETURN_NLL)
+        with pytest.raises(RuntimeError, match="exceeds float64 reliability"):      # tests/test_core.py:83-91
+            b.background_update(1e6, 1e22)
+        out = b.background_update(1e6, 1e22, raise_on_error=False)
+        assert all(o["status"] == L.BG_UNRELIABLE and o["roundoff_index"] >= 1.0 for o in out)
+        assert not b.download(0, "background_next").any()          # a failed chain proposes zeros
+        ok = b.background_update(10.0, 100.0)
+        assert all(o["status"] == L.BG_OK for o in ok)
+        assert not b.download(0, "background").any()              # nothing applied yet

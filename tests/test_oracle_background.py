@@ -94,3 +94,49 @@ def test_reference_literals_and_dense_specification():
     for bad in (dict(lam=-1.0), dict(lamFirst=np.inf)):
         with pytest.raises(ValueError):
             orc.csolveZeroCenteredBackground(w, r, bad.get("lam", 1.0), False, lamFirst=bad.get("lamFirst", 0.0))
+
+
+# ---- the Python control flow around the natives (core.py:8085-8378), expectations of the reference's own tests ---------
+def test_background_update_reference_expectations():
+    from oracle import background as bgo
+
+    # tests/test_core.py:58-92: one track, 64 bins, residual 1, invVar 8.53348
+    res = np.ones((1, 64), np.float32)
+    inv = np.full((1, 64), 8.53348, np.float32)
+    w, r, _ = orc.cbackgroundWeightedStatsWithSupport(res, inv)
+    healthy = bgo.solve_background(w, r, 401, 64.0, zero_center=False, use_nonnegative=False)
+    np.testing.assert_allclose(healthy, 1.0, rtol=1.0e-3)
+    warned, info = bgo.solve_background(w, r, 1771, 64.0, zero_center=False, use_nonnegative=False, return_info=True)
+    assert np.isfinite(warned).all() and info["roundoff_index"] >= 1.0e-2          # the reference logs a warning here
+    with pytest.raises(RuntimeError, match="exceeds float64 reliability"):
+        bgo.solve_background(w, r, 6427, 128.0, zero_center=False, use_nonnegative=False)
+    # tests/test_core.py:2542-2581: re-using the plain solution as initialBackground reproduces it; zero weights -> zeros
+    n = 48
+    x = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    res = np.vstack([-0.15 + 0.9 * np.exp(-((x - 0.2) ** 2) / 0.05), -0.10 + 0.7 * np.exp(-((x + 0.25) ** 2) / 0.08),
+                     0.05 * np.sin(np.linspace(0.0, 3.0 * np.pi, n, dtype=np.float32))]).astype(np.float32)
+    inv = np.vstack([np.linspace(0.7, 1.8, n, dtype=np.float32), np.linspace(1.4, 0.6, n, dtype=np.float32),
+                     np.full(n, 1.1, dtype=np.float32)])
+    w, r, sup = orc.cbackgroundWeightedStatsWithSupport(res, inv)
+    assert sup == n
+    for nonneg in (False, True):
+        plain = bgo.solve_background(w, r, 5, 0.8, zero_center=False, use_nonnegative=nonneg)
+        reused = bgo.solve_background(w, r, 5, 0.8, zero_center=False, use_nonnegative=nonneg, initial=plain)
+        np.testing.assert_allclose(reused, plain, atol=1.0e-5)
+        assert plain.dtype == np.float32
+    assert not bgo.solve_background(np.zeros(n), np.zeros(n), 5, 0.8).any()
+    assert bgo.penalties(12, 0.5) == (pytest.approx(0.5 * 144 / 4.0), pytest.approx(0.5 * 12.0 ** 4 / 16.0))   # :2703-2714
+
+
+def test_background_irls_penalises_negative_parts():
+    from oracle import background as bgo
+
+    rng = np.random.default_rng(8)
+    n = 4000
+    truth = 0.25 * np.sin(np.arange(n) / 300.0) - 0.05
+    w = 100.0 * np.exp(rng.normal(0, 0.2, n))
+    r = w * (truth + rng.normal(0, 0.05, n))
+    plain = bgo.solve_background(w, r, 40, 2.0, use_nonnegative=False)
+    soft, info = bgo.solve_background(w, r, 40, 2.0, use_nonnegative=True, multiplier=4.0, return_info=True)
+    assert info["passes"] >= 1 and (plain < 0).any()
+    assert np.minimum(soft, 0).sum() > np.minimum(plain, 0).sum()          # negative mass shrinks, softly
