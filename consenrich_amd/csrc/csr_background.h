@@ -475,13 +475,20 @@ struct BgBatch {
     const float *lamNat;                // natural lambda (exported) or null
     const float *xsNat;                 // natural smoothed state (Npad, d), level = component 0
     int xsStride;
-    double *w, *rhs, *wAdj, *keys, *sol;
+    double *w, *rhs, *wAdj, *sol;
+    unsigned long long *selAns;         // per chain x 2: order statistic being built bit by bit
+    const long long *selRank;           // per chain x 2: 0-based rank among the positive weights, -1 = unused
     unsigned char *maskPrev, *maskNew;
     const float *bgCur;
     float *bgNext;
     const unsigned char *active;        // chains still iterating
     const double *pen;                  // per chain negative-penalty weight
     unsigned int *flags;                // per chain: bit0 any negative, bit1 mask changed, bit2 non-finite solution
+    // per-chain reductions without atomics: every wavefront owns a run of <= BG_GPW 64-bin groups of ONE chain and writes
+    // one partial record; a per-chain workgroup then folds its records in a fixed order (deterministic)
+    const int *waveChain, *waveG0, *waveG1, *chainWave0, *chainWaveN;
+    int NW, pad_;
+    double *part;                       // NW x 2 partial records
     double *chainSum;                   // per chain: [sumW, support, shiftNum]
 };
 
@@ -506,56 +513,106 @@ __global__ __launch_bounds__(256) void k_bg_batch_stats(Prm p, BgBatch a) {
     }
     a.w[g] = ws;
     a.rhs[g] = rs;
-    a.keys[g] = (ws > 0.0 && isfinite(ws)) ? ws : __longlong_as_double(0x7ff0000000000000LL);   // +inf sorts last
 }
 
-// per chain: sum of weights and count of positive weights (fixed-shape reduction)
-__global__ __launch_bounds__(1024) void k_bg_chain_reduce(BgBatch a) {
-    __shared__ double s0[1024], s1[1024];
-    const int c = blockIdx.x;
-    const int64_t off = a.chainOff[c], n = a.chainLen[c];
-    double sw = 0.0, sp = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const double w = a.w[off + i];
-        sw += w;
-        sp += w > 0.0 ? 1.0 : 0.0;
-    }
-    s0[threadIdx.x] = sw; s1[threadIdx.x] = sp;
-    __syncthreads();
-    for (int wd = 512; wd > 0; wd >>= 1) {
-        if ((int)threadIdx.x < wd) { s0[threadIdx.x] += s0[threadIdx.x + wd]; s1[threadIdx.x] += s1[threadIdx.x + wd]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { a.chainSum[c * 3 + 0] = s0[0]; a.chainSum[c * 3 + 1] = s1[0]; }
-}
+constexpr int BG_GPW = 32;           // 64-bin groups per wavefront record
 
 // mode 0: maskPrev = (current background < 0)  (initialBackground, core.py:8306-8316)
-// mode 1: maskNew = (solution < 0) with per-chain flags (core.py:8331-8340)
 // mode 2: maskPrev = maskNew for the chains that iterate on
 __global__ __launch_bounds__(256) void k_bg_mask(Prm p, BgBatch a, int mode) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;      // Npad is a multiple of 64: whole wavefronts only
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= p.Npad) return;
-    const int c = a.groupChain[g >> 6];                             // wave-uniform (64-bin groups never straddle chains)
-    if (c < 0) return;
-    const bool inChain = g - a.chainOff[c] < a.chainLen[c];
-    if (mode == 0) {
-        if (inChain) a.maskPrev[g] = (a.bgCur != nullptr && (double)a.bgCur[g] < 0.0) ? 1 : 0;
+    const int c = a.groupChain[g >> 6];
+    if (c < 0 || g - a.chainOff[c] >= a.chainLen[c]) return;
+    if (mode == 0) { a.maskPrev[g] = (a.bgCur != nullptr && (double)a.bgCur[g] < 0.0) ? 1 : 0; return; }
+    if (a.active[c]) a.maskPrev[g] = a.maskNew[g];
+}
+
+// One pass over the bins with per-wavefront partial records (no atomics).  what:
+//   0  sums:    part = [sum w, #(w > 0)]                                        (core.py:8148, 8157-8160)
+//   1  select:  part = [#(key <= trial0), #(key <= trial1)] for bit `bit`      (median of the positive weights)
+//   2  mask:    maskNew = (solution < 0); part[0] = OR of {any negative, mask changed, non-finite} (core.py:8331-8340)
+//   3  finish:  bgNext = float32(solution) (0 without support); part[0] = sum w (next - current)^2 (core.py:5199-5215)
+__global__ __launch_bounds__(256) void k_bg_wave_pass(Prm p, BgBatch a, int what, int bit, const unsigned char *hasSupport) {
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= a.NW) return;
+    const int c = a.waveChain[wv];
+    const int64_t off = a.chainOff[c], len = a.chainLen[c];
+    double r0 = 0.0, r1 = 0.0;
+    unsigned int fl = 0u;
+    bool run = true;
+    unsigned long long t0 = 0, t1 = 0;
+    if (what == 1) {
+        run = a.selRank[2 * c] >= 0;
+        const unsigned long long low = (1ull << bit) - 1ull;
+        t0 = a.selAns[2 * c] | low; t1 = a.selAns[2 * c + 1] | low;
+    }
+    if (what == 2) run = a.active[c] != 0;
+    const bool sup = what == 3 ? hasSupport[c] != 0 : true;
+    if (run) {
+        for (int G = a.waveG0[wv]; G < a.waveG1[wv]; ++G) {
+            const int64_t g = ((int64_t)G << 6) + lane;
+            const bool in = g - off < len;
+            if (what == 0) {
+                const double w = in ? a.w[g] : 0.0;
+                r0 += w;
+                r1 += w > 0.0 ? 1.0 : 0.0;
+            } else if (what == 1) {
+                const double w = in ? a.w[g] : 0.0;
+                const bool ok = w > 0.0 && isfinite(w);
+                const unsigned long long key = (unsigned long long)__double_as_longlong(w);
+                r0 += (double)__popcll(__ballot(ok && key <= t0));
+                r1 += (double)__popcll(__ballot(ok && key <= t1));
+            } else if (what == 2) {
+                if (in) {
+                    const double x = a.sol[g];
+                    const unsigned char neg = x < 0.0 ? 1 : 0;
+                    a.maskNew[g] = neg;
+                    fl |= (neg ? 1u : 0u) | ((neg != a.maskPrev[g]) ? 2u : 0u) | (isfinite(x) ? 0u : 4u);
+                }
+            } else if (in) {
+                const float nx = sup ? (float)a.sol[g] : 0.f;
+                a.bgNext[g] = nx;
+                const double dlt = (double)nx - (a.bgCur ? (double)a.bgCur[g] : 0.0);
+                r0 += a.w[g] * dlt * dlt;
+            }
+        }
+    }
+    if (what == 1) {                                    // ballot counts are already wave totals
+        if (lane == 0) { a.part[2 * wv] = r0; a.part[2 * wv + 1] = r1; }
         return;
     }
-    if (!a.active[c]) return;
-    if (mode == 2) {
-        if (inChain) a.maskPrev[g] = a.maskNew[g];
+    if (what == 2) {
+        for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
+        if (lane == 0) a.part[2 * wv] = (double)fl;
         return;
     }
-    unsigned int f = 0u;
-    if (inChain) {
-        const double x = a.sol[g];
-        const unsigned char neg = x < 0.0 ? 1 : 0;
-        a.maskNew[g] = neg;
-        f = (neg ? 1u : 0u) | ((neg != a.maskPrev[g]) ? 2u : 0u) | (isfinite(x) ? 0u : 4u);
+    for (int o = 32; o > 0; o >>= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); }   // fixed butterfly order
+    if (lane == 0) { a.part[2 * wv] = r0; a.part[2 * wv + 1] = r1; }
+}
+
+// fold the records of every chain (one wavefront per chain, fixed order) and act on the totals
+__global__ __launch_bounds__(64) void k_bg_wave_fold(BgBatch a, int what, int bit) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int w0 = a.chainWave0[c], nw = a.chainWaveN[c];
+    double r0 = 0.0, r1 = 0.0;
+    unsigned int fl = 0u;
+    for (int i = lane; i < nw; i += 64) {
+        const double x0 = a.part[2 * (w0 + i)], x1 = a.part[2 * (w0 + i) + 1];
+        if (what == 2) fl |= (unsigned int)x0;
+        else { r0 += x0; r1 += x1; }
     }
-    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);         // one atomic per wavefront
-    if ((threadIdx.x & 63) == 0 && f) atomicOr(a.flags + c, f);
+    for (int o = 32; o > 0; o >>= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); fl |= __shfl_xor(fl, o); }
+    if (lane != 0) return;
+    if (what == 0) { a.chainSum[c * 3 + 0] = r0; a.chainSum[c * 3 + 1] = r1; }
+    else if (what == 1) {
+        // bit b of the k-th smallest key is 0 iff at least k+1 keys are <= (prefix | all-ones below b)
+        const long long k0 = a.selRank[2 * c], k1 = a.selRank[2 * c + 1];
+        if (k0 >= 0 && r0 < (double)(k0 + 1)) a.selAns[2 * c] |= (1ull << bit);
+        if (k1 >= 0 && r1 < (double)(k1 + 1)) a.selAns[2 * c + 1] |= (1ull << bit);
+    } else if (what == 2) a.flags[c] = fl;
+    else a.chainSum[c * 3 + 2] = r0;
 }
 
 // adjusted weights of the asymmetric IRLS (core.py:8312-8313, 8342-8343)
@@ -567,27 +624,6 @@ __global__ __launch_bounds__(256) void k_bg_adjust(Prm p, BgBatch a, int useMask
     double w = a.w[g];
     if (useMask && a.maskPrev[g]) w += a.pen[c];
     a.wAdj[g] = w;
-}
-
-// next background = float32(solution) (zero for chains without support); shift numerator sum w (next - current)^2
-__global__ __launch_bounds__(1024) void k_bg_finish(BgBatch a, const unsigned char *hasSupport) {
-    __shared__ double s0[1024];
-    const int c = blockIdx.x;
-    const int64_t off = a.chainOff[c], n = a.chainLen[c];
-    double num = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const float nx = hasSupport[c] ? (float)a.sol[off + i] : 0.f;
-        a.bgNext[off + i] = nx;
-        const double dlt = (double)nx - (a.bgCur ? (double)a.bgCur[off + i] : 0.0);
-        num += a.w[off + i] * dlt * dlt;
-    }
-    s0[threadIdx.x] = num;
-    __syncthreads();
-    for (int wd = 512; wd > 0; wd >>= 1) {
-        if ((int)threadIdx.x < wd) s0[threadIdx.x] += s0[threadIdx.x + wd];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.chainSum[c * 3 + 2] = s0[0];
 }
 
 }  // namespace csr

@@ -5,8 +5,6 @@
 #include "csr_device.h"
 #include "csr_background.h"
 
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -119,12 +117,10 @@ struct csr_ctx {
         BgPrm prm{};
         BgBatch bat{};
         int *dGroupChain = nullptr;
-        double *keysSorted = nullptr, *out1 = nullptr;
+        double *out1 = nullptr;
         unsigned char *dActive = nullptr, *dHasSup = nullptr;
         double *dPen = nullptr;
-        void *sortTemp = nullptr;
-        size_t sortBytes = 0;
-        int64_t *segEnd = nullptr;
+        long long *dSelRank = nullptr;
     } bg;
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -1629,8 +1625,10 @@ static int bg_setup(csr_ctx *c, int Bp) {
     CHECK(dalloc(c, &S.dGroupChain, N / 64));
     HIPOK(hipMemcpy(S.dGroupChain, gc.data(), sizeof(int) * gc.size(), hipMemcpyHostToDevice));
     a.groupChain = S.dGroupChain; a.chainOff = c->dChainOff; a.chainLen = c->dChainLen; a.nchains = nc;
-    CHECK(dalloc(c, &a.w, N)); CHECK(dalloc(c, &a.rhs, N)); CHECK(dalloc(c, &a.wAdj, N)); CHECK(dalloc(c, &a.keys, N));
-    CHECK(dalloc(c, &a.sol, N)); CHECK(dalloc(c, &S.keysSorted, N)); CHECK(dalloc(c, &S.out1, N));
+    CHECK(dalloc(c, &a.w, N)); CHECK(dalloc(c, &a.rhs, N)); CHECK(dalloc(c, &a.wAdj, N));
+    CHECK(dalloc(c, &a.sol, N)); CHECK(dalloc(c, &S.out1, N));
+    CHECK(dalloc(c, &a.selAns, 2 * nc)); CHECK(dalloc(c, &S.dSelRank, 2 * nc));
+    a.selRank = S.dSelRank;
     CHECK(dalloc(c, &a.maskPrev, N)); CHECK(dalloc(c, &a.maskNew, N));
     CHECK(dalloc(c, &S.dActive, nc)); CHECK(dalloc(c, &S.dHasSup, nc)); CHECK(dalloc(c, &S.dPen, nc));
     CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 3 * nc));
@@ -1638,17 +1636,30 @@ static int bg_setup(csr_ctx *c, int Bp) {
     HIPOK(hipMemsetAsync(S.out1, 0, 8 * N, c->stream));
     HIPOK(hipMemsetAsync(a.wAdj, 0, 8 * N, c->stream));
     a.active = S.dActive; a.pen = S.dPen;
-    std::vector<int64_t> segEnd(nc);
-    for (int i = 0; i < nc; ++i) segEnd[i] = off[i] + len[i];
-    CHECK(dalloc(c, &S.segEnd, nc));
-    HIPOK(hipMemcpy(S.segEnd, segEnd.data(), 8 * nc, hipMemcpyHostToDevice));
-    S.sortBytes = 0;
-    if (hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, S.sortBytes, a.keys, S.keysSorted, (int)N, nc, c->dChainOff,
-                                                  S.segEnd, 0, 64, c->stream) != hipSuccess)
-        return fail("segmented sort sizing failed");
-    char *tmp;
-    CHECK(dalloc(c, &tmp, (int64_t)S.sortBytes + 256));
-    S.sortTemp = tmp;
+    {
+        std::vector<int> wc, wg0, wg1, cw0(nc), cwn(nc);
+        for (int i = 0; i < nc; ++i) {
+            const int64_t G0 = off[i] / 64, G1 = (off[i] + len[i] + 63) / 64;
+            cw0[i] = (int)wc.size();
+            for (int64_t g = G0; g < G1; g += BG_GPW) {
+                wc.push_back(i);
+                wg0.push_back((int)g);
+                wg1.push_back((int)std::min<int64_t>(g + BG_GPW, G1));
+            }
+            cwn[i] = (int)wc.size() - cw0[i];
+        }
+        int *dwc, *dwg0, *dwg1, *dcw0, *dcwn;
+        CHECK(dalloc(c, &dwc, (int64_t)wc.size())); CHECK(dalloc(c, &dwg0, (int64_t)wc.size()));
+        CHECK(dalloc(c, &dwg1, (int64_t)wc.size())); CHECK(dalloc(c, &dcw0, nc)); CHECK(dalloc(c, &dcwn, nc));
+        HIPOK(hipMemcpy(dwc, wc.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dwg0, wg0.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dwg1, wg1.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dcw0, cw0.data(), 4 * nc, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dcwn, cwn.data(), 4 * nc, hipMemcpyHostToDevice));
+        a.waveChain = dwc; a.waveG0 = dwg0; a.waveG1 = dwg1; a.chainWave0 = dcw0; a.chainWaveN = dcwn;
+        a.NW = (int)wc.size();
+        CHECK(dalloc(c, &a.part, 2 * (int64_t)wc.size()));
+    }
     float *q;
     CHECK(nat_array(c, CSR_ARR_BACKGROUND_NEXT, &q)); a.bgNext = q;
     S.Bp = Bp;
@@ -1703,13 +1714,12 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
         Scope sc(c, "bg_batch_stats");
         hipLaunchKernelGGL(k_bg_batch_stats, dim3(gridN), dim3(256), 0, c->stream, p, a);
     }
-    hipLaunchKernelGGL(k_bg_chain_reduce, dim3(nc), dim3(1024), 0, c->stream, a);
-    {
-        Scope sc(c, "bg_median_sort");
-        if (hipcub::DeviceSegmentedRadixSort::SortKeys(S.sortTemp, S.sortBytes, a.keys, S.keysSorted, (int)c->Npad, nc,
-                                                      c->dChainOff, S.segEnd, 0, 64, c->stream) != hipSuccess)
-            return fail("segmented sort failed");
-    }
+    const int gridW = (a.NW + 3) / 4;
+    auto wave_pass = [&](int what, int bit, const unsigned char *hs) {
+        hipLaunchKernelGGL(k_bg_wave_pass, dim3(gridW), dim3(256), 0, c->stream, p, a, what, bit, hs);
+        hipLaunchKernelGGL(k_bg_wave_fold, dim3(nc), dim3(64), 0, c->stream, a, what, bit);
+    };
+    wave_pass(0, 0, nullptr);
     LAUNCH_CHECK("background statistics");
     std::vector<double> cs(3 * (size_t)nc);
     HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
@@ -1739,13 +1749,21 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     }
     // median of the positive weights = scale of the negative-part penalty (core.py:8287-8296)
     if (irls) {
-        std::vector<double> mid(2 * (size_t)nc, 0.0);
+        std::vector<long long> rank(2 * (size_t)nc, -1);
         for (int i = 0; i < nc; ++i) {
             if (!act[i]) continue;
-            const int64_t P = out[i].support, o0 = c->chains[i].off;
-            HIPOK(hipMemcpyAsync(&mid[2 * i], S.keysSorted + o0 + (P - 1) / 2, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPOK(hipMemcpyAsync(&mid[2 * i + 1], S.keysSorted + o0 + P / 2, 8, hipMemcpyDeviceToHost, c->stream));
+            rank[2 * i] = (out[i].support - 1) / 2;          // numpy.median: mean of the two middle order statistics
+            rank[2 * i + 1] = out[i].support / 2;
         }
+        HIPOK(hipMemcpyAsync(S.dSelRank, rank.data(), 8 * 2 * nc, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipMemsetAsync(a.selAns, 0, 8 * 2 * nc, c->stream));
+        {
+            Scope sc(c, "bg_median_select");
+            for (int bit = 62; bit >= 0; --bit) wave_pass(1, bit, nullptr);
+        }
+        LAUNCH_CHECK("median select");
+        std::vector<double> mid(2 * (size_t)nc, 0.0);
+        HIPOK(hipMemcpyAsync(mid.data(), a.selAns, 8 * 2 * nc, hipMemcpyDeviceToHost, c->stream));
         HIPOK(wait_stream(c));
         for (int i = 0; i < nc; ++i) {
             if (!act[i]) continue;
@@ -1787,8 +1805,7 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
         for (int pass = 0; pass < maxPasses; ++pass) {
             CHECK(harvest_bad());
             HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
-            HIPOK(hipMemsetAsync(a.flags, 0, sizeof(unsigned int) * nc, c->stream));
-            hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+            wave_pass(2, 0, nullptr);
             std::vector<unsigned int> fl(nc);
             HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
             HIPOK(wait_stream(c));
@@ -1817,8 +1834,7 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
         std::vector<unsigned char> all(nc);
         for (int i = 0; i < nc; ++i) all[i] = sup[i];
         HIPOK(hipMemcpyAsync(S.dActive, all.data(), nc, hipMemcpyHostToDevice, c->stream));
-        HIPOK(hipMemsetAsync(a.flags, 0, sizeof(unsigned int) * nc, c->stream));
-        hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+        wave_pass(2, 0, nullptr);
         std::vector<unsigned int> fl(nc);
         HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
         HIPOK(wait_stream(c));
@@ -1827,7 +1843,7 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     }
     for (int i = 0; i < nc; ++i) sup[i] = (out[i].status == CSR_BG_OK) ? 1 : 0;
     HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_bg_finish, dim3(nc), dim3(1024), 0, c->stream, a, S.dHasSup);
+    wave_pass(3, 0, S.dHasSup);
     LAUNCH_CHECK("k_bg_finish");
     HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
     HIPOK(wait_stream(c));

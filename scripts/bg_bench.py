@@ -42,3 +42,17 @@ print(json.dumps({"row": "8(f) rank 1 background solve", "bins": nb, "chains": l
                   "gpu_bins_per_s_kernels": nb / (best["kernel_total_ms"] * 1e-3),
                   "cpu_oracle_bins_per_s": lengths[i21] / cpu, "cpu_sample": f"chain of {lengths[i21]} bins, 1 thread",
                   "max_rel_diff_vs_oracle": err}))
+
+# ---- device-resident update on the bench batch (hg38 @200bp x 32): everything stays in HBM -------------------------
+from consenrich_amd.batch import DeviceBatch, ModelParams
+b = DeviceBatch(0)
+b.configure(ModelParams(state_dim=2), 32, lengths); b.synthesize(1234)
+b.stats(); b.forward_backward(L.RETURN_NLL, True)
+b.background_update(lamF, lam, negative_penalty_multiplier=1.0)
+b.synchronize(); b.profile(True)
+t = time.perf_counter(); info = b.background_update(lamF, lam, negative_penalty_multiplier=1.0); b.synchronize(); wall = time.perf_counter() - t
+kt = b.kernel_times(); b.profile(False)
+print(json.dumps({"row": "8(f) rank 1 device-resident update (hg38 x 32)", "wall_ms": round(wall * 1e3, 2),
+                  "irls_passes_max": max(o["passes"] for o in info),
+                  "kernels_ms": {k: round(v[1], 3) for k, v in kt.items() if k.startswith("bg_") or k == "export_natural"},
+                  "bins_per_s": nb / wall}))

@@ -665,6 +665,8 @@ def test_batch_background_update_matches_oracle(product, oracle, mode):
             assert info[c]["status"] == L.BG_OK and info[c]["support"] == int(np.count_nonzero(w > 0))
             assert info[c]["weight_sum"] == pytest.approx(float(w.sum()), rel=1e-12)
             assert info[c]["passes"] == rinfo["passes"], (mode, c)
+            if kw["use_nonnegative"]:
+                assert info[c]["weight_scale"] == float(np.median(w[w > 0.0])), (mode, c)      # exact order statistics
             assert info[c]["roundoff_index"] == pytest.approx(rinfo["roundoff_index"], rel=1e-9)
             assert float(np.abs(nxt[c] - ref).max()) <= max(1e-5, 10 * rinfo["roundoff_index"]) * scale + 1e-7, (mode, c)
             shift = np.sqrt(np.dot(w, ref.astype(np.float64) ** 2) / w.sum())
