@@ -355,10 +355,20 @@ struct FwdPTrend {
                           near_ulps(a.c01, b.c01, sqrtf(fabsf(a.c00 * a.c11)), k);
         return bits | near;
     }
+    struct Gain {            // what the state update of the same bin needs (also the content of the gain record)
+        double gs;
+        float p00, p10;
+    };
     // b, s: block / step of this bin (for the shifted pNoise store)
     template <bool STORE>
     __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
                                                 int64_t bfirst) {
+        Gain g;
+        advance<STORE>(p, c, in, b, s, i, bfirst, g);
+    }
+    template <bool STORE, class InT>
+    __device__ static __forceinline__ void advance(const Prm &p, Carry &c, const InT &in, int64_t b, int s, int64_t i,
+                                                   int64_t bfirst, Gain &gout) {
         const double kap = (p.flags & F_KAPPA) ? clampd((double)in.kap, p.kMin, p.kMax) : 1.0;
         const double lam = (p.flags & F_LAMBDA) ? clampd((double)in.lam, p.wMin, p.wMax) : 1.0;
         double qf = (double)in.qs;
@@ -388,6 +398,9 @@ struct FwdPTrend {
         c.c00 = (float)n00;
         c.c01 = (float)n01;
         c.c11 = (float)n11;
+        gout.gs = gG;
+        gout.p00 = (float)a00;
+        gout.p10 = (float)a10;
         if constexpr (STORE) {
             p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
             p.tPf[i] = make_float4(c.c00, c.c01, c.c01, c.c11);
@@ -423,9 +436,18 @@ struct FwdPLevel {
         const bool tol = fabs(a.p - b.p) <= rel * fmax(fabs(a.p), fabs(b.p));
         return bits | tol;
     }
+    struct Gain {
+        double gs, pp;
+    };
     template <bool STORE>
     __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
                                                 int64_t bfirst) {
+        Gain g;
+        advance<STORE>(p, c, in, b, s, i, bfirst, g);
+    }
+    template <bool STORE, class InT>
+    __device__ static __forceinline__ void advance(const Prm &p, Carry &c, const InT &in, int64_t b, int s, int64_t i,
+                                                   int64_t bfirst, Gain &gout) {
         const double kap = (p.flags & F_KAPPA) ? clampd((double)in.kap, p.kMin, p.kMax) : 1.0;
         const double lam = (p.flags & F_LAMBDA) ? clampd((double)in.lam, p.wMin, p.wMax) : 1.0;
         double qf = (double)in.qs;
@@ -439,6 +461,8 @@ struct FwdPLevel {
         const double gH = gG * r;
         const double ikh = fma(-pp, gG, 1.0);
         c.p = fma(gH, pp * pp, ikh * ikh * pp);
+        gout.gs = gG;
+        gout.pp = pp;
         if constexpr (STORE) {
             p.tXin[i] = pack_gain_level(gG, pp);
             p.tPf[i] = make_float4((float)c.p, 0.f, 0.f, 0.f);
@@ -575,6 +599,87 @@ struct FwdXLevel {
 };
 
 
+
+// ---- fused forward chains (tolerant validation only): covariance and state of a bin advance in the same step -------
+// With k-ulp validation both chains need the same ~80-bin window and a single validation pass, so one kernel replaces
+// two (one fixed launch/drain cost, no gain-record round trip through HBM for the state update).  The arithmetic is the
+// split chains' own (advance() / step() above are called as they are), so the results are the same numbers.
+struct FwdTrendFused {
+    static constexpr bool DMA = false;
+    static constexpr int NW = 1, ND = 1;
+    static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = false;
+    static constexpr int U = CSR_U_P;
+    struct Carry {
+        FwdPTrend::Carry P;
+        FwdXTrend::Carry X;
+        float pad_[2];
+    };
+    struct In {
+        double s0u, zbar;
+        float lam, kap, qs;
+    };
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
+        const FwdPTrend::In a = FwdPTrend::load(p, i, bq, s, len);
+        In in;
+        in.s0u = a.s0u; in.lam = a.lam; in.kap = a.kap; in.qs = a.qs;
+        in.zbar = p.tZbar[i];
+        return in;
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) {
+        Carry c;
+        c.P = FwdPTrend::init_true(p);
+        c.X = FwdXTrend::init_true(p);
+        c.pad_[0] = c.pad_[1] = 0.f;
+        return c;
+    }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return init_true(p); }
+    __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
+        return FwdPTrend::same(p, a.P, b.P) & FwdXTrend::same(p, a.X, b.X);
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
+                                                int64_t bfirst) {
+        FwdPTrend::Gain g;
+        FwdPTrend::advance<STORE>(p, c.P, in, b, s, i, bfirst, g);
+        FwdXTrend::In xin;
+        xin.zbar = in.zbar;
+        xin.gs = g.gs;
+        xin.cp = make_float2(g.p00, g.p10);
+        FwdXTrend::step<STORE>(p, c.X, xin, b, s, i, bfirst);
+    }
+};
+struct FwdLevelFused {
+    static constexpr bool DMA = false;
+    static constexpr int NW = 1, ND = 1;
+    static constexpr bool FWD = true;
+    static constexpr bool PINGPONG = false;
+    static constexpr int U = CSR_U_P;
+    struct Carry {
+        FwdPLevel::Carry P;
+        FwdXLevel::Carry X;
+    };
+    using In = FwdTrendFused::In;
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
+        return FwdTrendFused::load(p, i, bq, s, len);
+    }
+    __device__ static __forceinline__ Carry init_true(const Prm &p) { return Carry{FwdPLevel::init_true(p), FwdXLevel::init_true(p)}; }
+    __device__ static __forceinline__ Carry init_cold(const Prm &p) { return init_true(p); }
+    __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
+        return FwdPLevel::same(p, a.P, b.P) & FwdXLevel::same(p, a.X, b.X);
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
+                                                int64_t bfirst) {
+        FwdPLevel::Gain g;
+        FwdPLevel::advance<STORE>(p, c.P, in, b, s, i, bfirst, g);
+        FwdXLevel::In xin;
+        xin.zbar = in.zbar;
+        xin.gs = g.gs;
+        xin.pp = g.pp;
+        FwdXLevel::step<STORE>(p, c.X, xin, b, s, i, bfirst);
+    }
+};
 
 // ---- backward RTS chain, levelTrend (pyx:6758-6822) ------------------------------------------------------------
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32

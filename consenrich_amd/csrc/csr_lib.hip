@@ -105,6 +105,7 @@ struct csr_ctx {
     // pipeline is re-run synchronously from the first stage that did re-run blocks.
     bool deferEnabled = true;
     bool spinWait = true;
+    bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
     uint32_t pendFlags = 0, pendExport = 0;
@@ -208,6 +209,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_ADAPT"))) c->adaptWarm = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if (getenv("CONSENRICH_AMD_FORCE_ITERS")) c->deferEnabled = false;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
@@ -775,8 +777,14 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                            c->dChainNb);
         LAUNCH_CHECK("k_fwd_apn");
     } else {
-        const bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
-        if (c->mdl.state_dim == 2) {
+        bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
+        if (c->fuseFwd && c->xTolUlps > 0) {
+            // one stage (counter / window of the covariance stage; the window covers the state chain's needs too)
+            if (c->warmP < c->warmX) c->warmP = c->warmX;
+            dX = false;
+            if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+        } else if (c->mdl.state_dim == 2) {
             CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         } else {

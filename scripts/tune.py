@@ -27,5 +27,5 @@ for cfg in cfgs:
     for _ in range(5): step()
     b.synchronize(); dt=(time.perf_counter()-t)/5
     kt = b.kernel_times(); b.profile(False); r1=b.run_stats()
-    sel = {k: round(v[1]/5,3) for k,v in kt.items() if k in ("fwd_cov_chain","fwd_state_chain","bwd_chain","fwd_state_fix","fwd_cov_fix","bwd_fix","stats","residuals","export_natural")}
+    sel = {k: round(v[1]/5,3) for k,v in kt.items() if k in ("fwd_chain","fwd_fix","fwd_dstat","fwd_cov_chain","fwd_state_chain","bwd_chain","fwd_state_fix","fwd_cov_fix","bwd_fix","stats","residuals","export_natural")}
     print("warm",cfg,"ms/step %.3f (profiled %.2f)"%(clean*1e3, dt*1e3), "reruns/step p,x,b", [(r1[k]-r0[k])/5 for k in ("reruns_p","reruns_x","reruns_b")], "fixl", (r1["fix_launches"]-r0["fix_launches"])/5, sel, flush=True)

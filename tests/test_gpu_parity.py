@@ -150,6 +150,29 @@ def test_fused_pipeline_and_failed_optimistic_validation(product, d):
             assert fused["stats"]["pipeline_redos"] == 0
 
 
+@pytest.mark.parametrize("d", [2, 1])
+def test_fused_forward_chain_with_failed_optimistic_validation(product, d):
+    """Tolerant mode runs covariance and state in ONE chain kernel.  With a deliberately short window its optimistic
+    validation fails; the synchronous redo must land within the k-ulp budget of the sequential recursion, and a
+    sufficient window must give the same numbers as the split chains (CONSENRICH_AMD_FUSE=0 path = exact-mode path)."""
+    n_list = [5000, 37, 1, 12345, 64, 65]
+    seq = _run_batch(32 * 512, (0, 0, 0), d, n_list, 4, 100, xtol=0)
+    for blk, warm in ((64, (512, 512, 512)), (32, (0, 0, 0))):
+        fused = _run_batch(blk, warm, d, n_list, 4, 100, xtol=2, fused=True)
+        for key, val in seq.items():
+            if key == "stats":
+                continue
+            if not isinstance(key, str) and val.size == 0:       # pnoise / lag of the one-bin chain
+                assert fused[key].size == 0
+                continue
+            scale = 1.0 if isinstance(key, str) else float(np.abs(val).max())
+            np.testing.assert_allclose(fused[key], val, rtol=2e-6, atol=2e-6 * max(scale, 1e-30) if isinstance(key, str)
+                                       else 1e-6 * max(scale, 1e-30), err_msg=f"{blk} {warm} {key}")
+        if warm == (0, 0, 0):
+            assert fused["stats"]["pipeline_redos"] >= 1 and fused["stats"]["reruns_p"] > 0
+            assert fused["stats"]["reruns_x"] == 0             # no separate state stage in the fused path
+
+
 def test_ulp_tolerant_validation_stays_within_parity_budget(product):
     """Default mode: speculative carries are accepted within 2 float32 ulps.  Against the exact sequential run the
     tracks must agree far inside the 1e-5 budget (a few ulps on the level; the trend inherits ulp(level)-sized noise,
