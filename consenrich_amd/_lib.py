@@ -114,6 +114,10 @@ SYMBOLS = {
     "csr_batch_background_update": (C.c_int, [C.c_void_p, C.POINTER(BgCfg), C.POINTER(BgOut)]),
     "csr_batch_background_apply": (C.c_int, [C.c_void_p, C.c_char_p]),
     "csr_batch_set_background": (C.c_int, [C.c_void_p, C.c_int32, FP]),
+    "csr_format_bedgraph": (C.c_int64, [C.c_char_p, C.c_int64, I64P, I64P, C.c_int64, C.c_int64, C.c_int64, FP, C.c_int32,
+                                        C.c_char_p, C.c_int64]),
+    "csr_batch_format_bedgraph": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
+                                              C.c_int64, C.c_int64, C.c_char_p, C.c_int64]),
     "csr_solve_background": (C.c_int, [C.c_int32, I64P, DP, DP, C.c_double, C.c_double, C.c_int32, C.c_int32, DP, I64P,
                                        DP]),
     "csr_background_weighted_stats": (C.c_int, [C.c_int64, C.c_int64, FP, FP, DP, DP, I64P]),

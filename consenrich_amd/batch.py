@@ -206,6 +206,23 @@ class DeviceBatch:
             raise ValueError("background must have shape (chain_len,)")
         L.check(self._lib.csr_batch_set_background(self._ctx, chain, L.fp(a)))
 
+    def bedgraph_bytes(self, chain: int, name: str, chrom: str, start0: int, step: int, end_cap: int = 0, comp: int = 0,
+                       transform=None) -> bytes:
+        """bedGraph text (consenrich.py:9797-9805 format) of component `comp` of an exported array of one chain,
+        formatted on the device.  transform: None, "round4" (state track) or "sqrt" (uncertainty from a variance)."""
+        t = {None: 0, "none": 0, "round4": 1, "sqrt": 2}[transform]
+        cn = str(chrom).encode("ascii")
+        f = self._lib.csr_batch_format_bedgraph
+        size = f(self._ctx, chain, _ARR[name], comp, t, cn, int(start0), int(step), int(end_cap), None, 0)
+        if size < 0:
+            raise L.ConsenrichAMDError(L.last_error())
+        if size == 0:
+            return b""
+        buf = C.create_string_buffer(int(size))
+        if f(self._ctx, chain, _ARR[name], comp, t, cn, int(start0), int(step), int(end_cap), buf, int(size)) != size:
+            raise L.ConsenrichAMDError(L.last_error() or "bedGraph writer size mismatch")
+        return buf.raw
+
     def export(self, what: int):
         L.check(self._lib.csr_batch_export(self._ctx, int(what)))
 

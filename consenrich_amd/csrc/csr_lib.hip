@@ -4,6 +4,7 @@
 #include "../../include/consenrich_amd.h"
 #include "csr_device.h"
 #include "csr_background.h"
+#include "csr_writers.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1895,6 +1896,105 @@ extern "C" int csr_batch_set_background(csr_ctx *c, int32_t chain, const float *
     HIPOK(hipStreamSynchronize(c->stream));
     c->statsValid = c->haveFwd = c->haveBwd = false;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bedGraph writer (consenrich.py:9797-9805)
+// ---------------------------------------------------------------------------------------------------------------
+static DevBuf g_wrBuf;      // row lengths / offsets / text (+ staged host inputs)
+
+static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, const int64_t *hEnds, const float *hValues,
+                             const char *chrom, char *out, int64_t cap) {
+    const size_t cl = chrom ? strlen(chrom) : 0;
+    if (!chrom || cl == 0 || cl > 63) { fail("chromosome name must have 1..63 characters"); return -1; }
+    if (a.n < 0) { fail("negative row count"); return -1; }
+    if (a.n == 0) return 0;
+    memset(a.chrom, 0, sizeof(a.chrom));
+    memcpy(a.chrom, chrom, cl);
+    a.chromLen = (int)cl;
+    const int64_t n = a.n, nb = (n + 1023) / 1024;
+    const size_t maxRow = cl + 1 + 20 + 1 + 20 + 1 + 48 + 1;
+    size_t need_ = 0;
+    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
+    const size_t oLen = take(4 * (size_t)n), oOff = take(8 * (size_t)n), oBlk = take(8 * (size_t)(nb + 1));
+    const size_t oS = hStarts ? take(8 * (size_t)n) : 0, oE = hEnds ? take(8 * (size_t)n) : 0;
+    const size_t oV = hValues ? take(4 * (size_t)n) : 0;
+    // the text follows; its size is only known after pass 2, so reserve in two steps
+    if (g_wrBuf.reserve(need_) != 0) return -1;
+    char *base = (char *)g_wrBuf.ptr;
+    a.rowLen = (int *)(base + oLen); a.rowOff = (int64_t *)(base + oOff); a.blockSum = (int64_t *)(base + oBlk);
+    auto H = [&](hipError_t e) { if (e != hipSuccess) { fail("bedGraph writer: %s", hipGetErrorString(e)); return false; } return true; };
+    if (hStarts) {
+        if (!H(hipMemcpyAsync(base + oS, hStarts, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        if (!H(hipMemcpyAsync(base + oE, hEnds, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        a.starts = (const int64_t *)(base + oS); a.ends = (const int64_t *)(base + oE);
+    }
+    if (hValues) {
+        if (!H(hipMemcpyAsync(base + oV, hValues, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        a.values = (const float *)(base + oV); a.stride = 1; a.comp = 0;
+    }
+    {
+        Scope sc(c, "bedgraph_len_scan");
+        hipLaunchKernelGGL(k_bgw_len, dim3((int)nb), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL(k_bgw_scan_blocks, dim3(1), dim3(1024), 0, c->stream, a, nb);
+        hipLaunchKernelGGL(k_bgw_scan_rows, dim3((int)nb), dim3(1024), 0, c->stream, a);
+    }
+    int64_t total = 0;
+    if (!H(hipMemcpyAsync(&total, a.blockSum + nb, 8, hipMemcpyDeviceToHost, c->stream))) return -1;
+    if (!H(hipStreamSynchronize(c->stream))) return -1;
+    if (total < 0 || (size_t)total > maxRow * (size_t)n) { fail("bedGraph writer: inconsistent size"); return -1; }
+    if (!out) return total;
+    if (cap < total) { fail("bedGraph writer: output buffer too small (%lld < %lld)", (long long)cap, (long long)total); return -1; }
+    // text buffer: grow the work buffer if needed (the row tables are recomputed afterwards in that case)
+    const size_t oText = take((size_t)total);
+    if (need_ > g_wrBuf.cap) {
+        // simplest: a second, dedicated allocation for the text
+        static DevBuf textBuf;
+        if (textBuf.reserve((size_t)total) != 0) return -1;
+        a.out = (char *)textBuf.ptr;
+    } else {
+        a.out = base + oText;
+    }
+    {
+        Scope sc(c, "bedgraph_write");
+        hipLaunchKernelGGL(k_bgw_write, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess) { fail("bedGraph writer launch failed"); return -1; }
+    if (!H(hipMemcpyAsync(out, a.out, (size_t)total, hipMemcpyDeviceToHost, c->stream))) return -1;
+    if (!H(hipStreamSynchronize(c->stream))) return -1;
+    return total;
+}
+
+extern "C" int64_t csr_format_bedgraph(const char *chrom, int64_t n, const int64_t *starts, const int64_t *ends,
+                                       int64_t start0, int64_t step, int64_t end_cap, const float *values,
+                                       int32_t transform, char *out, int64_t out_capacity) {
+    if (n > 0 && !values) { fail("null values"); return -1; }
+    if ((starts == nullptr) != (ends == nullptr)) { fail("starts and ends must be given together"); return -1; }
+    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
+    csr_ctx *c = default_ctx();
+    if (!c || ctx_select(c) != 0) return -1;
+    BgwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
+    return bedgraph_impl(c, a, starts, ends, values, chrom, out, out_capacity);
+}
+
+extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp,
+                                             int32_t transform, const char *chrom, int64_t start0, int64_t step,
+                                             int64_t end_cap, char *out, int64_t out_capacity) {
+    if (need(c) != 0 || settle(c) != 0) return -1;
+    if (chain < 0 || chain >= (int)c->chains.size()) { fail("chain index out of range"); return -1; }
+    if (array_id < 0 || array_id >= CSR_ARR_COUNT || array_id == CSR_ARR_RESID) { fail("bad array id"); return -1; }
+    if (!c->nat[array_id]) { fail("array %d was not exported", array_id); return -1; }
+    const int64_t per = arr_comps(c, array_id);
+    if (comp < 0 || comp >= per) { fail("component out of range"); return -1; }
+    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
+    const ChainInfo &ci = c->chains[chain];
+    BgwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = ci.n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
+    a.values = c->nat[array_id] + ci.off * per; a.stride = (int)per; a.comp = comp;
+    return bedgraph_impl(c, a, nullptr, nullptr, nullptr, chrom, out, out_capacity);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -283,6 +283,23 @@ int csr_batch_background_apply(csr_ctx *ctx, const unsigned char *take);
 /* H2D a background track for one chain (NULL: zeros). */
 int csr_batch_set_background(csr_ctx *ctx, int32_t chain, const float *background);
 
+/* ---- track writer ------------------------------------------------------------------------------
+ * bedGraph text of one track, byte for byte what the reference emits (consenrich.py:9797-9805: pandas to_csv with
+ * sep="\t", header=False, index=False, float_format="%.4f", lineterminator="\n"; NaN -> empty field, +-inf -> inf/-inf).
+ * Rows: chrom \t start \t end \t value \n.  Intervals: starts/ends (n int64 each) or, if NULL, start0 + k*step with
+ * end = min(start + step, end_cap) (end_cap <= 0: no cap).  transform: CSR_BGW_NONE, CSR_BGW_ROUND4 (np.round(x, 4) in
+ * float32 = core.getPrimaryState, core.py:6145-6166) or CSR_BGW_SQRT (uncertainty = sqrt(P00), consenrich.py:9476).
+ * Returns the number of bytes of the text; writes it to `out` if out != NULL and out_capacity is large enough (call
+ * once with out = NULL to size the buffer).  Negative on error. */
+enum { CSR_BGW_NONE = 0, CSR_BGW_ROUND4 = 1, CSR_BGW_SQRT = 2 };
+int64_t csr_format_bedgraph(const char *chrom, int64_t n, const int64_t *starts, const int64_t *ends, int64_t start0,
+                            int64_t step, int64_t end_cap, const float *values, int32_t transform, char *out,
+                            int64_t out_capacity);
+/* Same for component `comp` of an exported array of one chain of a batch (values never leave the device as floats). */
+int64_t csr_batch_format_bedgraph(csr_ctx *ctx, int32_t chain, int32_t array_id, int32_t comp, int32_t transform,
+                                  const char *chrom, int64_t start0, int64_t step, int64_t end_cap, char *out,
+                                  int64_t out_capacity);
+
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */

