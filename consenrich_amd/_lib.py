@@ -73,7 +73,8 @@ class BgCfg(C.Structure):
 class BgOut(C.Structure):
     _fields_ = [
         ("support", C.c_int64), ("weight_sum", C.c_double), ("weight_scale", C.c_double),
-        ("roundoff_index", C.c_double), ("shift_rms", C.c_double), ("bad_index", C.c_int64),
+        ("roundoff_index", C.c_double), ("shift_rms", C.c_double), ("proposal_rms", C.c_double),
+        ("reference_rms", C.c_double), ("bad_index", C.c_int64),
         ("bad_value", C.c_double), ("passes", C.c_int32), ("status", C.c_int32),
     ]
 
@@ -124,6 +125,7 @@ SYMBOLS = {
     "csr_output_diagnostics": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, FP, FP, FP,
                                          FP]),
     "csr_batch_ecm": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.POINTER(EcmOut), DP]),
+    "csr_batch_ecm_masked": (C.c_int, [C.c_void_p, C.POINTER(EcmCfg), C.c_uint32, C.c_char_p, C.POINTER(EcmOut), DP]),
     "csr_batch_export": (C.c_int, [C.c_void_p, C.c_uint32]),
     "csr_batch_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "csr_batch_device_array": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), I64P]),

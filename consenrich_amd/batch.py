@@ -151,13 +151,16 @@ class DeviceBatch:
         return sd, sn
 
     def ecm(self, max_iters=50, inner_iters=5, rtol=1.0e-6, nu=8.0, use_lambda=False, use_kappa=True,
-            use_apn=False, use_qscale=False):
+            use_apn=False, use_qscale=False, chain_mask=None):
+        """chain_mask: optional per-chain booleans; chains with False keep their resident results untouched."""
         nc = len(self.chain_lens)
         cfg = L.EcmCfg(int(max_iters), int(inner_iters), float(np.float32(rtol)), float(np.float32(nu)),
                        int(use_lambda), int(use_kappa), int(use_apn), 0)
         outs = (L.EcmOut * nc)()
         path = np.zeros(nc * max(int(max_iters), 1))
-        L.check(self._lib.csr_batch_ecm(self._ctx, C.byref(cfg), L.USE_QSCALE if use_qscale else 0, outs, L.dp(path)))
+        mask = None if chain_mask is None else bytes(bytearray(int(bool(t)) for t in chain_mask))
+        L.check(self._lib.csr_batch_ecm_masked(self._ctx, C.byref(cfg), L.USE_QSCALE if use_qscale else 0, mask, outs,
+                                               L.dp(path)))
         return list(outs), path.reshape(nc, -1)
 
     def diagnostics(self, flags: int = 0):

@@ -488,8 +488,8 @@ struct BgBatch {
     // one partial record; a per-chain workgroup then folds its records in a fixed order (deterministic)
     const int *waveChain, *waveG0, *waveG1, *chainWave0, *chainWaveN;
     int NW, pad_;
-    double *part;                       // NW x 2 partial records
-    double *chainSum;                   // per chain: [sumW, support, shiftNum]
+    double *part;                       // NW x 4 partial records
+    double *chainSum;                   // per chain: [sumW, support, sum w d^2, sum w next^2, sum w cur^2]
 };
 
 // weight / rhs per bin exactly as the reference forms them (core.py:5064-5083): float32 invVar = 1/max(munc+pad,1e-8)
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_bg_wave_pass(Prm p, BgBatch a, int what
     if (wv >= a.NW) return;
     const int c = a.waveChain[wv];
     const int64_t off = a.chainOff[c], len = a.chainLen[c];
-    double r0 = 0.0, r1 = 0.0;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
     unsigned int fl = 0u;
     bool run = true;
     unsigned long long t0 = 0, t1 = 0;
@@ -574,45 +574,52 @@ __global__ __launch_bounds__(256) void k_bg_wave_pass(Prm p, BgBatch a, int what
             } else if (in) {
                 const float nx = sup ? (float)a.sol[g] : 0.f;
                 a.bgNext[g] = nx;
-                const double dlt = (double)nx - (a.bgCur ? (double)a.bgCur[g] : 0.0);
-                r0 += a.w[g] * dlt * dlt;
+                const double cur = a.bgCur ? (double)a.bgCur[g] : 0.0, dlt = (double)nx - cur, w = a.w[g];
+                r0 += w * dlt * dlt;                     // core.py:5209-5240: shift, proposal and reference RMS numerators
+                r1 += w * (double)nx * (double)nx;
+                r2 += w * cur * cur;
             }
         }
     }
+    double *rec = a.part + 4 * (int64_t)wv;
     if (what == 1) {                                    // ballot counts are already wave totals
-        if (lane == 0) { a.part[2 * wv] = r0; a.part[2 * wv + 1] = r1; }
+        if (lane == 0) { rec[0] = r0; rec[1] = r1; }
         return;
     }
     if (what == 2) {
         for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
-        if (lane == 0) a.part[2 * wv] = (double)fl;
+        if (lane == 0) rec[0] = (double)fl;
         return;
     }
-    for (int o = 32; o > 0; o >>= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); }   // fixed butterfly order
-    if (lane == 0) { a.part[2 * wv] = r0; a.part[2 * wv + 1] = r1; }
+    for (int o = 32; o > 0; o >>= 1) {                  // fixed butterfly order
+        r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o);
+    }
+    if (lane == 0) { rec[0] = r0; rec[1] = r1; rec[2] = r2; }
 }
 
 // fold the records of every chain (one wavefront per chain, fixed order) and act on the totals
 __global__ __launch_bounds__(64) void k_bg_wave_fold(BgBatch a, int what, int bit) {
     const int c = blockIdx.x, lane = threadIdx.x;
     const int w0 = a.chainWave0[c], nw = a.chainWaveN[c];
-    double r0 = 0.0, r1 = 0.0;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
     unsigned int fl = 0u;
     for (int i = lane; i < nw; i += 64) {
-        const double x0 = a.part[2 * (w0 + i)], x1 = a.part[2 * (w0 + i) + 1];
-        if (what == 2) fl |= (unsigned int)x0;
-        else { r0 += x0; r1 += x1; }
+        const double *rec = a.part + 4 * (int64_t)(w0 + i);
+        if (what == 2) fl |= (unsigned int)rec[0];
+        else { r0 += rec[0]; r1 += rec[1]; if (what == 3) r2 += rec[2]; }
     }
-    for (int o = 32; o > 0; o >>= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); fl |= __shfl_xor(fl, o); }
+    for (int o = 32; o > 0; o >>= 1) {
+        r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); fl |= __shfl_xor(fl, o);
+    }
     if (lane != 0) return;
-    if (what == 0) { a.chainSum[c * 3 + 0] = r0; a.chainSum[c * 3 + 1] = r1; }
+    if (what == 0) { a.chainSum[c * 5 + 0] = r0; a.chainSum[c * 5 + 1] = r1; }
     else if (what == 1) {
         // bit b of the k-th smallest key is 0 iff at least k+1 keys are <= (prefix | all-ones below b)
         const long long k0 = a.selRank[2 * c], k1 = a.selRank[2 * c + 1];
         if (k0 >= 0 && r0 < (double)(k0 + 1)) a.selAns[2 * c] |= (1ull << bit);
         if (k1 >= 0 && r1 < (double)(k1 + 1)) a.selAns[2 * c + 1] |= (1ull << bit);
     } else if (what == 2) a.flags[c] = fl;
-    else a.chainSum[c * 3 + 2] = r0;
+    else { a.chainSum[c * 5 + 2] = r0; a.chainSum[c * 5 + 3] = r1; a.chainSum[c * 5 + 4] = r2; }
 }
 
 // adjusted weights of the asymmetric IRLS (core.py:8312-8313, 8342-8343)

@@ -907,7 +907,15 @@ struct EcmState {
     bool haveInit = false, done = false;
 };
 
+extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
+                                    csr_ecm_out *out, double *nll_path);
 extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path) {
+    return csr_batch_ecm_masked(c, cfg, flags, nullptr, out, nll_path);
+}
+
+// chain_mask[c] == 0: chain c is left exactly as it is (results of its last fit stay resident); out[c].skipped = 2
+extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
+                                    csr_ecm_out *out, double *nll_path) {
     CHECK(need(c));
     CHECK(settle(c));
     if (!cfg || !out) return fail("null argument");
@@ -932,7 +940,9 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
     };
     // tiny chains: filter + smoother + NLL only (pyx:7998-8129)
     bool anyTiny = false, anyBig = false;
+    auto masked = [&](int i) { return chain_mask != nullptr && chain_mask[i] == 0; };
     for (int i = 0; i < nc; ++i) {
+        if (masked(i)) { out[i].skipped = 2; continue; }
         if (c->chains[i].n <= 5) { act[i] = 1; anyTiny = true; out[i].skipped = 1; }
         else anyBig = true;
     }
@@ -945,7 +955,7 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
             if (act[i]) { out[i].final_nll = out[i].initial_nll = nll[i]; st[i].done = true; }
     }
     if (anyBig) {
-        for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5) ? 1 : 0;
+        for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5 && !masked(i)) ? 1 : 0;
         CHECK(push_active());
         bool fwdFresh = false;   // forward results already match the current multipliers
         for (int64_t it = 0; it < cfg->max_iters; ++it) {
@@ -1001,7 +1011,7 @@ extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags,
             if (changed) CHECK(push_active());
         }
         for (int i = 0; i < nc; ++i) {
-            if (c->chains[i].n <= 5) continue;
+            if (c->chains[i].n <= 5 || masked(i)) continue;
             out[i].has_initial_nll = st[i].haveInit ? 1 : 0;
             out[i].final_nll = st[i].prev;
         }
@@ -1640,7 +1650,7 @@ static int bg_setup(csr_ctx *c, int Bp) {
     a.selRank = S.dSelRank;
     CHECK(dalloc(c, &a.maskPrev, N)); CHECK(dalloc(c, &a.maskNew, N));
     CHECK(dalloc(c, &S.dActive, nc)); CHECK(dalloc(c, &S.dHasSup, nc)); CHECK(dalloc(c, &S.dPen, nc));
-    CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 3 * nc));
+    CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 5 * nc));
     HIPOK(hipMemsetAsync(a.sol, 0, 8 * N, c->stream));
     HIPOK(hipMemsetAsync(S.out1, 0, 8 * N, c->stream));
     HIPOK(hipMemsetAsync(a.wAdj, 0, 8 * N, c->stream));
@@ -1667,7 +1677,7 @@ static int bg_setup(csr_ctx *c, int Bp) {
         HIPOK(hipMemcpy(dcwn, cwn.data(), 4 * nc, hipMemcpyHostToDevice));
         a.waveChain = dwc; a.waveG0 = dwg0; a.waveG1 = dwg1; a.chainWave0 = dcw0; a.chainWaveN = dcwn;
         a.NW = (int)wc.size();
-        CHECK(dalloc(c, &a.part, 2 * (int64_t)wc.size()));
+        CHECK(dalloc(c, &a.part, 4 * (int64_t)wc.size()));
     }
     float *q;
     CHECK(nat_array(c, CSR_ARR_BACKGROUND_NEXT, &q)); a.bgNext = q;
@@ -1730,8 +1740,8 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     };
     wave_pass(0, 0, nullptr);
     LAUNCH_CHECK("background statistics");
-    std::vector<double> cs(3 * (size_t)nc);
-    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> cs(5 * (size_t)nc);
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
     HIPOK(wait_stream(c));
     std::vector<unsigned char> act(nc, 0), sup(nc, 0);
     std::vector<double> pen(nc, 0.0);
@@ -1742,8 +1752,8 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
         csr_bg_out &o = out[i];
         memset(&o, 0, sizeof(o));
         o.bad_index = -1;
-        o.weight_sum = cs[3 * i];
-        o.support = (int64_t)cs[3 * i + 1];
+        o.weight_sum = cs[5 * i];
+        o.support = (int64_t)cs[5 * i + 1];
         if (o.support <= 0) { o.status = CSR_BG_NO_SUPPORT; continue; }       // core.py:8148-8149
         sup[i] = 1;
         const double meanPos = o.weight_sum / (double)o.support;              // core.py:8157-8166
@@ -1854,10 +1864,14 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
     wave_pass(3, 0, S.dHasSup);
     LAUNCH_CHECK("k_bg_finish");
-    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
     HIPOK(wait_stream(c));
-    for (int i = 0; i < nc; ++i)
-        out[i].shift_rms = out[i].weight_sum > 0.0 ? std::sqrt(cs[3 * i + 2] / out[i].weight_sum) : 0.0;
+    for (int i = 0; i < nc; ++i) {
+        const double sw = out[i].weight_sum;
+        out[i].shift_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 2] / sw) : 0.0;
+        out[i].proposal_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 3] / sw) : 0.0;
+        out[i].reference_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 4] / sw) : 0.0;
+    }
     return 0;
 }
 

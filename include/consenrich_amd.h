@@ -172,6 +172,10 @@ int csr_batch_forward_backward(csr_ctx *ctx, uint32_t flags, double *sum_d, doub
 int csr_batch_sums(csr_ctx *ctx, double *sum_d, double *sum_nll);
 /* a8-a9 over all chains in lock-step; out: n_chains entries; nll_path: n_chains*max_iters or NULL. */
 int csr_batch_ecm(csr_ctx *ctx, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path);
+/* Same, restricted to the chains with chain_mask[c] != 0 (NULL: all); the others keep the resident results of their last
+ * fit untouched (out[c].skipped = 2) -- chromosomes of a batch stop their outer background/ECM alternation independently. */
+int csr_batch_ecm_masked(csr_ctx *ctx, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
+                         csr_ecm_out *out, double *nll_path);
 
 enum { /* arrays, reference (natural) layout */
     CSR_ARR_D = 0,      /* (n)      float32 */
@@ -272,6 +276,7 @@ typedef struct csr_bg_out {
     double weight_sum, weight_scale;    /* sum of weights; median of the positive weights (IRLS penalty scale) */
     double roundoff_index;              /* eps * (1 + (4 lam_first + 16 lam) / mean positive weight), core.py:8160-8187 */
     double shift_rms;                   /* sqrt(sum w (next - current)^2 / sum w), core.py:5199-5215 */
+    double proposal_rms, reference_rms; /* same weighting of next / current (core.py:5216-5240: shift tolerance scale) */
     int64_t bad_index;                  /* first modified pivot (CSR_BG_BAD_PIVOT) */
     double bad_value;
     int32_t passes;                     /* IRLS re-solves performed */

@@ -828,3 +828,48 @@ def test_track_gather_over_rccl_single_rank():
         assert all(np.array_equal(out[i], local[i]) for i in range(len(lengths)))
     finally:
         dist.destroy_process_group()
+
+
+def test_device_resident_alternation_matches_cpu_twin(product, oracle):
+    """SURVEY a12 counterpart: several outer passes of [ECM phase with warm-started multipliers <-> background update ->
+    apply], all device-resident, against the same alternation composed from the oracle's natives on the host.
+    Chromosomes stop independently (chain masks).  Exact-mode validation keeps the discrete decisions (ECM iteration
+    counts, IRLS passes, stop pass) identical."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.driver import FitConfig, fit_batch
+    from oracle import background as bgo
+    from oracle import driver as odrv
+
+    n_list, m = [3000, 1200, 500], 4
+    mp = ModelParams(state_dim=2)
+    ins = _bg_batch_fixture(n_list, m, 5100, bg_amp=0.4)
+    pen = bgo.penalties(40, 2.0)
+    cfg = FitConfig(penalties=pen, ecm_iters=6, ecm_rtol=1e-4, inner_iters=3, outer_passes=6, min_outer=2, patience=1,
+                    shift_rtol=2e-2, neg_multiplier=2.0)
+    ocfg = dict(state_dim=2, F=mp.F, Q0=mp.Q0, state_init=mp.state_init, state_covar_init=mp.state_covar_init,
+                pad=mp.pad, lambda_bounds=mp.lambda_bounds, kappa_bounds=mp.kappa_bounds, block_len_intervals=500,
+                penalties=pen, ecm_iters=cfg.ecm_iters, ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu,
+                use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, fit_background=True, zero_center=False,
+                use_nonnegative=True, neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes,
+                min_outer=cfg.min_outer, shift_rtol=cfg.shift_rtol, patience=cfg.patience)
+    with DeviceBatch(0, x_tol_ulps=0) as b:
+        b.configure(mp, m, n_list)
+        for c, (data, munc) in enumerate(ins):
+            b.upload(c, data, munc)
+        fits = fit_batch(b, cfg)
+        got = [dict(bg=b.download(c, "background"), xs=b.download(c, "xs"), kap=b.download(c, "kappa"))
+               for c in range(len(n_list))]
+    assert len({f.passes for f in fits}) >= 1
+    for c, (data, munc) in enumerate(ins):
+        ref = odrv.fit_chain(data, munc, ocfg)
+        f = fits[c]
+        assert f.passes == ref["passes"] and f.converged == ref["converged"], (c, f, ref["passes"])
+        assert f.ecm_iters == ref["ecm_iters"] and f.irls_passes == ref["irls_passes"], (c, f.ecm_iters, ref["ecm_iters"])
+        np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-6)
+        np.testing.assert_allclose(f.shift, ref["shift"], rtol=1e-3, atol=1e-7)
+        scale = max(float(np.abs(ref["background"]).max()), 1e-3)
+        assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
+        lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
+        assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
+        close_mostly(got[c]["kap"], ref["kap"], frac=2e-2, cap=5e-2, msg=f"kappa chain {c}")
