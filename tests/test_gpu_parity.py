@@ -806,28 +806,31 @@ def test_bedgraph_writer_large_and_from_device_arrays(product, tmp_path):
 
 def test_track_gather_over_rccl_single_rank():
     """The final track gather with backend "nccl" (= RCCL on ROCm) on a CUDA tensor -- world size 1 here (the GPU test
-    box has one card; the 2-rank exchange itself is covered with gloo in tests/test_sharding_gloo.py)."""
-    import socket
+    box has one card; the 2-rank exchange itself is covered with gloo in tests/test_sharding_gloo.py).  Runs in a child
+    process: PyTorch ships its own HIP runtime and must initialise the device before this library does (as in bench.py);
+    the test process has already used the GPU through libconsenrich_amd.so."""
+    import subprocess
+    import sys
 
-    import torch
-    import torch.distributed as dist
-
-    from consenrich_amd.sharding import gather_tracks
-
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
-    try:
-        lengths = [1000, 37, 512]
-        rng = np.random.default_rng(1)
-        local = {i: rng.normal(size=(n, 2)).astype(np.float32) for i, n in enumerate(lengths)}
-        out = gather_tracks(local, lengths, 2, device="cuda:0")
-        assert all(np.array_equal(out[i], local[i]) for i in range(len(lengths)))
-    finally:
-        dist.destroy_process_group()
+    code = r"""
+import socket, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from consenrich_amd.sharding import gather_tracks
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+lengths = [1000, 37, 512]
+rng = np.random.default_rng(1)
+local = {i: rng.normal(size=(n, 2)).astype(np.float32) for i, n in enumerate(lengths)}
+out = gather_tracks(local, lengths, 2, device="cuda:0")
+assert all(np.array_equal(out[i], local[i]) for i in range(len(lengths)))
+dist.destroy_process_group()
+print("rccl gather ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_device_resident_alternation_matches_cpu_twin(product, oracle):
