@@ -646,7 +646,7 @@ def _bg_batch_fixture(n_list, m, seed, bg_amp=0.3):
     return ins
 
 
-@pytest.mark.parametrize("mode", ["irls", "plain", "zero_center", "lambda"])
+@pytest.mark.parametrize("mode", ["irls", "plain", "zero_center", "lambda", "level"])
 def test_batch_background_update_matches_oracle(product, oracle, mode):
     """Device-resident background update (weights / rhs from the resident data, guard, solve, asymmetric IRLS) against
     the oracle's restatement of core.py:5064-5137 + 8085-8378 evaluated on the downloaded smoothed level; then the
@@ -656,7 +656,7 @@ def test_batch_background_update_matches_oracle(product, oracle, mode):
     from oracle import background as bgo
 
     n_list, m = [6000, 777, 64, 20000], 5
-    mp = ModelParams(state_dim=2)
+    mp = ModelParams(state_dim=1 if mode == "level" else 2)
     ins = _bg_batch_fixture(n_list, m, 4100)
     lam_first, lam = bgo.penalties(60, 2.0)
     use_lambda = mode == "lambda"
