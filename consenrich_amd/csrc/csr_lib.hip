@@ -107,6 +107,9 @@ struct csr_ctx {
     bool deferEnabled = true;
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    // debugging switches, read once from the environment at creation (never on the launch path)
+    bool dbgPoison = false, dbgProbe = false, dbgFence = false, dbgLog = false;
+    int dbgForceIters = 0;
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
     uint32_t pendFlags = 0, pendExport = 0;
@@ -211,7 +214,11 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
-    if (getenv("CONSENRICH_AMD_FORCE_ITERS")) c->deferEnabled = false;
+    if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
+    c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
+    c->dbgProbe = getenv("CONSENRICH_AMD_PROBE") != nullptr;
+    c->dbgFence = getenv("CONSENRICH_AMD_FENCE") != nullptr;
+    c->dbgLog = getenv("CONSENRICH_AMD_DEBUG") != nullptr;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
@@ -687,7 +694,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     p.xTolUlps = c->xTolUlps;
     p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + stage;
     const int grid = (int)c->NG;
-    if (getenv("CONSENRICH_AMD_POISON")) {
+    if (c->dbgPoison) {
         HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
         HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
         HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
@@ -704,12 +711,11 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         }
     }
     LAUNCH_CHECK(name);
-    if (getenv("CONSENRICH_AMD_PROBE")) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
+    if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
     int which = 0;
-    const char *dbgForce = getenv("CONSENRICH_AMD_FORCE_ITERS");
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
-        p.debugForce = (dbgForce && it < atoi(dbgForce)) ? 1 : 0;
-        if (getenv("CONSENRICH_AMD_FENCE")) p.debugForce |= 2;
+        p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
+        if (c->dbgFence) p.debugForce |= 2;
         {
             Scope sc(c, fixName);
             hipLaunchKernelGGL(k_chain_fix<CH>, dim3(grid), dim3(64), 0, c->stream, p, which);
@@ -720,7 +726,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         if (defer) return 0;
         CHECK(read_mail(c, 16));
         const unsigned int fresh = take_fresh(c, stage);
-        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
+        if (c->dbgLog) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
         if (fresh == 0) {
             if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) c->optimistic[stage] = true;
             return 0;
@@ -781,7 +787,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
         LAUNCH_CHECK("k_fwd_apn");
     } else {
         bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
-        if (c->fuseFwd && c->xTolUlps > 0) {
+        // Fused chain: only without per-bin multipliers.  Its state recursion warms up on SPECULATIVE gains (the split
+        // state chain reads the validated ones), so it needs covariance-window + state-window bins where the gains vary
+        // from bin to bin; measured in the ECM loop (kappa per bin): 9 of 24 optimistic validations failed with the
+        // 80-bin window, 6.3 vs 4.7 ms per ECM iteration.  With constant multipliers 80 bins give zero re-runs.
+        if (c->fuseFwd && c->xTolUlps > 0 && !(flags & (F_KAPPA | F_LAMBDA | F_QSCALE))) {
             // one stage (counter / window of the covariance stage; the window covers the state chain's needs too)
             if (c->warmP < c->warmX) c->warmP = c->warmX;
             dX = false;
@@ -847,8 +857,15 @@ static int settle(csr_ctx *c) {
         stage_reruns(c, stg) += fresh;
         c->optimistic[stg] = false;
         grow_warm(c, stage_warm(c, stg), fresh);
+        // a failed optimistic validation costs a whole pipeline: widen that stage's window by half (up to 4x the mode's
+        // default; beyond that the data simply has long memory and synchronous validation is the right mode)
+        if (c->adaptWarm) {
+            int &w = stage_warm(c, stg);
+            const int cap = 4 * (c->xTolUlps > 0 ? 80 : 256);
+            if (w < cap) w = std::min(cap, (w + w / 2 + 15) / 16 * 16);
+        }
         if (firstFail < 0) firstFail = stg;
-        if (getenv("CONSENRICH_AMD_DEBUG")) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
+        if (c->dbgLog) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
     }
     if (firstFail < 0) return 0;
     c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation

@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-SHORT = {"k_stats": "stats", "k_resid": "residuals", "k_export_tiled": "export_natural", "FwdPTrend": "fwd_cov_chain",
+SHORT = {"k_stats": "stats", "k_resid": "residuals", "k_export_tiled": "export_natural", "FwdTrendFused": "fwd_chain", "FwdPTrend": "fwd_cov_chain",
          "FwdXTrend": "fwd_state_chain", "BwdTrend": "bwd_chain", "k_fwd_dstat": "fwd_dstat", "k_bwd_lag": "bwd_lagcov"}
 
 

@@ -77,7 +77,7 @@ def test_product_matches_live_oracle(product, oracle, name):
             assert np.asarray(got[k]).item() == pytest.approx(np.asarray(v).item(), rel=RTOL, abs=ATOL), f"{name}:{k}"
 
 
-def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0, fused=False):
+def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0, fused=False, mult=True):
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
 
@@ -91,7 +91,7 @@ def _run_batch(block_len, warm, d, n_list, m, seed, flags_extra=0, xtol=0, fused
             b.upload(c, data, munc)
             b.upload_multipliers(c, lam, kap, qs)
         b.stats()
-        fl = L.RETURN_NLL | L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE | flags_extra
+        fl = L.RETURN_NLL | ((L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE) if mult else 0) | flags_extra
         if fused:       # everything queued behind the optimistic pipeline, one synchronisation in sums()
             b.forward_backward(fl, want_sums=False)
             b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
@@ -156,9 +156,10 @@ def test_fused_forward_chain_with_failed_optimistic_validation(product, d):
     validation fails; the synchronous redo must land within the k-ulp budget of the sequential recursion, and a
     sufficient window must give the same numbers as the split chains (CONSENRICH_AMD_FUSE=0 path = exact-mode path)."""
     n_list = [5000, 37, 1, 12345, 64, 65]
-    seq = _run_batch(32 * 512, (0, 0, 0), d, n_list, 4, 100, xtol=0)
+    # (the fused kernel is used without per-bin multipliers only: with them the split chains need the shorter window)
+    seq = _run_batch(32 * 512, (0, 0, 0), d, n_list, 4, 100, xtol=0, mult=False)
     for blk, warm in ((64, (512, 512, 512)), (32, (0, 0, 0))):
-        fused = _run_batch(blk, warm, d, n_list, 4, 100, xtol=2, fused=True)
+        fused = _run_batch(blk, warm, d, n_list, 4, 100, xtol=2, fused=True, mult=False)
         for key, val in seq.items():
             if key == "stats":
                 continue
