@@ -64,6 +64,23 @@ struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// growable device work space owned by a context (freed with it)
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (ptr) hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+};
+
 struct csr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -127,6 +144,7 @@ struct csr_ctx {
         double *dPen = nullptr;
         long long *dSelRank = nullptr;
     } bg;
+    DevBuf bgBuf, wrBuf, textBuf;       // host-buffer background solver / bedGraph writer work space (this device)
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // profiling
@@ -238,6 +256,8 @@ extern "C" void csr_destroy(csr_ctx *c) {
             hipEventDestroy(pr.second);
         }
     for (hipEvent_t ev : c->eventPool) hipEventDestroy(ev);
+    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
+        if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) hipHostFree(c->hMail);
     if (c->evFork) hipEventDestroy(c->evFork);
     if (c->evJoin) hipEventDestroy(c->evJoin);
@@ -513,6 +533,8 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     p.chainSumD = reinterpret_cast<double *>(c->dMail + 16);
     p.chainSumNLL = p.chainSumD + n_chains;
     for (unsigned int &v : c->lastCnt) v = 0;
+    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
+        if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) hipHostFree(c->hMail);
     c->hMail = nullptr;
     HIPOK(hipHostMalloc((void **)&c->hMail, c->mailBytes));
@@ -1442,22 +1464,6 @@ extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n
 // ---------------------------------------------------------------------------------------------------------------
 // background update natives (pyx:944-1096, 9700-9724)
 // ---------------------------------------------------------------------------------------------------------------
-struct DevBuf {
-    void *ptr = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (ptr) hipFree(ptr);
-        ptr = nullptr;
-        cap = 0;
-        const size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&ptr, want);
-        if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-        cap = want;
-        return 0;
-    }
-};
-static DevBuf g_bgBuf;      // work space of the background solver (default context's device), grown on demand
 
 // blocks of Bp bins per chain; the last block absorbs a remainder shorter than 4 bins (interiors need >= 2 bins)
 static void bg_partition(const std::vector<int64_t> &off, const std::vector<int64_t> &len, int Bp, std::vector<int4> &blk,
@@ -1551,8 +1557,8 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
     const size_t oG = take(8 * 2 * NR * blk.size());
     const size_t oBI = take(8 * blk.size()), oBV = take(8 * blk.size());
     const size_t oCBI = take(8 * n_chains), oCBV = take(8 * n_chains), oMu = take(8 * n_chains);
-    CHECK(g_bgBuf.reserve(need_));
-    char *base = (char *)g_bgBuf.ptr;
+    CHECK(c->bgBuf.reserve(need_));
+    char *base = (char *)c->bgBuf.ptr;
     p.chainOff = (const int64_t *)(base + oOff); p.chainLen = (const int64_t *)(base + oLen);
     p.chainFirstBlk = (const int64_t *)(base + oFirst); p.chainNumBlk = (const int64_t *)(base + oNum);
     p.blk = (const int4 *)(base + oBlk);
@@ -1604,8 +1610,8 @@ extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *
     CHECK(ctx_select(c));
     const size_t mat = sizeof(float) * (size_t)m * n, vec = 8 * (size_t)n;
     const size_t matA = (mat + 255) / 256 * 256, vecA = (vec + 255) / 256 * 256;
-    CHECK(g_bgBuf.reserve(2 * matA + 2 * vecA + 256));
-    char *base = (char *)g_bgBuf.ptr;
+    CHECK(c->bgBuf.reserve(2 * matA + 2 * vecA + 256));
+    char *base = (char *)c->bgBuf.ptr;
     float *dr = (float *)base, *di = (float *)(base + matA);
     double *dw = (double *)(base + 2 * matA), *dh = (double *)(base + 2 * matA + vecA);
     unsigned long long *ds = (unsigned long long *)(base + 2 * matA + 2 * vecA);
@@ -1934,7 +1940,6 @@ extern "C" int csr_batch_set_background(csr_ctx *c, int32_t chain, const float *
 // ---------------------------------------------------------------------------------------------------------------
 // bedGraph writer (consenrich.py:9797-9805)
 // ---------------------------------------------------------------------------------------------------------------
-static DevBuf g_wrBuf;      // row lengths / offsets / text (+ staged host inputs)
 
 static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, const int64_t *hEnds, const float *hValues,
                              const char *chrom, char *out, int64_t cap) {
@@ -1953,8 +1958,8 @@ static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, cons
     const size_t oS = hStarts ? take(8 * (size_t)n) : 0, oE = hEnds ? take(8 * (size_t)n) : 0;
     const size_t oV = hValues ? take(4 * (size_t)n) : 0;
     // the text follows; its size is only known after pass 2, so reserve in two steps
-    if (g_wrBuf.reserve(need_) != 0) return -1;
-    char *base = (char *)g_wrBuf.ptr;
+    if (c->wrBuf.reserve(need_) != 0) return -1;
+    char *base = (char *)c->wrBuf.ptr;
     a.rowLen = (int *)(base + oLen); a.rowOff = (int64_t *)(base + oOff); a.blockSum = (int64_t *)(base + oBlk);
     auto H = [&](hipError_t e) { if (e != hipSuccess) { fail("bedGraph writer: %s", hipGetErrorString(e)); return false; } return true; };
     if (hStarts) {
@@ -1980,11 +1985,10 @@ static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, cons
     if (cap < total) { fail("bedGraph writer: output buffer too small (%lld < %lld)", (long long)cap, (long long)total); return -1; }
     // text buffer: grow the work buffer if needed (the row tables are recomputed afterwards in that case)
     const size_t oText = take((size_t)total);
-    if (need_ > g_wrBuf.cap) {
-        // simplest: a second, dedicated allocation for the text
-        static DevBuf textBuf;
-        if (textBuf.reserve((size_t)total) != 0) return -1;
-        a.out = (char *)textBuf.ptr;
+    if (need_ > c->wrBuf.cap) {
+        // a second, dedicated allocation for the text (growing wrBuf would drop the row tables just computed)
+        if (c->textBuf.reserve((size_t)total) != 0) return -1;
+        a.out = (char *)c->textBuf.ptr;
     } else {
         a.out = base + oText;
     }
