@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1224,6 +1225,11 @@ extern "C" int csr_batch_synthesize(csr_ctx *c, uint64_t seed) {
 //     CONSENRICH_AMD_DEVICE or 0)
 // ---------------------------------------------------------------------------------------------------------------
 static csr_ctx *g_default = nullptr;
+// The reference-shaped entry points share ONE default context (device buffers cached across calls): they serialise on
+// this mutex, so calls from several host threads are safe (the reference's callers are single-threaded per chromosome,
+// core.py:3290, but run beside thread pools).  Batch contexts are independent; one thread per context.
+static std::recursive_mutex g_defaultMutex;
+#define DEFAULT_CTX_GUARD std::lock_guard<std::recursive_mutex> guard_(g_defaultMutex)
 static csr_ctx *default_ctx() {
     if (!g_default) {
         int dev = 0;
@@ -1260,6 +1266,7 @@ static int import_nat(csr_ctx *c, const float *host, int ncomp, int64_t rows, in
 }
 
 extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_fwd_out *out) {
+    DEFAULT_CTX_GUARD;
     if (!mdl || !io || !out) return fail("null argument");
     if (io->m <= 0 || io->n <= 0) return fail("empty input must be handled by the caller (pyx:6494-6501)");
     if (!io->data || !io->munc || !io->D) return fail("null host buffer");
@@ -1289,6 +1296,7 @@ extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_
 extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, const float *data, const float *xf,
                                  const float *Pf, const float *pnoise, float *xs, float *Ps, float *lag,
                                  int64_t lag_rows, float *resid) {
+    DEFAULT_CTX_GUARD;
     if (!mdl || !data || !xf || !Pf || !pnoise || !xs || !Ps || !lag || !resid) return fail("null argument");
     if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:6737)");
     if (lag_rows < std::max<int64_t>(n - 1, 1)) return fail("lagCovSmoothed too small");
@@ -1321,6 +1329,7 @@ extern "C" int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg 
                                         const float *data, const float *munc, const float *qscale, float *lambda,
                                         float *kappa, float *xs, float *Ps, float *lag, float *resid,
                                         double *nll_path, csr_ecm_out *out) {
+    DEFAULT_CTX_GUARD;
     if (!mdl || !cfg || !data || !munc || !xs || !Ps || !lag || !resid || !out) return fail("null argument");
     if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:7999)");
     if (cfg->use_lambda && !lambda) return fail("use_lambda without lambda buffer");
@@ -1345,6 +1354,7 @@ extern "C" int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg 
 extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t n, const double *xs, const double *Ps,
                                                      const double *lag, const double *F, double *sum_level,
                                                      double *sum_trend, int64_t *count) {
+    DEFAULT_CTX_GUARD;
     if (!sum_level || !sum_trend || !count) return fail("null argument");
     *sum_level = 0.0; *sum_trend = 0.0;
     *count = n - 1 > 0 ? n - 1 : 0;
@@ -1427,6 +1437,7 @@ extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n
                                       const float *lambda, const float *kappa, const float *qscale,
                                       const float *pnoise, float *sum_gain0, float *sum_gain1, float *effq_level,
                                       float *effq_trend, float *munc_trace) {
+    DEFAULT_CTX_GUARD;
     if (!mdl || !Pf || !munc || !sum_gain0 || !sum_gain1 || !effq_level || !effq_trend || !munc_trace)
         return fail("null argument");
     if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
@@ -1515,6 +1526,7 @@ static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
 extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weight, const double *rhs,
                                     double lam, double lam_first, int32_t zero_center, int32_t block_len, double *out,
                                     int64_t *bad_index, double *bad_value) {
+    DEFAULT_CTX_GUARD;
     if (n_chains <= 0 || !n || !weight || !rhs || !out) return fail("null / empty argument");
     if (!std::isfinite(lam_first) || lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
     if (!std::isfinite(lam) || lam < 0.0) return fail("lam must be finite and nonnegative");
@@ -1603,6 +1615,7 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
 
 extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var,
                                              double *weight, double *rhs, int64_t *support) {
+    DEFAULT_CTX_GUARD;
     if (!resid || !inv_var || !weight || !rhs || !support) return fail("null argument");
     if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
     csr_ctx *c = default_ctx();
@@ -2005,6 +2018,7 @@ static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, cons
 extern "C" int64_t csr_format_bedgraph(const char *chrom, int64_t n, const int64_t *starts, const int64_t *ends,
                                        int64_t start0, int64_t step, int64_t end_cap, const float *values,
                                        int32_t transform, char *out, int64_t out_capacity) {
+    DEFAULT_CTX_GUARD;
     if (n > 0 && !values) { fail("null values"); return -1; }
     if ((starts == nullptr) != (ends == nullptr)) { fail("starts and ends must be given together"); return -1; }
     if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }

@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads and exports every symbol the header declares (no compute without a GPU), the product
 fails loudly when it cannot run, the host-side mirror raises the reference's errors before any launch, and the
 sharding logic is right."""
+import ctypes as C
 import os
 import re
 
@@ -176,3 +177,29 @@ def test_lpt_sharding_of_hg38():
     assert shard_bound(lens, 4) == pytest.approx(3.89, abs=0.02)
     assert shard_bound(lens, 2) == pytest.approx(2.0, abs=0.01)
     assert sum(hg38_chain_lengths(50)) == 57500042
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """The boundary is a C ABI: compile a strict-C99 translation unit against include/consenrich_amd.h, link it with the
+    shared library, run it (no GPU needed) and compare the struct sizes it prints with the ctypes mirrors."""
+    import shutil
+    import subprocess
+
+    from consenrich_amd import _lib as L
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L.lib()                                                        # builds the library if necessary
+    exe = tmp_path / "abi_check"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "abi_check.c"), "-o", str(exe), "-L", libdir, "-lconsenrich_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    fields = r.stdout.split()
+    assert int(fields[1]) == L.lib().csr_abi_version()
+    sizes = [int(v) for v in fields[5:11]]
+    assert sizes == [C.sizeof(L.Model), C.sizeof(L.EcmCfg), C.sizeof(L.EcmOut), C.sizeof(L.BgCfg), C.sizeof(L.BgOut),
+                     C.sizeof(L.RunStats)]
