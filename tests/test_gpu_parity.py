@@ -877,3 +877,77 @@ def test_device_resident_alternation_matches_cpu_twin(product, oracle):
         lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
         assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
         close_mostly(got[c]["kap"], ref["kap"], frac=2e-2, cap=5e-2, msg=f"kappa chain {c}")
+
+
+def test_whole_genome_batch_matches_oracle_config3(product, oracle):
+    """BASELINE config 3 at full size: all 22 hg38 autosomes @200 bp (14.4 M bins) x 8 samples in ONE batch, forward +
+    RTS smoother + uncertainty track, every bin of every chromosome against the CPU oracle (throughput mode, k = 2)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.sharding import hg38_chain_lengths
+
+    lengths = hg38_chain_lengths(200)
+    m = 8
+    mp = ModelParams(state_dim=2)
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    worst = {"xs": 0.0, "unc": 0.0}
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, lengths)
+        ins = []
+        for c, n in enumerate(lengths):
+            data, munc = cases.synth(n, m, 9000 + c)
+            b.upload(c, data, munc)
+            ins.append((data, munc))
+        b.stats()
+        sd, sn = b.forward_backward(L.RETURN_NLL)
+        b.export(L.EXPORT_SMOOTH)
+        for c, n in enumerate(lengths):
+            data, munc = ins[c]
+            xf, Pf, pn = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+            r = oracle.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0,
+                                    intervalToBlockMap=(np.arange(n) // 500).astype(np.int32), blockCount=n // 500 + 1,
+                                    stateInit=0.0, stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf,
+                                    pNoiseForward=pn, returnNLL=True, ECM_useObsPrecisionReweighting=False,
+                                    ECM_useProcessPrecisionReweighting=False)
+            bk = oracle.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+            xs, Ps = b.download(c, "xs"), b.download(c, "Ps")
+            assert sn[c] == pytest.approx(r[3], rel=1e-8), c
+            lvl = np.maximum(np.abs(bk[0][:, :1].astype(np.float64)), 1.0)
+            err = np.abs(xs.astype(np.float64) - bk[0]) / lvl
+            assert err.max() <= RTOL, (c, err.max())
+            unc_g, unc_o = np.sqrt(Ps[:, 0, 0].astype(np.float64)), np.sqrt(bk[1][:, 0, 0].astype(np.float64))
+            np.testing.assert_allclose(unc_g, unc_o, rtol=RTOL, atol=ATOL, err_msg=f"uncertainty chain {c}")
+            worst["xs"] = max(worst["xs"], float(err.max()))
+            worst["unc"] = max(worst["unc"], float(np.abs(unc_g / unc_o - 1).max()))
+            ins[c] = None
+    assert worst["xs"] <= 2e-6                      # measured: a few float32 ulps of the level
+
+
+def test_scaling_the_data_by_two_scales_the_fit_exactly(product):
+    """Size-independent property: the filter / smoother are linear in the data given the uncertainties, and a factor of
+    two is exact in binary floating point -- in exact mode 2 x data must give bit-for-bit 2 x (xf, xs, residuals) and the
+    same covariances, on a chromosome-sized chain."""
+    n, m = 1244783, 4
+    data, munc = cases.synth(n, m, 777)
+    a = _full_chain_from(product, data, munc)
+    b2 = _full_chain_from(product, (2.0 * data).astype(np.float32), munc)
+    for k in ("xf", "xs", "resid"):
+        assert np.array_equal(b2[k], 2.0 * a[k]), k
+    for k in ("Pf", "Ps", "lag", "pn"):
+        assert np.array_equal(b2[k], a[k]), k
+
+
+def _full_chain_from(mod, data, munc):
+    n, d = data.shape[1], 2
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    bm = (np.arange(n) // 500).astype(np.int32)
+    xf, Pf, pn = np.zeros((n, d), np.float32), np.zeros((n, d, d), np.float32), np.zeros((n, d, d), np.float32)
+    mod.set_validation(0)
+    mod.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0, intervalToBlockMap=bm,
+                     blockCount=int(bm.max()) + 1, stateInit=0.0, stateCovarInit=1000.0, stateForward=xf,
+                     stateCovarForward=Pf, pNoiseForward=pn, returnNLL=False, ECM_useObsPrecisionReweighting=False,
+                     ECM_useProcessPrecisionReweighting=False)
+    bk = mod.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+    return dict(xf=xf, Pf=Pf, pn=pn[: n - 1], xs=bk[0], Ps=bk[1], lag=bk[2][: n - 1], resid=bk[3])
