@@ -50,6 +50,8 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
+    int natOut;         // smoother (levelTrend): 1 = write xs / Ps / lag straight into the reference-layout arrays below
+    float *natXs, *natPs, *natLag;
     const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
     int qFromMult;      // smoother: 1 = process noise is the constant float32(Q0) (internal forward pass without
                         //           kappa / qScale / APN), 0 = read the stored / imported pNoise array tQ
@@ -315,6 +317,7 @@ __device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) 
 #define CSR_U_B 4
 #endif
 struct FwdPTrend {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = true;
@@ -415,6 +418,7 @@ struct FwdPTrend {
 
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = true;
@@ -476,6 +480,7 @@ struct FwdPLevel {
 
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
 struct FwdXTrend {
+    static constexpr bool NATOUT = false;
     static constexpr bool FWD = true;
     static constexpr bool PINGPONG = true;   // measured: pays only for the latency-bound state chain
     static constexpr int U = CSR_U_X;
@@ -543,6 +548,7 @@ struct FwdXTrend {
 
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = true;
     static constexpr int NW = 6, ND = 3;
     __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
@@ -605,6 +611,7 @@ struct FwdXLevel {
 // two (one fixed launch/drain cost, no gain-record round trip through HBM for the state update).  The arithmetic is the
 // split chains' own (advance() / step() above are called as they are), so the results are the same numbers.
 struct FwdTrendFused {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = true;
@@ -650,6 +657,7 @@ struct FwdTrendFused {
     }
 };
 struct FwdLevelFused {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = true;
@@ -685,6 +693,7 @@ struct FwdLevelFused {
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
 struct BwdTrend {
+    static constexpr bool NATOUT = true;     // main phase can emit the reference layout through LDS tiles (walk_nat)
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = false;
@@ -750,8 +759,14 @@ struct BwdTrend {
         g.J11 = fma(g.c11, v11, g.c10 * v01);
         return g;
     }
-    template <bool STORE>
-    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+    struct Out {            // what one bin contributes to the outputs
+        float2 xs;
+        float4 ps, lag;
+        bool hasLag;
+    };
+    template <bool WANT>
+    __device__ static __forceinline__ void advance(const Prm &p, Carry &c, const In &in, Out &o) {
+        o.hasLag = false;
         if (c.fresh) {      // pyx:6744-6750
             c.x0 = in.xf.x; c.x1 = in.xf.y;
             c.p00 = in.pf.x; c.p01 = in.pf.y; c.p10 = in.pf.z; c.p11 = in.pf.w;
@@ -773,23 +788,35 @@ struct BwdTrend {
             c.p01 = (float)((double)in.pf.y + fma(g.J01, r11, g.J00 * r01));
             c.p10 = c.p01;                                     // pyx:6821
             c.p11 = (float)((double)in.pf.w + fma(g.J11, r11, g.J10 * r01));
-            if constexpr (STORE) {
+            if constexpr (WANT) {
                 // lag-one covariance C[k] = Pf F^T + J (Ps[k+1] - PPred), pyx:6825-6844 (dP uses the incoming carry)
-                p.tLag[i] = make_float4((float)(g.c00 + fma(g.J01, d10, g.J00 * d00)),
-                                        (float)(g.c01 + fma(g.J01, d11, g.J00 * d01)),
-                                        (float)(g.c10 + fma(g.J11, d10, g.J10 * d00)),
-                                        (float)(g.c11 + fma(g.J11, d11, g.J10 * d01)));
+                o.lag = make_float4((float)(g.c00 + fma(g.J01, d10, g.J00 * d00)),
+                                    (float)(g.c01 + fma(g.J01, d11, g.J00 * d01)),
+                                    (float)(g.c10 + fma(g.J11, d10, g.J10 * d00)),
+                                    (float)(g.c11 + fma(g.J11, d11, g.J10 * d01)));
+                o.hasLag = true;
             }
         }
+        if constexpr (WANT) {
+            o.xs = make_float2(c.x0, c.x1);
+            o.ps = make_float4(c.p00, c.p01, c.p10, c.p11);
+        }
+    }
+    template <bool STORE>
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+        Out o;
+        advance<STORE>(p, c, in, o);
         if constexpr (STORE) {
-            p.tXs[i] = make_float2(c.x0, c.x1);
-            p.tPs[i] = make_float4(c.p00, c.p01, c.p10, c.p11);
+            if (o.hasLag) p.tLag[i] = o.lag;
+            p.tXs[i] = o.xs;
+            p.tPs[i] = o.ps;
         }
     }
 };
 
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
+    static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = false;
@@ -932,6 +959,111 @@ __device__ __forceinline__ void walk_block(const Prm &p, typename CH::Carry &c, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Main phase of the smoother with outputs in the REFERENCE layout (no export pass for xs / Ps / lag).  A lane's own
+// stores would be 64 scattered 16-byte pieces per instruction (measured: the chain gets 3x slower).  Instead the
+// wavefront stages 8 steps x 64 lanes per array in LDS; 8 consecutive bins of a lane are 128 contiguous bytes in the
+// natural layout, so 8 threads write one full line and an instruction writes 8 full lines.
+// ---------------------------------------------------------------------------------------------------------------
+struct NatTiles {
+    float4 ps[8][65], lag[8][65];       // [row = step within the batch][lane], padded against bank conflicts
+    float2 xs[8][65];
+    int gbase[64], len[64], last[64];   // natural index of the lane's block, valid steps (0 = inactive), chain's last block
+};
+template <class CH>
+__device__ __forceinline__ void walk_nat(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act, bool lastBlk,
+                                         int gbase, NatTiles &T) {
+    const int lane = threadIdx.x;
+    const int B = p.B;
+    const int64_t base = tbase(bq, B);
+    T.gbase[lane] = gbase;
+    T.len[lane] = act ? len : 0;
+    T.last[lane] = lastBlk ? 1 : 0;
+    float4 *natPs = reinterpret_cast<float4 *>(p.natPs), *natLag = reinterpret_cast<float4 *>(p.natLag);
+    float2 *natXs = reinterpret_cast<float2 *>(p.natXs);
+    typename CH::In cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s = B - 1 - u;
+        if (act && s < len) cur[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+    }
+#pragma unroll 1
+    for (int s8 = B - 8; s8 >= 0; s8 -= 8) {
+        if (s8 >= 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 - 1 - u;
+                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            }
+        }
+        const bool any = __any(act && s8 < len);
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 + 7 - u;
+                if (act && s < len) {
+                    typename CH::Out o;
+                    CH::template advance<true>(p, c, cur[u], o);
+                    T.xs[7 - u][lane] = o.xs;
+                    T.ps[7 - u][lane] = o.ps;
+                    if (o.hasLag) T.lag[7 - u][lane] = o.lag;
+                }
+            }
+            __syncthreads();
+            // float4 arrays: thread -> (lane L = k*8 + t/8, row r = t%8): 8 threads cover one 128-byte line
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int L = k * 8 + (lane >> 3), r = lane & 7, s = s8 + r;
+                const int ln = T.len[L];
+                if (s < ln) {
+                    const int64_t g = (int64_t)T.gbase[L] + s;
+                    natPs[g] = T.ps[r][L];
+                    if (!(T.last[L] && s == ln - 1)) natLag[g] = T.lag[r][L];     // the chain's last bin has no lag row
+                }
+            }
+            // float2 array: thread -> (lane L = k*16 + t/4, rows 2*(t%4), +1): 16 bytes per thread, 64 bytes per lane
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = k * 16 + (lane >> 2), r = (lane & 3) * 2, s = s8 + r;
+                const int ln = T.len[L];
+                if (s + 1 < ln) {
+                    const float2 a = T.xs[r][L], b2 = T.xs[r + 1][L];
+                    *reinterpret_cast<float4 *>(natXs + (int64_t)T.gbase[L] + s) = make_float4(a.x, a.y, b2.x, b2.y);
+                } else if (s < ln) {
+                    natXs[(int64_t)T.gbase[L] + s] = T.xs[r][L];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+}
+
+// Re-run path of the validation kernel with natural outputs: blocks re-run rarely, so every lane simply writes its own
+// bins (scattered 16-byte stores) -- no LDS, which keeps the validation kernel's dispatch cheap (an LDS allocation alone
+// made it 6x slower to launch).
+template <class CH>
+__device__ __forceinline__ void walk_nat_direct(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                                bool lastBlk, int gbase) {
+    const int64_t base = tbase(bq, p.B);
+    float4 *natPs = reinterpret_cast<float4 *>(p.natPs), *natLag = reinterpret_cast<float4 *>(p.natLag);
+    float2 *natXs = reinterpret_cast<float2 *>(p.natXs);
+    (void)lastBlk;
+#pragma unroll 1
+    for (int s = p.B - 1; s >= 0; --s) {
+        if (act && s < len) {
+            const typename CH::In in = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            typename CH::Out o;
+            CH::template advance<true>(p, c, in, o);
+            const int64_t g = (int64_t)gbase + s;
+            natXs[g] = o.xs;
+            natPs[g] = o.ps;
+            if (o.hasLag) natLag[g] = o.lag;
+        }
+    }
+}
+
 // Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
 template <class CH>
 __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
@@ -983,7 +1115,14 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
             walk_block<CH, false>(p, c, bq, len, act, bfirst, 0, hi);
         }
         if (live) cin[b] = c;
-        walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        if constexpr (CH::NATOUT) {
+            // dynamic LDS: only launches with natOut allocate the tiles (sizeof(NatTiles) bytes)
+            extern __shared__ __attribute__((aligned(16))) unsigned char natTileMem[];
+            if (p.natOut) walk_nat<CH>(p, c, b, bi.y, live, b == blast, bi.x, *reinterpret_cast<NatTiles *>(natTileMem));
+            else walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        } else {
+            walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        }
         if (live) cout[b] = c;
     }
 }
@@ -1127,7 +1266,12 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     // and the LDS allocation alone made this kernel's dispatch ~6x slower)
     if (live && !rerun) onxt[b] = ocur[self];
     if (!__any(rerun)) return;
-    walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
+    if constexpr (CH::NATOUT) {
+        if (p.natOut) walk_nat_direct<CH>(p, c, b, bi.y, rerun, b == blast, bi.x);
+        else walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
+    } else {
+        walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
+    }
     if (rerun) {
         onxt[b] = c;
         atomicAdd(p.rerunCount, 1u);

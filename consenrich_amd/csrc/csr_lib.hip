@@ -104,6 +104,9 @@ struct csr_ctx {
     int64_t Npad = 0, NB = 0, NG = 0, TN = 0;
     bool statsValid = false;
     bool haveFwd = false, haveBwd = false;
+    bool smoothNat = false;     // the last smoother pass wrote xs / Ps / lag straight into the natural arrays (the
+                                // block-transposed copies are stale; nothing but the ECM E-steps reads those)
+    bool pendNatOut = false;
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
     uint32_t fwdFlags = 0;
     Prm p{};
@@ -125,6 +128,7 @@ struct csr_ctx {
     bool deferEnabled = true;
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
     // debugging switches, read once from the environment at creation (never on the launch path)
     bool dbgPoison = false, dbgProbe = false, dbgFence = false, dbgLog = false;
     int dbgForceIters = 0;
@@ -233,6 +237,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
     c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
     c->dbgProbe = getenv("CONSENRICH_AMD_PROBE") != nullptr;
@@ -730,7 +735,9 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                                    c->stream, p);
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
-            hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+            size_t lds = 0;
+            if constexpr (CH::NATOUT) lds = p.natOut ? sizeof(NatTiles) : 0;
+            hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), lds, c->stream, p);
         }
     }
     LAUNCH_CHECK(name);
@@ -842,11 +849,20 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     return 0;
 }
 
-static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false) {
+static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false) {
     if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
     Prm p = c->p;
     p.flags = c->fwdFlags;
     p.chainActive = active;
+    natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
+    if (natOut) {
+        CHECK(nat_array(c, CSR_ARR_XS, &p.natXs));
+        CHECK(nat_array(c, CSR_ARR_PS, &p.natPs));
+        CHECK(nat_array(c, CSR_ARR_LAG, &p.natLag));
+        p.natOut = 1;
+    }
+    c->smoothNat = natOut;
+    c->pendNatOut = natOut;
     // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
     p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
@@ -895,9 +911,10 @@ static int settle(csr_ctx *c) {
     if (firstFail <= ST_X && pf) {
         const bool bwdToo = pb || c->haveBwd;
         CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false));
-        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false));
+        const bool nat = c->pendNatOut;
+        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat));
     } else if (pb) {
-        CHECK(backward_impl(c, true, c->pendActiveB, false));
+        CHECK(backward_impl(c, true, c->pendActiveB, false, c->pendNatOut));
     }
     if (pe) CHECK(export_impl(c, pe));      // arrays exported from the unvalidated results
     CHECK(read_mail(c, c->mailBytes));
@@ -926,7 +943,7 @@ extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, doub
 
 extern "C" int csr_batch_backward(csr_ctx *c) {
     CHECK(need(c));
-    CHECK(backward_impl(c, true, nullptr, true));
+    CHECK(backward_impl(c, true, nullptr, true, true));
     return 0;       // validated at the next settle point
 }
 
@@ -936,7 +953,7 @@ extern "C" int csr_batch_forward_backward(csr_ctx *c, uint32_t flags, double *su
     CHECK(need(c));
     CHECK(settle(c));
     CHECK(forward_impl(c, flags, true, nullptr, true, true));
-    CHECK(backward_impl(c, true, nullptr, true));
+    CHECK(backward_impl(c, true, nullptr, true, true));
     if (sum_d || sum_nll) return read_sums(c, sum_d, sum_nll);
     return 0;       // validation stays pending until the next settle point (sums, download, synchronize, new inputs)
 }
@@ -1124,9 +1141,9 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     }
     if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
         if (!c->haveBwd) return fail("no smoothed results to export");
-        CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
+        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
     }
-    if (what & CSR_EXPORT_SMOOTH) {
+    if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat) {      // smoothNat: the smoother already wrote the natural arrays
         CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
         CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
     }
@@ -1757,7 +1774,7 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
         if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
         CHECK(flush_export(c, L));
     }
