@@ -50,6 +50,9 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
+    int predCompact;    // fused forward chain: only the NIS epilogue reads the gain record, and only P00pred of it --
+                        // store that float (tPP, 4 B/bin) instead of the 16-byte record
+    float *tPP;
     int natOut;         // smoother (levelTrend): 1 = write xs / Ps / lag straight into the reference-layout arrays below
     float *natXs, *natPs, *natLag;
     const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
@@ -405,7 +408,8 @@ struct FwdPTrend {
         gout.p00 = (float)a00;
         gout.p10 = (float)a10;
         if constexpr (STORE) {
-            p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
+            if (p.predCompact) p.tPP[i] = (float)a00;
+            else p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
             p.tPf[i] = make_float4(c.c00, c.c01, c.c01, c.c11);
             // pNoiseForward[k-1] = Q used to reach k (pyx:504-508): shifted store, skipped at the chain's first bin
             if (!p.qFromMult) {     // constant float32(Q0) otherwise: neither stored nor read back (smoother, export)
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
                 else if (b > bi.z) { const float2 v = p.tXf[tidx(b - 1, p.B - 1, p.B)]; x0 = v.x; x1 = v.y; }
                 else { x0 = (double)(float)p.init; x1 = 0.0; }
                 xp0 = r32(fma(p.F01, x1, p.F00 * x0));
-                pp = (double)p.tXin[i].z;
+                pp = p.predCompact ? (double)p.tPP[i] : (double)p.tXin[i].z;
             } else {
                 if (s > 0) xp0 = p.tXd[i - 64];
                 else if (b > bi.z) xp0 = p.tXd[tidx(b - 1, p.B - 1, p.B)];

@@ -520,7 +520,7 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     CHECK(dalloc(c, &p.tS0u, T)); CHECK(dalloc(c, &p.tZbar, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
     CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
     CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
-    CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T));
+    CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T)); CHECK(dalloc(c, &p.tPP, T));
     CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
     if (mdl->state_dim == 1) { CHECK(dalloc(c, &p.tXd, T)); }
     // multipliers default to 1 (the reference's cold start, pyx:7901/7914) until csr_batch_upload_multipliers
@@ -825,6 +825,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             // one stage (counter / window of the covariance stage; the window covers the state chain's needs too)
             if (c->warmP < c->warmX) c->warmP = c->warmX;
             dX = false;
+            p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
             if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
         } else if (c->mdl.state_dim == 2) {
