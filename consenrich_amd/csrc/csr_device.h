@@ -53,6 +53,9 @@ struct Prm {
     int predCompact;    // fused forward chain: only the NIS epilogue reads the gain record, and only P00pred of it --
                         // store that float (tPP, 4 B/bin) instead of the 16-byte record
     float *tPP;
+    int estepKappa;     // ECM: the smoother's main phase also evaluates the kappa E-step of the transition it just
+                        // smoothed (pyx:8244-8298): it holds the moments of bins k and k+1 and the lag covariance
+    int storeMoments;   // 0: inner ECM sweeps whose smoothed moments nobody reads are not stored at all
     int natOut;         // smoother (levelTrend): 1 = write xs / Ps / lag straight into the reference-layout arrays below
     float *natXs, *natPs, *natLag;
     const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
@@ -693,6 +696,46 @@ struct FwdLevelFused {
     }
 };
 
+// kappa E-step of one transition k -> k+1 (pyx:8244-8298 with the MAT2 helpers pyx:4123-4175) from the float32 smoothed
+// moments of both bins and the lag-one covariance; qsNext = qScale[k+1] (1 if unused)
+__device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, float4 pk, float2 ya, float4 pk1, float4 lg,
+                                                   float qsNext) {
+    const double x0 = xa.x, x1 = xa.y, y0 = ya.x, y1 = ya.y;
+    const double f00 = p.F00, f01 = p.F01, f10 = p.F10, f11 = p.F11;
+    const double xx00 = (double)pk.x + x0 * x0, xx01 = (double)pk.y + x0 * x1;
+    const double xx10 = (double)pk.z + x1 * x0, xx11 = (double)pk.w + x1 * x1;
+    const double yy00 = (double)pk1.x + y0 * y0, yy01 = (double)pk1.y + y0 * y1;
+    const double yy10 = (double)pk1.z + y1 * y0, yy11 = (double)pk1.w + y1 * y1;
+    const double xy00 = (double)lg.x + x0 * y0, xy01 = (double)lg.y + x0 * y1;
+    const double xy10 = (double)lg.z + x1 * y0, xy11 = (double)lg.w + x1 * y1;
+    // yx = xy^T, Ft = F^T : ww = yy - yx Ft - F xy + (F xx) Ft
+    double w00 = yy00 - (xy00 * f00 + xy10 * f01);
+    double w01 = yy01 - (xy00 * f10 + xy10 * f11);
+    double w10 = yy10 - (xy01 * f00 + xy11 * f01);
+    double w11 = yy11 - (xy01 * f10 + xy11 * f11);
+    w00 -= (f00 * xy00 + f01 * xy10);
+    w01 -= (f00 * xy01 + f01 * xy11);
+    w10 -= (f10 * xy00 + f11 * xy10);
+    w11 -= (f10 * xy01 + f11 * xy11);
+    const double g00 = f00 * xx00 + f01 * xx10, g01 = f00 * xx01 + f01 * xx11;
+    const double g10 = f10 * xx00 + f11 * xx10, g11 = f10 * xx01 + f11 * xx11;
+    w00 += (g00 * f00 + g01 * f01);
+    w01 += (g00 * f10 + g01 * f11);
+    w10 += (g10 * f00 + g11 * f01);
+    w11 += (g10 * f10 + g11 * f11);
+    if (w00 < 0.0) w00 = 0.0;
+    if (w11 < 0.0) w11 = 0.0;
+    const double det = p.Q00 * p.Q11 - p.Q01 * p.Q10;
+    const double qi00 = p.Q11 / det, qi01 = -p.Q01 / det, qi10 = -p.Q10 / det, qi11 = p.Q00 / det;
+    double delta = qi00 * w00 + qi01 * w10 + qi10 * w01 + qi11 * w11;
+    if (p.flags & F_QSCALE) delta = delta / (double)qsNext;
+    if (delta < 0.0) delta = 0.0;
+    double kap = (p.nu + (double)p.d) / (p.nu + delta);
+    if (kap < p.kMin) kap = p.kMin;
+    else if (kap > p.kMax) kap = p.kMax;
+    return (float)kap;
+}
+
 // ---- backward RTS chain, levelTrend (pyx:6758-6822) ------------------------------------------------------------
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
@@ -807,13 +850,28 @@ struct BwdTrend {
         }
     }
     template <bool STORE>
-    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
+                                                int64_t bfirst) {
         Out o;
-        advance<STORE>(p, c, in, o);
         if constexpr (STORE) {
-            if (o.hasLag) p.tLag[i] = o.lag;
-            p.tXs[i] = o.xs;
-            p.tPs[i] = o.ps;
+            const Carry nextBin = c;        // float32 smoothed moments of bin k+1 (exactly what is / would be stored)
+            advance<true>(p, c, in, o);
+            if (p.estepKappa) {
+                if (o.hasLag) {
+                    const int64_t nx = (s + 1 < p.B) ? i + 64 : tidx(b + 1, 0, p.B);
+                    const float qs = (p.flags & F_QSCALE) ? p.tQs[nx] : 1.0f;
+                    p.tKap[nx] = estep_kappa_trend(p, o.xs, o.ps, make_float2(nextBin.x0, nextBin.x1),
+                                                   make_float4(nextBin.p00, nextBin.p01, nextBin.p10, nextBin.p11), o.lag, qs);
+                }
+                if (s == 0 && b == bfirst) p.tKap[i] = 1.0f;      // processPrecExp[0] = 1 (pyx:8245)
+            }
+            if (p.storeMoments) {
+                if (o.hasLag) p.tLag[i] = o.lag;
+                p.tXs[i] = o.xs;
+                p.tPs[i] = o.ps;
+            }
+        } else {
+            advance<false>(p, c, in, o);
         }
     }
 };
@@ -1432,43 +1490,14 @@ __global__ __launch_bounds__(256) void k_estep_kappa(Prm p) {
     const int64_t nx = next_slot(p, b, s, bi);
     if (nx < 0) return;
     const float4 lg = p.tLag[slot];
-    double delta;
     if (p.d == 2) {
-        const float2 xa = p.tXs[slot], ya = p.tXs[nx];
-        const float4 pk = p.tPs[slot], pk1 = p.tPs[nx];
-        const double x0 = xa.x, x1 = xa.y, y0 = ya.x, y1 = ya.y;
-        const double f00 = p.F00, f01 = p.F01, f10 = p.F10, f11 = p.F11;
-        const double xx00 = (double)pk.x + x0 * x0, xx01 = (double)pk.y + x0 * x1;
-        const double xx10 = (double)pk.z + x1 * x0, xx11 = (double)pk.w + x1 * x1;
-        const double yy00 = (double)pk1.x + y0 * y0, yy01 = (double)pk1.y + y0 * y1;
-        const double yy10 = (double)pk1.z + y1 * y0, yy11 = (double)pk1.w + y1 * y1;
-        const double xy00 = (double)lg.x + x0 * y0, xy01 = (double)lg.y + x0 * y1;
-        const double xy10 = (double)lg.z + x1 * y0, xy11 = (double)lg.w + x1 * y1;
-        // yx = xy^T, Ft = F^T : ww = yy - yx Ft - F xy + (F xx) Ft
-        double w00 = yy00 - (xy00 * f00 + xy10 * f01);
-        double w01 = yy01 - (xy00 * f10 + xy10 * f11);
-        double w10 = yy10 - (xy01 * f00 + xy11 * f01);
-        double w11 = yy11 - (xy01 * f10 + xy11 * f11);
-        w00 -= (f00 * xy00 + f01 * xy10);
-        w01 -= (f00 * xy01 + f01 * xy11);
-        w10 -= (f10 * xy00 + f11 * xy10);
-        w11 -= (f10 * xy01 + f11 * xy11);
-        const double g00 = f00 * xx00 + f01 * xx10, g01 = f00 * xx01 + f01 * xx11;
-        const double g10 = f10 * xx00 + f11 * xx10, g11 = f10 * xx01 + f11 * xx11;
-        w00 += (g00 * f00 + g01 * f01);
-        w01 += (g00 * f10 + g01 * f11);
-        w10 += (g10 * f00 + g11 * f01);
-        w11 += (g10 * f10 + g11 * f11);
-        if (w00 < 0.0) w00 = 0.0;
-        if (w11 < 0.0) w11 = 0.0;
-        const double det = p.Q00 * p.Q11 - p.Q01 * p.Q10;
-        const double qi00 = p.Q11 / det, qi01 = -p.Q01 / det, qi10 = -p.Q10 / det, qi11 = p.Q00 / det;
-        delta = qi00 * w00 + qi01 * w10 + qi10 * w01 + qi11 * w11;
-    } else {
-        const double x0 = p.tXs[slot].x, y0 = p.tXs[nx].x;
-        const double pk = p.tPs[slot].x, pk1 = p.tPs[nx].x, ck = lg.x;
-        delta = ((pk1 + y0 * y0) - (2.0 * (ck + x0 * y0)) + (pk + x0 * x0)) * (1.0 / p.Q00);
+        p.tKap[nx] = estep_kappa_trend(p, p.tXs[slot], p.tPs[slot], p.tXs[nx], p.tPs[nx], lg,
+                                       (p.flags & F_QSCALE) ? p.tQs[nx] : 1.0f);
+        return;
     }
+    const double x0 = p.tXs[slot].x, y0 = p.tXs[nx].x;
+    const double pk = p.tPs[slot].x, pk1 = p.tPs[nx].x, ck = lg.x;
+    double delta = ((pk1 + y0 * y0) - (2.0 * (ck + x0 * y0)) + (pk + x0 * x0)) * (1.0 / p.Q00);
     if (p.flags & F_QSCALE) delta = delta / (double)p.tQs[nx];
     if (delta < 0.0) delta = 0.0;
     double kap = (p.nu + (double)p.d) / (p.nu + delta);

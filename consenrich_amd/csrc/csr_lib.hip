@@ -107,6 +107,8 @@ struct csr_ctx {
     bool smoothNat = false;     // the last smoother pass wrote xs / Ps / lag straight into the natural arrays (the
                                 // block-transposed copies are stale; nothing but the ECM E-steps reads those)
     bool pendNatOut = false;
+    int pendEstep = 0;
+    bool fuseEstep = true;      // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
     uint32_t fwdFlags = 0;
     Prm p{};
@@ -238,6 +240,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_FUSE_ESTEP"))) c->fuseEstep = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
     c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
     c->dbgProbe = getenv("CONSENRICH_AMD_PROBE") != nullptr;
@@ -850,11 +853,17 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     return 0;
 }
 
-static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false) {
+// estep: 0 = plain smoother; 1 = ECM sweep whose kappa E-step is evaluated inside the smoother chain, moments stored;
+//        2 = same, but the smoothed moments are not stored (an inner sweep nobody reads them from)
+static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false,
+                         int estep = 0) {
     if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
     Prm p = c->p;
     p.flags = c->fwdFlags;
     p.chainActive = active;
+    p.estepKappa = estep != 0 ? 1 : 0;
+    p.storeMoments = estep == 2 ? 0 : 1;
+    c->pendEstep = estep;
     natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
     if (natOut) {
         CHECK(nat_array(c, CSR_ARR_XS, &p.natXs));
@@ -913,9 +922,10 @@ static int settle(csr_ctx *c) {
         const bool bwdToo = pb || c->haveBwd;
         CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false));
         const bool nat = c->pendNatOut;
-        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat));
+        const int es = c->pendEstep;
+        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat, es));
     } else if (pb) {
-        CHECK(backward_impl(c, true, c->pendActiveB, false, c->pendNatOut));
+        CHECK(backward_impl(c, true, c->pendActiveB, false, c->pendNatOut, c->pendEstep));
     }
     if (pe) CHECK(export_impl(c, pe));      // arrays exported from the unvalidated results
     CHECK(read_mail(c, c->mailBytes));
@@ -1022,8 +1032,14 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
                 if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
                 fwdFresh = false;
-                CHECK(backward_impl(c, true, c->dActive, true));
-                CHECK(settle(c));          // the E-steps consume validated smoothed moments
+                // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments
+                // of bins k and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself;
+                // only the last inner sweep's moments can become the result of this iteration, the others are not
+                // even stored
+                const bool fusedE = c->fuseEstep && cfg->use_kappa && !cfg->use_lambda && c->mdl.state_dim == 2;
+                const int es = !fusedE ? 0 : (inner + 1 == cfg->inner_iters ? 1 : 2);
+                CHECK(backward_impl(c, true, c->dActive, true, false, es));
+                CHECK(settle(c));          // the next sweep (or the E-step kernels) consume validated results
                 Prm p = c->p;
                 p.flags = fl;
                 p.chainActive = c->dActive;
@@ -1032,7 +1048,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
                     hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
                     LAUNCH_CHECK("k_estep_lambda");
                 }
-                if (cfg->use_kappa) {
+                if (cfg->use_kappa && !fusedE) {
                     Scope sc(c, "estep_kappa");
                     hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
                     LAUNCH_CHECK("k_estep_kappa");
