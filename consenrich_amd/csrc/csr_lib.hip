@@ -90,7 +90,10 @@ struct csr_ctx {
     // speculative warm-up in bins (multiples of 16).  Defaults follow the validation mode (mode_warm_defaults): bitwise
     // coalescence of float32-rounded trajectories needs ~4x the window that k-ulp agreement does.
     int warmP = 256, warmX = 256, warmB = 128;
-    bool pinP = false, pinX = false, pinB = false;
+    bool pinP = false, pinX = false, pinB = false, pinFM = false;
+    int warmFM = 160;           // fused forward chain with per-bin multipliers
+    int *fwdWindow = nullptr;   // window variable of the forward stage being launched (see stage_warm)
+    int *lastFwdWindow = nullptr;   // ... of the last forward stage launched (a failed settle widens that one)
     bool Bfixed = false;
     bool adaptWarm = true;
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
@@ -234,6 +237,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WARM_P"))) { c->warmP = atoi(e); c->pinP = true; }
     if ((e = getenv("CONSENRICH_AMD_WARM_X"))) { c->warmX = atoi(e); c->pinX = true; }
     if ((e = getenv("CONSENRICH_AMD_WARM_B"))) { c->warmB = atoi(e); c->pinB = true; }
+    if ((e = getenv("CONSENRICH_AMD_WARM_FM"))) { c->warmFM = atoi(e); c->pinFM = true; }
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_ADAPT"))) c->adaptWarm = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
@@ -709,7 +713,10 @@ static void grow_warm(csr_ctx *c, int &warmRef, unsigned int fresh) {
     if (c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
         warmRef = std::min(8192, warmRef * 2);
 }
-static int &stage_warm(csr_ctx *c, int stage) { return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB); }
+static int &stage_warm(csr_ctx *c, int stage) {
+    if (stage == ST_P && c->fwdWindow) return *c->fwdWindow;        // fused forward chain with its own window
+    return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB);
+}
 static int64_t &stage_reruns(csr_ctx *c, int stage) {
     return stage == ST_P ? c->rs.reruns_p : (stage == ST_X ? c->rs.reruns_x : c->rs.reruns_b);
 }
@@ -820,18 +827,24 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
         LAUNCH_CHECK("k_fwd_apn");
     } else {
         bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
-        // Fused chain: only without per-bin multipliers.  Its state recursion warms up on SPECULATIVE gains (the split
-        // state chain reads the validated ones), so it needs covariance-window + state-window bins where the gains vary
-        // from bin to bin; measured in the ECM loop (kappa per bin): 9 of 24 optimistic validations failed with the
-        // 80-bin window, 6.3 vs 4.7 ms per ECM iteration.  With constant multipliers 80 bins give zero re-runs.
-        if (c->fuseFwd && c->xTolUlps > 0 && !(flags & (F_KAPPA | F_LAMBDA | F_QSCALE))) {
-            // one stage (counter / window of the covariance stage; the window covers the state chain's needs too)
+        // Fused chain (tolerant mode).  Its state recursion warms up on SPECULATIVE gains (the split state chain reads the
+        // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) it needs about covariance-window +
+        // state-window bins: with the plain 80-bin window 9 of 24 optimistic validations failed there (6.3 ms per ECM
+        // iteration), with 160 bins none (3.6 ms; split chains 4.3 ms).  Constant multipliers: 80 bins, zero re-runs.
+        if (c->fuseFwd && c->xTolUlps > 0) {
+            // one stage (counter of the covariance stage; the window covers the state chain's needs too)
+            const bool mult = (flags & (F_KAPPA | F_LAMBDA | F_QSCALE)) != 0;
             if (c->warmP < c->warmX) c->warmP = c->warmX;
+            if (c->warmFM < 2 * c->warmP && !c->pinFM) c->warmFM = 2 * c->warmP;
+            c->fwdWindow = mult ? &c->warmFM : &c->warmP;
             dX = false;
             p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
             if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            c->lastFwdWindow = c->fwdWindow;
+            c->fwdWindow = nullptr;
         } else if (c->mdl.state_dim == 2) {
+            c->lastFwdWindow = nullptr;
             CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         } else {
@@ -905,11 +918,12 @@ static int settle(csr_ctx *c) {
         if (fresh == 0) continue;
         stage_reruns(c, stg) += fresh;
         c->optimistic[stg] = false;
-        grow_warm(c, stage_warm(c, stg), fresh);
+        int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow : stage_warm(c, stg);
+        grow_warm(c, wstage, fresh);
         // a failed optimistic validation costs a whole pipeline: widen that stage's window by half (up to 4x the mode's
         // default; beyond that the data simply has long memory and synchronous validation is the right mode)
         if (c->adaptWarm) {
-            int &w = stage_warm(c, stg);
+            int &w = wstage;
             const int cap = 4 * (c->xTolUlps > 0 ? 80 : 256);
             if (w < cap) w = std::min(cap, (w + w / 2 + 15) / 16 * 16);
         }
