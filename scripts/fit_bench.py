@@ -1,0 +1,27 @@
+"""Whole-genome device-resident fit (SURVEY a12 counterpart, consenrich_amd/driver.py): hg38 autosomes @200bp x 32 synthetic
+samples, outer alternation of fixed-background ECM phases and background updates, everything resident in HBM.
+Reports wall time, per-chromosome pass / iteration counts and the kernel-time breakdown."""
+import sys, os, time, json
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests", "golden"))
+import numpy as np
+import bg_cases
+from consenrich_amd import _lib as L
+from consenrich_amd.batch import DeviceBatch, ModelParams
+from consenrich_amd.driver import FitConfig, fit_batch
+from consenrich_amd.sharding import hg38_chain_lengths
+
+m = int(os.environ.get("M", "32"))
+lengths = hg38_chain_lengths(200)
+b = DeviceBatch(0)
+b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
+cfg = FitConfig(penalties=bg_cases.penalties(750, 128.0), ecm_iters=int(os.environ.get("ECM_ITERS", "50")), ecm_rtol=1e-6,
+                inner_iters=5, outer_passes=int(os.environ.get("OUTER", "8")), min_outer=3, patience=2, shift_rtol=5e-3)
+b.synchronize(); b.profile(True)
+t = time.perf_counter(); fits = fit_batch(b, cfg); b.synchronize(); wall = time.perf_counter() - t
+kt = b.kernel_times(); b.profile(False)
+ecm_total = sum(sum(f.ecm_iters) for f in fits)
+print(json.dumps({"workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {sum(lengths)} bins", "wall_s": round(wall, 3),
+                  "outer_passes": [f.passes for f in fits], "converged": [f.converged for f in fits],
+                  "ecm_iterations_total_over_chains": ecm_total, "ecm_iters_first_chain": fits[0].ecm_iters,
+                  "shift_first_chain": [round(x, 6) for x in fits[0].shift],
+                  "kernel_ms": {k: round(v[1], 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])[:10]}}))
