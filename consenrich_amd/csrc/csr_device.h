@@ -323,6 +323,7 @@ __device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) 
 #define CSR_U_B 4
 #endif
 struct FwdPTrend {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -425,6 +426,7 @@ struct FwdPTrend {
 
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -487,6 +489,7 @@ struct FwdPLevel {
 
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
 struct FwdXTrend {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool FWD = true;
     static constexpr bool PINGPONG = true;   // measured: pays only for the latency-bound state chain
@@ -555,6 +558,7 @@ struct FwdXTrend {
 
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = true;
     static constexpr int NW = 6, ND = 3;
@@ -619,6 +623,7 @@ struct FwdXLevel {
 // split chains' own (advance() / step() above are called as they are), so the results are the same numbers.
 struct FwdTrendFused {
     static constexpr bool NATOUT = false;
+    static constexpr bool NATOUT_FWD = true;   // main phase can also emit xf / Pf in the reference layout (walk_nat_fwd)
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
     static constexpr bool FWD = true;
@@ -664,6 +669,7 @@ struct FwdTrendFused {
     }
 };
 struct FwdLevelFused {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -740,6 +746,7 @@ __device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, floa
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
 struct BwdTrend {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = true;     // main phase can emit the reference layout through LDS tiles (walk_nat)
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -878,6 +885,7 @@ struct BwdTrend {
 
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
+    static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -1126,6 +1134,83 @@ __device__ __forceinline__ void walk_nat_direct(const Prm &p, typename CH::Carry
     }
 }
 
+// Forward counterpart of walk_nat for the fused forward chain: the blocked stores stay (the smoother reads them), and the
+// filtered state / covariance are ALSO written in the reference layout through the same LDS tiles, so the export pass
+// has nothing left to convert but D.  natXs / natPs point at the natural xf / Pf arrays here.
+template <class CH>
+__device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                             int64_t bfirst, int gbase, NatTiles &T) {
+    const int lane = threadIdx.x;
+    const int B = p.B;
+    const int64_t base = tbase(bq, B);
+    T.gbase[lane] = gbase;
+    T.len[lane] = act ? len : 0;
+    float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
+    float2 *natXf = reinterpret_cast<float2 *>(p.natXs);
+    typename CH::In cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (act && u < len) cur[u] = CH::load(p, base + (int64_t)u * 64, bq, u, len);
+#pragma unroll 1
+    for (int s8 = 0; s8 < B; s8 += 8) {
+        if (s8 + 8 < B) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 + 8 + u;
+                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            }
+        }
+        if (__any(act && s8 < len)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 + u;
+                if (act && s < len) {
+                    CH::template step<true>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst);
+                    T.xs[u][lane] = make_float2(c.X.x0, c.X.x1);
+                    T.ps[u][lane] = make_float4(c.P.c00, c.P.c01, c.P.c01, c.P.c11);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int L = k * 8 + (lane >> 3), r = lane & 7, s = s8 + r;
+                if (s < T.len[L]) natPf[(int64_t)T.gbase[L] + s] = T.ps[r][L];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = k * 16 + (lane >> 2), r = (lane & 3) * 2, s = s8 + r;
+                const int ln = T.len[L];
+                if (s + 1 < ln) {
+                    const float2 a = T.xs[r][L], b2 = T.xs[r + 1][L];
+                    *reinterpret_cast<float4 *>(natXf + (int64_t)T.gbase[L] + s) = make_float4(a.x, a.y, b2.x, b2.y);
+                } else if (s < ln) {
+                    natXf[(int64_t)T.gbase[L] + s] = T.xs[r][L];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+}
+// re-run path (validation kernel): scattered natural stores, no LDS
+template <class CH>
+__device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                                    int64_t bfirst, int gbase) {
+    const int64_t base = tbase(bq, p.B);
+    float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
+    float2 *natXf = reinterpret_cast<float2 *>(p.natXs);
+#pragma unroll 1
+    for (int s = 0; s < p.B; ++s) {
+        if (act && s < len) {
+            const typename CH::In in = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            CH::template step<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst);
+            natXf[(int64_t)gbase + s] = make_float2(c.X.x0, c.X.x1);
+            natPf[(int64_t)gbase + s] = make_float4(c.P.c00, c.P.c01, c.P.c01, c.P.c11);
+        }
+    }
+}
+
 // Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
 template <class CH>
 __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
@@ -1157,7 +1242,13 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
             walk_block<CH, false>(p, c, b - q, B, act, bfirst, lo, B);
         }
         if (live) cin[b] = c;
-        walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        if constexpr (CH::NATOUT_FWD) {
+            extern __shared__ __attribute__((aligned(16))) unsigned char natTileMemF[];
+            if (p.natOut) walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
+            else walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        } else {
+            walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+        }
         if (live) cout[b] = c;
     } else {
         const int avail = live ? (int)(blast - b) : 0;         // following blocks of this chain
@@ -1330,6 +1421,9 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     if (!__any(rerun)) return;
     if constexpr (CH::NATOUT) {
         if (p.natOut) walk_nat_direct<CH>(p, c, b, bi.y, rerun, b == blast, bi.x);
+        else walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
+    } else if constexpr (CH::NATOUT_FWD) {
+        if (p.natOut) walk_nat_fwd_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
         else walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
     } else {
         walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);

@@ -110,6 +110,7 @@ struct csr_ctx {
     bool smoothNat = false;     // the last smoother pass wrote xs / Ps / lag straight into the natural arrays (the
                                 // block-transposed copies are stale; nothing but the ECM E-steps reads those)
     bool pendNatOut = false;
+    bool fwdNat = false, pendFwdNat = false;   // the last forward pass wrote xf / Pf in the reference layout too
     int pendEstep = 0;
     bool fuseEstep = true;      // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
@@ -134,6 +135,7 @@ struct csr_ctx {
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
     bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
+    bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
     // debugging switches, read once from the environment at creation (never on the launch path)
     bool dbgPoison = false, dbgProbe = false, dbgFence = false, dbgLog = false;
     int dbgForceIters = 0;
@@ -244,6 +246,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE_ESTEP"))) c->fuseEstep = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
     c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
@@ -749,7 +752,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
             size_t lds = 0;
-            if constexpr (CH::NATOUT) lds = p.natOut ? sizeof(NatTiles) : 0;
+            if constexpr (CH::NATOUT || CH::NATOUT_FWD) lds = p.natOut ? sizeof(NatTiles) : 0;
             hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), lds, c->stream, p);
         }
     }
@@ -815,13 +818,15 @@ static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
 }
 
 static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
-                        bool side = false) {
+                        bool side = false, bool natOut = false) {
     if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
     p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
     defer = defer && c->deferEnabled;
+    c->fwdNat = false;
+    c->pendFwdNat = natOut;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
         Scope sc(c, "fwd_apn_sequential");
@@ -842,6 +847,12 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             c->fwdWindow = mult ? &c->warmFM : &c->warmP;
             dX = false;
             p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
+            if (natOut && c->natOutEnabled && c->natOutFwd && c->mdl.state_dim == 2) {     // xf / Pf also in the reference layout
+                CHECK(nat_array(c, CSR_ARR_XF, &p.natXs));
+                CHECK(nat_array(c, CSR_ARR_PF, &p.natPs));
+                p.natOut = 1;
+                c->fwdNat = true;
+            }
             if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             c->lastFwdWindow = c->fwdWindow;
@@ -937,7 +948,7 @@ static int settle(csr_ctx *c) {
     c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation
     if (firstFail <= ST_X && pf) {
         const bool bwdToo = pb || c->haveBwd;
-        CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false));
+        CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false, c->pendFwdNat));
         const bool nat = c->pendNatOut;
         const int es = c->pendEstep;
         if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat, es));
@@ -964,7 +975,7 @@ static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
 extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
     CHECK(need(c));
     CHECK(settle(c));
-    CHECK(forward_impl(c, flags, true, nullptr, true, false));
+    CHECK(forward_impl(c, flags, true, nullptr, true, false, true));
     if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
     return 0;
 }
@@ -980,7 +991,7 @@ extern "C" int csr_batch_backward(csr_ctx *c) {
 extern "C" int csr_batch_forward_backward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
     CHECK(need(c));
     CHECK(settle(c));
-    CHECK(forward_impl(c, flags, true, nullptr, true, true));
+    CHECK(forward_impl(c, flags, true, nullptr, true, true, true));
     CHECK(backward_impl(c, true, nullptr, true, true));
     if (sum_d || sum_nll) return read_sums(c, sum_d, sum_nll);
     return 0;       // validation stays pending until the next settle point (sums, download, synchronize, new inputs)
@@ -1161,8 +1172,10 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
         CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
-        CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
-        CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
+        if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
+            CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
+            CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
+        }
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
         CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
         if (constQ) {
