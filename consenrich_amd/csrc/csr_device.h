@@ -1212,7 +1212,10 @@ __device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::C
 }
 
 // Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
-template <class CH>
+// NAT = true: separate instantiation whose main phase writes the reference layout through LDS tiles (walk_nat*); the
+// plain one stays as lean as before (the tile walkers cost ~50-100 VGPRs and slowed the ECM sweeps by 25 % when both
+// paths lived in one kernel).
+template <class CH, bool NAT = false>
 __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
@@ -1242,10 +1245,9 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
             walk_block<CH, false>(p, c, b - q, B, act, bfirst, lo, B);
         }
         if (live) cin[b] = c;
-        if constexpr (CH::NATOUT_FWD) {
+        if constexpr (NAT && CH::NATOUT_FWD) {
             extern __shared__ __attribute__((aligned(16))) unsigned char natTileMemF[];
-            if (p.natOut) walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
-            else walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+            walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
         } else {
             walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         }
@@ -1268,11 +1270,10 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
             walk_block<CH, false>(p, c, bq, len, act, bfirst, 0, hi);
         }
         if (live) cin[b] = c;
-        if constexpr (CH::NATOUT) {
-            // dynamic LDS: only launches with natOut allocate the tiles (sizeof(NatTiles) bytes)
+        if constexpr (NAT && CH::NATOUT) {
+            // dynamic LDS (sizeof(NatTiles) bytes) of this instantiation only
             extern __shared__ __attribute__((aligned(16))) unsigned char natTileMem[];
-            if (p.natOut) walk_nat<CH>(p, c, b, bi.y, live, b == blast, bi.x, *reinterpret_cast<NatTiles *>(natTileMem));
-            else walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
+            walk_nat<CH>(p, c, b, bi.y, live, b == blast, bi.x, *reinterpret_cast<NatTiles *>(natTileMem));
         } else {
             walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         }
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(64) void k_probe(Prm p) {
 // Validation / fix-up pass: a block whose recorded carry-in differs from its neighbour's current carry-out is re-run
 // from that carry.  Iterated (ping-pong outCur/outNext) until no block re-runs: the fixed point is the sequential
 // recursion.  which = 0: read A write B; 1: read B write A.
-template <class CH>
+template <class CH, bool NAT = false>
 __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
@@ -1419,12 +1420,10 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
     // and the LDS allocation alone made this kernel's dispatch ~6x slower)
     if (live && !rerun) onxt[b] = ocur[self];
     if (!__any(rerun)) return;
-    if constexpr (CH::NATOUT) {
-        if (p.natOut) walk_nat_direct<CH>(p, c, b, bi.y, rerun, b == blast, bi.x);
-        else walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
-    } else if constexpr (CH::NATOUT_FWD) {
-        if (p.natOut) walk_nat_fwd_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
-        else walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
+    if constexpr (NAT && CH::NATOUT) {
+        walk_nat_direct<CH>(p, c, b, bi.y, rerun, b == blast, bi.x);
+    } else if constexpr (NAT && CH::NATOUT_FWD) {
+        walk_nat_fwd_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
     } else {
         walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
     }

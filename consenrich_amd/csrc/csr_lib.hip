@@ -751,9 +751,14 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                                    c->stream, p);
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
-            size_t lds = 0;
-            if constexpr (CH::NATOUT || CH::NATOUT_FWD) lds = p.natOut ? sizeof(NatTiles) : 0;
-            hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), lds, c->stream, p);
+            bool launched = false;
+            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
+                if (p.natOut) {
+                    hipLaunchKernelGGL((k_chain_spec<CH, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((k_chain_spec<CH, false>), dim3(grid), dim3(64), 0, c->stream, p);
         }
     }
     LAUNCH_CHECK(name);
@@ -764,7 +769,14 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         if (c->dbgFence) p.debugForce |= 2;
         {
             Scope sc(c, fixName);
-            hipLaunchKernelGGL(k_chain_fix<CH>, dim3(grid), dim3(64), 0, c->stream, p, which);
+            bool launched = false;
+            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
+                if (p.natOut) {
+                    hipLaunchKernelGGL((k_chain_fix<CH, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((k_chain_fix<CH, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
         }
         LAUNCH_CHECK(fixName);
         c->rs.fix_launches++;
