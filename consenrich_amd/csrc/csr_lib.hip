@@ -764,10 +764,15 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     LAUNCH_CHECK(name);
     if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
     int which = 0;
+    // Validation passes are launched in bursts once the first one has re-run blocks: a correction travels one block per
+    // pass (bit-exact state chains need hundreds of passes), and reading the counter after every pass costs a host round
+    // trip each.  A burst whose passes re-ran nothing at all is the fixed point (a pass without re-runs copies the
+    // carries unchanged, so all later ones are empty too); at most burst-1 empty passes are wasted.
+    int burst = 1;
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
         p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
         if (c->dbgFence) p.debugForce |= 2;
-        {
+        for (int rep = 0; rep < burst; ++rep) {
             Scope sc(c, fixName);
             bool launched = false;
             if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
@@ -777,10 +782,10 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                 }
             }
             if (!launched) hipLaunchKernelGGL((k_chain_fix<CH, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+            c->rs.fix_launches++;
+            which ^= 1;
         }
         LAUNCH_CHECK(fixName);
-        c->rs.fix_launches++;
-        which ^= 1;
         if (defer) return 0;
         CHECK(read_mail(c, 16));
         const unsigned int fresh = take_fresh(c, stage);
@@ -791,6 +796,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         }
         stage_reruns(c, stage) += fresh;
         if (it == 0) grow_warm(c, warmRef, fresh);
+        if (c->dbgForceIters == 0) burst = it == 0 ? 2 : std::min(32, burst * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
