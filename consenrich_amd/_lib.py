@@ -119,6 +119,13 @@ SYMBOLS = {
                                         C.c_char_p, C.c_int64]),
     "csr_batch_format_bedgraph": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
                                               C.c_int64, C.c_int64, C.c_char_p, C.c_int64]),
+    "csr_observation_total_information": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), DP,
+                                                    C.c_double, C.c_double, DP]),
+    "csr_fold_mask_and_information": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32), I64P, I64P,
+                                                C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), DP, DP, C.c_double,
+                                                C.c_double, C.POINTER(C.c_uint8), DP, DP, DP, DP]),
+    "csr_batch_make_fold": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32), I64P, I64P,
+                                      C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_float, DP, DP, DP]),
     "csr_solve_background": (C.c_int, [C.c_int32, I64P, DP, DP, C.c_double, C.c_double, C.c_int32, C.c_int32, DP, I64P,
                                        DP]),
     "csr_background_weighted_stats": (C.c_int, [C.c_int64, C.c_int64, FP, FP, DP, DP, I64P]),

@@ -226,6 +226,22 @@ class DeviceBatch:
             raise L.ConsenrichAMDError(L.last_error() or "bedGraph writer size mismatch")
         return buf.raw
 
+    def make_fold(self, src: int, dst: int, block_len: int, fold: int, block_fold, reps_count, reps, pad: float,
+                  rho: float = 0.0, masked_variance: float = 1.0e30):
+        """Delete-block calibration fold as an extra chain (uncertainty.py:1370-1419, cuncertainty.pyx:160-305): chain `dst`
+        receives chain `src`'s data and variances with the fold's deleted (replicate, block) cells masked; returns the
+        (kept, heldout, h) information tracks.  Fit all chains afterwards (ecm / driver.fit_batch)."""
+        n = self.chain_lens[src]
+        bf = np.ascontiguousarray(block_fold, np.int32)
+        rc = np.ascontiguousarray(reps_count, np.int64)
+        rb = np.ascontiguousarray(reps, np.int64)
+        kept, held, h = np.empty(n), np.empty(n), np.empty(n)
+        L.check(self._lib.csr_batch_make_fold(self._ctx, int(src), int(dst), int(block_len), int(fold),
+                                              bf.ctypes.data_as(C.POINTER(C.c_int32)), rc.ctypes.data_as(L.I64P),
+                                              rb.ctypes.data_as(L.I64P), rb.shape[1], 0, float(pad), float(rho),
+                                              float(masked_variance), L.dp(kept), L.dp(held), L.dp(h)))
+        return kept, held, h
+
     def export(self, what: int):
         L.check(self._lib.csr_batch_export(self._ctx, int(what)))
 

@@ -5,6 +5,7 @@
 #include "csr_device.h"
 #include "csr_background.h"
 #include "csr_writers.h"
+#include "csr_folds.h"
 
 #include <algorithm>
 #include <cmath>
@@ -2128,6 +2129,153 @@ extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t 
     a.n = ci.n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
     a.values = c->nat[array_id] + ci.off * per; a.stride = (int)per; a.comp = comp;
     return bedgraph_impl(c, a, nullptr, nullptr, nullptr, chrom, out, out_capacity);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
+// ---------------------------------------------------------------------------------------------------------------
+static int fold_stage(csr_ctx *c, size_t bytes, char **base) {
+    CHECK(c->wrBuf.reserve(bytes));
+    *base = (char *)c->wrBuf.ptr;
+    return 0;
+}
+
+extern "C" int csr_observation_total_information(int64_t m, int64_t n, const void *munc, int32_t munc_is_f64,
+                                                 const uint8_t *active, const double *lambda, double pad, double rho,
+                                                 double *total) {
+    DEFAULT_CTX_GUARD;
+    if (!munc || !active || !total) return fail("null argument");
+    if (m < 1 || n < 1) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oM = take(es * mn), oA = take(mn), oL = take(8 * (size_t)n), oT = take(8 * (size_t)n);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
+    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = n; a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1;
+    a.active = (const uint8_t *)(base + oA); a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL);
+    a.pad = pad; a.rho = rho; a.total = (double *)(base + oT);
+    {
+        Scope sc(c, "fold_total");
+        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_total");
+    HIPOK(hipMemcpyAsync(total, a.total, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int csr_fold_mask_and_information(int64_t m, int64_t n, int64_t block_len, int64_t fold,
+                                             const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
+                                             int64_t slots, const void *munc, int32_t munc_is_f64, const uint8_t *active,
+                                             const double *total, const double *lambda, double pad, double rho,
+                                             uint8_t *mask, double *kept, double *heldout, double *h, double *nominal) {
+    DEFAULT_CTX_GUARD;
+    if (!block_fold || !reps_count || !reps || !munc || !active || !total || !mask || !kept || !heldout || !h)
+        return fail("null argument");
+    if (m < 1 || n < 1 || block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const int64_t bc = (n + block_len - 1) / block_len;
+    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n, nv = 8 * (size_t)n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oM = take(es * mn), oA = take(mn), oK = take(mn), oL = take(nv), oT = take(nv);
+    const size_t oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc), oRB = take(8 * (size_t)bc * slots);
+    const size_t oKe = take(nv), oHe = take(nv), oH = take(nv), oNo = take(nv);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oT, total, nv, hipMemcpyHostToDevice, c->stream));
+    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, nv, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = n; a.blockLen = block_len; a.fold = fold; a.slots = slots;
+    a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1; a.active = (const uint8_t *)(base + oA);
+    a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT);
+    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
+    a.pad = pad; a.rho = rho; a.wantNominal = nominal ? 1 : 0;
+    a.mask = (uint8_t *)(base + oK); a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe);
+    a.h = (double *)(base + oH); a.nominal = (double *)(base + oNo);
+    {
+        Scope sc(c, "fold_mask");
+        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_mask");
+    HIPOK(hipMemcpyAsync(mask, a.mask, mn, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
+    if (nominal) HIPOK(hipMemcpyAsync(nominal, a.nominal, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int csr_batch_make_fold(csr_ctx *c, int32_t src, int32_t dst, int64_t block_len, int64_t fold,
+                                   const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
+                                   int64_t slots, int32_t use_lambda, double pad, double rho, float masked_variance,
+                                   double *kept, double *heldout, double *h) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    const int nc = (int)c->chains.size();
+    if (src < 0 || src >= nc || dst < 0 || dst >= nc || src == dst) return fail("bad chain index");
+    if (!block_fold || !reps_count || !reps || !kept || !heldout || !h) return fail("null argument");
+    const ChainInfo &cs = c->chains[src], &cd = c->chains[dst];
+    if (cs.n != cd.n) return fail("fold chain must have the length of its source chain");
+    if (block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
+    const int64_t n = cs.n, m = c->m, bc = (n + block_len - 1) / block_len;
+    const size_t nv = 8 * (size_t)n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oL = take(nv), oT = take(nv), oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc),
+                 oRB = take(8 * (size_t)bc * slots), oKe = take(nv), oHe = take(nv), oH = take(nv);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = c->Npad; a.blockLen = block_len; a.fold = fold; a.slots = slots;
+    a.munc = c->p.munc + cs.off; a.muncF64 = 0; a.hasActive = 0;
+    a.useLambda = use_lambda ? 1 : 0;
+    if (use_lambda) {
+        // natural float32 lambda of the source chain -> double track on the device (the natives take float64)
+        return fail("use_lambda folds need an exported lambda track: not supported in this entry point yet");
+    }
+    a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT); a.total = (double *)(base + oT);
+    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
+    a.pad = pad; a.rho = rho;
+    a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe); a.h = (double *)(base + oH);
+    a.srcData = c->p.data + cs.off;
+    a.dstData = const_cast<float *>(c->p.data) + cd.off;
+    a.dstMunc = const_cast<float *>(c->p.munc) + cd.off;
+    a.maskedVariance = masked_variance;
+    {
+        Scope sc(c, "fold_make");
+        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_mask");
+    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -305,6 +305,26 @@ int64_t csr_batch_format_bedgraph(csr_ctx *ctx, int32_t chain, int32_t array_id,
                                   const char *chrom, int64_t start0, int64_t step, int64_t end_cap, char *out,
                                   int64_t out_capacity);
 
+/* ---- natives of the delete-block uncertainty calibration (cuncertainty.pyx) -------------------
+ * csr_observation_total_information = cobservationTotalInformation (pyx:97-157); csr_fold_mask_and_information =
+ * cmakeFoldMaskAndInformation (pyx:160-305) after its argument validation.  munc is float32 (munc_is_f64 = 0) or float64,
+ * (m,n) C-order; active (m,n) uint8; lambda NULL = useLambda False; reps (block_count, slots) int64; nominal may be NULL.
+ * Same summation orders as the reference, IEEE division / sqrt: the tracks are bit-identical. */
+int csr_observation_total_information(int64_t m, int64_t n, const void *munc, int32_t munc_is_f64, const uint8_t *active,
+                                      const double *lambda, double pad, double rho, double *total);
+int csr_fold_mask_and_information(int64_t m, int64_t n, int64_t block_len, int64_t fold, const int32_t *block_fold,
+                                  const int64_t *reps_count, const int64_t *reps, int64_t slots, const void *munc,
+                                  int32_t munc_is_f64, const uint8_t *active, const double *total, const double *lambda,
+                                  double pad, double rho, uint8_t *mask, double *kept, double *heldout, double *h,
+                                  double *nominal);
+/* A fold as an extra chain of a batch (uncertainty.py:1370-1419 runs one fit per fold): chain `dst` (same length as
+ * `src`) receives src's data and src's variances with the fold's deleted cells set to masked_variance (the reference:
+ * 1e30, constants.py:387); kept / heldout / h (n doubles each, host) as above with every cell active, total computed on
+ * the fly.  Nothing but the fold spec and the three tracks crosses PCIe. */
+int csr_batch_make_fold(csr_ctx *ctx, int32_t src, int32_t dst, int64_t block_len, int64_t fold, const int32_t *block_fold,
+                        const int64_t *reps_count, const int64_t *reps, int64_t slots, int32_t use_lambda, double pad,
+                        double rho, float masked_variance, double *kept, double *heldout, double *h);
+
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */

@@ -716,3 +716,82 @@ int64_t cor_solve_background(int64_t n, const double *weight, const double *rhs_
     if (bad >= 0 && bad_value) *bad_value = badv;
     return bad;
 }
+
+
+/* ================================================================================================================
+ * delete-block calibration natives (cuncertainty.pyx)
+ * ================================================================================================================ */
+static double exchangeable_information(double sum_w, double sum_sqrt, int64_t count, double rho) { /* unc:37-57 */
+    if (count <= 0 || sum_w <= 0.0) return 0.0;
+    if (rho <= 0.0) return sum_w;
+    const double omr = 1.0 - rho;
+    const double denom = omr + rho * (double)count;
+    const double adjusted = sum_w / omr - rho * sum_sqrt * sum_sqrt / (omr * denom);
+    return adjusted > sum_w ? sum_w : adjusted;
+}
+static inline double munc_at(const void *munc, int f64, int64_t idx) {
+    return f64 ? ((const double *)munc)[idx] : (double)((const float *)munc)[idx];
+}
+
+void cor_total_information(int64_t m, int64_t n, const void *munc, int munc_f64, const uint8_t *active,
+                           const double *lambda, double pad, double rho, double *total) { /* unc:131-156 */
+    for (int64_t i = 0; i < n; ++i) {
+        double tot = 0.0, ssq = 0.0;
+        int64_t count = 0;
+        const double lam = lambda ? lambda[i] : 1.0;
+        for (int64_t j = 0; j < m; ++j) {
+            if (active[j * n + i] != 0) {
+                const double v = lam / (munc_at(munc, munc_f64, j * n + i) + pad);
+                tot += v;
+                if (rho > 0.0) { ssq += sqrt(v); ++count; }
+            }
+        }
+        total[i] = rho > 0.0 ? exchangeable_information(tot, ssq, count, rho) : tot;
+    }
+}
+
+void cor_fold_mask_information(int64_t m, int64_t n, int64_t block_len, int64_t fold, const int32_t *block_fold,
+                               const int64_t *reps_count, const int64_t *reps, int64_t slots, const void *munc,
+                               int munc_f64, const uint8_t *active, const double *total, const double *lambda, double pad,
+                               double rho, uint8_t *mask, double *kept, double *heldout, double *h, double *nominal) {
+    const int64_t block_count = (n + block_len - 1) / block_len;
+    for (int64_t k = 0; k < m * n; ++k) mask[k] = 1;
+    for (int64_t i = 0; i < n; ++i) { heldout[i] = 0.0; if (nominal) nominal[i] = 0.0; }
+    for (int64_t b = 0; b < block_count; ++b) { /* unc:253-272 */
+        if (block_fold[b] != fold) continue;
+        const int64_t start = b * block_len, end = start + block_len > n ? n : start + block_len;
+        for (int64_t hh = 0; hh < reps_count[b]; ++hh) {
+            const int64_t rep = reps[b * slots + hh];
+            for (int64_t i = start; i < end; ++i) {
+                mask[rep * n + i] = 0;
+                if (active[rep * n + i] != 0) {
+                    double v = 1.0 / (munc_at(munc, munc_f64, rep * n + i) + pad);
+                    if (lambda) v *= lambda[i];
+                    if (rho <= 0.0) heldout[i] += v;
+                    if (nominal) nominal[i] += v;
+                }
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) { /* unc:273-302 */
+        const double tot = total[i];
+        if (rho > 0.0) {
+            double kp = 0.0, ssq = 0.0;
+            int64_t count = 0;
+            const double lam = lambda ? lambda[i] : 1.0;
+            for (int64_t j = 0; j < m; ++j)
+                if (active[j * n + i] != 0 && mask[j * n + i] != 0) {
+                    const double v = lam / (munc_at(munc, munc_f64, j * n + i) + pad);
+                    kp += v;
+                    ssq += sqrt(v);
+                    ++count;
+                }
+            kp = exchangeable_information(kp, ssq, count, rho);
+            kept[i] = kp;
+            heldout[i] = tot - kp;
+        } else {
+            kept[i] = tot - heldout[i];
+        }
+        h[i] = tot > 0.0 ? heldout[i] / tot : NAN;
+    }
+}

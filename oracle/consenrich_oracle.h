@@ -116,6 +116,18 @@ int64_t cor_background_stats(int64_t m, int64_t n, const float *resid, const flo
 int64_t cor_solve_background(int64_t n, const double *weight, const double *rhs, double lam, int zero_center,
                              double lam_first, double *out, double *bad_value);
 
+/* ---- delete-block calibration natives (src/consenrich/cuncertainty.pyx, "unc") -------------- */
+/* unc:97-157 `cobservationTotalInformation`: total[i] = sum over active cells of lambda_i / (munc[j,i] + pad), with the
+ * exchangeable-correlation correction (unc:37-57) when rho > 0.  munc is float32 (munc_f64 = 0) or float64. */
+void cor_total_information(int64_t m, int64_t n, const void *munc, int munc_f64, const uint8_t *active,
+                           const double *lambda /* or NULL */, double pad, double rho, double *total);
+/* unc:160-305 `cmakeFoldMaskAndInformation` (after its argument validation): mask (m,n) uint8, kept / heldout / h (n),
+ * nominal (n) or NULL.  reps is (block_count, slots) row-major. */
+void cor_fold_mask_information(int64_t m, int64_t n, int64_t block_len, int64_t fold, const int32_t *block_fold,
+                               const int64_t *reps_count, const int64_t *reps, int64_t slots, const void *munc,
+                               int munc_f64, const uint8_t *active, const double *total, const double *lambda, double pad,
+                               double rho, uint8_t *mask, double *kept, double *heldout, double *h, double *nominal);
+
 #ifdef __cplusplus
 }
 #endif

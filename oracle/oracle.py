@@ -499,3 +499,111 @@ def csolveZeroCenteredBackground(weightTrack, rhsTrack, lam, zeroCenter=True, la
         raise RuntimeError("roughness-penalized LDL factorization required pivot "
                            f"modification at index {bad} (pivot={badv.value:.6g}, floor={1.0e-12:.6g}).")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
+# ---------------------------------------------------------------------------------------------------------------------
+_U8 = C.POINTER(C.c_uint8)
+_I32 = C.POINTER(C.c_int32)
+_I64 = C.POINTER(C.c_int64)
+
+
+def _munc_arg(matrixMunc):
+    a = np.asarray(matrixMunc)
+    if a.dtype == np.float64:
+        a = np.ascontiguousarray(a, np.float64)
+        return a, 1
+    a = np.ascontiguousarray(a, np.float32)
+    return a, 0
+
+
+def _check_rho_pad(pad, rho):
+    if not np.isfinite(pad):
+        raise ValueError("observation information pad must be finite")
+    if not np.isfinite(rho) or rho < 0.0 or rho >= 1.0:
+        raise ValueError("replicate dependence rho must be in [0, 1)")
+
+
+def cobservationTotalInformation(matrixMunc, activeMask, lambdaExp, useLambda, pad, replicateDependenceRho=0.0):
+    munc, f64 = _munc_arg(matrixMunc)
+    act = np.ascontiguousarray(activeMask, np.uint8)
+    lam = np.ascontiguousarray(lambdaExp, np.float64)
+    m, n = munc.shape
+    if act.shape != (m, n):
+        raise ValueError("activeMask must match matrixMunc shape")
+    if useLambda and lam.shape[0] != n:
+        raise ValueError("fullObservationPrecision must match interval count")
+    _check_rho_pad(pad, replicateDependenceRho)
+    total = np.zeros(n)
+    f = lib().cor_total_information
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_int, _U8, _DP, C.c_double, C.c_double, _DP]
+    f(m, n, munc.ctypes.data, f64, act.ctypes.data_as(_U8), lam.ctypes.data_as(_DP) if useLambda else None, float(pad),
+      float(replicateDependenceRho), total.ctypes.data_as(_DP))
+    return total
+
+
+def check_fold_spec(m, n, blockLen, fold, blockFold, repsByBlockCount, repsByBlock):
+    """argument validation of cuncertainty.pyx:175-231 (shared by the oracle and the product mirror's tests)"""
+    if m < 1 or n < 1 or blockLen < 1:
+        raise ValueError("invalid uncertainty calibration mask dimensions")
+    if fold < 0:
+        raise ValueError("fold must be nonnegative")
+    bc = (n + blockLen - 1) // blockLen
+    if blockFold.shape[0] != bc or repsByBlockCount.shape[0] != bc or repsByBlock.shape[0] != bc:
+        raise ValueError("fold spec has inconsistent block count")
+    slots = repsByBlock.shape[1]
+    if slots < m:
+        raise ValueError("fold spec replicate matrix must allow every sample")
+    if np.any(blockFold < 0):
+        raise ValueError("fold spec contains negative fold id")
+    if np.any(repsByBlockCount < 1) or np.any(repsByBlockCount > m) or np.any(repsByBlockCount > slots):
+        raise ValueError("fold spec deleted-replicate count is out of bounds")
+    for b in range(bc):
+        r = repsByBlock[b, : repsByBlockCount[b]]
+        if np.any(r < 0) or np.any(r >= m):
+            raise ValueError("fold spec replicate is out of bounds")
+        if len(set(r.tolist())) != len(r):
+            raise ValueError("fold spec contains a duplicate replicate")
+
+
+def cmakeFoldMaskAndInformation(m, n, blockLen, fold, blockFold, repsByBlockCount, repsByBlock, matrixMunc, activeMask,
+                                totalInfo, lambdaExp, useLambda, pad, replicateDependenceRho=0.0,
+                                returnNominalHeldout=False):
+    munc, f64 = _munc_arg(matrixMunc)
+    act = np.ascontiguousarray(activeMask, np.uint8)
+    bf = np.ascontiguousarray(blockFold, np.int32)
+    rc = np.ascontiguousarray(repsByBlockCount, np.int64)
+    rb = np.ascontiguousarray(repsByBlock, np.int64)
+    tot = np.ascontiguousarray(totalInfo, np.float64)
+    lam = np.ascontiguousarray(lambdaExp, np.float64)
+    if m < 1 or n < 1 or blockLen < 1:
+        raise ValueError("invalid uncertainty calibration mask dimensions")
+    if fold < 0:
+        raise ValueError("fold must be nonnegative")
+    if munc.shape != (m, n):
+        raise ValueError("matrixMunc shape does not match fold spec")
+    if act.shape != (m, n):
+        raise ValueError("activeMask must match matrixMunc shape")
+    if tot.shape[0] != n:
+        raise ValueError("total information must match interval count")
+    if useLambda and lam.shape[0] != n:
+        raise ValueError("fullObservationPrecision must match interval count")
+    _check_rho_pad(pad, replicateDependenceRho)
+    check_fold_spec(m, n, blockLen, fold, bf, rc, rb)
+    mask = np.ones((m, n), np.uint8)
+    kept, held, h = np.empty(n), np.zeros(n), np.empty(n)
+    nominal = np.zeros(n) if returnNominalHeldout else None
+    f = lib().cor_fold_mask_information
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, _I32, _I64, _I64, C.c_int64, C.c_void_p, C.c_int, _U8, _DP,
+                  _DP, C.c_double, C.c_double, _U8, _DP, _DP, _DP, _DP]
+    f(m, n, int(blockLen), int(fold), bf.ctypes.data_as(_I32), rc.ctypes.data_as(_I64), rb.ctypes.data_as(_I64),
+      rb.shape[1], munc.ctypes.data, f64, act.ctypes.data_as(_U8), tot.ctypes.data_as(_DP),
+      lam.ctypes.data_as(_DP) if useLambda else None, float(pad), float(replicateDependenceRho), mask.ctypes.data_as(_U8),
+      kept.ctypes.data_as(_DP), held.ctypes.data_as(_DP), h.ctypes.data_as(_DP),
+      nominal.ctypes.data_as(_DP) if nominal is not None else None)
+    if returnNominalHeldout:
+        return mask, kept, held, h, nominal
+    return mask, kept, held, h

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import bg_cases  # noqa: E402
+import unc_cases  # noqa: E402
 import cases  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from oracle import ref_loader  # noqa: E402
@@ -69,6 +70,20 @@ def main() -> int:
         raise SystemExit("oracle != reference for cbackgroundWeightedStatsWithSupport")
     np.savez_compressed(os.path.join(HERE, "bg_stats.npz"), weight=w_ref, rhs=r_ref, support=np.int64(s_ref))
     n_written += 1
+    # delete-block calibration natives (cuncertainty.pyx)
+    from consenrich import cuncertainty as ref_unc  # noqa: E402  (compiled by `make -C oracle ref`)
+
+    for case in unc_cases.cases():
+        munc, act, lam, spec = unc_cases.inputs(case)
+        ref_spec = ref_unc.cmakeFoldSpec(case["m"], case["n"], case["block_len"], case["folds"], 0.5, case["seed"] + 1)
+        if not all(np.array_equal(a, b) for a, b in zip(spec, ref_spec)):
+            raise SystemExit(f"fold spec restatement != reference for {case['name']}")
+        out_ref, out_orc = unc_cases.run(ref_unc, case), unc_cases.run(orc, case)
+        for key, val in out_ref.items():
+            if not np.array_equal(val, out_orc[key], equal_nan=True):
+                raise SystemExit(f"oracle != reference for case {case['name']} key {key}")
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out_ref)
+        n_written += 1
     print(f"{n_written} fixtures written; oracle == reference on all of them")
     return 0
 

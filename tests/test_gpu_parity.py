@@ -951,3 +951,81 @@ def _full_chain_from(mod, data, munc):
                      ECM_useProcessPrecisionReweighting=False)
     bk = mod.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
     return dict(xf=xf, Pf=Pf, pn=pn[: n - 1], xs=bk[0], Ps=bk[1], lag=bk[2][: n - 1], resid=bk[3])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# delete-block calibration natives (cuncertainty.pyx:97-157, 160-305) -- bit-identical tracks
+# ---------------------------------------------------------------------------------------------------------------
+import unc_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in unc_cases.cases()])
+def test_fold_natives_match_golden_bit_for_bit(name):
+    from consenrich_amd import cuncertainty as amd
+
+    case = {c["name"]: c for c in unc_cases.cases()}[name]
+    got = unc_cases.run(amd, case)
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert set(got) == set(gold.files)
+    for k in gold.files:
+        assert got[k].dtype == gold[k].dtype and np.array_equal(got[k], gold[k], equal_nan=True), k
+
+
+def test_fold_natives_contract_and_chromosome_size(oracle):
+    from consenrich_amd import cuncertainty as amd
+
+    case = {c["name"]: c for c in unc_cases.cases()}["unc_m4_n20"]
+    munc, act, lam, (bf, rc, rb) = unc_cases.inputs(case)
+    tot = amd.cobservationTotalInformation(munc, act, lam, False, 1e-4, 0.0)
+    with pytest.raises(ValueError, match="duplicate replicate"):
+        bad = rb.copy(); bad[0, 1] = bad[0, 0]
+        amd.cmakeFoldMaskAndInformation(4, 20, 5, 0, bf, rc, bad, munc, act, tot, lam, False, 1e-4)
+    with pytest.raises(ValueError, match="fold must be nonnegative"):
+        amd.cmakeFoldMaskAndInformation(4, 20, 5, -1, bf, rc, rb, munc, act, tot, lam, False, 1e-4)
+    with pytest.raises(ValueError, match="rho must be in"):
+        amd.cobservationTotalInformation(munc, act, lam, False, 1e-4, 1.5)
+    assert len(amd.cmakeFoldMaskAndInformation(4, 20, 5, 0, bf, rc, rb, munc, act, tot, lam, False, 1e-4)) == 4
+    # chromosome-sized, against the CPU oracle
+    big = dict(name="big", m=16, n=1244783, block_len=250, folds=2, rho=0.1, use_lam=True, f64=False, seed=5)
+    a, b = unc_cases.run(amd, big), unc_cases.run(oracle, big)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_folds_as_extra_chains_of_a_batch(product, oracle):
+    """DeviceBatch.make_fold: the folds of a chromosome become chains of the same batch (device-side masked copy); the
+    information tracks equal the natives', and fitting the fold chain equals fitting host-masked matrices."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n, m, bl, folds = 6000, 6, 40, 2
+    mp = ModelParams(state_dim=2)
+    data, munc = cases.synth(n, m, 321)
+    bf, rc, rb = unc_cases.fold_spec(m, n, bl, folds, 0.5, 17)
+    act = np.ones((m, n), np.uint8)
+    tot = oracle.cobservationTotalInformation(munc, act, np.ones(n), False, float(np.float32(mp.pad)), 0.0)
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, [n] * (1 + folds))
+        b.upload(0, data, munc)
+        for f in range(folds):
+            b.upload(1 + f, np.zeros_like(data), np.ones_like(munc))          # overwritten by make_fold
+        tracks = [b.make_fold(0, 1 + f, bl, f, bf, rc, rb, pad=float(np.float32(mp.pad))) for f in range(folds)]
+        b.stats()
+        b.forward_backward(L.RETURN_NLL)
+        b.export(L.EXPORT_SMOOTH)
+        xs = [b.download(c, "xs") for c in range(1 + folds)]
+    for f in range(folds):
+        mask, kept, held, h = oracle.cmakeFoldMaskAndInformation(m, n, bl, f, bf, rc, rb, munc, act, tot, np.ones(n), False,
+                                                                 float(np.float32(mp.pad)), 0.0)
+        for got, ref in zip(tracks[f], (kept, held, h)):
+            assert np.array_equal(got, ref, equal_nan=True)
+        masked = munc.copy()
+        masked[mask == 0] = np.float32(1.0e30)                     # core.py:2759-2780
+        with DeviceBatch(0) as b2:
+            b2.configure(mp, m, [n])
+            b2.upload(0, data, masked)
+            b2.stats()
+            b2.forward_backward(L.RETURN_NLL)
+            b2.export(L.EXPORT_SMOOTH)
+            assert np.array_equal(xs[1 + f], b2.download(0, "xs"))
+    assert not np.array_equal(xs[0], xs[1])

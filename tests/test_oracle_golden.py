@@ -20,9 +20,11 @@ def _build_oracle():
 
 def test_every_case_has_a_fixture():
     import bg_cases
+    import unc_cases
 
     have = {f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz")}
-    assert have == set(CASES) | {c["name"] for c in bg_cases.solve_cases()} | {"bg_stats"}
+    assert have == (set(CASES) | {c["name"] for c in bg_cases.solve_cases()} | {"bg_stats"}
+                    | {c["name"] for c in unc_cases.cases()})
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
