@@ -1,0 +1,646 @@
+// csr_host_pipeline.inl -- part of csr_lib.hip (one translation unit; included in this order): statistics, speculative chains with deferred validation, forward / backward / ECM, export
+// clang-format off is NOT needed; this file is plain C++/HIP host code.
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute
+// ---------------------------------------------------------------------------------------------------------------
+template <int TS, int TL>
+static void launch_stats(csr_ctx *c, const Prm &p) {
+    const int grid = (int)(c->NG * (c->B / TS) * (64 / TL));
+    hipLaunchKernelGGL((k_stats<TS, TL>), dim3(grid), dim3(256), 0, c->stream, p);
+}
+
+extern "C" int csr_batch_stats(csr_ctx *c) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    Prm p = c->p;
+    {
+        Scope sc(c, "stats");
+        int ts = c->statsTile;
+        if (ts == 0) ts = 64;
+        if (c->B % ts != 0) ts = 32;
+        if (ts == 128) launch_stats<128, 16>(c, p);
+        else if (ts == 64) launch_stats<64, 16>(c, p);
+        else launch_stats<32, 16>(c, p);
+    }
+    LAUNCH_CHECK("k_stats");
+    c->statsValid = true;
+    c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
+
+// Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
+// 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
+// step: poll first, block only if the stream is still busy after ~200 us.
+static hipError_t wait_stream(csr_ctx *c) {
+    if (c->spinWait) {
+        for (int i = 0; i < 20000; ++i) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+static int read_mail(csr_ctx *c, size_t bytes) {
+    HIPOK(hipMemcpyAsync(c->hMail, c->dMail, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    return 0;
+}
+static unsigned int take_fresh(csr_ctx *c, int stage) {
+    const unsigned int now = reinterpret_cast<const unsigned int *>(c->hMail)[stage];
+    const unsigned int fresh = now - c->lastCnt[stage];
+    c->lastCnt[stage] = now;
+    return fresh;
+}
+// adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data (longer filter
+// memory); lengthen it for the following sweeps.  Results do not depend on it.
+static void grow_warm(csr_ctx *c, int &warmRef, unsigned int fresh) {
+    if (c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
+        warmRef = std::min(8192, warmRef * 2);
+}
+static int &stage_warm(csr_ctx *c, int stage) {
+    if (stage == ST_P && c->fwdWindow) return *c->fwdWindow;        // fused forward chain with its own window
+    return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB);
+}
+static int64_t &stage_reruns(csr_ctx *c, int stage) {
+    return stage == ST_P ? c->rs.reruns_p : (stage == ST_X ? c->rs.reruns_x : c->rs.reruns_b);
+}
+
+// Speculative pass + validation/fix-up.  defer = true: launch the speculative pass and ONE validation pass and return
+// without a host round trip (the stage's monotonic counter is checked at the next settle point); otherwise iterate
+// validation passes to the fixed point here.
+template <class CH>
+static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int stage, bool defer) {
+    static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
+    int &warmRef = stage_warm(c, stage);
+    p.warm = warmRef;
+    p.xTolUlps = c->xTolUlps;
+    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + stage;
+    const int grid = (int)c->NG;
+    if (c->dbgPoison) {
+        HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
+        HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
+        HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
+    }
+    {
+        Scope sc(c, name);
+        if constexpr (CH::DMA) {
+            if (c->useDma)
+                hipLaunchKernelGGL(k_chain_spec_dma<CH>, dim3(grid), dim3(64), sizeof(unsigned) * DMA_R * CH::NW * 64,
+                                   c->stream, p);
+            else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
+        } else {
+            bool launched = false;
+            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
+                if (p.natOut) {
+                    hipLaunchKernelGGL((k_chain_spec<CH, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((k_chain_spec<CH, false>), dim3(grid), dim3(64), 0, c->stream, p);
+        }
+    }
+    LAUNCH_CHECK(name);
+    if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
+    int which = 0;
+    // Validation passes are launched in bursts once the first one has re-run blocks: a correction travels one block per
+    // pass (bit-exact state chains need hundreds of passes), and reading the counter after every pass costs a host round
+    // trip each.  A burst whose passes re-ran nothing at all is the fixed point (a pass without re-runs copies the
+    // carries unchanged, so all later ones are empty too); at most burst-1 empty passes are wasted.
+    int burst = 1;
+    for (int64_t it = 0; it <= c->NB + 1; ++it) {
+        p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
+        if (c->dbgFence) p.debugForce |= 2;
+        for (int rep = 0; rep < burst; ++rep) {
+            Scope sc(c, fixName);
+            bool launched = false;
+            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
+                if (p.natOut) {
+                    hipLaunchKernelGGL((k_chain_fix<CH, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((k_chain_fix<CH, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+            c->rs.fix_launches++;
+            which ^= 1;
+        }
+        LAUNCH_CHECK(fixName);
+        if (defer) return 0;
+        CHECK(read_mail(c, 16));
+        const unsigned int fresh = take_fresh(c, stage);
+        if (c->dbgLog) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
+        if (fresh == 0) {
+            if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) c->optimistic[stage] = true;
+            return 0;
+        }
+        stage_reruns(c, stage) += fresh;
+        if (it == 0) grow_warm(c, warmRef, fresh);
+        if (c->dbgForceIters == 0) burst = it == 0 ? 2 : std::min(32, burst * 2);
+    }
+    return fail("%s: speculative fix-up did not reach a fixed point", name);
+}
+
+static void join_side(csr_ctx *c) {
+    if (c->sidePending) {
+        hipStreamWaitEvent(c->stream, c->evJoin, 0);
+        c->sidePending = false;
+    }
+}
+
+// NIS/NLL epilogue; side = true runs it on the side stream (forked after the state chain) so that it overlaps the
+// latency-bound smoother chain.
+static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
+    hipStream_t st = c->stream;
+    if (side) {
+        join_side(c);
+        HIPOK(hipEventRecord(c->evFork, c->stream));
+        HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+        st = c->side;
+    }
+    {
+        Scope sc(c, "fwd_dstat", st);
+        hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, st, p);
+    }
+    LAUNCH_CHECK("k_fwd_dstat");
+    {
+        Scope sc(c, "chain_sums", st);
+        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, st, p, c->dChainFirst, c->dChainNb);
+    }
+    LAUNCH_CHECK("k_chain_sums");
+    if (side) {
+        HIPOK(hipEventRecord(c->evJoin, c->side));
+        c->sidePending = true;
+    }
+    return 0;
+}
+
+static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
+                        bool side = false, bool natOut = false) {
+    if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
+    Prm p = c->p;
+    p.flags = flags;
+    p.chainActive = active;
+    p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
+    defer = defer && c->deferEnabled;
+    c->fwdNat = false;
+    c->pendFwdNat = natOut;
+    const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
+    if (seq) {
+        Scope sc(c, "fwd_apn_sequential");
+        hipLaunchKernelGGL(k_fwd_apn, dim3(((int)c->chains.size() + 63) / 64), dim3(64), 0, c->stream, p, c->dChainFirst,
+                           c->dChainNb);
+        LAUNCH_CHECK("k_fwd_apn");
+    } else {
+        bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
+        // Fused chain (tolerant mode).  Its state recursion warms up on SPECULATIVE gains (the split state chain reads the
+        // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) it needs about covariance-window +
+        // state-window bins: with the plain 80-bin window 9 of 24 optimistic validations failed there (6.3 ms per ECM
+        // iteration), with 160 bins none (3.6 ms; split chains 4.3 ms).  Constant multipliers: 80 bins, zero re-runs.
+        if (c->fuseFwd && c->xTolUlps > 0) {
+            // one stage (counter of the covariance stage; the window covers the state chain's needs too)
+            const bool mult = (flags & (F_KAPPA | F_LAMBDA | F_QSCALE)) != 0;
+            if (c->warmP < c->warmX) c->warmP = c->warmX;
+            if (c->warmFM < 2 * c->warmP && !c->pinFM) c->warmFM = 2 * c->warmP;
+            c->fwdWindow = mult ? &c->warmFM : &c->warmP;
+            dX = false;
+            p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
+            if (natOut && c->natOutEnabled && c->natOutFwd && c->mdl.state_dim == 2) {     // xf / Pf also in the reference layout
+                CHECK(nat_array(c, CSR_ARR_XF, &p.natXs));
+                CHECK(nat_array(c, CSR_ARR_PF, &p.natPs));
+                p.natOut = 1;
+                c->fwdNat = true;
+            }
+            if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            c->lastFwdWindow = c->fwdWindow;
+            c->fwdWindow = nullptr;
+        } else if (c->mdl.state_dim == 2) {
+            c->lastFwdWindow = nullptr;
+            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+        } else {
+            CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+        }
+        if (wantD) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
+        if (dP || dX) {
+            c->pendFwd = true;
+            c->pendFlags = flags;
+            c->pendWantD = wantD;
+            c->pendActiveF = active;
+        }
+    }
+    c->haveFwd = true;
+    c->haveBwd = false;
+    c->fwdInternal = true;
+    c->fwdFlags = flags;
+    return 0;
+}
+
+// estep: 0 = plain smoother; 1 = ECM sweep whose kappa E-step is evaluated inside the smoother chain, moments stored;
+//        2 = same, but the smoothed moments are not stored (an inner sweep nobody reads them from)
+static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false,
+                         int estep = 0) {
+    if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
+    Prm p = c->p;
+    p.flags = c->fwdFlags;
+    p.chainActive = active;
+    p.estepKappa = estep != 0 ? 1 : 0;
+    p.storeMoments = estep == 2 ? 0 : 1;
+    c->pendEstep = estep;
+    natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
+    if (natOut) {
+        CHECK(nat_array(c, CSR_ARR_XS, &p.natXs));
+        CHECK(nat_array(c, CSR_ARR_PS, &p.natPs));
+        CHECK(nat_array(c, CSR_ARR_LAG, &p.natLag));
+        p.natOut = 1;
+    }
+    c->smoothNat = natOut;
+    c->pendNatOut = natOut;
+    // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
+    p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
+    (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
+    const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
+    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    if (dB) {
+        c->pendBwd = true;
+        c->pendActiveB = active;
+    }
+    c->haveBwd = true;
+    return 0;
+}
+
+// Settle point: every optimistically launched stage is checked (one mailbox copy, one host sync).  If a stage re-ran
+// blocks in its single validation pass, its results -- and everything computed from them -- are not yet the fixed
+// point: the pipeline is re-run synchronously from that stage and the stage goes back to synchronous validation
+// until a clean pass re-arms it.  After settle() the mailbox mirror holds the current per-chain sums.
+static int settle(csr_ctx *c) {
+    join_side(c);
+    if (!c->pendFwd && !c->pendBwd) return 0;
+    CHECK(read_mail(c, c->mailBytes));
+    const bool pf = c->pendFwd, pb = c->pendBwd;
+    const uint32_t pe = c->pendExport;
+    c->pendFwd = c->pendBwd = false;
+    c->pendExport = 0;
+    int firstFail = -1;
+    for (int stg = ST_P; stg <= ST_B; ++stg) {
+        const unsigned int fresh = take_fresh(c, stg);
+        if (fresh == 0) continue;
+        stage_reruns(c, stg) += fresh;
+        c->optimistic[stg] = false;
+        int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow : stage_warm(c, stg);
+        grow_warm(c, wstage, fresh);
+        // a failed optimistic validation costs a whole pipeline: widen that stage's window by half (up to 4x the mode's
+        // default; beyond that the data simply has long memory and synchronous validation is the right mode)
+        if (c->adaptWarm) {
+            int &w = wstage;
+            const int cap = 4 * (c->xTolUlps > 0 ? 80 : 256);
+            if (w < cap) w = std::min(cap, (w + w / 2 + 15) / 16 * 16);
+        }
+        if (firstFail < 0) firstFail = stg;
+        if (c->dbgLog) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
+    }
+    if (firstFail < 0) return 0;
+    c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation
+    if (firstFail <= ST_X && pf) {
+        const bool bwdToo = pb || c->haveBwd;
+        CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false, c->pendFwdNat));
+        const bool nat = c->pendNatOut;
+        const int es = c->pendEstep;
+        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat, es));
+    } else if (pb) {
+        CHECK(backward_impl(c, true, c->pendActiveB, false, c->pendNatOut, c->pendEstep));
+    }
+    if (pe) CHECK(export_impl(c, pe));      // arrays exported from the unvalidated results
+    CHECK(read_mail(c, c->mailBytes));
+    for (int stg = ST_P; stg <= ST_B; ++stg) (void)take_fresh(c, stg);
+    return 0;
+}
+
+static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
+    const size_t nc = c->chains.size();
+    const bool pending = c->pendFwd || c->pendBwd;
+    CHECK(settle(c));
+    if (!pending) CHECK(read_mail(c, c->mailBytes));
+    const double *hs = reinterpret_cast<const double *>(c->hMail + 16);
+    if (sum_d) memcpy(sum_d, hs, sizeof(double) * nc);
+    if (sum_nll) memcpy(sum_nll, hs + nc, sizeof(double) * nc);
+    return 0;
+}
+
+extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, false, true));
+    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
+    return 0;
+}
+
+extern "C" int csr_batch_backward(csr_ctx *c) {
+    CHECK(need(c));
+    CHECK(backward_impl(c, true, nullptr, true, true));
+    return 0;       // validated at the next settle point
+}
+
+// forward (NIS, optional NLL) + backward as one pipeline: one host synchronisation, the NIS/NLL epilogue overlapped
+// with the smoother chain.  Equivalent to csr_batch_forward followed by csr_batch_backward.
+extern "C" int csr_batch_forward_backward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, true, true));
+    CHECK(backward_impl(c, true, nullptr, true, true));
+    if (sum_d || sum_nll) return read_sums(c, sum_d, sum_nll);
+    return 0;       // validation stays pending until the next settle point (sums, download, synchronize, new inputs)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ECM (pyx:7660-8442 / 7153-7657) over all chains in lock-step; converged chains are masked out
+// ---------------------------------------------------------------------------------------------------------------
+struct EcmState {
+    double prev = 1.0e16, cur = 0.0;
+    bool haveInit = false, done = false;
+};
+
+extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
+                                    csr_ecm_out *out, double *nll_path);
+extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path) {
+    return csr_batch_ecm_masked(c, cfg, flags, nullptr, out, nll_path);
+}
+
+// chain_mask[c] == 0: chain c is left exactly as it is (results of its last fit stay resident); out[c].skipped = 2
+extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
+                                    csr_ecm_out *out, double *nll_path) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!cfg || !out) return fail("null argument");
+    if (!c->statsValid) CHECK(csr_batch_stats(c));
+    const int nc = (int)c->chains.size();
+    uint32_t fl = flags & (F_QSCALE);
+    if (cfg->use_lambda) fl |= F_LAMBDA;
+    if (cfg->use_kappa) fl |= F_KAPPA;
+    if (cfg->use_apn) fl |= F_APN;
+    c->p.nu = cfg->nu;
+    std::vector<EcmState> st(nc);
+    std::vector<unsigned char> act(nc, 0);
+    std::vector<double> nll(nc);
+    for (int i = 0; i < nc; ++i) {
+        csr_ecm_out &o = out[i];
+        memset(&o, 0, sizeof(o));
+    }
+    auto push_active = [&]() -> int {
+        HIPOK(hipMemcpyAsync(c->dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    // tiny chains: filter + smoother + NLL only (pyx:7998-8129)
+    bool anyTiny = false, anyBig = false;
+    auto masked = [&](int i) { return chain_mask != nullptr && chain_mask[i] == 0; };
+    for (int i = 0; i < nc; ++i) {
+        if (masked(i)) { out[i].skipped = 2; continue; }
+        if (c->chains[i].n <= 5) { act[i] = 1; anyTiny = true; out[i].skipped = 1; }
+        else anyBig = true;
+    }
+    if (anyTiny) {
+        CHECK(push_active());
+        CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));
+        CHECK(backward_impl(c, true, c->dActive, true));
+        CHECK(read_sums(c, nullptr, nll.data()));
+        for (int i = 0; i < nc; ++i)
+            if (act[i]) { out[i].final_nll = out[i].initial_nll = nll[i]; st[i].done = true; }
+    }
+    if (anyBig) {
+        for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5 && !masked(i)) ? 1 : 0;
+        CHECK(push_active());
+        bool fwdFresh = false;   // forward results already match the current multipliers
+        for (int64_t it = 0; it < cfg->max_iters; ++it) {
+            for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
+                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
+                fwdFresh = false;
+                // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments
+                // of bins k and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself;
+                // only the last inner sweep's moments can become the result of this iteration, the others are not
+                // even stored
+                const bool fusedE = c->fuseEstep && cfg->use_kappa && !cfg->use_lambda && c->mdl.state_dim == 2;
+                const int es = !fusedE ? 0 : (inner + 1 == cfg->inner_iters ? 1 : 2);
+                CHECK(backward_impl(c, true, c->dActive, true, false, es));
+                CHECK(settle(c));          // the next sweep (or the E-step kernels) consume validated results
+                Prm p = c->p;
+                p.flags = fl;
+                p.chainActive = c->dActive;
+                if (cfg->use_lambda) {
+                    Scope sc(c, "estep_lambda");
+                    hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                    LAUNCH_CHECK("k_estep_lambda");
+                }
+                if (cfg->use_kappa && !fusedE) {
+                    Scope sc(c, "estep_kappa");
+                    hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                    LAUNCH_CHECK("k_estep_kappa");
+                }
+            }
+            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));      // pyx:8300
+            // the multipliers do not change until the next E-step: the next sweep may reuse this forward pass,
+            // unless adaptive process noise made it depend on returnNLL-independent state only (it does not)
+            fwdFresh = (cfg->inner_iters > 0);
+            CHECK(read_sums(c, nullptr, nll.data()));
+            bool anyLeft = false, changed = false;
+            for (int i = 0; i < nc; ++i) {
+                if (!act[i]) continue;
+                EcmState &s = st[i];
+                csr_ecm_out &o = out[i];
+                o.iters_done = it + 1;
+                s.cur = nll[i];
+                if (nll_path) nll_path[(int64_t)i * cfg->max_iters + it] = s.cur;
+                const bool havePrev = s.haveInit;       // pyx:8337-8407
+                if (!havePrev) { o.initial_nll = s.cur; s.haveInit = true; }
+                else if (s.cur > s.prev + (1.0e-12 * std::fmax(std::fabs(s.prev), 1.0))) o.nll_increase_count += 1;
+                double delta, scale;
+                if (havePrev) { delta = std::fabs(s.cur - s.prev); scale = std::fabs(s.prev); }
+                else { delta = 0.0; scale = std::fabs(s.cur); }
+                if (std::fabs(s.cur) > scale) scale = std::fabs(s.cur);
+                if (scale < 1.0) scale = 1.0;
+                if (havePrev) { o.rel_improvement = (s.prev - s.cur) / scale; o.abs_rel_change = delta / scale; }
+                else { o.rel_improvement = 0.0; o.abs_rel_change = 0.0; }
+                const double tol = cfg->rtol * scale;
+                s.prev = s.cur;
+                if (havePrev && delta <= tol) o.stable_iters += 1; else o.stable_iters = 0;
+                if (o.stable_iters >= 2) { o.converged = 1; s.done = true; act[i] = 0; changed = true; }
+                else anyLeft = true;
+            }
+            if (!anyLeft) break;
+            if (changed) CHECK(push_active());
+        }
+        for (int i = 0; i < nc; ++i) {
+            if (c->chains[i].n <= 5 || masked(i)) continue;
+            out[i].has_initial_nll = st[i].haveInit ? 1 : 0;
+            out[i].final_nll = st[i].prev;
+        }
+    }
+    c->fwdFlags = fl;
+    c->haveFwd = c->haveBwd = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// export / download
+// ---------------------------------------------------------------------------------------------------------------
+
+// Exports may be queued behind an optimistically validated pipeline: they are re-issued by settle() if it fails.
+extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
+    CHECK(need(c));
+    join_side(c);
+    if (c->pendFwd || c->pendBwd) c->pendExport |= what;
+    return export_impl(c, what);
+}
+
+extern "C" int csr_batch_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
+    CHECK(need(c));
+    if (!c->haveFwd) return fail("no forward results");
+    return read_sums(c, sum_d, sum_nll);
+}
+
+static int flush_export(csr_ctx *c, ExpList &L) {
+    if (L.count == 0) return 0;
+    {
+        Scope sc(c, "export_natural");
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, c->p, L);
+    }
+    LAUNCH_CHECK("k_export_tiled");
+    L.count = 0;
+    return 0;
+}
+static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, int n, int skipLast) {
+    if (L.count == 8) CHECK(flush_export(c, L));       // one launch converts up to eight arrays
+    float *dst;
+    CHECK(nat_array(c, id, &dst));
+    ExpDesc &d = L.d[L.count++];
+    memset(&d, 0, sizeof(d));
+    d.src = src; d.dst = dst; d.E = E; d.n = n; d.skipLast = skipLast;
+    return 0;
+}
+
+static int export_impl(csr_ctx *c, uint32_t what) {
+    const int d = c->mdl.state_dim;
+    const Prm &p = c->p;
+    const int nv = d, nm = d * d;      // exported components of state vectors / covariance matrices
+    ExpList L;
+    memset(&L, 0, sizeof(L));
+    if (what & CSR_EXPORT_FORWARD) {
+        if (!c->haveFwd) return fail("no forward results to export");
+        CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
+        if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
+            CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
+            CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
+        }
+        const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
+        CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
+        if (constQ) {
+            ExpDesc &e = L.d[L.count - 1];
+            e.cval[0] = (float)p.Q00;
+            e.cval[1] = d == 2 ? (float)p.Q01 : 0.f;
+            e.cval[2] = d == 2 ? (float)p.Q10 : 0.f;
+            e.cval[3] = d == 2 ? (float)p.Q11 : 0.f;
+        }
+    }
+    if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
+        if (!c->haveBwd) return fail("no smoothed results to export");
+        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
+    }
+    if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat) {      // smoothNat: the smoother already wrote the natural arrays
+        CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
+        CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
+    }
+    if (what & CSR_EXPORT_MULT) {
+        CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
+        CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));
+        CHECK(add_export(c, L, CSR_ARR_QSCALE, p.tQs, 1, 1, 0));
+    }
+    CHECK(flush_export(c, L));
+    if (what & CSR_EXPORT_RESID) {
+        float *xs, *res;
+        CHECK(nat_array(c, CSR_ARR_XS, &xs));
+        CHECK(nat_array(c, CSR_ARR_RESID, &res));
+        Scope sc(c, "residuals");
+        if ((c->m & 3) == 0)
+            hipLaunchKernelGGL(k_resid_v4, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m, c->stream,
+                               c->p, xs, d, res, c->Npad);
+        else
+            hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
+                               c->p, xs, d, res, c->Npad);
+        LAUNCH_CHECK("k_resid");
+    }
+    return 0;
+}
+
+extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, int64_t *n_elems) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
+    float *ptr;
+    CHECK(nat_array(c, id, &ptr));
+    if (dev_ptr) *dev_ptr = ptr;
+    if (n_elems) *n_elems = arr_comps(c, id) * c->Npad;
+    return 0;
+}
+
+extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *host_dst) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
+    if (!host_dst) return fail("null host buffer");
+    if (id == CSR_ARR_BACKGROUND && !c->nat[id]) {       // no background set yet: it is identically zero
+        float *q;
+        CHECK(nat_array(c, id, &q));
+    }
+    if (!c->nat[id]) return fail("array %d was not exported", id);
+    const ChainInfo &ci = c->chains[chain];
+    const int64_t per = arr_comps(c, id);
+    int64_t rows = ci.n;
+    if (id == CSR_ARR_PNOISE || id == CSR_ARR_LAG) rows = ci.n - 1;
+    if (rows > 0)
+        HIPOK(hipMemcpyAsync(host_dst, c->nat[id] + ci.off * per, sizeof(float) * per * rows, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthetic fill (bench / scale tests)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_batch_synthesize(csr_ctx *c, uint64_t seed) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!c->dLatent) CHECK(dalloc(c, &c->dLatent, c->Npad));
+    std::vector<float> lat((size_t)c->Npad, 0.f);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (size_t ch = 0; ch < c->chains.size(); ++ch) {
+        const ChainInfo &ci = c->chains[ch];
+        double x = 0.0;
+        for (int64_t k = 0; k < ci.n; ++k) {
+            // Irwin-Hall(12) normal approximation is plenty for a synthetic random walk
+            double acc = 0.0;
+            const uint64_t a = next(), b = next();
+            for (int q = 0; q < 6; ++q) acc += (double)((a >> (q * 10)) & 1023) / 1024.0;
+            for (int q = 0; q < 6; ++q) acc += (double)((b >> (q * 10)) & 1023) / 1024.0;
+            x += 0.03 * (acc - 6.0);
+            lat[(size_t)(ci.off + k)] = (float)x;
+        }
+    }
+    HIPOK(hipMemcpy(c->dLatent, lat.data(), sizeof(float) * c->Npad, hipMemcpyHostToDevice));
+    {
+        Scope sc(c, "synthesize");
+        hipLaunchKernelGGL(k_synth, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, c->p, c->dLatent,
+                           const_cast<float *>(c->p.data), const_cast<float *>(c->p.munc), seed, c->Npad);
+    }
+    LAUNCH_CHECK("k_synth");
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+

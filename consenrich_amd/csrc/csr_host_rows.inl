@@ -1,0 +1,804 @@
+// csr_host_rows.inl -- part of csr_lib.hip (one translation unit; included in this order): host side of the SURVEY 8(f) rows: diagnostics, background update, bedGraph writer, calibration folds
+// clang-format off is NOT needed; this file is plain C++/HIP host code.
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-interval output diagnostics (core.py:7734-7878)
+// ---------------------------------------------------------------------------------------------------------------
+static int launch_diag(csr_ctx *c, uint32_t flags, bool usePnoise) {
+    DiagArgs a;
+    memset(&a, 0, sizeof(a));
+    float *q;
+    CHECK(nat_array(c, CSR_ARR_PF, &q)); a.Pf = q;
+    if (usePnoise) { CHECK(nat_array(c, CSR_ARR_PNOISE, &q)); a.pn = q; }
+    if (flags & CSR_USE_LAMBDA) { CHECK(nat_array(c, CSR_ARR_LAMBDA, &q)); a.lam = q; }
+    if (flags & CSR_USE_KAPPA) { CHECK(nat_array(c, CSR_ARR_KAPPA, &q)); a.kap = q; }
+    if (flags & CSR_USE_QSCALE) { CHECK(nat_array(c, CSR_ARR_QSCALE, &q)); a.qs = q; }
+    CHECK(nat_array(c, CSR_ARR_SUMGAIN0, &a.g0));
+    CHECK(nat_array(c, CSR_ARR_SUMGAIN1, &a.g1));
+    CHECK(nat_array(c, CSR_ARR_EFFQ_LEVEL, &a.eql));
+    CHECK(nat_array(c, CSR_ARR_EFFQ_TREND, &a.eqt));
+    CHECK(nat_array(c, CSR_ARR_MUNCTRACE, &a.trace));
+    a.chainOff = c->dChainOff;
+    a.chainLen = c->dChainLen;
+    a.nchains = (int)c->chains.size();
+    Prm p = c->p;
+    p.chainActive = nullptr;
+    {
+        Scope sc(c, "diagnostics");
+        hipLaunchKernelGGL(k_diag_natural, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, p, a);
+    }
+    LAUNCH_CHECK("k_diag_natural");
+    return 0;
+}
+
+extern "C" int csr_batch_diagnostics(csr_ctx *c, uint32_t flags) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!c->haveFwd) return fail("no forward results: run csr_batch_forward / csr_batch_ecm first");
+    const uint32_t mult = flags & (CSR_USE_LAMBDA | CSR_USE_KAPPA | CSR_USE_QSCALE);
+    CHECK(export_impl(c, CSR_EXPORT_FORWARD | (mult ? CSR_EXPORT_MULT : 0u)));
+    return launch_diag(c, flags, !(flags & CSR_USE_KAPPA));
+}
+
+extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n, const float *Pf, const float *munc,
+                                      const float *lambda, const float *kappa, const float *qscale,
+                                      const float *pnoise, float *sum_gain0, float *sum_gain1, float *effq_level,
+                                      float *effq_trend, float *munc_trace) {
+    DEFAULT_CTX_GUARD;
+    if (!mdl || !Pf || !munc || !sum_gain0 || !sum_gain1 || !effq_level || !effq_trend || !munc_trace)
+        return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(configure_single(c, mdl, m, n));
+    CHECK(settle(c));
+    const ChainInfo &ci = c->chains[0];
+    const int dd = mdl->state_dim * mdl->state_dim;
+    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.munc) + ci.off, sizeof(float) * c->Npad, munc, sizeof(float) * n,
+                           sizeof(float) * n, (size_t)m, hipMemcpyHostToDevice, c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    uint32_t flags = 0;
+    struct { const float *src; int id; int64_t comps, rows; uint32_t flag; } in[5] = {
+        {Pf, CSR_ARR_PF, dd, n, 0u}, {pnoise, CSR_ARR_PNOISE, dd, n - 1, 0u}, {lambda, CSR_ARR_LAMBDA, 1, n, CSR_USE_LAMBDA},
+        {kappa, CSR_ARR_KAPPA, 1, n, CSR_USE_KAPPA}, {qscale, CSR_ARR_QSCALE, 1, n, CSR_USE_QSCALE}};
+    for (auto &e : in) {
+        if (!e.src) continue;
+        flags |= e.flag;
+        float *dst;
+        CHECK(nat_array(c, e.id, &dst));
+        if (e.rows > 0)
+            HIPOK(hipMemcpyAsync(dst + ci.off * e.comps, e.src, sizeof(float) * e.comps * e.rows, hipMemcpyHostToDevice,
+                                 c->stream));
+    }
+    CHECK(launch_diag(c, flags, pnoise != nullptr && kappa == nullptr));
+    float *outs[5] = {sum_gain0, sum_gain1, effq_level, effq_trend, munc_trace};
+    const int ids[5] = {CSR_ARR_SUMGAIN0, CSR_ARR_SUMGAIN1, CSR_ARR_EFFQ_LEVEL, CSR_ARR_EFFQ_TREND, CSR_ARR_MUNCTRACE};
+    for (int k = 0; k < 5; ++k)
+        HIPOK(hipMemcpyAsync(outs[k], c->nat[ids[k]] + ci.off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// background update natives (pyx:944-1096, 9700-9724)
+// ---------------------------------------------------------------------------------------------------------------
+
+// blocks of Bp bins per chain; the last block absorbs a remainder shorter than 4 bins (interiors need >= 2 bins)
+static void bg_partition(const std::vector<int64_t> &off, const std::vector<int64_t> &len, int Bp, std::vector<int4> &blk,
+                         std::vector<int64_t> &first, std::vector<int64_t> &nblk) {
+    const size_t nc = off.size();
+    first.assign(nc, 0);
+    nblk.assign(nc, 0);
+    blk.clear();
+    for (size_t i = 0; i < nc; ++i) {
+        int64_t K = (len[i] + Bp - 1) / Bp;
+        if (K > 1 && len[i] - (K - 1) * Bp < 4) K -= 1;
+        first[i] = (int64_t)blk.size();
+        nblk[i] = K;
+        for (int64_t k = 0; k < K; ++k) {
+            int4 b;
+            b.x = (int)(off[i] + k * Bp);
+            b.y = (int)(k + 1 < K ? Bp : len[i] - (K - 1) * Bp);
+            b.z = (int)i;
+            b.w = k + 1 < K ? 1 : 0;
+            blk.push_back(b);
+        }
+    }
+}
+
+template <int NR>
+static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
+    {
+        Scope sc(c, "bg_local");
+        hipLaunchKernelGGL(k_bg_local<NR>, dim3((int)p.NGk), dim3(64), 0, c->stream, p);
+    }
+    {
+        Scope sc(c, "bg_sep_assemble");
+        hipLaunchKernelGGL(k_bg_sep_assemble<NR>, dim3((int)((p.NBk + 255) / 256)), dim3(256), 0, c->stream, p);
+    }
+    {
+        Scope sc(c, "bg_reduced");
+        hipLaunchKernelGGL(k_bg_reduced<NR>, dim3(p.nchains), dim3(64), 0, c->stream, p);
+    }
+    {
+        Scope sc(c, "bg_combine");
+        hipLaunchKernelGGL(k_bg_combine<NR>, dim3((int)((p.NGk * p.SB * 64 + 255) / 256)), dim3(256), 0, c->stream, p);
+    }
+    if (center) {
+        Scope sc(c, "bg_center");
+        hipLaunchKernelGGL(k_bg_center, dim3(p.nchains), dim3(1024), 0, c->stream, p);
+    }
+}
+
+extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weight, const double *rhs,
+                                    double lam, double lam_first, int32_t zero_center, int32_t block_len, double *out,
+                                    int64_t *bad_index, double *bad_value) {
+    DEFAULT_CTX_GUARD;
+    if (n_chains <= 0 || !n || !weight || !rhs || !out) return fail("null / empty argument");
+    if (!std::isfinite(lam_first) || lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
+    if (!std::isfinite(lam) || lam < 0.0) return fail("lam must be finite and nonnegative");
+    int Bp = block_len > 0 ? block_len : 1024;
+    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
+    if (Bp < 8) return fail("block_len must be at least 8");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    // partition
+    std::vector<int64_t> off(n_chains), first, nblk, len(n, n + n_chains);
+    std::vector<int4> blk;
+    int64_t N = 0;
+    for (int i = 0; i < n_chains; ++i) {
+        if (n[i] <= 0) return fail("chain %d is empty", i);
+        off[i] = N;
+        N += n[i];
+        if (N >= ((int64_t)1 << 31)) return fail("batch too large");
+    }
+    bg_partition(off, len, Bp, blk, first, nblk);
+    const int NR = zero_center ? 2 : 1;
+    BgPrm p;
+    memset(&p, 0, sizeof(p));
+    p.nchains = n_chains; p.Bp = Bp; p.SB = Bp + 4; p.NR = NR;
+    p.NBk = (int64_t)blk.size();
+    p.NGk = (p.NBk + 63) / 64;
+    p.lam = lam; p.lamF = lam_first;
+    // carve the work buffer
+    const size_t TN = (size_t)p.NGk * p.SB * 64;
+    size_t need_ = 0;
+    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
+    const size_t oOff = take(8 * n_chains), oLen = take(8 * n_chains), oFirst = take(8 * n_chains), oNum = take(8 * n_chains);
+    const size_t oBlk = take(sizeof(int4) * blk.size());
+    const size_t oW = take(8 * N), oR = take(8 * N), oO0 = take(8 * N), oO1 = take(8 * N);
+    const size_t oInvd = take(8 * TN), oL1 = take(8 * TN);
+    size_t oX[6];
+    for (int j = 0; j < NR + 4; ++j) oX[j] = take(8 * TN);
+    const size_t oT = take(8 * 16 * blk.size()), ot = take(8 * 4 * NR * blk.size());
+    const size_t oSI = take(8 * (7 + 2 * NR) * blk.size()), oSO = take(8 * (3 + 2 * NR) * blk.size());
+    const size_t oG = take(8 * 2 * NR * blk.size());
+    const size_t oBI = take(8 * blk.size()), oBV = take(8 * blk.size());
+    const size_t oCBI = take(8 * n_chains), oCBV = take(8 * n_chains), oMu = take(8 * n_chains);
+    CHECK(c->bgBuf.reserve(need_));
+    char *base = (char *)c->bgBuf.ptr;
+    p.chainOff = (const int64_t *)(base + oOff); p.chainLen = (const int64_t *)(base + oLen);
+    p.chainFirstBlk = (const int64_t *)(base + oFirst); p.chainNumBlk = (const int64_t *)(base + oNum);
+    p.blk = (const int4 *)(base + oBlk);
+    p.w = (const double *)(base + oW); p.rhs = (const double *)(base + oR);
+    p.out0 = (double *)(base + oO0); p.out1 = (double *)(base + oO1);
+    p.invd = (double *)(base + oInvd); p.l1 = (double *)(base + oL1);
+    for (int j = 0; j < NR + 4; ++j) p.X[j] = (double *)(base + oX[j]);
+    p.T = (double *)(base + oT); p.t = (double *)(base + ot);
+    p.sepIn = (double *)(base + oSI); p.sepOut = (double *)(base + oSO); p.sepG = (double *)(base + oG);
+    p.badIdx = (int64_t *)(base + oBI); p.badVal = (double *)(base + oBV);
+    p.chainBadIdx = (int64_t *)(base + oCBI); p.chainBadVal = (double *)(base + oCBV); p.chainMu = (double *)(base + oMu);
+    HIPOK(hipMemcpyAsync(base + oOff, off.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oLen, len.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oFirst, first.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oNum, nblk.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oW, weight, 8 * N, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oR, rhs, 8 * N, hipMemcpyHostToDevice, c->stream));
+    if (NR == 2) launch_bg<2>(c, p, true);
+    else launch_bg<1>(c, p, false);
+    LAUNCH_CHECK("background solve");
+    std::vector<int64_t> cbi(n_chains);
+    std::vector<double> cbv(n_chains);
+    HIPOK(hipMemcpyAsync(out, p.out0, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(cbi.data(), p.chainBadIdx, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(cbv.data(), p.chainBadVal, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_chains; ++i) {
+        if (n[i] == 1) {                                   // pyx:1001-1011
+            out[off[i]] = 0.0;
+            cbi[i] = -1;
+            if (!zero_center) {
+                if (weight[off[i]] < 1.0e-12) { cbi[i] = 0; cbv[i] = weight[off[i]]; }
+                else out[off[i]] = rhs[off[i]] / weight[off[i]];
+            }
+        }
+        if (bad_index) bad_index[i] = cbi[i];
+        if (bad_value) bad_value[i] = cbi[i] >= 0 ? cbv[i] : 0.0;
+    }
+    return 0;
+}
+
+extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var,
+                                             double *weight, double *rhs, int64_t *support) {
+    DEFAULT_CTX_GUARD;
+    if (!resid || !inv_var || !weight || !rhs || !support) return fail("null argument");
+    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const size_t mat = sizeof(float) * (size_t)m * n, vec = 8 * (size_t)n;
+    const size_t matA = (mat + 255) / 256 * 256, vecA = (vec + 255) / 256 * 256;
+    CHECK(c->bgBuf.reserve(2 * matA + 2 * vecA + 256));
+    char *base = (char *)c->bgBuf.ptr;
+    float *dr = (float *)base, *di = (float *)(base + matA);
+    double *dw = (double *)(base + 2 * matA), *dh = (double *)(base + 2 * matA + vecA);
+    unsigned long long *ds = (unsigned long long *)(base + 2 * matA + 2 * vecA);
+    HIPOK(hipMemcpyAsync(dr, resid, mat, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(di, inv_var, mat, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(ds, 0, 8, c->stream));
+    {
+        Scope sc(c, "bg_weighted_stats");
+        hipLaunchKernelGGL(k_bg_weighted_stats, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, m, n, dr, di, dw, dh, ds);
+    }
+    LAUNCH_CHECK("k_bg_weighted_stats");
+    unsigned long long sup = 0;
+    HIPOK(hipMemcpyAsync(weight, dw, vec, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(rhs, dh, vec, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(&sup, ds, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    *support = (int64_t)sup;
+    return 0;
+}
+
+// ---- device-resident background update of a batch (core.py:5064-5137, 8085-8378) ---------------------------------
+static int bg_setup(csr_ctx *c, int Bp) {
+    csr_ctx::BgState &S = c->bg;
+    if (S.ready && S.Bp == Bp) return 0;
+    if (S.ready) return fail("the background partition size cannot change after its first use in a batch");
+    const int nc = (int)c->chains.size();
+    std::vector<int64_t> off(nc), len(nc), first, nblk;
+    for (int i = 0; i < nc; ++i) { off[i] = c->chains[i].off; len[i] = c->chains[i].n; }
+    std::vector<int4> blk;
+    bg_partition(off, len, Bp, blk, first, nblk);
+    BgPrm &p = S.prm;
+    memset(&p, 0, sizeof(p));
+    p.nchains = nc; p.Bp = Bp; p.SB = Bp + 4;
+    p.NBk = (int64_t)blk.size();
+    p.NGk = (p.NBk + 63) / 64;
+    const int64_t TN = p.NGk * p.SB * 64, N = c->Npad;
+    int64_t *dFirst, *dNum;
+    int4 *dBlk;
+    CHECK(dalloc(c, &dFirst, nc)); CHECK(dalloc(c, &dNum, nc)); CHECK(dalloc(c, &dBlk, p.NBk));
+    HIPOK(hipMemcpy(dFirst, first.data(), 8 * nc, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dNum, nblk.data(), 8 * nc, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice));
+    p.chainOff = c->dChainOff; p.chainLen = c->dChainLen; p.chainFirstBlk = dFirst; p.chainNumBlk = dNum; p.blk = dBlk;
+    CHECK(dalloc(c, &p.invd, TN)); CHECK(dalloc(c, &p.l1, TN));
+    for (int j = 0; j < 6; ++j) CHECK(dalloc(c, &p.X[j], TN));
+    CHECK(dalloc(c, &p.T, 16 * p.NBk)); CHECK(dalloc(c, &p.t, 8 * p.NBk));
+    CHECK(dalloc(c, &p.sepIn, 11 * p.NBk)); CHECK(dalloc(c, &p.sepOut, 7 * p.NBk)); CHECK(dalloc(c, &p.sepG, 4 * p.NBk));
+    CHECK(dalloc(c, &p.badIdx, p.NBk)); CHECK(dalloc(c, &p.badVal, p.NBk));
+    CHECK(dalloc(c, &p.chainBadIdx, nc)); CHECK(dalloc(c, &p.chainBadVal, nc)); CHECK(dalloc(c, &p.chainMu, nc));
+    BgBatch &a = S.bat;
+    memset(&a, 0, sizeof(a));
+    std::vector<int> gc((size_t)(N / 64), -1);
+    for (int i = 0; i < nc; ++i)
+        for (int64_t g = off[i] / 64; g < (off[i] + len[i] + 63) / 64; ++g) gc[(size_t)g] = i;
+    CHECK(dalloc(c, &S.dGroupChain, N / 64));
+    HIPOK(hipMemcpy(S.dGroupChain, gc.data(), sizeof(int) * gc.size(), hipMemcpyHostToDevice));
+    a.groupChain = S.dGroupChain; a.chainOff = c->dChainOff; a.chainLen = c->dChainLen; a.nchains = nc;
+    CHECK(dalloc(c, &a.w, N)); CHECK(dalloc(c, &a.rhs, N)); CHECK(dalloc(c, &a.wAdj, N));
+    CHECK(dalloc(c, &a.sol, N)); CHECK(dalloc(c, &S.out1, N));
+    CHECK(dalloc(c, &a.selAns, 2 * nc)); CHECK(dalloc(c, &S.dSelRank, 2 * nc));
+    a.selRank = S.dSelRank;
+    CHECK(dalloc(c, &a.maskPrev, N)); CHECK(dalloc(c, &a.maskNew, N));
+    CHECK(dalloc(c, &S.dActive, nc)); CHECK(dalloc(c, &S.dHasSup, nc)); CHECK(dalloc(c, &S.dPen, nc));
+    CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 5 * nc));
+    HIPOK(hipMemsetAsync(a.sol, 0, 8 * N, c->stream));
+    HIPOK(hipMemsetAsync(S.out1, 0, 8 * N, c->stream));
+    HIPOK(hipMemsetAsync(a.wAdj, 0, 8 * N, c->stream));
+    a.active = S.dActive; a.pen = S.dPen;
+    {
+        std::vector<int> wc, wg0, wg1, cw0(nc), cwn(nc);
+        for (int i = 0; i < nc; ++i) {
+            const int64_t G0 = off[i] / 64, G1 = (off[i] + len[i] + 63) / 64;
+            cw0[i] = (int)wc.size();
+            for (int64_t g = G0; g < G1; g += BG_GPW) {
+                wc.push_back(i);
+                wg0.push_back((int)g);
+                wg1.push_back((int)std::min<int64_t>(g + BG_GPW, G1));
+            }
+            cwn[i] = (int)wc.size() - cw0[i];
+        }
+        int *dwc, *dwg0, *dwg1, *dcw0, *dcwn;
+        CHECK(dalloc(c, &dwc, (int64_t)wc.size())); CHECK(dalloc(c, &dwg0, (int64_t)wc.size()));
+        CHECK(dalloc(c, &dwg1, (int64_t)wc.size())); CHECK(dalloc(c, &dcw0, nc)); CHECK(dalloc(c, &dcwn, nc));
+        HIPOK(hipMemcpy(dwc, wc.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dwg0, wg0.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dwg1, wg1.data(), 4 * wc.size(), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dcw0, cw0.data(), 4 * nc, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(dcwn, cwn.data(), 4 * nc, hipMemcpyHostToDevice));
+        a.waveChain = dwc; a.waveG0 = dwg0; a.waveG1 = dwg1; a.chainWave0 = dcw0; a.chainWaveN = dcwn;
+        a.NW = (int)wc.size();
+        CHECK(dalloc(c, &a.part, 4 * (int64_t)wc.size()));
+    }
+    float *q;
+    CHECK(nat_array(c, CSR_ARR_BACKGROUND_NEXT, &q)); a.bgNext = q;
+    S.Bp = Bp;
+    S.ready = true;
+    return 0;
+}
+
+static int bg_solve_active(csr_ctx *c, const csr_bg_cfg *cfg) {
+    csr_ctx::BgState &S = c->bg;
+    BgPrm p = S.prm;
+    p.NR = cfg->zero_center ? 2 : 1;
+    p.lam = cfg->lam; p.lamF = cfg->lam_first;
+    p.w = S.bat.wAdj; p.rhs = S.bat.rhs;
+    p.out0 = S.bat.sol; p.out1 = S.out1;
+    p.active = S.dActive;
+    if (p.NR == 2) launch_bg<2>(c, p, true);
+    else launch_bg<1>(c, p, false);
+    LAUNCH_CHECK("background solve");
+    return 0;
+}
+
+extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, csr_bg_out *out) {
+    CHECK(need(c));
+    if (!cfg || !out) return fail("null argument");
+    CHECK(settle(c));
+    if (!c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
+    if (!std::isfinite(cfg->lam_first) || cfg->lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
+    if (!std::isfinite(cfg->lam) || cfg->lam < 0.0) return fail("lam must be finite and nonnegative");
+    int Bp = cfg->block_len > 0 ? cfg->block_len : 1024;
+    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
+    if (Bp < 8) return fail("block_len must be at least 8");
+    CHECK(bg_setup(c, Bp));
+    csr_ctx::BgState &S = c->bg;
+    BgBatch &a = S.bat;
+    const int nc = (int)c->chains.size();
+    const int gridN = (int)((c->Npad + 255) / 256);
+    // natural smoothed level (+ lambda)
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+        if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        CHECK(flush_export(c, L));
+    }
+    a.xsNat = c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
+    a.useLambda = cfg->use_lambda ? 1 : 0;
+    a.lamNat = cfg->use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr;
+    a.padf = (float)c->mdl.pad; a.wMinf = (float)c->mdl.w_min; a.wMaxf = (float)c->mdl.w_max;
+    a.bgCur = S.haveCur ? c->nat[CSR_ARR_BACKGROUND] : nullptr;
+    Prm p = c->p;
+    {
+        Scope sc(c, "bg_batch_stats");
+        hipLaunchKernelGGL(k_bg_batch_stats, dim3(gridN), dim3(256), 0, c->stream, p, a);
+    }
+    const int gridW = (a.NW + 3) / 4;
+    auto wave_pass = [&](int what, int bit, const unsigned char *hs) {
+        hipLaunchKernelGGL(k_bg_wave_pass, dim3(gridW), dim3(256), 0, c->stream, p, a, what, bit, hs);
+        hipLaunchKernelGGL(k_bg_wave_fold, dim3(nc), dim3(64), 0, c->stream, a, what, bit);
+    };
+    wave_pass(0, 0, nullptr);
+    LAUNCH_CHECK("background statistics");
+    std::vector<double> cs(5 * (size_t)nc);
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    std::vector<unsigned char> act(nc, 0), sup(nc, 0);
+    std::vector<double> pen(nc, 0.0);
+    std::vector<int> prevValid(nc, 0);
+    const double mult = cfg->negative_penalty_multiplier;
+    bool irls = cfg->use_nonnegative && std::isfinite(mult) && mult > 0.0;
+    for (int i = 0; i < nc; ++i) {
+        csr_bg_out &o = out[i];
+        memset(&o, 0, sizeof(o));
+        o.bad_index = -1;
+        o.weight_sum = cs[5 * i];
+        o.support = (int64_t)cs[5 * i + 1];
+        if (o.support <= 0) { o.status = CSR_BG_NO_SUPPORT; continue; }       // core.py:8148-8149
+        sup[i] = 1;
+        const double meanPos = o.weight_sum / (double)o.support;              // core.py:8157-8166
+        const double ratio = 1.0 + (4.0 * cfg->lam_first + 16.0 * cfg->lam) / meanPos;
+        o.roundoff_index = 2.220446049250313e-16 * ratio;
+        if (!std::isfinite(meanPos) || meanPos <= 0.0 || !std::isfinite(ratio) || ratio <= 0.0 || o.roundoff_index >= 1.0) {
+            o.status = CSR_BG_UNRELIABLE;
+            sup[i] = 0;
+            continue;
+        }
+        act[i] = 1;
+    }
+    // median of the positive weights = scale of the negative-part penalty (core.py:8287-8296)
+    if (irls) {
+        std::vector<long long> rank(2 * (size_t)nc, -1);
+        for (int i = 0; i < nc; ++i) {
+            if (!act[i]) continue;
+            rank[2 * i] = (out[i].support - 1) / 2;          // numpy.median: mean of the two middle order statistics
+            rank[2 * i + 1] = out[i].support / 2;
+        }
+        HIPOK(hipMemcpyAsync(S.dSelRank, rank.data(), 8 * 2 * nc, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipMemsetAsync(a.selAns, 0, 8 * 2 * nc, c->stream));
+        {
+            Scope sc(c, "bg_median_select");
+            for (int bit = 62; bit >= 0; --bit) wave_pass(1, bit, nullptr);
+        }
+        LAUNCH_CHECK("median select");
+        std::vector<double> mid(2 * (size_t)nc, 0.0);
+        HIPOK(hipMemcpyAsync(mid.data(), a.selAns, 8 * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i) {
+            if (!act[i]) continue;
+            double scale = 0.5 * (mid[2 * i] + mid[2 * i + 1]);
+            if (!std::isfinite(scale) || scale <= 0.0) scale = 1.0;
+            out[i].weight_scale = scale;
+            pen[i] = mult * scale;
+            if (!std::isfinite(pen[i]) || pen[i] <= 0.0) pen[i] = 0.0;          // that chain: plain solve
+        }
+    }
+    HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(S.dPen, pen.data(), 8 * nc, hipMemcpyHostToDevice, c->stream));
+    // first solve (core.py:8306-8324)
+    const bool useInit = irls && cfg->use_initial;
+    if (useInit) {
+        hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 0);
+        for (int i = 0; i < nc; ++i) prevValid[i] = 1;
+    }
+    hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, useInit ? 1 : 0);
+    CHECK(bg_solve_active(c, cfg));
+    auto harvest_bad = [&]() -> int {
+        std::vector<int64_t> bi(nc);
+        std::vector<double> bv(nc);
+        HIPOK(hipMemcpyAsync(bi.data(), S.prm.chainBadIdx, 8 * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipMemcpyAsync(bv.data(), S.prm.chainBadVal, 8 * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i)
+            if (act[i] && bi[i] >= 0 && out[i].status == CSR_BG_OK) {
+                out[i].status = CSR_BG_BAD_PIVOT;
+                out[i].bad_index = bi[i];
+                out[i].bad_value = bv[i];
+                act[i] = 0;
+            }
+        return 0;
+    };
+    const int maxPasses = cfg->max_passes > 0 ? cfg->max_passes : 5;
+    if (irls) {
+        for (int pass = 0; pass < maxPasses; ++pass) {
+            CHECK(harvest_bad());
+            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+            wave_pass(2, 0, nullptr);
+            std::vector<unsigned int> fl(nc);
+            HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(wait_stream(c));
+            bool any = false;
+            for (int i = 0; i < nc; ++i) {
+                if (!act[i]) continue;
+                if (fl[i] & 4u) { out[i].status = CSR_BG_NONFINITE; act[i] = 0; continue; }
+                if (pen[i] <= 0.0) { act[i] = 0; continue; }
+                if (prevValid[i] && !(fl[i] & 2u)) { act[i] = 0; continue; }       // same negative set: done
+                if (!(fl[i] & 1u)) { act[i] = 0; continue; }                       // nothing negative: done
+                prevValid[i] = 1;
+                out[i].passes = pass + 1;
+                any = true;
+            }
+            if (!any) break;
+            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 2);
+            hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
+            CHECK(bg_solve_active(c, cfg));
+        }
+    }
+    CHECK(harvest_bad());
+    // finite check of the final solutions of chains that never went through the mask kernel is covered by k_bg_mask
+    // in the IRLS path; the plain path checks here
+    if (!irls) {
+        std::vector<unsigned char> all(nc);
+        for (int i = 0; i < nc; ++i) all[i] = sup[i];
+        HIPOK(hipMemcpyAsync(S.dActive, all.data(), nc, hipMemcpyHostToDevice, c->stream));
+        wave_pass(2, 0, nullptr);
+        std::vector<unsigned int> fl(nc);
+        HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        for (int i = 0; i < nc; ++i)
+            if (sup[i] && (fl[i] & 4u) && out[i].status == CSR_BG_OK) out[i].status = CSR_BG_NONFINITE;
+    }
+    for (int i = 0; i < nc; ++i) sup[i] = (out[i].status == CSR_BG_OK) ? 1 : 0;
+    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
+    wave_pass(3, 0, S.dHasSup);
+    LAUNCH_CHECK("k_bg_finish");
+    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    for (int i = 0; i < nc; ++i) {
+        const double sw = out[i].weight_sum;
+        out[i].shift_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 2] / sw) : 0.0;
+        out[i].proposal_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 3] / sw) : 0.0;
+        out[i].reference_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 4] / sw) : 0.0;
+    }
+    return 0;
+}
+
+static int bg_current(csr_ctx *c, float **cur) {
+    CHECK(nat_array(c, CSR_ARR_BACKGROUND, cur));       // zero-initialised on first use
+    c->bg.haveCur = true;
+    c->p.bg = *cur;
+    return 0;
+}
+
+extern "C" int csr_batch_background_apply(csr_ctx *c, const unsigned char *take) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (!c->bg.ready) return fail("no background proposal: run csr_batch_background_update first");
+    float *cur;
+    CHECK(bg_current(c, &cur));
+    const float *nxt = c->nat[CSR_ARR_BACKGROUND_NEXT];
+    for (size_t i = 0; i < c->chains.size(); ++i) {
+        if (take && !take[i]) continue;
+        const ChainInfo &ci = c->chains[i];
+        HIPOK(hipMemcpyAsync(cur + ci.off, nxt + ci.off, sizeof(float) * ci.n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+extern "C" int csr_batch_set_background(csr_ctx *c, int32_t chain, const float *background) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    float *cur;
+    CHECK(bg_current(c, &cur));
+    const ChainInfo &ci = c->chains[chain];
+    if (background) HIPOK(hipMemcpyAsync(cur + ci.off, background, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
+    else HIPOK(hipMemsetAsync(cur + ci.off, 0, sizeof(float) * ci.n, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bedGraph writer (consenrich.py:9797-9805)
+// ---------------------------------------------------------------------------------------------------------------
+
+static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, const int64_t *hEnds, const float *hValues,
+                             const char *chrom, char *out, int64_t cap) {
+    const size_t cl = chrom ? strlen(chrom) : 0;
+    if (!chrom || cl == 0 || cl > 63) { fail("chromosome name must have 1..63 characters"); return -1; }
+    if (a.n < 0) { fail("negative row count"); return -1; }
+    if (a.n == 0) return 0;
+    memset(a.chrom, 0, sizeof(a.chrom));
+    memcpy(a.chrom, chrom, cl);
+    a.chromLen = (int)cl;
+    const int64_t n = a.n, nb = (n + 1023) / 1024;
+    const size_t maxRow = cl + 1 + 20 + 1 + 20 + 1 + 48 + 1;
+    size_t need_ = 0;
+    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
+    const size_t oLen = take(4 * (size_t)n), oOff = take(8 * (size_t)n), oBlk = take(8 * (size_t)(nb + 1));
+    const size_t oS = hStarts ? take(8 * (size_t)n) : 0, oE = hEnds ? take(8 * (size_t)n) : 0;
+    const size_t oV = hValues ? take(4 * (size_t)n) : 0;
+    // the text follows; its size is only known after pass 2, so reserve in two steps
+    if (c->wrBuf.reserve(need_) != 0) return -1;
+    char *base = (char *)c->wrBuf.ptr;
+    a.rowLen = (int *)(base + oLen); a.rowOff = (int64_t *)(base + oOff); a.blockSum = (int64_t *)(base + oBlk);
+    auto H = [&](hipError_t e) { if (e != hipSuccess) { fail("bedGraph writer: %s", hipGetErrorString(e)); return false; } return true; };
+    if (hStarts) {
+        if (!H(hipMemcpyAsync(base + oS, hStarts, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        if (!H(hipMemcpyAsync(base + oE, hEnds, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        a.starts = (const int64_t *)(base + oS); a.ends = (const int64_t *)(base + oE);
+    }
+    if (hValues) {
+        if (!H(hipMemcpyAsync(base + oV, hValues, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
+        a.values = (const float *)(base + oV); a.stride = 1; a.comp = 0;
+    }
+    {
+        Scope sc(c, "bedgraph_len_scan");
+        hipLaunchKernelGGL(k_bgw_len, dim3((int)nb), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL(k_bgw_scan_blocks, dim3(1), dim3(1024), 0, c->stream, a, nb);
+        hipLaunchKernelGGL(k_bgw_scan_rows, dim3((int)nb), dim3(1024), 0, c->stream, a);
+    }
+    int64_t total = 0;
+    if (!H(hipMemcpyAsync(&total, a.blockSum + nb, 8, hipMemcpyDeviceToHost, c->stream))) return -1;
+    if (!H(hipStreamSynchronize(c->stream))) return -1;
+    if (total < 0 || (size_t)total > maxRow * (size_t)n) { fail("bedGraph writer: inconsistent size"); return -1; }
+    if (!out) return total;
+    if (cap < total) { fail("bedGraph writer: output buffer too small (%lld < %lld)", (long long)cap, (long long)total); return -1; }
+    // text buffer: grow the work buffer if needed (the row tables are recomputed afterwards in that case)
+    const size_t oText = take((size_t)total);
+    if (need_ > c->wrBuf.cap) {
+        // a second, dedicated allocation for the text (growing wrBuf would drop the row tables just computed)
+        if (c->textBuf.reserve((size_t)total) != 0) return -1;
+        a.out = (char *)c->textBuf.ptr;
+    } else {
+        a.out = base + oText;
+    }
+    {
+        Scope sc(c, "bedgraph_write");
+        hipLaunchKernelGGL(k_bgw_write, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess) { fail("bedGraph writer launch failed"); return -1; }
+    if (!H(hipMemcpyAsync(out, a.out, (size_t)total, hipMemcpyDeviceToHost, c->stream))) return -1;
+    if (!H(hipStreamSynchronize(c->stream))) return -1;
+    return total;
+}
+
+extern "C" int64_t csr_format_bedgraph(const char *chrom, int64_t n, const int64_t *starts, const int64_t *ends,
+                                       int64_t start0, int64_t step, int64_t end_cap, const float *values,
+                                       int32_t transform, char *out, int64_t out_capacity) {
+    DEFAULT_CTX_GUARD;
+    if (n > 0 && !values) { fail("null values"); return -1; }
+    if ((starts == nullptr) != (ends == nullptr)) { fail("starts and ends must be given together"); return -1; }
+    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
+    csr_ctx *c = default_ctx();
+    if (!c || ctx_select(c) != 0) return -1;
+    BgwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
+    return bedgraph_impl(c, a, starts, ends, values, chrom, out, out_capacity);
+}
+
+extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp,
+                                             int32_t transform, const char *chrom, int64_t start0, int64_t step,
+                                             int64_t end_cap, char *out, int64_t out_capacity) {
+    if (need(c) != 0 || settle(c) != 0) return -1;
+    if (chain < 0 || chain >= (int)c->chains.size()) { fail("chain index out of range"); return -1; }
+    if (array_id < 0 || array_id >= CSR_ARR_COUNT || array_id == CSR_ARR_RESID) { fail("bad array id"); return -1; }
+    if (!c->nat[array_id]) { fail("array %d was not exported", array_id); return -1; }
+    const int64_t per = arr_comps(c, array_id);
+    if (comp < 0 || comp >= per) { fail("component out of range"); return -1; }
+    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
+    const ChainInfo &ci = c->chains[chain];
+    BgwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = ci.n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
+    a.values = c->nat[array_id] + ci.off * per; a.stride = (int)per; a.comp = comp;
+    return bedgraph_impl(c, a, nullptr, nullptr, nullptr, chrom, out, out_capacity);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
+// ---------------------------------------------------------------------------------------------------------------
+static int fold_stage(csr_ctx *c, size_t bytes, char **base) {
+    CHECK(c->wrBuf.reserve(bytes));
+    *base = (char *)c->wrBuf.ptr;
+    return 0;
+}
+
+extern "C" int csr_observation_total_information(int64_t m, int64_t n, const void *munc, int32_t munc_is_f64,
+                                                 const uint8_t *active, const double *lambda, double pad, double rho,
+                                                 double *total) {
+    DEFAULT_CTX_GUARD;
+    if (!munc || !active || !total) return fail("null argument");
+    if (m < 1 || n < 1) return fail("empty input must be handled by the caller");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oM = take(es * mn), oA = take(mn), oL = take(8 * (size_t)n), oT = take(8 * (size_t)n);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
+    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = n; a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1;
+    a.active = (const uint8_t *)(base + oA); a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL);
+    a.pad = pad; a.rho = rho; a.total = (double *)(base + oT);
+    {
+        Scope sc(c, "fold_total");
+        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_total");
+    HIPOK(hipMemcpyAsync(total, a.total, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int csr_fold_mask_and_information(int64_t m, int64_t n, int64_t block_len, int64_t fold,
+                                             const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
+                                             int64_t slots, const void *munc, int32_t munc_is_f64, const uint8_t *active,
+                                             const double *total, const double *lambda, double pad, double rho,
+                                             uint8_t *mask, double *kept, double *heldout, double *h, double *nominal) {
+    DEFAULT_CTX_GUARD;
+    if (!block_fold || !reps_count || !reps || !munc || !active || !total || !mask || !kept || !heldout || !h)
+        return fail("null argument");
+    if (m < 1 || n < 1 || block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    const int64_t bc = (n + block_len - 1) / block_len;
+    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n, nv = 8 * (size_t)n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oM = take(es * mn), oA = take(mn), oK = take(mn), oL = take(nv), oT = take(nv);
+    const size_t oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc), oRB = take(8 * (size_t)bc * slots);
+    const size_t oKe = take(nv), oHe = take(nv), oH = take(nv), oNo = take(nv);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oT, total, nv, hipMemcpyHostToDevice, c->stream));
+    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, nv, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = n; a.blockLen = block_len; a.fold = fold; a.slots = slots;
+    a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1; a.active = (const uint8_t *)(base + oA);
+    a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT);
+    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
+    a.pad = pad; a.rho = rho; a.wantNominal = nominal ? 1 : 0;
+    a.mask = (uint8_t *)(base + oK); a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe);
+    a.h = (double *)(base + oH); a.nominal = (double *)(base + oNo);
+    {
+        Scope sc(c, "fold_mask");
+        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_mask");
+    HIPOK(hipMemcpyAsync(mask, a.mask, mn, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
+    if (nominal) HIPOK(hipMemcpyAsync(nominal, a.nominal, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int csr_batch_make_fold(csr_ctx *c, int32_t src, int32_t dst, int64_t block_len, int64_t fold,
+                                   const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
+                                   int64_t slots, int32_t use_lambda, double pad, double rho, float masked_variance,
+                                   double *kept, double *heldout, double *h) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    const int nc = (int)c->chains.size();
+    if (src < 0 || src >= nc || dst < 0 || dst >= nc || src == dst) return fail("bad chain index");
+    if (!block_fold || !reps_count || !reps || !kept || !heldout || !h) return fail("null argument");
+    const ChainInfo &cs = c->chains[src], &cd = c->chains[dst];
+    if (cs.n != cd.n) return fail("fold chain must have the length of its source chain");
+    if (block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
+    const int64_t n = cs.n, m = c->m, bc = (n + block_len - 1) / block_len;
+    const size_t nv = 8 * (size_t)n;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    const size_t oL = take(nv), oT = take(nv), oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc),
+                 oRB = take(8 * (size_t)bc * slots), oKe = take(nv), oHe = take(nv), oH = take(nv);
+    char *base;
+    CHECK(fold_stage(c, need_, &base));
+    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
+    FoldArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n = n; a.stride = c->Npad; a.blockLen = block_len; a.fold = fold; a.slots = slots;
+    a.munc = c->p.munc + cs.off; a.muncF64 = 0; a.hasActive = 0;
+    a.useLambda = use_lambda ? 1 : 0;
+    if (use_lambda) {
+        // natural float32 lambda of the source chain -> double track on the device (the natives take float64)
+        return fail("use_lambda folds need an exported lambda track: not supported in this entry point yet");
+    }
+    a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT); a.total = (double *)(base + oT);
+    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
+    a.pad = pad; a.rho = rho;
+    a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe); a.h = (double *)(base + oH);
+    a.srcData = c->p.data + cs.off;
+    a.dstData = const_cast<float *>(c->p.data) + cd.off;
+    a.dstMunc = const_cast<float *>(c->p.munc) + cd.off;
+    a.maskedVariance = masked_variance;
+    {
+        Scope sc(c, "fold_make");
+        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_fold_mask");
+    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->statsValid = c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+

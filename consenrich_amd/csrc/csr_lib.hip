@@ -408,1915 +408,9 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
         if (e_ != hipSuccess) return fail("launch %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-// ---------------------------------------------------------------------------------------------------------------
-// batch configuration
-// ---------------------------------------------------------------------------------------------------------------
-static void fill_model(csr_ctx *c) {
-    Prm &p = c->p;
-    const csr_model &m = c->mdl;
-    p.d = m.state_dim;
-    p.F00 = m.F[0]; p.F01 = m.F[1]; p.F10 = m.F[2]; p.F11 = m.F[3];
-    p.Q00 = m.Q0[0]; p.Q01 = m.Q0[1]; p.Q10 = m.Q0[2]; p.Q11 = m.Q0[3];
-    if (m.state_dim == 1) { p.F00 = 1; p.F01 = 0; p.F10 = 0; p.F11 = 1; p.Q01 = p.Q10 = p.Q11 = 0; }
-    p.init = m.state_init; p.cinit = m.state_covar_init; p.pad = m.pad;
-    p.wMin = m.w_min; p.wMax = m.w_max; p.kMin = m.k_min; p.kMax = m.k_max;
-    p.apnMinQ = m.apn_min_q; p.apnMaxQ = m.apn_max_q; p.apnThresh = m.apn_thresh;
-    p.apnScale = m.apn_scale; p.apnPC = m.apn_pc;
-    p.qDiag = 0.5 * (m.Q0[0] + m.Q0[3]);
-    p.nu = 8.0;
-}
-
-extern "C" int csr_batch_set_model(csr_ctx *c, const csr_model *mdl) {
-    if (!c || !mdl) return fail("null argument");
-    if (!c->configured) return fail("batch not configured");
-    if (mdl->state_dim != c->mdl.state_dim) return fail("state_dim cannot change without reconfiguring the batch");
-    CHECK(ctx_select(c));
-    CHECK(settle(c));
-    if (mdl->pad != c->mdl.pad) c->statsValid = false;
-    c->mdl = *mdl;
-    fill_model(c);
-    c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, int32_t n_chains,
-                                   const int64_t *chain_len) {
-    if (!c || !mdl || !chain_len) return fail("null argument");
-    if (mdl->state_dim != 1 && mdl->state_dim != 2) return fail("state_dim must be 1 or 2");
-    if (m <= 0 || n_chains <= 0) return fail("m and n_chains must be positive");
-    CHECK(ctx_select(c));
-    HIPOK(hipStreamSynchronize(c->stream));
-    free_batch(c);
-    c->mdl = *mdl;
-    c->m = m;
-    c->chains.clear();
-    if (!c->Bfixed || c->B == 0) {
-        // enough blocks to occupy the chip (>= ~16k lanes) without inflating the warm-up share more than needed
-        int64_t total = 0;
-        for (int i = 0; i < n_chains; ++i) total += chain_len[i];
-        // with the 80-bin windows of the tolerant mode 128-bin blocks give ~1.7 waves/SIMD at genome scale, which hides
-        // the chains' load latency better than the smaller warm-up share of 256-bin blocks pays (0.36 -> 0.24 ms)
-        // below 2 M bins the chains are purely latency-bound (< 1 wave per SIMD): 32-bin blocks shorten every lane's walk
-        // (80 + 32 instead of 80 + 64 steps; 0.436 -> 0.414 ms on a 1/8-genome shard).  Bit-exact mode keeps 64: its
-        // state chain repairs one block per validation pass, shorter blocks mean more passes.
-        c->B = total >= (int64_t)24000000 ? 256 : (total >= (int64_t)2000000 ? 128 : (c->xTolUlps > 0 ? 32 : 64));
-    }
-    const int B = c->B;
-    int64_t off = 0, nb = 0;
-    for (int i = 0; i < n_chains; ++i) {
-        if (chain_len[i] <= 0) return fail("chain %d has non-positive length", i);
-        ChainInfo ci;
-        ci.n = chain_len[i];
-        ci.off = off;
-        ci.b0 = nb;
-        ci.nb = (ci.n + B - 1) / B;
-        c->chains.push_back(ci);
-        off += (ci.n + 63) / 64 * 64;
-        nb += ci.nb;
-    }
-    if (off >= (int64_t)1 << 31) return fail("batch too large: %lld bins (limit 2^31)", (long long)off);
-    c->Npad = off;
-    c->NB = nb;
-    c->NG = (nb + 63) / 64;
-    c->TN = c->NG * (int64_t)B * 64;
-
-    Prm &p = c->p;
-    memset(&p, 0, sizeof(p));
-    fill_model(c);
-    p.B = B; p.m = (int)m; p.nchains = n_chains; p.NB = c->NB; p.NG = c->NG; p.Npad = c->Npad;
-
-    // block table
-    std::vector<int4> blk((size_t)nb);
-    std::vector<int> bch((size_t)nb);
-    std::vector<int64_t> cf(n_chains), cn(n_chains);
-    for (int i = 0; i < n_chains; ++i) {
-        const ChainInfo &ci = c->chains[i];
-        cf[i] = ci.b0; cn[i] = ci.nb;
-        for (int64_t k = 0; k < ci.nb; ++k) {
-            int4 e;
-            e.x = (int)(ci.off + k * B);
-            e.y = (int)std::min<int64_t>(B, ci.n - k * B);
-            e.z = (int)ci.b0;
-            e.w = (int)(ci.b0 + ci.nb - 1);
-            blk[(size_t)(ci.b0 + k)] = e;
-            bch[(size_t)(ci.b0 + k)] = i;
-        }
-    }
-    int4 *dblk; int *dbch;
-    CHECK(dalloc(c, &dblk, nb));
-    CHECK(dalloc(c, &dbch, nb));
-    CHECK(dalloc(c, &c->dChainFirst, n_chains));
-    CHECK(dalloc(c, &c->dChainNb, n_chains));
-    CHECK(dalloc(c, &c->dActive, n_chains));
-    HIPOK(hipMemcpy(dblk, blk.data(), sizeof(int4) * nb, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(dbch, bch.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(c->dChainFirst, cf.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(c->dChainNb, cn.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
-    {
-        std::vector<int64_t> co(n_chains), cl(n_chains);
-        for (int i = 0; i < n_chains; ++i) { co[i] = c->chains[i].off; cl[i] = c->chains[i].n; }
-        CHECK(dalloc(c, &c->dChainOff, n_chains));
-        CHECK(dalloc(c, &c->dChainLen, n_chains));
-        HIPOK(hipMemcpy(c->dChainOff, co.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(c->dChainLen, cl.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice));
-    }
-    HIPOK(hipMemset(c->dActive, 1, n_chains));
-    p.blk = dblk; p.blkChain = dbch; p.chainActive = nullptr; p.bg = nullptr;
-
-    float *dd, *dm;
-    CHECK(dalloc(c, &dd, m * c->Npad));
-    CHECK(dalloc(c, &dm, m * c->Npad));
-    HIPOK(hipMemsetAsync(dd, 0, sizeof(float) * m * c->Npad, c->stream));
-    HIPOK(hipMemsetAsync(dm, 0, sizeof(float) * m * c->Npad, c->stream));
-    p.data = dd; p.munc = dm;
-
-    const int64_t T = c->TN;
-    CHECK(dalloc(c, &p.tS0u, T)); CHECK(dalloc(c, &p.tZbar, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
-    CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
-    CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
-    CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T)); CHECK(dalloc(c, &p.tPP, T));
-    CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
-    if (mdl->state_dim == 1) { CHECK(dalloc(c, &p.tXd, T)); }
-    // multipliers default to 1 (the reference's cold start, pyx:7901/7914) until csr_batch_upload_multipliers
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tLam, 0x3f800000, (size_t)T, c->stream));
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tKap, 0x3f800000, (size_t)T, c->stream));
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tQs, 0x3f800000, (size_t)T, c->stream));
-    // defined contents for slots no kernel writes (pNoise/lag tails, padding)
-    HIPOK(hipMemsetAsync(p.tQ, 0, sizeof(float4) * T, c->stream));
-    HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));
-    HIPOK(hipMemsetAsync(p.tD, 0, sizeof(float) * T, c->stream));
-    CHECK(dalloc(c, &p.blkSumD, nb)); CHECK(dalloc(c, &p.blkSumNLL, nb));
-    c->mailBytes = 16 + sizeof(double) * 2 * (size_t)n_chains;
-    CHECK(dalloc(c, &c->dMail, (int64_t)c->mailBytes));
-    HIPOK(hipMemsetAsync(c->dMail, 0, c->mailBytes, c->stream));
-    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail);
-    p.chainSumD = reinterpret_cast<double *>(c->dMail + 16);
-    p.chainSumNLL = p.chainSumD + n_chains;
-    for (unsigned int &v : c->lastCnt) v = 0;
-    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
-        if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
-    if (c->hMail) hipHostFree(c->hMail);
-    c->hMail = nullptr;
-    HIPOK(hipHostMalloc((void **)&c->hMail, c->mailBytes));
-    memset(c->hMail, 0, c->mailBytes);
-    char *ci_, *coa, *cob;
-    CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
-    p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;
-    c->configured = true;
-    c->rs = csr_run_stats{};
-    return 0;
-}
-
-static int need(csr_ctx *c) {
-    if (!c) return fail("null context");
-    if (!c->configured) return fail("batch not configured");
-    return ctx_select(c);
-}
-
-extern "C" int64_t csr_batch_chain_offset(csr_ctx *c, int32_t chain) {
-    if (!c || !c->configured || chain < 0 || chain >= (int)c->chains.size()) return -1;
-    return c->chains[chain].off;
-}
-
-extern "C" int csr_batch_upload(csr_ctx *c, int32_t chain, const float *data, const float *munc) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
-    if (!data || !munc) return fail("null host buffer");
-    const ChainInfo &ci = c->chains[chain];
-    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.data) + ci.off, sizeof(float) * c->Npad, data, sizeof(float) * ci.n,
-                           sizeof(float) * ci.n, (size_t)c->m, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.munc) + ci.off, sizeof(float) * c->Npad, munc, sizeof(float) * ci.n,
-                           sizeof(float) * ci.n, (size_t)c->m, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-static int grid_slots(csr_ctx *c) { return (int)((c->TN + 255) / 256); }
-
-static int64_t arr_comps(csr_ctx *c, int id);
-// natural device scratch for per-bin float arrays (import/export); lazily allocated
-static int nat_array(csr_ctx *c, int id, float **out) {
-    if (!c->nat[id]) {
-        const int64_t per = arr_comps(c, id);
-        CHECK(dalloc(c, &c->nat[id], per * c->Npad));
-        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * c->Npad, c->stream));
-    }
-    *out = c->nat[id];
-    return 0;
-}
-static int64_t arr_comps(csr_ctx *c, int id);
-static int64_t arr_comps_impl(csr_ctx *c, int id) {
-    const int d = c->mdl.state_dim;
-    switch (id) {
-        case CSR_ARR_D: case CSR_ARR_LAMBDA: case CSR_ARR_KAPPA: case CSR_ARR_QSCALE: case CSR_ARR_SUMGAIN0:
-        case CSR_ARR_SUMGAIN1: case CSR_ARR_EFFQ_LEVEL: case CSR_ARR_EFFQ_TREND: case CSR_ARR_MUNCTRACE:
-        case CSR_ARR_BACKGROUND: case CSR_ARR_BACKGROUND_NEXT: return 1;
-        case CSR_ARR_XF: case CSR_ARR_XS: return d;
-        case CSR_ARR_RESID: return c->m;
-        default: return d * d;
-    }
-}
-
-static int64_t arr_comps(csr_ctx *c, int id) { return arr_comps_impl(c, id); }
-
-static int import_vec(csr_ctx *c, int chain, const float *host, float *blocked) {
-    // stage through the natural scratch of CSR_ARR_D (1 comp) then scatter into the blocked array
-    float *scr;
-    CHECK(nat_array(c, CSR_ARR_D, &scr));
-    const ChainInfo &ci = c->chains[chain];
-    HIPOK(hipMemcpyAsync(scr + ci.off, host, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
-    return 0;
-}
-
-extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const float *lambda, const float *kappa,
-                                            const float *qscale) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
-    const float *src[3] = {lambda, kappa, qscale};
-    float *dst[3] = {c->p.tLam, c->p.tKap, c->p.tQs};
-    float *scr;
-    CHECK(nat_array(c, CSR_ARR_D, &scr));
-    // restrict the scatter to this chain so other chains' multipliers stay untouched
-    std::vector<unsigned char> act(c->chains.size(), 0);
-    act[chain] = 1;
-    HIPOK(hipMemcpyAsync(c->dActive, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < 3; ++k) {
-        if (!src[k]) continue;
-        CHECK(import_vec(c, chain, src[k], dst[k]));
-        Prm p = c->p;
-        p.chainActive = c->dActive;
-        {
-            Scope sc(c, "import_f32");
-            // k_import_f32 ignores chainActive; use the export-style guard by launching the guarded variant below
-            hipLaunchKernelGGL(k_import_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, scr, 1, 0, dst[k], 1, 0);
-        }
-        LAUNCH_CHECK("k_import_f32");
-        HIPOK(hipStreamSynchronize(c->stream));
-    }
-    c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// compute
-// ---------------------------------------------------------------------------------------------------------------
-template <int TS, int TL>
-static void launch_stats(csr_ctx *c, const Prm &p) {
-    const int grid = (int)(c->NG * (c->B / TS) * (64 / TL));
-    hipLaunchKernelGGL((k_stats<TS, TL>), dim3(grid), dim3(256), 0, c->stream, p);
-}
-
-extern "C" int csr_batch_stats(csr_ctx *c) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    Prm p = c->p;
-    {
-        Scope sc(c, "stats");
-        int ts = c->statsTile;
-        if (ts == 0) ts = 64;
-        if (c->B % ts != 0) ts = 32;
-        if (ts == 128) launch_stats<128, 16>(c, p);
-        else if (ts == 64) launch_stats<64, 16>(c, p);
-        else launch_stats<32, 16>(c, p);
-    }
-    LAUNCH_CHECK("k_stats");
-    c->statsValid = true;
-    c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
-
-// Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
-// 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
-// step: poll first, block only if the stream is still busy after ~200 us.
-static hipError_t wait_stream(csr_ctx *c) {
-    if (c->spinWait) {
-        for (int i = 0; i < 20000; ++i) {
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) return hipSuccess;
-            if (q != hipErrorNotReady) return q;
-        }
-    }
-    return hipStreamSynchronize(c->stream);
-}
-static int read_mail(csr_ctx *c, size_t bytes) {
-    HIPOK(hipMemcpyAsync(c->hMail, c->dMail, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(wait_stream(c));
-    return 0;
-}
-static unsigned int take_fresh(csr_ctx *c, int stage) {
-    const unsigned int now = reinterpret_cast<const unsigned int *>(c->hMail)[stage];
-    const unsigned int fresh = now - c->lastCnt[stage];
-    c->lastCnt[stage] = now;
-    return fresh;
-}
-// adaptive warm-up: many first-pass mismatches mean the speculation window is too short for this data (longer filter
-// memory); lengthen it for the following sweeps.  Results do not depend on it.
-static void grow_warm(csr_ctx *c, int &warmRef, unsigned int fresh) {
-    if (c->adaptWarm && (int64_t)fresh > std::max<int64_t>(4, c->NB / 256) && warmRef < 8192)
-        warmRef = std::min(8192, warmRef * 2);
-}
-static int &stage_warm(csr_ctx *c, int stage) {
-    if (stage == ST_P && c->fwdWindow) return *c->fwdWindow;        // fused forward chain with its own window
-    return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB);
-}
-static int64_t &stage_reruns(csr_ctx *c, int stage) {
-    return stage == ST_P ? c->rs.reruns_p : (stage == ST_X ? c->rs.reruns_x : c->rs.reruns_b);
-}
-
-// Speculative pass + validation/fix-up.  defer = true: launch the speculative pass and ONE validation pass and return
-// without a host round trip (the stage's monotonic counter is checked at the next settle point); otherwise iterate
-// validation passes to the fixed point here.
-template <class CH>
-static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, int stage, bool defer) {
-    static_assert(sizeof(typename CH::Carry) <= 32, "carry buffers are sized for 32 bytes per block");
-    int &warmRef = stage_warm(c, stage);
-    p.warm = warmRef;
-    p.xTolUlps = c->xTolUlps;
-    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + stage;
-    const int grid = (int)c->NG;
-    if (c->dbgPoison) {
-        HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
-        HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
-        HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
-    }
-    {
-        Scope sc(c, name);
-        if constexpr (CH::DMA) {
-            if (c->useDma)
-                hipLaunchKernelGGL(k_chain_spec_dma<CH>, dim3(grid), dim3(64), sizeof(unsigned) * DMA_R * CH::NW * 64,
-                                   c->stream, p);
-            else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
-        } else {
-            bool launched = false;
-            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
-                if (p.natOut) {
-                    hipLaunchKernelGGL((k_chain_spec<CH, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
-                    launched = true;
-                }
-            }
-            if (!launched) hipLaunchKernelGGL((k_chain_spec<CH, false>), dim3(grid), dim3(64), 0, c->stream, p);
-        }
-    }
-    LAUNCH_CHECK(name);
-    if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
-    int which = 0;
-    // Validation passes are launched in bursts once the first one has re-run blocks: a correction travels one block per
-    // pass (bit-exact state chains need hundreds of passes), and reading the counter after every pass costs a host round
-    // trip each.  A burst whose passes re-ran nothing at all is the fixed point (a pass without re-runs copies the
-    // carries unchanged, so all later ones are empty too); at most burst-1 empty passes are wasted.
-    int burst = 1;
-    for (int64_t it = 0; it <= c->NB + 1; ++it) {
-        p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
-        if (c->dbgFence) p.debugForce |= 2;
-        for (int rep = 0; rep < burst; ++rep) {
-            Scope sc(c, fixName);
-            bool launched = false;
-            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
-                if (p.natOut) {
-                    hipLaunchKernelGGL((k_chain_fix<CH, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
-                    launched = true;
-                }
-            }
-            if (!launched) hipLaunchKernelGGL((k_chain_fix<CH, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
-            c->rs.fix_launches++;
-            which ^= 1;
-        }
-        LAUNCH_CHECK(fixName);
-        if (defer) return 0;
-        CHECK(read_mail(c, 16));
-        const unsigned int fresh = take_fresh(c, stage);
-        if (c->dbgLog) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
-        if (fresh == 0) {
-            if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) c->optimistic[stage] = true;
-            return 0;
-        }
-        stage_reruns(c, stage) += fresh;
-        if (it == 0) grow_warm(c, warmRef, fresh);
-        if (c->dbgForceIters == 0) burst = it == 0 ? 2 : std::min(32, burst * 2);
-    }
-    return fail("%s: speculative fix-up did not reach a fixed point", name);
-}
-
-static void join_side(csr_ctx *c) {
-    if (c->sidePending) {
-        hipStreamWaitEvent(c->stream, c->evJoin, 0);
-        c->sidePending = false;
-    }
-}
-
-// NIS/NLL epilogue; side = true runs it on the side stream (forked after the state chain) so that it overlaps the
-// latency-bound smoother chain.
-static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
-    hipStream_t st = c->stream;
-    if (side) {
-        join_side(c);
-        HIPOK(hipEventRecord(c->evFork, c->stream));
-        HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
-        st = c->side;
-    }
-    {
-        Scope sc(c, "fwd_dstat", st);
-        hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, st, p);
-    }
-    LAUNCH_CHECK("k_fwd_dstat");
-    {
-        Scope sc(c, "chain_sums", st);
-        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, st, p, c->dChainFirst, c->dChainNb);
-    }
-    LAUNCH_CHECK("k_chain_sums");
-    if (side) {
-        HIPOK(hipEventRecord(c->evJoin, c->side));
-        c->sidePending = true;
-    }
-    return 0;
-}
-
-static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
-                        bool side = false, bool natOut = false) {
-    if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
-    Prm p = c->p;
-    p.flags = flags;
-    p.chainActive = active;
-    p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
-    defer = defer && c->deferEnabled;
-    c->fwdNat = false;
-    c->pendFwdNat = natOut;
-    const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
-    if (seq) {
-        Scope sc(c, "fwd_apn_sequential");
-        hipLaunchKernelGGL(k_fwd_apn, dim3(((int)c->chains.size() + 63) / 64), dim3(64), 0, c->stream, p, c->dChainFirst,
-                           c->dChainNb);
-        LAUNCH_CHECK("k_fwd_apn");
-    } else {
-        bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
-        // Fused chain (tolerant mode).  Its state recursion warms up on SPECULATIVE gains (the split state chain reads the
-        // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) it needs about covariance-window +
-        // state-window bins: with the plain 80-bin window 9 of 24 optimistic validations failed there (6.3 ms per ECM
-        // iteration), with 160 bins none (3.6 ms; split chains 4.3 ms).  Constant multipliers: 80 bins, zero re-runs.
-        if (c->fuseFwd && c->xTolUlps > 0) {
-            // one stage (counter of the covariance stage; the window covers the state chain's needs too)
-            const bool mult = (flags & (F_KAPPA | F_LAMBDA | F_QSCALE)) != 0;
-            if (c->warmP < c->warmX) c->warmP = c->warmX;
-            if (c->warmFM < 2 * c->warmP && !c->pinFM) c->warmFM = 2 * c->warmP;
-            c->fwdWindow = mult ? &c->warmFM : &c->warmP;
-            dX = false;
-            p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
-            if (natOut && c->natOutEnabled && c->natOutFwd && c->mdl.state_dim == 2) {     // xf / Pf also in the reference layout
-                CHECK(nat_array(c, CSR_ARR_XF, &p.natXs));
-                CHECK(nat_array(c, CSR_ARR_PF, &p.natPs));
-                p.natOut = 1;
-                c->fwdNat = true;
-            }
-            if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
-            else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
-            c->lastFwdWindow = c->fwdWindow;
-            c->fwdWindow = nullptr;
-        } else if (c->mdl.state_dim == 2) {
-            c->lastFwdWindow = nullptr;
-            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
-            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
-        } else {
-            CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
-            CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
-        }
-        if (wantD) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
-        if (dP || dX) {
-            c->pendFwd = true;
-            c->pendFlags = flags;
-            c->pendWantD = wantD;
-            c->pendActiveF = active;
-        }
-    }
-    c->haveFwd = true;
-    c->haveBwd = false;
-    c->fwdInternal = true;
-    c->fwdFlags = flags;
-    return 0;
-}
-
-// estep: 0 = plain smoother; 1 = ECM sweep whose kappa E-step is evaluated inside the smoother chain, moments stored;
-//        2 = same, but the smoothed moments are not stored (an inner sweep nobody reads them from)
-static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false,
-                         int estep = 0) {
-    if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
-    Prm p = c->p;
-    p.flags = c->fwdFlags;
-    p.chainActive = active;
-    p.estepKappa = estep != 0 ? 1 : 0;
-    p.storeMoments = estep == 2 ? 0 : 1;
-    c->pendEstep = estep;
-    natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
-    if (natOut) {
-        CHECK(nat_array(c, CSR_ARR_XS, &p.natXs));
-        CHECK(nat_array(c, CSR_ARR_PS, &p.natPs));
-        CHECK(nat_array(c, CSR_ARR_LAG, &p.natLag));
-        p.natOut = 1;
-    }
-    c->smoothNat = natOut;
-    c->pendNatOut = natOut;
-    // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
-    p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
-    (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
-    const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
-    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
-    else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
-    if (dB) {
-        c->pendBwd = true;
-        c->pendActiveB = active;
-    }
-    c->haveBwd = true;
-    return 0;
-}
-
-// Settle point: every optimistically launched stage is checked (one mailbox copy, one host sync).  If a stage re-ran
-// blocks in its single validation pass, its results -- and everything computed from them -- are not yet the fixed
-// point: the pipeline is re-run synchronously from that stage and the stage goes back to synchronous validation
-// until a clean pass re-arms it.  After settle() the mailbox mirror holds the current per-chain sums.
-static int settle(csr_ctx *c) {
-    join_side(c);
-    if (!c->pendFwd && !c->pendBwd) return 0;
-    CHECK(read_mail(c, c->mailBytes));
-    const bool pf = c->pendFwd, pb = c->pendBwd;
-    const uint32_t pe = c->pendExport;
-    c->pendFwd = c->pendBwd = false;
-    c->pendExport = 0;
-    int firstFail = -1;
-    for (int stg = ST_P; stg <= ST_B; ++stg) {
-        const unsigned int fresh = take_fresh(c, stg);
-        if (fresh == 0) continue;
-        stage_reruns(c, stg) += fresh;
-        c->optimistic[stg] = false;
-        int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow : stage_warm(c, stg);
-        grow_warm(c, wstage, fresh);
-        // a failed optimistic validation costs a whole pipeline: widen that stage's window by half (up to 4x the mode's
-        // default; beyond that the data simply has long memory and synchronous validation is the right mode)
-        if (c->adaptWarm) {
-            int &w = wstage;
-            const int cap = 4 * (c->xTolUlps > 0 ? 80 : 256);
-            if (w < cap) w = std::min(cap, (w + w / 2 + 15) / 16 * 16);
-        }
-        if (firstFail < 0) firstFail = stg;
-        if (c->dbgLog) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
-    }
-    if (firstFail < 0) return 0;
-    c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation
-    if (firstFail <= ST_X && pf) {
-        const bool bwdToo = pb || c->haveBwd;
-        CHECK(forward_impl(c, c->pendFlags, c->pendWantD, c->pendActiveF, false, false, c->pendFwdNat));
-        const bool nat = c->pendNatOut;
-        const int es = c->pendEstep;
-        if (bwdToo) CHECK(backward_impl(c, true, pb ? c->pendActiveB : c->pendActiveF, false, nat, es));
-    } else if (pb) {
-        CHECK(backward_impl(c, true, c->pendActiveB, false, c->pendNatOut, c->pendEstep));
-    }
-    if (pe) CHECK(export_impl(c, pe));      // arrays exported from the unvalidated results
-    CHECK(read_mail(c, c->mailBytes));
-    for (int stg = ST_P; stg <= ST_B; ++stg) (void)take_fresh(c, stg);
-    return 0;
-}
-
-static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
-    const size_t nc = c->chains.size();
-    const bool pending = c->pendFwd || c->pendBwd;
-    CHECK(settle(c));
-    if (!pending) CHECK(read_mail(c, c->mailBytes));
-    const double *hs = reinterpret_cast<const double *>(c->hMail + 16);
-    if (sum_d) memcpy(sum_d, hs, sizeof(double) * nc);
-    if (sum_nll) memcpy(sum_nll, hs + nc, sizeof(double) * nc);
-    return 0;
-}
-
-extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    CHECK(forward_impl(c, flags, true, nullptr, true, false, true));
-    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
-    return 0;
-}
-
-extern "C" int csr_batch_backward(csr_ctx *c) {
-    CHECK(need(c));
-    CHECK(backward_impl(c, true, nullptr, true, true));
-    return 0;       // validated at the next settle point
-}
-
-// forward (NIS, optional NLL) + backward as one pipeline: one host synchronisation, the NIS/NLL epilogue overlapped
-// with the smoother chain.  Equivalent to csr_batch_forward followed by csr_batch_backward.
-extern "C" int csr_batch_forward_backward(csr_ctx *c, uint32_t flags, double *sum_d, double *sum_nll) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    CHECK(forward_impl(c, flags, true, nullptr, true, true, true));
-    CHECK(backward_impl(c, true, nullptr, true, true));
-    if (sum_d || sum_nll) return read_sums(c, sum_d, sum_nll);
-    return 0;       // validation stays pending until the next settle point (sums, download, synchronize, new inputs)
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// ECM (pyx:7660-8442 / 7153-7657) over all chains in lock-step; converged chains are masked out
-// ---------------------------------------------------------------------------------------------------------------
-struct EcmState {
-    double prev = 1.0e16, cur = 0.0;
-    bool haveInit = false, done = false;
-};
-
-extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
-                                    csr_ecm_out *out, double *nll_path);
-extern "C" int csr_batch_ecm(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, csr_ecm_out *out, double *nll_path) {
-    return csr_batch_ecm_masked(c, cfg, flags, nullptr, out, nll_path);
-}
-
-// chain_mask[c] == 0: chain c is left exactly as it is (results of its last fit stay resident); out[c].skipped = 2
-extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t flags, const unsigned char *chain_mask,
-                                    csr_ecm_out *out, double *nll_path) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (!cfg || !out) return fail("null argument");
-    if (!c->statsValid) CHECK(csr_batch_stats(c));
-    const int nc = (int)c->chains.size();
-    uint32_t fl = flags & (F_QSCALE);
-    if (cfg->use_lambda) fl |= F_LAMBDA;
-    if (cfg->use_kappa) fl |= F_KAPPA;
-    if (cfg->use_apn) fl |= F_APN;
-    c->p.nu = cfg->nu;
-    std::vector<EcmState> st(nc);
-    std::vector<unsigned char> act(nc, 0);
-    std::vector<double> nll(nc);
-    for (int i = 0; i < nc; ++i) {
-        csr_ecm_out &o = out[i];
-        memset(&o, 0, sizeof(o));
-    }
-    auto push_active = [&]() -> int {
-        HIPOK(hipMemcpyAsync(c->dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
-        HIPOK(hipStreamSynchronize(c->stream));
-        return 0;
-    };
-    // tiny chains: filter + smoother + NLL only (pyx:7998-8129)
-    bool anyTiny = false, anyBig = false;
-    auto masked = [&](int i) { return chain_mask != nullptr && chain_mask[i] == 0; };
-    for (int i = 0; i < nc; ++i) {
-        if (masked(i)) { out[i].skipped = 2; continue; }
-        if (c->chains[i].n <= 5) { act[i] = 1; anyTiny = true; out[i].skipped = 1; }
-        else anyBig = true;
-    }
-    if (anyTiny) {
-        CHECK(push_active());
-        CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));
-        CHECK(backward_impl(c, true, c->dActive, true));
-        CHECK(read_sums(c, nullptr, nll.data()));
-        for (int i = 0; i < nc; ++i)
-            if (act[i]) { out[i].final_nll = out[i].initial_nll = nll[i]; st[i].done = true; }
-    }
-    if (anyBig) {
-        for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5 && !masked(i)) ? 1 : 0;
-        CHECK(push_active());
-        bool fwdFresh = false;   // forward results already match the current multipliers
-        for (int64_t it = 0; it < cfg->max_iters; ++it) {
-            for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
-                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
-                fwdFresh = false;
-                // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments
-                // of bins k and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself;
-                // only the last inner sweep's moments can become the result of this iteration, the others are not
-                // even stored
-                const bool fusedE = c->fuseEstep && cfg->use_kappa && !cfg->use_lambda && c->mdl.state_dim == 2;
-                const int es = !fusedE ? 0 : (inner + 1 == cfg->inner_iters ? 1 : 2);
-                CHECK(backward_impl(c, true, c->dActive, true, false, es));
-                CHECK(settle(c));          // the next sweep (or the E-step kernels) consume validated results
-                Prm p = c->p;
-                p.flags = fl;
-                p.chainActive = c->dActive;
-                if (cfg->use_lambda) {
-                    Scope sc(c, "estep_lambda");
-                    hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
-                    LAUNCH_CHECK("k_estep_lambda");
-                }
-                if (cfg->use_kappa && !fusedE) {
-                    Scope sc(c, "estep_kappa");
-                    hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
-                    LAUNCH_CHECK("k_estep_kappa");
-                }
-            }
-            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));      // pyx:8300
-            // the multipliers do not change until the next E-step: the next sweep may reuse this forward pass,
-            // unless adaptive process noise made it depend on returnNLL-independent state only (it does not)
-            fwdFresh = (cfg->inner_iters > 0);
-            CHECK(read_sums(c, nullptr, nll.data()));
-            bool anyLeft = false, changed = false;
-            for (int i = 0; i < nc; ++i) {
-                if (!act[i]) continue;
-                EcmState &s = st[i];
-                csr_ecm_out &o = out[i];
-                o.iters_done = it + 1;
-                s.cur = nll[i];
-                if (nll_path) nll_path[(int64_t)i * cfg->max_iters + it] = s.cur;
-                const bool havePrev = s.haveInit;       // pyx:8337-8407
-                if (!havePrev) { o.initial_nll = s.cur; s.haveInit = true; }
-                else if (s.cur > s.prev + (1.0e-12 * std::fmax(std::fabs(s.prev), 1.0))) o.nll_increase_count += 1;
-                double delta, scale;
-                if (havePrev) { delta = std::fabs(s.cur - s.prev); scale = std::fabs(s.prev); }
-                else { delta = 0.0; scale = std::fabs(s.cur); }
-                if (std::fabs(s.cur) > scale) scale = std::fabs(s.cur);
-                if (scale < 1.0) scale = 1.0;
-                if (havePrev) { o.rel_improvement = (s.prev - s.cur) / scale; o.abs_rel_change = delta / scale; }
-                else { o.rel_improvement = 0.0; o.abs_rel_change = 0.0; }
-                const double tol = cfg->rtol * scale;
-                s.prev = s.cur;
-                if (havePrev && delta <= tol) o.stable_iters += 1; else o.stable_iters = 0;
-                if (o.stable_iters >= 2) { o.converged = 1; s.done = true; act[i] = 0; changed = true; }
-                else anyLeft = true;
-            }
-            if (!anyLeft) break;
-            if (changed) CHECK(push_active());
-        }
-        for (int i = 0; i < nc; ++i) {
-            if (c->chains[i].n <= 5 || masked(i)) continue;
-            out[i].has_initial_nll = st[i].haveInit ? 1 : 0;
-            out[i].final_nll = st[i].prev;
-        }
-    }
-    c->fwdFlags = fl;
-    c->haveFwd = c->haveBwd = true;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// export / download
-// ---------------------------------------------------------------------------------------------------------------
-
-// Exports may be queued behind an optimistically validated pipeline: they are re-issued by settle() if it fails.
-extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
-    CHECK(need(c));
-    join_side(c);
-    if (c->pendFwd || c->pendBwd) c->pendExport |= what;
-    return export_impl(c, what);
-}
-
-extern "C" int csr_batch_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
-    CHECK(need(c));
-    if (!c->haveFwd) return fail("no forward results");
-    return read_sums(c, sum_d, sum_nll);
-}
-
-static int flush_export(csr_ctx *c, ExpList &L) {
-    if (L.count == 0) return 0;
-    {
-        Scope sc(c, "export_natural");
-        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, c->p, L);
-    }
-    LAUNCH_CHECK("k_export_tiled");
-    L.count = 0;
-    return 0;
-}
-static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, int n, int skipLast) {
-    if (L.count == 8) CHECK(flush_export(c, L));       // one launch converts up to eight arrays
-    float *dst;
-    CHECK(nat_array(c, id, &dst));
-    ExpDesc &d = L.d[L.count++];
-    memset(&d, 0, sizeof(d));
-    d.src = src; d.dst = dst; d.E = E; d.n = n; d.skipLast = skipLast;
-    return 0;
-}
-
-static int export_impl(csr_ctx *c, uint32_t what) {
-    const int d = c->mdl.state_dim;
-    const Prm &p = c->p;
-    const int nv = d, nm = d * d;      // exported components of state vectors / covariance matrices
-    ExpList L;
-    memset(&L, 0, sizeof(L));
-    if (what & CSR_EXPORT_FORWARD) {
-        if (!c->haveFwd) return fail("no forward results to export");
-        CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
-        if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
-            CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
-            CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
-        }
-        const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
-        CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
-        if (constQ) {
-            ExpDesc &e = L.d[L.count - 1];
-            e.cval[0] = (float)p.Q00;
-            e.cval[1] = d == 2 ? (float)p.Q01 : 0.f;
-            e.cval[2] = d == 2 ? (float)p.Q10 : 0.f;
-            e.cval[3] = d == 2 ? (float)p.Q11 : 0.f;
-        }
-    }
-    if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
-        if (!c->haveBwd) return fail("no smoothed results to export");
-        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
-    }
-    if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat) {      // smoothNat: the smoother already wrote the natural arrays
-        CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
-        CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
-    }
-    if (what & CSR_EXPORT_MULT) {
-        CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
-        CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));
-        CHECK(add_export(c, L, CSR_ARR_QSCALE, p.tQs, 1, 1, 0));
-    }
-    CHECK(flush_export(c, L));
-    if (what & CSR_EXPORT_RESID) {
-        float *xs, *res;
-        CHECK(nat_array(c, CSR_ARR_XS, &xs));
-        CHECK(nat_array(c, CSR_ARR_RESID, &res));
-        Scope sc(c, "residuals");
-        if ((c->m & 3) == 0)
-            hipLaunchKernelGGL(k_resid_v4, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m, c->stream,
-                               c->p, xs, d, res, c->Npad);
-        else
-            hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
-                               c->p, xs, d, res, c->Npad);
-        LAUNCH_CHECK("k_resid");
-    }
-    return 0;
-}
-
-extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, int64_t *n_elems) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
-    float *ptr;
-    CHECK(nat_array(c, id, &ptr));
-    if (dev_ptr) *dev_ptr = ptr;
-    if (n_elems) *n_elems = arr_comps(c, id) * c->Npad;
-    return 0;
-}
-
-extern "C" int csr_batch_download(csr_ctx *c, int32_t chain, int32_t id, void *host_dst) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
-    if (id < 0 || id >= CSR_ARR_COUNT) return fail("bad array id");
-    if (!host_dst) return fail("null host buffer");
-    if (id == CSR_ARR_BACKGROUND && !c->nat[id]) {       // no background set yet: it is identically zero
-        float *q;
-        CHECK(nat_array(c, id, &q));
-    }
-    if (!c->nat[id]) return fail("array %d was not exported", id);
-    const ChainInfo &ci = c->chains[chain];
-    const int64_t per = arr_comps(c, id);
-    int64_t rows = ci.n;
-    if (id == CSR_ARR_PNOISE || id == CSR_ARR_LAG) rows = ci.n - 1;
-    if (rows > 0)
-        HIPOK(hipMemcpyAsync(host_dst, c->nat[id] + ci.off * per, sizeof(float) * per * rows, hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// synthetic fill (bench / scale tests)
-// ---------------------------------------------------------------------------------------------------------------
-extern "C" int csr_batch_synthesize(csr_ctx *c, uint64_t seed) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (!c->dLatent) CHECK(dalloc(c, &c->dLatent, c->Npad));
-    std::vector<float> lat((size_t)c->Npad, 0.f);
-    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
-    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
-    for (size_t ch = 0; ch < c->chains.size(); ++ch) {
-        const ChainInfo &ci = c->chains[ch];
-        double x = 0.0;
-        for (int64_t k = 0; k < ci.n; ++k) {
-            // Irwin-Hall(12) normal approximation is plenty for a synthetic random walk
-            double acc = 0.0;
-            const uint64_t a = next(), b = next();
-            for (int q = 0; q < 6; ++q) acc += (double)((a >> (q * 10)) & 1023) / 1024.0;
-            for (int q = 0; q < 6; ++q) acc += (double)((b >> (q * 10)) & 1023) / 1024.0;
-            x += 0.03 * (acc - 6.0);
-            lat[(size_t)(ci.off + k)] = (float)x;
-        }
-    }
-    HIPOK(hipMemcpy(c->dLatent, lat.data(), sizeof(float) * c->Npad, hipMemcpyHostToDevice));
-    {
-        Scope sc(c, "synthesize");
-        hipLaunchKernelGGL(k_synth, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, c->p, c->dLatent,
-                           const_cast<float *>(c->p.data), const_cast<float *>(c->p.munc), seed, c->Npad);
-    }
-    LAUNCH_CHECK("k_synth");
-    HIPOK(hipStreamSynchronize(c->stream));
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// (1) reference-shaped single-chain entry points on host buffers (default context, device from
-//     CONSENRICH_AMD_DEVICE or 0)
-// ---------------------------------------------------------------------------------------------------------------
-static csr_ctx *g_default = nullptr;
-// The reference-shaped entry points share ONE default context (device buffers cached across calls): they serialise on
-// this mutex, so calls from several host threads are safe (the reference's callers are single-threaded per chromosome,
-// core.py:3290, but run beside thread pools).  Batch contexts are independent; one thread per context.
-static std::recursive_mutex g_defaultMutex;
-#define DEFAULT_CTX_GUARD std::lock_guard<std::recursive_mutex> guard_(g_defaultMutex)
-static csr_ctx *default_ctx() {
-    if (!g_default) {
-        int dev = 0;
-        if (const char *e = getenv("CONSENRICH_AMD_DEVICE")) dev = atoi(e);
-        g_default = csr_create(dev);
-        // the drop-in single-chain callables favour parity: bit-exact sequential semantics unless told otherwise
-        if (g_default && !getenv("CONSENRICH_AMD_XTOL_ULPS")) {
-            g_default->xTolUlps = 0;
-            mode_warm_defaults(g_default);
-        }
-    }
-    return g_default;
-}
-
-static int configure_single(csr_ctx *c, const csr_model *mdl, int64_t m, int64_t n) {
-    const bool reuse = c->configured && c->chains.size() == 1 && c->chains[0].n == n && c->m == m &&
-                       c->mdl.state_dim == mdl->state_dim;
-    if (reuse) return csr_batch_set_model(c, mdl);
-    return csr_batch_configure(c, mdl, m, 1, &n);
-}
-
-static int import_nat(csr_ctx *c, const float *host, int ncomp, int64_t rows, int64_t rowShift, float *dst, int dstStride) {
-    // host natural (rows, ncomp) -> blocked float slots (dstStride floats per slot), bins [rowShift, rowShift+rows)
-    float *scr;
-    CHECK(nat_array(c, CSR_ARR_PS, &scr));   // 4 (or 1) floats per bin of natural scratch
-    if (rows > 0)
-        HIPOK(hipMemcpyAsync(scr + (c->chains[0].off + rowShift) * ncomp, host, sizeof(float) * ncomp * rows,
-                             hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < ncomp; ++k) {
-        hipLaunchKernelGGL(k_import_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, c->p, scr, ncomp, k, dst, dstStride, k);
-        LAUNCH_CHECK("k_import_f32");
-    }
-    return 0;
-}
-
-extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_fwd_out *out) {
-    DEFAULT_CTX_GUARD;
-    if (!mdl || !io || !out) return fail("null argument");
-    if (io->m <= 0 || io->n <= 0) return fail("empty input must be handled by the caller (pyx:6494-6501)");
-    if (!io->data || !io->munc || !io->D) return fail("null host buffer");
-    if ((io->flags & CSR_USE_LAMBDA) && !io->lambda) return fail("CSR_USE_LAMBDA without lambda");
-    if ((io->flags & CSR_USE_KAPPA) && !io->kappa) return fail("CSR_USE_KAPPA without kappa");
-    if ((io->flags & CSR_USE_QSCALE) && !io->qscale) return fail("CSR_USE_QSCALE without qscale");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(configure_single(c, mdl, io->m, io->n));
-    CHECK(csr_batch_upload(c, 0, io->data, io->munc));
-    CHECK(csr_batch_upload_multipliers(c, 0, (io->flags & CSR_USE_LAMBDA) ? io->lambda : nullptr,
-                                       (io->flags & CSR_USE_KAPPA) ? io->kappa : nullptr,
-                                       (io->flags & CSR_USE_QSCALE) ? io->qscale : nullptr));
-    CHECK(csr_batch_stats(c));
-    CHECK(csr_batch_forward(c, io->flags, &out->sum_d, &out->sum_nll));
-    CHECK(csr_batch_export(c, CSR_EXPORT_FORWARD));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_D, io->D));
-    if (io->xf) {
-        if (!io->Pf || !io->pnoise) return fail("xf/Pf/pnoise must be given together");
-        CHECK(csr_batch_download(c, 0, CSR_ARR_XF, io->xf));
-        CHECK(csr_batch_download(c, 0, CSR_ARR_PF, io->Pf));
-        CHECK(csr_batch_download(c, 0, CSR_ARR_PNOISE, io->pnoise));
-    }
-    return 0;
-}
-
-extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, const float *data, const float *xf,
-                                 const float *Pf, const float *pnoise, float *xs, float *Ps, float *lag,
-                                 int64_t lag_rows, float *resid) {
-    DEFAULT_CTX_GUARD;
-    if (!mdl || !data || !xf || !Pf || !pnoise || !xs || !Ps || !lag || !resid) return fail("null argument");
-    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:6737)");
-    if (lag_rows < std::max<int64_t>(n - 1, 1)) return fail("lagCovSmoothed too small");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(configure_single(c, mdl, m, n));
-    // only `data` matters for the smoother (residuals); munc is not an input of cbackwardPass
-    const ChainInfo &ci = c->chains[0];
-    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.data) + ci.off, sizeof(float) * c->Npad, data, sizeof(float) * n,
-                           sizeof(float) * n, (size_t)m, hipMemcpyHostToDevice, c->stream));
-    c->statsValid = false;
-    const int d = mdl->state_dim;
-    CHECK(import_nat(c, xf, d, n, 0, (float *)c->p.tXf, 2));
-    CHECK(import_nat(c, Pf, d * d, n, 0, (float *)c->p.tPf, 4));
-    if (n > 1) CHECK(import_nat(c, pnoise, d * d, n - 1, 0, (float *)c->p.tQ, 4));
-    c->haveFwd = true;
-    c->fwdInternal = false;
-    c->fwdFlags = 0;
-    CHECK(backward_impl(c, true, nullptr));
-    CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_RESID, resid));
-    c->haveFwd = c->haveBwd = false;   // imported filter results are not a reusable forward pass
-    return 0;
-}
-
-extern "C" int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg *cfg, int64_t m, int64_t n,
-                                        const float *data, const float *munc, const float *qscale, float *lambda,
-                                        float *kappa, float *xs, float *Ps, float *lag, float *resid,
-                                        double *nll_path, csr_ecm_out *out) {
-    DEFAULT_CTX_GUARD;
-    if (!mdl || !cfg || !data || !munc || !xs || !Ps || !lag || !resid || !out) return fail("null argument");
-    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller (pyx:7999)");
-    if (cfg->use_lambda && !lambda) return fail("use_lambda without lambda buffer");
-    if (cfg->use_kappa && !kappa) return fail("use_kappa without kappa buffer");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(configure_single(c, mdl, m, n));
-    CHECK(csr_batch_upload(c, 0, data, munc));
-    CHECK(csr_batch_upload_multipliers(c, 0, cfg->use_lambda ? lambda : nullptr, cfg->use_kappa ? kappa : nullptr, qscale));
-    CHECK(csr_batch_stats(c));
-    CHECK(csr_batch_ecm(c, cfg, qscale ? CSR_USE_QSCALE : 0u, out, nll_path));
-    CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID | CSR_EXPORT_MULT));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));
-    CHECK(csr_batch_download(c, 0, CSR_ARR_RESID, resid));
-    if (cfg->use_lambda) CHECK(csr_batch_download(c, 0, CSR_ARR_LAMBDA, lambda));
-    if (cfg->use_kappa) CHECK(csr_batch_download(c, 0, CSR_ARR_KAPPA, kappa));
-    return 0;
-}
-
-extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t n, const double *xs, const double *Ps,
-                                                     const double *lag, const double *F, double *sum_level,
-                                                     double *sum_trend, int64_t *count) {
-    DEFAULT_CTX_GUARD;
-    if (!sum_level || !sum_trend || !count) return fail("null argument");
-    *sum_level = 0.0; *sum_trend = 0.0;
-    *count = n - 1 > 0 ? n - 1 : 0;
-    if (n - 1 <= 0) return 0;
-    if (!xs || !Ps || !lag) return fail("null host buffer");
-    if (state_dim == 2 && !F) return fail("matrixF required for the levelTrend model");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(ctx_select(c));
-    const int d = state_dim;
-    double *dxs = nullptr, *dPs = nullptr, *dlag = nullptr, *dpart = nullptr;
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, 512);
-    auto cleanup = [&]() { hipFree(dxs); hipFree(dPs); hipFree(dlag); hipFree(dpart); };
-    if (hipMalloc((void **)&dxs, sizeof(double) * n * d) != hipSuccess || hipMalloc((void **)&dPs, sizeof(double) * n * d * d) != hipSuccess ||
-        hipMalloc((void **)&dlag, sizeof(double) * (n - 1) * d * d) != hipSuccess ||
-        hipMalloc((void **)&dpart, sizeof(double) * 2 * grid) != hipSuccess) {
-        cleanup();
-        return fail("hipMalloc failed in transition sums");
-    }
-    hipMemcpyAsync(dxs, xs, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(dPs, Ps, sizeof(double) * n * d * d, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(dlag, lag, sizeof(double) * (n - 1) * d * d, hipMemcpyHostToDevice, c->stream);
-    {
-        Scope sc(c, "transition_sums");
-        hipLaunchKernelGGL(k_tsums, dim3(grid), dim3(256), 0, c->stream, d, n, dxs, dPs, dlag, d == 2 ? F[0] : 1.0,
-                           d == 2 ? F[1] : 0.0, d == 2 ? F[2] : 0.0, d == 2 ? F[3] : 1.0, dpart, dpart + grid);
-    }
-    std::vector<double> part(2 * grid);
-    hipError_t e = hipMemcpyAsync(part.data(), dpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (e != hipSuccess) return fail("transition sums failed: %s", hipGetErrorString(e));
-    double aL = 0.0, aT = 0.0;
-    for (int i = 0; i < grid; ++i) { aL += part[i]; aT += part[grid + i]; }
-    *sum_level = aL;
-    *sum_trend = (d == 2) ? aT : 0.0;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// per-interval output diagnostics (core.py:7734-7878)
-// ---------------------------------------------------------------------------------------------------------------
-static int launch_diag(csr_ctx *c, uint32_t flags, bool usePnoise) {
-    DiagArgs a;
-    memset(&a, 0, sizeof(a));
-    float *q;
-    CHECK(nat_array(c, CSR_ARR_PF, &q)); a.Pf = q;
-    if (usePnoise) { CHECK(nat_array(c, CSR_ARR_PNOISE, &q)); a.pn = q; }
-    if (flags & CSR_USE_LAMBDA) { CHECK(nat_array(c, CSR_ARR_LAMBDA, &q)); a.lam = q; }
-    if (flags & CSR_USE_KAPPA) { CHECK(nat_array(c, CSR_ARR_KAPPA, &q)); a.kap = q; }
-    if (flags & CSR_USE_QSCALE) { CHECK(nat_array(c, CSR_ARR_QSCALE, &q)); a.qs = q; }
-    CHECK(nat_array(c, CSR_ARR_SUMGAIN0, &a.g0));
-    CHECK(nat_array(c, CSR_ARR_SUMGAIN1, &a.g1));
-    CHECK(nat_array(c, CSR_ARR_EFFQ_LEVEL, &a.eql));
-    CHECK(nat_array(c, CSR_ARR_EFFQ_TREND, &a.eqt));
-    CHECK(nat_array(c, CSR_ARR_MUNCTRACE, &a.trace));
-    a.chainOff = c->dChainOff;
-    a.chainLen = c->dChainLen;
-    a.nchains = (int)c->chains.size();
-    Prm p = c->p;
-    p.chainActive = nullptr;
-    {
-        Scope sc(c, "diagnostics");
-        hipLaunchKernelGGL(k_diag_natural, dim3((int)((c->Npad + 255) / 256)), dim3(256), 0, c->stream, p, a);
-    }
-    LAUNCH_CHECK("k_diag_natural");
-    return 0;
-}
-
-extern "C" int csr_batch_diagnostics(csr_ctx *c, uint32_t flags) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (!c->haveFwd) return fail("no forward results: run csr_batch_forward / csr_batch_ecm first");
-    const uint32_t mult = flags & (CSR_USE_LAMBDA | CSR_USE_KAPPA | CSR_USE_QSCALE);
-    CHECK(export_impl(c, CSR_EXPORT_FORWARD | (mult ? CSR_EXPORT_MULT : 0u)));
-    return launch_diag(c, flags, !(flags & CSR_USE_KAPPA));
-}
-
-extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n, const float *Pf, const float *munc,
-                                      const float *lambda, const float *kappa, const float *qscale,
-                                      const float *pnoise, float *sum_gain0, float *sum_gain1, float *effq_level,
-                                      float *effq_trend, float *munc_trace) {
-    DEFAULT_CTX_GUARD;
-    if (!mdl || !Pf || !munc || !sum_gain0 || !sum_gain1 || !effq_level || !effq_trend || !munc_trace)
-        return fail("null argument");
-    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(configure_single(c, mdl, m, n));
-    CHECK(settle(c));
-    const ChainInfo &ci = c->chains[0];
-    const int dd = mdl->state_dim * mdl->state_dim;
-    HIPOK(hipMemcpy2DAsync(const_cast<float *>(c->p.munc) + ci.off, sizeof(float) * c->Npad, munc, sizeof(float) * n,
-                           sizeof(float) * n, (size_t)m, hipMemcpyHostToDevice, c->stream));
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    uint32_t flags = 0;
-    struct { const float *src; int id; int64_t comps, rows; uint32_t flag; } in[5] = {
-        {Pf, CSR_ARR_PF, dd, n, 0u}, {pnoise, CSR_ARR_PNOISE, dd, n - 1, 0u}, {lambda, CSR_ARR_LAMBDA, 1, n, CSR_USE_LAMBDA},
-        {kappa, CSR_ARR_KAPPA, 1, n, CSR_USE_KAPPA}, {qscale, CSR_ARR_QSCALE, 1, n, CSR_USE_QSCALE}};
-    for (auto &e : in) {
-        if (!e.src) continue;
-        flags |= e.flag;
-        float *dst;
-        CHECK(nat_array(c, e.id, &dst));
-        if (e.rows > 0)
-            HIPOK(hipMemcpyAsync(dst + ci.off * e.comps, e.src, sizeof(float) * e.comps * e.rows, hipMemcpyHostToDevice,
-                                 c->stream));
-    }
-    CHECK(launch_diag(c, flags, pnoise != nullptr && kappa == nullptr));
-    float *outs[5] = {sum_gain0, sum_gain1, effq_level, effq_trend, munc_trace};
-    const int ids[5] = {CSR_ARR_SUMGAIN0, CSR_ARR_SUMGAIN1, CSR_ARR_EFFQ_LEVEL, CSR_ARR_EFFQ_TREND, CSR_ARR_MUNCTRACE};
-    for (int k = 0; k < 5; ++k)
-        HIPOK(hipMemcpyAsync(outs[k], c->nat[ids[k]] + ci.off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// background update natives (pyx:944-1096, 9700-9724)
-// ---------------------------------------------------------------------------------------------------------------
-
-// blocks of Bp bins per chain; the last block absorbs a remainder shorter than 4 bins (interiors need >= 2 bins)
-static void bg_partition(const std::vector<int64_t> &off, const std::vector<int64_t> &len, int Bp, std::vector<int4> &blk,
-                         std::vector<int64_t> &first, std::vector<int64_t> &nblk) {
-    const size_t nc = off.size();
-    first.assign(nc, 0);
-    nblk.assign(nc, 0);
-    blk.clear();
-    for (size_t i = 0; i < nc; ++i) {
-        int64_t K = (len[i] + Bp - 1) / Bp;
-        if (K > 1 && len[i] - (K - 1) * Bp < 4) K -= 1;
-        first[i] = (int64_t)blk.size();
-        nblk[i] = K;
-        for (int64_t k = 0; k < K; ++k) {
-            int4 b;
-            b.x = (int)(off[i] + k * Bp);
-            b.y = (int)(k + 1 < K ? Bp : len[i] - (K - 1) * Bp);
-            b.z = (int)i;
-            b.w = k + 1 < K ? 1 : 0;
-            blk.push_back(b);
-        }
-    }
-}
-
-template <int NR>
-static void launch_bg(csr_ctx *c, const BgPrm &p, bool center) {
-    {
-        Scope sc(c, "bg_local");
-        hipLaunchKernelGGL(k_bg_local<NR>, dim3((int)p.NGk), dim3(64), 0, c->stream, p);
-    }
-    {
-        Scope sc(c, "bg_sep_assemble");
-        hipLaunchKernelGGL(k_bg_sep_assemble<NR>, dim3((int)((p.NBk + 255) / 256)), dim3(256), 0, c->stream, p);
-    }
-    {
-        Scope sc(c, "bg_reduced");
-        hipLaunchKernelGGL(k_bg_reduced<NR>, dim3(p.nchains), dim3(64), 0, c->stream, p);
-    }
-    {
-        Scope sc(c, "bg_combine");
-        hipLaunchKernelGGL(k_bg_combine<NR>, dim3((int)((p.NGk * p.SB * 64 + 255) / 256)), dim3(256), 0, c->stream, p);
-    }
-    if (center) {
-        Scope sc(c, "bg_center");
-        hipLaunchKernelGGL(k_bg_center, dim3(p.nchains), dim3(1024), 0, c->stream, p);
-    }
-}
-
-extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const double *weight, const double *rhs,
-                                    double lam, double lam_first, int32_t zero_center, int32_t block_len, double *out,
-                                    int64_t *bad_index, double *bad_value) {
-    DEFAULT_CTX_GUARD;
-    if (n_chains <= 0 || !n || !weight || !rhs || !out) return fail("null / empty argument");
-    if (!std::isfinite(lam_first) || lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
-    if (!std::isfinite(lam) || lam < 0.0) return fail("lam must be finite and nonnegative");
-    int Bp = block_len > 0 ? block_len : 1024;
-    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
-    if (Bp < 8) return fail("block_len must be at least 8");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(ctx_select(c));
-    // partition
-    std::vector<int64_t> off(n_chains), first, nblk, len(n, n + n_chains);
-    std::vector<int4> blk;
-    int64_t N = 0;
-    for (int i = 0; i < n_chains; ++i) {
-        if (n[i] <= 0) return fail("chain %d is empty", i);
-        off[i] = N;
-        N += n[i];
-        if (N >= ((int64_t)1 << 31)) return fail("batch too large");
-    }
-    bg_partition(off, len, Bp, blk, first, nblk);
-    const int NR = zero_center ? 2 : 1;
-    BgPrm p;
-    memset(&p, 0, sizeof(p));
-    p.nchains = n_chains; p.Bp = Bp; p.SB = Bp + 4; p.NR = NR;
-    p.NBk = (int64_t)blk.size();
-    p.NGk = (p.NBk + 63) / 64;
-    p.lam = lam; p.lamF = lam_first;
-    // carve the work buffer
-    const size_t TN = (size_t)p.NGk * p.SB * 64;
-    size_t need_ = 0;
-    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
-    const size_t oOff = take(8 * n_chains), oLen = take(8 * n_chains), oFirst = take(8 * n_chains), oNum = take(8 * n_chains);
-    const size_t oBlk = take(sizeof(int4) * blk.size());
-    const size_t oW = take(8 * N), oR = take(8 * N), oO0 = take(8 * N), oO1 = take(8 * N);
-    const size_t oInvd = take(8 * TN), oL1 = take(8 * TN);
-    size_t oX[6];
-    for (int j = 0; j < NR + 4; ++j) oX[j] = take(8 * TN);
-    const size_t oT = take(8 * 16 * blk.size()), ot = take(8 * 4 * NR * blk.size());
-    const size_t oSI = take(8 * (7 + 2 * NR) * blk.size()), oSO = take(8 * (3 + 2 * NR) * blk.size());
-    const size_t oG = take(8 * 2 * NR * blk.size());
-    const size_t oBI = take(8 * blk.size()), oBV = take(8 * blk.size());
-    const size_t oCBI = take(8 * n_chains), oCBV = take(8 * n_chains), oMu = take(8 * n_chains);
-    CHECK(c->bgBuf.reserve(need_));
-    char *base = (char *)c->bgBuf.ptr;
-    p.chainOff = (const int64_t *)(base + oOff); p.chainLen = (const int64_t *)(base + oLen);
-    p.chainFirstBlk = (const int64_t *)(base + oFirst); p.chainNumBlk = (const int64_t *)(base + oNum);
-    p.blk = (const int4 *)(base + oBlk);
-    p.w = (const double *)(base + oW); p.rhs = (const double *)(base + oR);
-    p.out0 = (double *)(base + oO0); p.out1 = (double *)(base + oO1);
-    p.invd = (double *)(base + oInvd); p.l1 = (double *)(base + oL1);
-    for (int j = 0; j < NR + 4; ++j) p.X[j] = (double *)(base + oX[j]);
-    p.T = (double *)(base + oT); p.t = (double *)(base + ot);
-    p.sepIn = (double *)(base + oSI); p.sepOut = (double *)(base + oSO); p.sepG = (double *)(base + oG);
-    p.badIdx = (int64_t *)(base + oBI); p.badVal = (double *)(base + oBV);
-    p.chainBadIdx = (int64_t *)(base + oCBI); p.chainBadVal = (double *)(base + oCBV); p.chainMu = (double *)(base + oMu);
-    HIPOK(hipMemcpyAsync(base + oOff, off.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oLen, len.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oFirst, first.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oNum, nblk.data(), 8 * n_chains, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oW, weight, 8 * N, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oR, rhs, 8 * N, hipMemcpyHostToDevice, c->stream));
-    if (NR == 2) launch_bg<2>(c, p, true);
-    else launch_bg<1>(c, p, false);
-    LAUNCH_CHECK("background solve");
-    std::vector<int64_t> cbi(n_chains);
-    std::vector<double> cbv(n_chains);
-    HIPOK(hipMemcpyAsync(out, p.out0, 8 * N, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(cbi.data(), p.chainBadIdx, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(cbv.data(), p.chainBadVal, 8 * n_chains, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < n_chains; ++i) {
-        if (n[i] == 1) {                                   // pyx:1001-1011
-            out[off[i]] = 0.0;
-            cbi[i] = -1;
-            if (!zero_center) {
-                if (weight[off[i]] < 1.0e-12) { cbi[i] = 0; cbv[i] = weight[off[i]]; }
-                else out[off[i]] = rhs[off[i]] / weight[off[i]];
-            }
-        }
-        if (bad_index) bad_index[i] = cbi[i];
-        if (bad_value) bad_value[i] = cbi[i] >= 0 ? cbv[i] : 0.0;
-    }
-    return 0;
-}
-
-extern "C" int csr_background_weighted_stats(int64_t m, int64_t n, const float *resid, const float *inv_var,
-                                             double *weight, double *rhs, int64_t *support) {
-    DEFAULT_CTX_GUARD;
-    if (!resid || !inv_var || !weight || !rhs || !support) return fail("null argument");
-    if (m <= 0 || n <= 0) return fail("empty input must be handled by the caller");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(ctx_select(c));
-    const size_t mat = sizeof(float) * (size_t)m * n, vec = 8 * (size_t)n;
-    const size_t matA = (mat + 255) / 256 * 256, vecA = (vec + 255) / 256 * 256;
-    CHECK(c->bgBuf.reserve(2 * matA + 2 * vecA + 256));
-    char *base = (char *)c->bgBuf.ptr;
-    float *dr = (float *)base, *di = (float *)(base + matA);
-    double *dw = (double *)(base + 2 * matA), *dh = (double *)(base + 2 * matA + vecA);
-    unsigned long long *ds = (unsigned long long *)(base + 2 * matA + 2 * vecA);
-    HIPOK(hipMemcpyAsync(dr, resid, mat, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(di, inv_var, mat, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemsetAsync(ds, 0, 8, c->stream));
-    {
-        Scope sc(c, "bg_weighted_stats");
-        hipLaunchKernelGGL(k_bg_weighted_stats, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, m, n, dr, di, dw, dh, ds);
-    }
-    LAUNCH_CHECK("k_bg_weighted_stats");
-    unsigned long long sup = 0;
-    HIPOK(hipMemcpyAsync(weight, dw, vec, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(rhs, dh, vec, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(&sup, ds, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    *support = (int64_t)sup;
-    return 0;
-}
-
-// ---- device-resident background update of a batch (core.py:5064-5137, 8085-8378) ---------------------------------
-static int bg_setup(csr_ctx *c, int Bp) {
-    csr_ctx::BgState &S = c->bg;
-    if (S.ready && S.Bp == Bp) return 0;
-    if (S.ready) return fail("the background partition size cannot change after its first use in a batch");
-    const int nc = (int)c->chains.size();
-    std::vector<int64_t> off(nc), len(nc), first, nblk;
-    for (int i = 0; i < nc; ++i) { off[i] = c->chains[i].off; len[i] = c->chains[i].n; }
-    std::vector<int4> blk;
-    bg_partition(off, len, Bp, blk, first, nblk);
-    BgPrm &p = S.prm;
-    memset(&p, 0, sizeof(p));
-    p.nchains = nc; p.Bp = Bp; p.SB = Bp + 4;
-    p.NBk = (int64_t)blk.size();
-    p.NGk = (p.NBk + 63) / 64;
-    const int64_t TN = p.NGk * p.SB * 64, N = c->Npad;
-    int64_t *dFirst, *dNum;
-    int4 *dBlk;
-    CHECK(dalloc(c, &dFirst, nc)); CHECK(dalloc(c, &dNum, nc)); CHECK(dalloc(c, &dBlk, p.NBk));
-    HIPOK(hipMemcpy(dFirst, first.data(), 8 * nc, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(dNum, nblk.data(), 8 * nc, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(dBlk, blk.data(), sizeof(int4) * blk.size(), hipMemcpyHostToDevice));
-    p.chainOff = c->dChainOff; p.chainLen = c->dChainLen; p.chainFirstBlk = dFirst; p.chainNumBlk = dNum; p.blk = dBlk;
-    CHECK(dalloc(c, &p.invd, TN)); CHECK(dalloc(c, &p.l1, TN));
-    for (int j = 0; j < 6; ++j) CHECK(dalloc(c, &p.X[j], TN));
-    CHECK(dalloc(c, &p.T, 16 * p.NBk)); CHECK(dalloc(c, &p.t, 8 * p.NBk));
-    CHECK(dalloc(c, &p.sepIn, 11 * p.NBk)); CHECK(dalloc(c, &p.sepOut, 7 * p.NBk)); CHECK(dalloc(c, &p.sepG, 4 * p.NBk));
-    CHECK(dalloc(c, &p.badIdx, p.NBk)); CHECK(dalloc(c, &p.badVal, p.NBk));
-    CHECK(dalloc(c, &p.chainBadIdx, nc)); CHECK(dalloc(c, &p.chainBadVal, nc)); CHECK(dalloc(c, &p.chainMu, nc));
-    BgBatch &a = S.bat;
-    memset(&a, 0, sizeof(a));
-    std::vector<int> gc((size_t)(N / 64), -1);
-    for (int i = 0; i < nc; ++i)
-        for (int64_t g = off[i] / 64; g < (off[i] + len[i] + 63) / 64; ++g) gc[(size_t)g] = i;
-    CHECK(dalloc(c, &S.dGroupChain, N / 64));
-    HIPOK(hipMemcpy(S.dGroupChain, gc.data(), sizeof(int) * gc.size(), hipMemcpyHostToDevice));
-    a.groupChain = S.dGroupChain; a.chainOff = c->dChainOff; a.chainLen = c->dChainLen; a.nchains = nc;
-    CHECK(dalloc(c, &a.w, N)); CHECK(dalloc(c, &a.rhs, N)); CHECK(dalloc(c, &a.wAdj, N));
-    CHECK(dalloc(c, &a.sol, N)); CHECK(dalloc(c, &S.out1, N));
-    CHECK(dalloc(c, &a.selAns, 2 * nc)); CHECK(dalloc(c, &S.dSelRank, 2 * nc));
-    a.selRank = S.dSelRank;
-    CHECK(dalloc(c, &a.maskPrev, N)); CHECK(dalloc(c, &a.maskNew, N));
-    CHECK(dalloc(c, &S.dActive, nc)); CHECK(dalloc(c, &S.dHasSup, nc)); CHECK(dalloc(c, &S.dPen, nc));
-    CHECK(dalloc(c, &a.flags, nc)); CHECK(dalloc(c, &a.chainSum, 5 * nc));
-    HIPOK(hipMemsetAsync(a.sol, 0, 8 * N, c->stream));
-    HIPOK(hipMemsetAsync(S.out1, 0, 8 * N, c->stream));
-    HIPOK(hipMemsetAsync(a.wAdj, 0, 8 * N, c->stream));
-    a.active = S.dActive; a.pen = S.dPen;
-    {
-        std::vector<int> wc, wg0, wg1, cw0(nc), cwn(nc);
-        for (int i = 0; i < nc; ++i) {
-            const int64_t G0 = off[i] / 64, G1 = (off[i] + len[i] + 63) / 64;
-            cw0[i] = (int)wc.size();
-            for (int64_t g = G0; g < G1; g += BG_GPW) {
-                wc.push_back(i);
-                wg0.push_back((int)g);
-                wg1.push_back((int)std::min<int64_t>(g + BG_GPW, G1));
-            }
-            cwn[i] = (int)wc.size() - cw0[i];
-        }
-        int *dwc, *dwg0, *dwg1, *dcw0, *dcwn;
-        CHECK(dalloc(c, &dwc, (int64_t)wc.size())); CHECK(dalloc(c, &dwg0, (int64_t)wc.size()));
-        CHECK(dalloc(c, &dwg1, (int64_t)wc.size())); CHECK(dalloc(c, &dcw0, nc)); CHECK(dalloc(c, &dcwn, nc));
-        HIPOK(hipMemcpy(dwc, wc.data(), 4 * wc.size(), hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(dwg0, wg0.data(), 4 * wc.size(), hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(dwg1, wg1.data(), 4 * wc.size(), hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(dcw0, cw0.data(), 4 * nc, hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(dcwn, cwn.data(), 4 * nc, hipMemcpyHostToDevice));
-        a.waveChain = dwc; a.waveG0 = dwg0; a.waveG1 = dwg1; a.chainWave0 = dcw0; a.chainWaveN = dcwn;
-        a.NW = (int)wc.size();
-        CHECK(dalloc(c, &a.part, 4 * (int64_t)wc.size()));
-    }
-    float *q;
-    CHECK(nat_array(c, CSR_ARR_BACKGROUND_NEXT, &q)); a.bgNext = q;
-    S.Bp = Bp;
-    S.ready = true;
-    return 0;
-}
-
-static int bg_solve_active(csr_ctx *c, const csr_bg_cfg *cfg) {
-    csr_ctx::BgState &S = c->bg;
-    BgPrm p = S.prm;
-    p.NR = cfg->zero_center ? 2 : 1;
-    p.lam = cfg->lam; p.lamF = cfg->lam_first;
-    p.w = S.bat.wAdj; p.rhs = S.bat.rhs;
-    p.out0 = S.bat.sol; p.out1 = S.out1;
-    p.active = S.dActive;
-    if (p.NR == 2) launch_bg<2>(c, p, true);
-    else launch_bg<1>(c, p, false);
-    LAUNCH_CHECK("background solve");
-    return 0;
-}
-
-extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, csr_bg_out *out) {
-    CHECK(need(c));
-    if (!cfg || !out) return fail("null argument");
-    CHECK(settle(c));
-    if (!c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
-    if (!std::isfinite(cfg->lam_first) || cfg->lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
-    if (!std::isfinite(cfg->lam) || cfg->lam < 0.0) return fail("lam must be finite and nonnegative");
-    int Bp = cfg->block_len > 0 ? cfg->block_len : 1024;
-    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
-    if (Bp < 8) return fail("block_len must be at least 8");
-    CHECK(bg_setup(c, Bp));
-    csr_ctx::BgState &S = c->bg;
-    BgBatch &a = S.bat;
-    const int nc = (int)c->chains.size();
-    const int gridN = (int)((c->Npad + 255) / 256);
-    // natural smoothed level (+ lambda)
-    {
-        ExpList L;
-        memset(&L, 0, sizeof(L));
-        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
-        if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
-        CHECK(flush_export(c, L));
-    }
-    a.xsNat = c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
-    a.useLambda = cfg->use_lambda ? 1 : 0;
-    a.lamNat = cfg->use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr;
-    a.padf = (float)c->mdl.pad; a.wMinf = (float)c->mdl.w_min; a.wMaxf = (float)c->mdl.w_max;
-    a.bgCur = S.haveCur ? c->nat[CSR_ARR_BACKGROUND] : nullptr;
-    Prm p = c->p;
-    {
-        Scope sc(c, "bg_batch_stats");
-        hipLaunchKernelGGL(k_bg_batch_stats, dim3(gridN), dim3(256), 0, c->stream, p, a);
-    }
-    const int gridW = (a.NW + 3) / 4;
-    auto wave_pass = [&](int what, int bit, const unsigned char *hs) {
-        hipLaunchKernelGGL(k_bg_wave_pass, dim3(gridW), dim3(256), 0, c->stream, p, a, what, bit, hs);
-        hipLaunchKernelGGL(k_bg_wave_fold, dim3(nc), dim3(64), 0, c->stream, a, what, bit);
-    };
-    wave_pass(0, 0, nullptr);
-    LAUNCH_CHECK("background statistics");
-    std::vector<double> cs(5 * (size_t)nc);
-    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(wait_stream(c));
-    std::vector<unsigned char> act(nc, 0), sup(nc, 0);
-    std::vector<double> pen(nc, 0.0);
-    std::vector<int> prevValid(nc, 0);
-    const double mult = cfg->negative_penalty_multiplier;
-    bool irls = cfg->use_nonnegative && std::isfinite(mult) && mult > 0.0;
-    for (int i = 0; i < nc; ++i) {
-        csr_bg_out &o = out[i];
-        memset(&o, 0, sizeof(o));
-        o.bad_index = -1;
-        o.weight_sum = cs[5 * i];
-        o.support = (int64_t)cs[5 * i + 1];
-        if (o.support <= 0) { o.status = CSR_BG_NO_SUPPORT; continue; }       // core.py:8148-8149
-        sup[i] = 1;
-        const double meanPos = o.weight_sum / (double)o.support;              // core.py:8157-8166
-        const double ratio = 1.0 + (4.0 * cfg->lam_first + 16.0 * cfg->lam) / meanPos;
-        o.roundoff_index = 2.220446049250313e-16 * ratio;
-        if (!std::isfinite(meanPos) || meanPos <= 0.0 || !std::isfinite(ratio) || ratio <= 0.0 || o.roundoff_index >= 1.0) {
-            o.status = CSR_BG_UNRELIABLE;
-            sup[i] = 0;
-            continue;
-        }
-        act[i] = 1;
-    }
-    // median of the positive weights = scale of the negative-part penalty (core.py:8287-8296)
-    if (irls) {
-        std::vector<long long> rank(2 * (size_t)nc, -1);
-        for (int i = 0; i < nc; ++i) {
-            if (!act[i]) continue;
-            rank[2 * i] = (out[i].support - 1) / 2;          // numpy.median: mean of the two middle order statistics
-            rank[2 * i + 1] = out[i].support / 2;
-        }
-        HIPOK(hipMemcpyAsync(S.dSelRank, rank.data(), 8 * 2 * nc, hipMemcpyHostToDevice, c->stream));
-        HIPOK(hipMemsetAsync(a.selAns, 0, 8 * 2 * nc, c->stream));
-        {
-            Scope sc(c, "bg_median_select");
-            for (int bit = 62; bit >= 0; --bit) wave_pass(1, bit, nullptr);
-        }
-        LAUNCH_CHECK("median select");
-        std::vector<double> mid(2 * (size_t)nc, 0.0);
-        HIPOK(hipMemcpyAsync(mid.data(), a.selAns, 8 * 2 * nc, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(wait_stream(c));
-        for (int i = 0; i < nc; ++i) {
-            if (!act[i]) continue;
-            double scale = 0.5 * (mid[2 * i] + mid[2 * i + 1]);
-            if (!std::isfinite(scale) || scale <= 0.0) scale = 1.0;
-            out[i].weight_scale = scale;
-            pen[i] = mult * scale;
-            if (!std::isfinite(pen[i]) || pen[i] <= 0.0) pen[i] = 0.0;          // that chain: plain solve
-        }
-    }
-    HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(S.dPen, pen.data(), 8 * nc, hipMemcpyHostToDevice, c->stream));
-    // first solve (core.py:8306-8324)
-    const bool useInit = irls && cfg->use_initial;
-    if (useInit) {
-        hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 0);
-        for (int i = 0; i < nc; ++i) prevValid[i] = 1;
-    }
-    hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, useInit ? 1 : 0);
-    CHECK(bg_solve_active(c, cfg));
-    auto harvest_bad = [&]() -> int {
-        std::vector<int64_t> bi(nc);
-        std::vector<double> bv(nc);
-        HIPOK(hipMemcpyAsync(bi.data(), S.prm.chainBadIdx, 8 * nc, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipMemcpyAsync(bv.data(), S.prm.chainBadVal, 8 * nc, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(wait_stream(c));
-        for (int i = 0; i < nc; ++i)
-            if (act[i] && bi[i] >= 0 && out[i].status == CSR_BG_OK) {
-                out[i].status = CSR_BG_BAD_PIVOT;
-                out[i].bad_index = bi[i];
-                out[i].bad_value = bv[i];
-                act[i] = 0;
-            }
-        return 0;
-    };
-    const int maxPasses = cfg->max_passes > 0 ? cfg->max_passes : 5;
-    if (irls) {
-        for (int pass = 0; pass < maxPasses; ++pass) {
-            CHECK(harvest_bad());
-            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
-            wave_pass(2, 0, nullptr);
-            std::vector<unsigned int> fl(nc);
-            HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
-            HIPOK(wait_stream(c));
-            bool any = false;
-            for (int i = 0; i < nc; ++i) {
-                if (!act[i]) continue;
-                if (fl[i] & 4u) { out[i].status = CSR_BG_NONFINITE; act[i] = 0; continue; }
-                if (pen[i] <= 0.0) { act[i] = 0; continue; }
-                if (prevValid[i] && !(fl[i] & 2u)) { act[i] = 0; continue; }       // same negative set: done
-                if (!(fl[i] & 1u)) { act[i] = 0; continue; }                       // nothing negative: done
-                prevValid[i] = 1;
-                out[i].passes = pass + 1;
-                any = true;
-            }
-            if (!any) break;
-            HIPOK(hipMemcpyAsync(S.dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 2);
-            hipLaunchKernelGGL(k_bg_adjust, dim3(gridN), dim3(256), 0, c->stream, p, a, 1);
-            CHECK(bg_solve_active(c, cfg));
-        }
-    }
-    CHECK(harvest_bad());
-    // finite check of the final solutions of chains that never went through the mask kernel is covered by k_bg_mask
-    // in the IRLS path; the plain path checks here
-    if (!irls) {
-        std::vector<unsigned char> all(nc);
-        for (int i = 0; i < nc; ++i) all[i] = sup[i];
-        HIPOK(hipMemcpyAsync(S.dActive, all.data(), nc, hipMemcpyHostToDevice, c->stream));
-        wave_pass(2, 0, nullptr);
-        std::vector<unsigned int> fl(nc);
-        HIPOK(hipMemcpyAsync(fl.data(), a.flags, sizeof(unsigned int) * nc, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(wait_stream(c));
-        for (int i = 0; i < nc; ++i)
-            if (sup[i] && (fl[i] & 4u) && out[i].status == CSR_BG_OK) out[i].status = CSR_BG_NONFINITE;
-    }
-    for (int i = 0; i < nc; ++i) sup[i] = (out[i].status == CSR_BG_OK) ? 1 : 0;
-    HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
-    wave_pass(3, 0, S.dHasSup);
-    LAUNCH_CHECK("k_bg_finish");
-    HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * nc, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(wait_stream(c));
-    for (int i = 0; i < nc; ++i) {
-        const double sw = out[i].weight_sum;
-        out[i].shift_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 2] / sw) : 0.0;
-        out[i].proposal_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 3] / sw) : 0.0;
-        out[i].reference_rms = sw > 0.0 ? std::sqrt(cs[5 * i + 4] / sw) : 0.0;
-    }
-    return 0;
-}
-
-static int bg_current(csr_ctx *c, float **cur) {
-    CHECK(nat_array(c, CSR_ARR_BACKGROUND, cur));       // zero-initialised on first use
-    c->bg.haveCur = true;
-    c->p.bg = *cur;
-    return 0;
-}
-
-extern "C" int csr_batch_background_apply(csr_ctx *c, const unsigned char *take) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (!c->bg.ready) return fail("no background proposal: run csr_batch_background_update first");
-    float *cur;
-    CHECK(bg_current(c, &cur));
-    const float *nxt = c->nat[CSR_ARR_BACKGROUND_NEXT];
-    for (size_t i = 0; i < c->chains.size(); ++i) {
-        if (take && !take[i]) continue;
-        const ChainInfo &ci = c->chains[i];
-        HIPOK(hipMemcpyAsync(cur + ci.off, nxt + ci.off, sizeof(float) * ci.n, hipMemcpyDeviceToDevice, c->stream));
-    }
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-extern "C" int csr_batch_set_background(csr_ctx *c, int32_t chain, const float *background) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
-    float *cur;
-    CHECK(bg_current(c, &cur));
-    const ChainInfo &ci = c->chains[chain];
-    if (background) HIPOK(hipMemcpyAsync(cur + ci.off, background, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
-    else HIPOK(hipMemsetAsync(cur + ci.off, 0, sizeof(float) * ci.n, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// bedGraph writer (consenrich.py:9797-9805)
-// ---------------------------------------------------------------------------------------------------------------
-
-static int64_t bedgraph_impl(csr_ctx *c, BgwArgs a, const int64_t *hStarts, const int64_t *hEnds, const float *hValues,
-                             const char *chrom, char *out, int64_t cap) {
-    const size_t cl = chrom ? strlen(chrom) : 0;
-    if (!chrom || cl == 0 || cl > 63) { fail("chromosome name must have 1..63 characters"); return -1; }
-    if (a.n < 0) { fail("negative row count"); return -1; }
-    if (a.n == 0) return 0;
-    memset(a.chrom, 0, sizeof(a.chrom));
-    memcpy(a.chrom, chrom, cl);
-    a.chromLen = (int)cl;
-    const int64_t n = a.n, nb = (n + 1023) / 1024;
-    const size_t maxRow = cl + 1 + 20 + 1 + 20 + 1 + 48 + 1;
-    size_t need_ = 0;
-    auto take = [&](size_t bytes) { const size_t o = need_; need_ += (bytes + 255) / 256 * 256; return o; };
-    const size_t oLen = take(4 * (size_t)n), oOff = take(8 * (size_t)n), oBlk = take(8 * (size_t)(nb + 1));
-    const size_t oS = hStarts ? take(8 * (size_t)n) : 0, oE = hEnds ? take(8 * (size_t)n) : 0;
-    const size_t oV = hValues ? take(4 * (size_t)n) : 0;
-    // the text follows; its size is only known after pass 2, so reserve in two steps
-    if (c->wrBuf.reserve(need_) != 0) return -1;
-    char *base = (char *)c->wrBuf.ptr;
-    a.rowLen = (int *)(base + oLen); a.rowOff = (int64_t *)(base + oOff); a.blockSum = (int64_t *)(base + oBlk);
-    auto H = [&](hipError_t e) { if (e != hipSuccess) { fail("bedGraph writer: %s", hipGetErrorString(e)); return false; } return true; };
-    if (hStarts) {
-        if (!H(hipMemcpyAsync(base + oS, hStarts, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
-        if (!H(hipMemcpyAsync(base + oE, hEnds, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
-        a.starts = (const int64_t *)(base + oS); a.ends = (const int64_t *)(base + oE);
-    }
-    if (hValues) {
-        if (!H(hipMemcpyAsync(base + oV, hValues, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream))) return -1;
-        a.values = (const float *)(base + oV); a.stride = 1; a.comp = 0;
-    }
-    {
-        Scope sc(c, "bedgraph_len_scan");
-        hipLaunchKernelGGL(k_bgw_len, dim3((int)nb), dim3(1024), 0, c->stream, a);
-        hipLaunchKernelGGL(k_bgw_scan_blocks, dim3(1), dim3(1024), 0, c->stream, a, nb);
-        hipLaunchKernelGGL(k_bgw_scan_rows, dim3((int)nb), dim3(1024), 0, c->stream, a);
-    }
-    int64_t total = 0;
-    if (!H(hipMemcpyAsync(&total, a.blockSum + nb, 8, hipMemcpyDeviceToHost, c->stream))) return -1;
-    if (!H(hipStreamSynchronize(c->stream))) return -1;
-    if (total < 0 || (size_t)total > maxRow * (size_t)n) { fail("bedGraph writer: inconsistent size"); return -1; }
-    if (!out) return total;
-    if (cap < total) { fail("bedGraph writer: output buffer too small (%lld < %lld)", (long long)cap, (long long)total); return -1; }
-    // text buffer: grow the work buffer if needed (the row tables are recomputed afterwards in that case)
-    const size_t oText = take((size_t)total);
-    if (need_ > c->wrBuf.cap) {
-        // a second, dedicated allocation for the text (growing wrBuf would drop the row tables just computed)
-        if (c->textBuf.reserve((size_t)total) != 0) return -1;
-        a.out = (char *)c->textBuf.ptr;
-    } else {
-        a.out = base + oText;
-    }
-    {
-        Scope sc(c, "bedgraph_write");
-        hipLaunchKernelGGL(k_bgw_write, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-    }
-    if (hipGetLastError() != hipSuccess) { fail("bedGraph writer launch failed"); return -1; }
-    if (!H(hipMemcpyAsync(out, a.out, (size_t)total, hipMemcpyDeviceToHost, c->stream))) return -1;
-    if (!H(hipStreamSynchronize(c->stream))) return -1;
-    return total;
-}
-
-extern "C" int64_t csr_format_bedgraph(const char *chrom, int64_t n, const int64_t *starts, const int64_t *ends,
-                                       int64_t start0, int64_t step, int64_t end_cap, const float *values,
-                                       int32_t transform, char *out, int64_t out_capacity) {
-    DEFAULT_CTX_GUARD;
-    if (n > 0 && !values) { fail("null values"); return -1; }
-    if ((starts == nullptr) != (ends == nullptr)) { fail("starts and ends must be given together"); return -1; }
-    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
-    csr_ctx *c = default_ctx();
-    if (!c || ctx_select(c) != 0) return -1;
-    BgwArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n = n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
-    return bedgraph_impl(c, a, starts, ends, values, chrom, out, out_capacity);
-}
-
-extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp,
-                                             int32_t transform, const char *chrom, int64_t start0, int64_t step,
-                                             int64_t end_cap, char *out, int64_t out_capacity) {
-    if (need(c) != 0 || settle(c) != 0) return -1;
-    if (chain < 0 || chain >= (int)c->chains.size()) { fail("chain index out of range"); return -1; }
-    if (array_id < 0 || array_id >= CSR_ARR_COUNT || array_id == CSR_ARR_RESID) { fail("bad array id"); return -1; }
-    if (!c->nat[array_id]) { fail("array %d was not exported", array_id); return -1; }
-    const int64_t per = arr_comps(c, array_id);
-    if (comp < 0 || comp >= per) { fail("component out of range"); return -1; }
-    if (transform < 0 || transform > 2) { fail("bad transform"); return -1; }
-    const ChainInfo &ci = c->chains[chain];
-    BgwArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n = ci.n; a.transform = transform; a.start0 = start0; a.step = step; a.endCap = end_cap;
-    a.values = c->nat[array_id] + ci.off * per; a.stride = (int)per; a.comp = comp;
-    return bedgraph_impl(c, a, nullptr, nullptr, nullptr, chrom, out, out_capacity);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
-// ---------------------------------------------------------------------------------------------------------------
-static int fold_stage(csr_ctx *c, size_t bytes, char **base) {
-    CHECK(c->wrBuf.reserve(bytes));
-    *base = (char *)c->wrBuf.ptr;
-    return 0;
-}
-
-extern "C" int csr_observation_total_information(int64_t m, int64_t n, const void *munc, int32_t munc_is_f64,
-                                                 const uint8_t *active, const double *lambda, double pad, double rho,
-                                                 double *total) {
-    DEFAULT_CTX_GUARD;
-    if (!munc || !active || !total) return fail("null argument");
-    if (m < 1 || n < 1) return fail("empty input must be handled by the caller");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(ctx_select(c));
-    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n;
-    size_t need_ = 0;
-    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
-    const size_t oM = take(es * mn), oA = take(mn), oL = take(8 * (size_t)n), oT = take(8 * (size_t)n);
-    char *base;
-    CHECK(fold_stage(c, need_, &base));
-    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
-    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    FoldArgs a;
-    memset(&a, 0, sizeof(a));
-    a.m = m; a.n = n; a.stride = n; a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1;
-    a.active = (const uint8_t *)(base + oA); a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL);
-    a.pad = pad; a.rho = rho; a.total = (double *)(base + oT);
-    {
-        Scope sc(c, "fold_total");
-        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-    }
-    LAUNCH_CHECK("k_fold_total");
-    HIPOK(hipMemcpyAsync(total, a.total, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-extern "C" int csr_fold_mask_and_information(int64_t m, int64_t n, int64_t block_len, int64_t fold,
-                                             const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
-                                             int64_t slots, const void *munc, int32_t munc_is_f64, const uint8_t *active,
-                                             const double *total, const double *lambda, double pad, double rho,
-                                             uint8_t *mask, double *kept, double *heldout, double *h, double *nominal) {
-    DEFAULT_CTX_GUARD;
-    if (!block_fold || !reps_count || !reps || !munc || !active || !total || !mask || !kept || !heldout || !h)
-        return fail("null argument");
-    if (m < 1 || n < 1 || block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
-    csr_ctx *c = default_ctx();
-    if (!c) return -1;
-    CHECK(ctx_select(c));
-    const int64_t bc = (n + block_len - 1) / block_len;
-    const size_t es = munc_is_f64 ? 8 : 4, mn = (size_t)m * n, nv = 8 * (size_t)n;
-    size_t need_ = 0;
-    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
-    const size_t oM = take(es * mn), oA = take(mn), oK = take(mn), oL = take(nv), oT = take(nv);
-    const size_t oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc), oRB = take(8 * (size_t)bc * slots);
-    const size_t oKe = take(nv), oHe = take(nv), oH = take(nv), oNo = take(nv);
-    char *base;
-    CHECK(fold_stage(c, need_, &base));
-    HIPOK(hipMemcpyAsync(base + oM, munc, es * mn, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oA, active, mn, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oT, total, nv, hipMemcpyHostToDevice, c->stream));
-    if (lambda) HIPOK(hipMemcpyAsync(base + oL, lambda, nv, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
-    FoldArgs a;
-    memset(&a, 0, sizeof(a));
-    a.m = m; a.n = n; a.stride = n; a.blockLen = block_len; a.fold = fold; a.slots = slots;
-    a.munc = base + oM; a.muncF64 = munc_is_f64 ? 1 : 0; a.hasActive = 1; a.active = (const uint8_t *)(base + oA);
-    a.useLambda = lambda ? 1 : 0; a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT);
-    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
-    a.pad = pad; a.rho = rho; a.wantNominal = nominal ? 1 : 0;
-    a.mask = (uint8_t *)(base + oK); a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe);
-    a.h = (double *)(base + oH); a.nominal = (double *)(base + oNo);
-    {
-        Scope sc(c, "fold_mask");
-        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-    }
-    LAUNCH_CHECK("k_fold_mask");
-    HIPOK(hipMemcpyAsync(mask, a.mask, mn, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
-    if (nominal) HIPOK(hipMemcpyAsync(nominal, a.nominal, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-extern "C" int csr_batch_make_fold(csr_ctx *c, int32_t src, int32_t dst, int64_t block_len, int64_t fold,
-                                   const int32_t *block_fold, const int64_t *reps_count, const int64_t *reps,
-                                   int64_t slots, int32_t use_lambda, double pad, double rho, float masked_variance,
-                                   double *kept, double *heldout, double *h) {
-    CHECK(need(c));
-    CHECK(settle(c));
-    const int nc = (int)c->chains.size();
-    if (src < 0 || src >= nc || dst < 0 || dst >= nc || src == dst) return fail("bad chain index");
-    if (!block_fold || !reps_count || !reps || !kept || !heldout || !h) return fail("null argument");
-    const ChainInfo &cs = c->chains[src], &cd = c->chains[dst];
-    if (cs.n != cd.n) return fail("fold chain must have the length of its source chain");
-    if (block_len < 1 || slots < 1) return fail("invalid uncertainty calibration mask dimensions");
-    const int64_t n = cs.n, m = c->m, bc = (n + block_len - 1) / block_len;
-    const size_t nv = 8 * (size_t)n;
-    size_t need_ = 0;
-    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
-    const size_t oL = take(nv), oT = take(nv), oBF = take(4 * (size_t)bc), oRC = take(8 * (size_t)bc),
-                 oRB = take(8 * (size_t)bc * slots), oKe = take(nv), oHe = take(nv), oH = take(nv);
-    char *base;
-    CHECK(fold_stage(c, need_, &base));
-    HIPOK(hipMemcpyAsync(base + oBF, block_fold, 4 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oRC, reps_count, 8 * (size_t)bc, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(base + oRB, reps, 8 * (size_t)bc * slots, hipMemcpyHostToDevice, c->stream));
-    FoldArgs a;
-    memset(&a, 0, sizeof(a));
-    a.m = m; a.n = n; a.stride = c->Npad; a.blockLen = block_len; a.fold = fold; a.slots = slots;
-    a.munc = c->p.munc + cs.off; a.muncF64 = 0; a.hasActive = 0;
-    a.useLambda = use_lambda ? 1 : 0;
-    if (use_lambda) {
-        // natural float32 lambda of the source chain -> double track on the device (the natives take float64)
-        return fail("use_lambda folds need an exported lambda track: not supported in this entry point yet");
-    }
-    a.lambda = (const double *)(base + oL); a.totalIn = (const double *)(base + oT); a.total = (double *)(base + oT);
-    a.blockFold = (const int32_t *)(base + oBF); a.repsCount = (const int64_t *)(base + oRC); a.reps = (const int64_t *)(base + oRB);
-    a.pad = pad; a.rho = rho;
-    a.kept = (double *)(base + oKe); a.heldout = (double *)(base + oHe); a.h = (double *)(base + oH);
-    a.srcData = c->p.data + cs.off;
-    a.dstData = const_cast<float *>(c->p.data) + cd.off;
-    a.dstMunc = const_cast<float *>(c->p.munc) + cd.off;
-    a.maskedVariance = masked_variance;
-    {
-        Scope sc(c, "fold_make");
-        hipLaunchKernelGGL(k_fold_total, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-        hipLaunchKernelGGL(k_fold_mask, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-    }
-    LAUNCH_CHECK("k_fold_mask");
-    HIPOK(hipMemcpyAsync(kept, a.kept, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(heldout, a.heldout, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipMemcpyAsync(h, a.h, nv, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    c->statsValid = c->haveFwd = c->haveBwd = false;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// debugging aids (not part of the public ABI)
-// ---------------------------------------------------------------------------------------------------------------
-extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uint32_t flags, int force, unsigned int *count) {
-    CHECK(need(c));
-    Prm p = c->p;
-    p.flags = flags;
-    p.debugForce = force;
-    p.warm = kind == 0 ? c->warmP : (kind == 1 ? c->warmX : c->warmB);
-    const int grid = (int)c->NG;
-    CHECK(settle(c));
-    p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + ST_DEBUG;
-    if (op == 0) {
-        if (kind == 0) hipLaunchKernelGGL(k_chain_spec<FwdPTrend>, dim3(grid), dim3(64), 0, c->stream, p);
-        if (kind == 1) hipLaunchKernelGGL(k_chain_spec<FwdXTrend>, dim3(grid), dim3(64), 0, c->stream, p);
-        if (kind == 2) hipLaunchKernelGGL(k_chain_spec<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p);
-    } else {
-        if (kind == 0) hipLaunchKernelGGL(k_chain_fix<FwdPTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
-        if (kind == 1) hipLaunchKernelGGL(k_chain_fix<FwdXTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
-        if (kind == 2) hipLaunchKernelGGL(k_chain_fix<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
-    }
-    LAUNCH_CHECK("debug chain step");
-    CHECK(read_mail(c, 16));
-    const unsigned int fresh = take_fresh(c, ST_DEBUG);
-    if (count) *count = fresh;
-    c->haveFwd = true;
-    return 0;
-}
-extern "C" int csr_debug_read(csr_ctx *c, int buf, void *dst, int64_t bytes) {
-    CHECK(need(c));
-    const void *src = nullptr;
-    switch (buf) {
-        case 0: src = c->p.carryIn; break;
-        case 1: src = c->p.carryOutA; break;
-        case 2: src = c->p.carryOutB; break;
-        case 3: src = c->p.tPf; break;
-        case 4: src = c->p.tS0u; break;
-        default: return fail("bad debug buffer");
-    }
-    HIPOK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
-    return 0;
-}
+// The rest of the host library, split by concern (same translation unit, order matters: later parts use earlier ones)
+#include "csr_host_batch.inl"
+#include "csr_host_pipeline.inl"
+#include "csr_host_single.inl"
+#include "csr_host_rows.inl"
+#include "csr_host_debug.inl"
