@@ -144,8 +144,9 @@ def test_fused_pipeline_and_failed_optimistic_validation(product, d):
                 assert np.array_equal(val, fused[key]), f"block={blk} warm={warm} {key}"
             else:
                 np.testing.assert_allclose(fused[key], val, rtol=1e-6, atol=1e-7, err_msg=f"{blk} {warm} {key}")
+        deferred = os.environ.get("CONSENRICH_AMD_DEFER", "1") != "0"       # the switch that disables optimistic launches
         if warm == (0, 16, 0):
-            assert fused["stats"]["pipeline_redos"] >= 1 and fused["stats"]["reruns_b"] > 0
+            assert fused["stats"]["reruns_b"] > 0 and (fused["stats"]["pipeline_redos"] >= 1 or not deferred)
         else:
             assert fused["stats"]["pipeline_redos"] == 0
 
@@ -170,8 +171,10 @@ def test_fused_forward_chain_with_failed_optimistic_validation(product, d):
             np.testing.assert_allclose(fused[key], val, rtol=2e-6, atol=2e-6 * max(scale, 1e-30) if isinstance(key, str)
                                        else 1e-6 * max(scale, 1e-30), err_msg=f"{blk} {warm} {key}")
         if warm == (0, 0, 0):
-            assert fused["stats"]["pipeline_redos"] >= 1 and fused["stats"]["reruns_p"] > 0
-            assert fused["stats"]["reruns_x"] == 0             # no separate state stage in the fused path
+            deferred = os.environ.get("CONSENRICH_AMD_DEFER", "1") != "0"
+            fusing = os.environ.get("CONSENRICH_AMD_FUSE", "1") != "0"
+            assert fused["stats"]["reruns_p"] > 0 and (fused["stats"]["pipeline_redos"] >= 1 or not deferred)
+            assert fused["stats"]["reruns_x"] == 0 or not fusing       # no separate state stage in the fused path
 
 
 def test_ulp_tolerant_validation_stays_within_parity_budget(product):
@@ -710,9 +713,14 @@ def test_batch_background_update_matches_oracle(product, oracle, mode):
         b2.stats()
         sd2, sn2 = b2.forward_backward(fl)
         b2.export(L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        # (tolerant validation: two batches with different window histories may accept different k-ulp carries, so the
+        # comparison is to the documented tolerance, not bitwise -- bit-exactness is test_folds_as_extra_chains' job)
         for c in range(len(n_list)):
-            assert np.array_equal(got[c][0], b2.download(c, "xs")) and np.array_equal(got[c][1], b2.download(c, "resid"))
-        assert np.array_equal(sn, sn2)
+            xs2, rs2 = b2.download(c, "xs"), b2.download(c, "resid")
+            lvl = np.maximum(np.abs(xs2[:, :1].astype(np.float64)), 1.0)
+            assert np.all(np.abs(got[c][0].astype(np.float64) - xs2) <= RTOL * lvl)
+            assert np.all(np.abs(got[c][1].astype(np.float64) - rs2) <= RTOL * lvl + ATOL)
+        np.testing.assert_allclose(sn, sn2, rtol=1e-8)
 
 
 def test_batch_background_error_statuses(product):
