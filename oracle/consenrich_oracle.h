@@ -128,6 +128,45 @@ void cor_fold_mask_information(int64_t m, int64_t n, int64_t block_len, int64_t 
                                int munc_f64, const uint8_t *active, const double *total, const double *lambda, double pad,
                                double rho, uint8_t *mask, double *kept, double *heldout, double *h, double *nominal);
 
+/* ---- initial process-noise (Q0) seed natives (qseed_oracle.c) -------------------------------- */
+enum {
+    COR_QSEED_ERR_DATA = 1,        /* "active matrixData values must be finite"             pyx:1580 */
+    COR_QSEED_ERR_OBSVAR = 2,      /* "active obsVar values must be positive finite"        pyx:1589 */
+    COR_QSEED_ERR_TRANSITION = 3,  /* "active transition values must be finite"             pyx:1593 */
+    COR_QSEED_ERR_PRECISION = 4,   /* "active transition precision must be positive finite" pyx:1596 */
+    COR_QSEED_ERR_SAMPLECAP = 5,   /* "precisionSampleCap must be positive"                 pyx:1572 */
+    COR_QSEED_ERR_POOLED = 6,      /* "active pooled observations must be finite with positive variance" pyx:1862 */
+    COR_QSEED_ERR_POST_DELTA = 7,  /* "deltas must be finite"                               pyx:2003 */
+    COR_QSEED_ERR_POST_S2 = 8,     /* "samplingVariances must be nonnegative finite"        pyx:2005 */
+    COR_QSEED_ERR_POST_W = 9,      /* "transitionWeights must be positive finite"           pyx:2007 */
+    COR_QSEED_ERR_POST_SCORE = 10, /* "q seed posterior produced a nonfinite score"         pyx:2112 */
+    COR_QSEED_ERR_POST_NORM = 11   /* "q seed posterior normalization failed"               pyx:2121 */
+};
+typedef struct cor_qseed_diag {
+    int64_t pairCount, sampledPairCount, precisionSampleCount, scanCount, candidateTransitionCount,
+        selectedTransitionCount;
+    int32_t cappedMode, pad_;
+    double precisionCap, precisionCapFraction, transitionSampleFraction;
+} cor_qseed_diag;
+typedef struct cor_qseed_post {
+    int64_t transitionCount;
+    int32_t ok, pad_;
+    double effectiveTransitionCount, medianSamplingVariance, priorLevel, posteriorModeLevel, posteriorMedianLevel,
+        posteriorQ05Level, posteriorQ95Level, transitionQ90;
+} cor_qseed_post;
+/* pyx:1441-1797 `cEstimateSameTrackProcessNoiseTransitions` on float64 (m,n) matrices + uint8 activity mask */
+int64_t cor_qseed_same_track(int64_t m, int64_t n, const double *data, const double *obs, const uint8_t *active,
+                             double capQuantile, double capMultiplier, int64_t maxTransitionSamples,
+                             int64_t precisionSampleCap, int64_t signalPanelSize, double *deltas, double *svar,
+                             double *weights, cor_qseed_diag *dg);
+/* pyx:1800-1902 `cEstimatePooledProcessNoiseTransitions` */
+int64_t cor_qseed_pooled(int64_t m, int64_t n, const double *data, const double *obs, const uint8_t *active,
+                         double *deltas, double *svar, double *weights);
+/* pyx:1905-2146 `cQSeedPosteriorFromTransitions` */
+int cor_qseed_posterior(int64_t count, const double *deltas, const double *s2, const double *weights, double qFloor,
+                        double qCap, double robustTNu, double qSeedPriorLevel, int64_t minTransitions,
+                        double priorLogSd, double defaultTNu, int64_t gridSize, cor_qseed_post *out);
+
 #ifdef __cplusplus
 }
 #endif

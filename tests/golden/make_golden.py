@@ -21,8 +21,10 @@ sys.path.insert(0, HERE)
 
 import bg_cases  # noqa: E402
 import unc_cases  # noqa: E402
+import qseed_cases  # noqa: E402
 import cases  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
+from oracle import qseed as orc_qseed  # noqa: E402
 from oracle import ref_loader  # noqa: E402
 
 
@@ -82,6 +84,20 @@ def main() -> int:
         for key, val in out_ref.items():
             if not np.array_equal(val, out_orc[key], equal_nan=True):
                 raise SystemExit(f"oracle != reference for case {case['name']} key {key}")
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out_ref)
+        n_written += 1
+    # Q0 seed natives (pyx:1441-2146) and the caller's composition run on the reference's natives
+    import functools
+
+    for case in qseed_cases.native_cases():
+        out_ref, out_orc = qseed_cases.run_native(ref, case), qseed_cases.run_native(orc_qseed, case)
+        qseed_cases.same(out_ref, out_orc)
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out_ref)
+        n_written += 1
+    for case in qseed_cases.estimate_cases():
+        out_ref = qseed_cases.run_estimate(functools.partial(orc_qseed.estimate_initial_process_noise, ref), case)
+        out_orc = qseed_cases.run_estimate(functools.partial(orc_qseed.estimate_initial_process_noise, orc_qseed), case)
+        qseed_cases.same(out_ref, out_orc)
         np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out_ref)
         n_written += 1
     print(f"{n_written} fixtures written; oracle == reference on all of them")

@@ -20,11 +20,13 @@ def _build_oracle():
 
 def test_every_case_has_a_fixture():
     import bg_cases
+    import qseed_cases
     import unc_cases
 
     have = {f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz")}
     assert have == (set(CASES) | {c["name"] for c in bg_cases.solve_cases()} | {"bg_stats"}
-                    | {c["name"] for c in unc_cases.cases()})
+                    | {c["name"] for c in unc_cases.cases()}
+                    | {c["name"] for c in qseed_cases.native_cases() + qseed_cases.estimate_cases()})
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
