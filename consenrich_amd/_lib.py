@@ -79,6 +79,45 @@ class BgOut(C.Structure):
     ]
 
 
+class QseedSampleCfg(C.Structure):
+    _fields_ = [("precision_cap_quantile", C.c_double), ("precision_cap_multiplier", C.c_double),
+                ("max_transition_samples", C.c_int64), ("precision_sample_cap", C.c_int64),
+                ("signal_panel_size", C.c_int64)]
+
+
+class QseedSampleDiag(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("pair_count", "sampled_pair_count", "precision_sample_count", "scan_count",
+                                         "candidate_count", "selected_count")] + \
+               [("capped_mode", C.c_int32), ("reserved", C.c_int32), ("precision_cap", C.c_double),
+                ("precision_cap_fraction", C.c_double), ("transition_sample_fraction", C.c_double)]
+
+
+class QseedPostCfg(C.Structure):
+    _fields_ = [("q_floor", C.c_double), ("q_cap", C.c_double), ("robust_t_nu", C.c_double),
+                ("q_seed_prior_level", C.c_double), ("min_transitions", C.c_int64), ("prior_log_sd", C.c_double),
+                ("default_t_nu", C.c_double), ("grid_size", C.c_int64)]
+
+
+class QseedPost(C.Structure):
+    _fields_ = [("transition_count", C.c_int64), ("ok", C.c_int32), ("reserved", C.c_int32)] + \
+               [(k, C.c_double) for k in ("effective_transition_count", "median_sampling_variance", "prior_level",
+                                          "posterior_mode", "posterior_median", "posterior_q05", "posterior_q95",
+                                          "transition_q90")]
+
+
+class QseedCfg(C.Structure):
+    _fields_ = [("sample", QseedSampleCfg), ("pad", C.c_double), ("min_q", C.c_double), ("max_q", C.c_double),
+                ("delta_f", C.c_double), ("robust_t_nu", C.c_double), ("q_seed_prior_level", C.c_double),
+                ("min_transitions", C.c_int64), ("prior_log_sd", C.c_double), ("default_t_nu", C.c_double),
+                ("grid_size", C.c_int64), ("state_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
+class QseedOut(C.Structure):
+    _fields_ = [("q_level", C.c_double), ("q_trend", C.c_double), ("level_pre_clamp", C.c_double),
+                ("trend_pre_clamp", C.c_double), ("source", C.c_int32), ("reason", C.c_int32),
+                ("sample", QseedSampleDiag), ("post", QseedPost)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -144,6 +183,11 @@ SYMBOLS = {
     "csr_backward_pass": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, C.c_int64, FP]),
     "csr_fixed_background_ecm": (C.c_int, [C.POINTER(Model), C.POINTER(EcmCfg), C.c_int64, C.c_int64, FP, FP, FP, FP,
                                            FP, FP, FP, FP, FP, DP, C.POINTER(EcmOut)]),
+    "csr_qseed_same_track": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), C.POINTER(QseedSampleCfg), DP, DP,
+                                       DP, I64P, C.POINTER(QseedSampleDiag)]),
+    "csr_qseed_pooled": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), DP, DP, DP, I64P]),
+    "csr_qseed_posterior": (C.c_int, [C.c_int64, DP, DP, DP, C.POINTER(QseedPostCfg), C.POINTER(QseedPost)]),
+    "csr_batch_qseed": (C.c_int, [C.c_void_p, C.POINTER(QseedCfg), C.POINTER(QseedOut)]),
     "csr_expected_transition_residual_sums": (C.c_int, [C.c_int32, C.c_int64, DP, DP, DP, DP, DP, DP, I64P]),
 }
 

@@ -242,6 +242,21 @@ class DeviceBatch:
                                               float(masked_variance), L.dp(kept), L.dp(held), L.dp(h)))
         return kept, held, h
 
+    def qseed(self, *, pad: float, stateModel: str = "levelTrend", minQ: float = 1.0e-6, maxQ: float = 1000.0,
+              deltaF: float = 1.0, robustTNu=8.0, qSeedPriorLevel: float = 1.0e-5):
+        """Initial process-noise seed of every chain (core.py:3621-3780 `_estimateInitialProcessNoiseFromData`) from the
+        resident float32 data / variance matrices: list of (matrixQ float32 (2,2), diagnostics dict), one per chain."""
+        from . import qseed as Q
+
+        for name, v in (("minQ", minQ), ("minQ", qSeedPriorLevel)):
+            if not np.isfinite(v) or v <= 0.0:
+                raise ValueError(f"`{name}` must be positive and finite")
+        cfg = Q.seed_config(pad=pad, stateModel=stateModel, minQ=minQ, maxQ=maxQ, deltaF=deltaF, robustTNu=robustTNu,
+                            qSeedPriorLevel=qSeedPriorLevel)
+        out = (L.QseedOut * len(self.chain_lens))()
+        Q._call(self._lib.csr_batch_qseed(self._ctx, C.byref(cfg), out))
+        return [Q.seed_result(o, float(minQ)) for o in out]
+
     def export(self, what: int):
         L.check(self._lib.csr_batch_export(self._ctx, int(what)))
 

@@ -602,3 +602,11 @@ def cbackgroundWeightedStatsWithSupport(residualMatrix, invVarMatrix):
     sup = C.c_int64(0)
     L.check(L.lib().csr_background_weighted_stats(m, n, L.fp(res), L.fp(inv), L.dp(w), L.dp(r), C.byref(sup)))
     return w, r, int(sup.value)
+
+
+# natives of the initial process-noise seed (pyx:1441-2146), implemented in consenrich_amd/qseed.py
+from .qseed import (  # noqa: E402,F401
+    cEstimatePooledProcessNoiseTransitions,
+    cEstimateSameTrackProcessNoiseTransitions,
+    cQSeedPosteriorFromTransitions,
+)

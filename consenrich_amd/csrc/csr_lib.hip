@@ -6,8 +6,10 @@
 #include "csr_background.h"
 #include "csr_writers.h"
 #include "csr_folds.h"
+#include "csr_qseed.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace csr;
@@ -157,6 +160,7 @@ struct csr_ctx {
         double *dPen = nullptr;
         long long *dSelRank = nullptr;
     } bg;
+    DevBuf qsBuf;                       // Q0-seed work space
     DevBuf bgBuf, wrBuf, textBuf;       // host-buffer background solver / bedGraph writer work space (this device)
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -273,7 +277,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
             hipEventDestroy(pr.second);
         }
     for (hipEvent_t ev : c->eventPool) hipEventDestroy(ev);
-    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
+    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf})
         if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) hipHostFree(c->hMail);
     if (c->evFork) hipEventDestroy(c->evFork);
@@ -413,4 +417,5 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
 #include "csr_host_pipeline.inl"
 #include "csr_host_single.inl"
 #include "csr_host_rows.inl"
+#include "csr_host_qseed.inl"
 #include "csr_host_debug.inl"

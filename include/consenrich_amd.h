@@ -325,6 +325,65 @@ int csr_batch_make_fold(csr_ctx *ctx, int32_t src, int32_t dst, int64_t block_le
                         const int64_t *reps_count, const int64_t *reps, int64_t slots, int32_t use_lambda, double pad,
                         double rho, float masked_variance, double *kept, double *heldout, double *h);
 
+/* ---- the initial process-noise (Q0) seed ---------------------------------------------------------
+ * csr_qseed_same_track = cEstimateSameTrackProcessNoiseTransitions (cconsenrich.pyx:1441-1797), csr_qseed_pooled =
+ * cEstimatePooledProcessNoiseTransitions (pyx:1800-1902), csr_qseed_posterior = cQSeedPosteriorFromTransitions
+ * (pyx:1905-2146), all after the Python-level argument validation.  Matrices are (m,n) C-order float64 + uint8 mask, as
+ * the reference's natives take them; outputs need capacity min(n-1, max_transition_samples > 0 ? that : n-1) (same
+ * track) or n-1 (pooled).  Data-dependent errors return nonzero with the reference's message in csr_last_error().
+ * The sampled columns are gathered and reduced on the device; the bounded tail (two quantiles of <= precision_sample_cap
+ * precisions, the stable ordering of <= 32 000 signal levels, the 64-point grid posterior over <= 2048 transitions) is
+ * host arithmetic inside the library, in the reference's operation order (bit-identical transitions). */
+typedef struct csr_qseed_sample_cfg {
+    double precision_cap_quantile, precision_cap_multiplier;   /* core.py:277-278: 0.95, 20 */
+    int64_t max_transition_samples, precision_sample_cap, signal_panel_size;   /* core.py:273-276: 32000, 32000, 2048 */
+} csr_qseed_sample_cfg;
+typedef struct csr_qseed_sample_diag {
+    int64_t pair_count, sampled_pair_count, precision_sample_count, scan_count, candidate_count, selected_count;
+    int32_t capped_mode, reserved;
+    double precision_cap, precision_cap_fraction, transition_sample_fraction;
+} csr_qseed_sample_diag;
+typedef struct csr_qseed_post_cfg {
+    double q_floor, q_cap /* may be +inf */, robust_t_nu, q_seed_prior_level;
+    int64_t min_transitions;        /* core.py:272: 8 */
+    double prior_log_sd, default_t_nu;   /* core.py:279-280: log 4, 8 */
+    int64_t grid_size;              /* core.py:275: 64 */
+} csr_qseed_post_cfg;
+typedef struct csr_qseed_post {
+    int64_t transition_count;
+    int32_t ok, reserved;
+    double effective_transition_count, median_sampling_variance, prior_level, posterior_mode, posterior_median,
+        posterior_q05, posterior_q95, transition_q90;
+} csr_qseed_post;
+int csr_qseed_same_track(int64_t m, int64_t n, const double *data, const double *obs_var, const uint8_t *active,
+                         const csr_qseed_sample_cfg *cfg, double *deltas, double *sampling_var, double *weights,
+                         int64_t *out_count, csr_qseed_sample_diag *diag);
+int csr_qseed_pooled(int64_t m, int64_t n, const double *data, const double *obs_var, const uint8_t *active,
+                     double *deltas, double *sampling_var, double *weights, int64_t *out_count);
+int csr_qseed_posterior(int64_t count, const double *deltas, const double *sampling_var, const double *weights,
+                        const csr_qseed_post_cfg *cfg, csr_qseed_post *out);
+/* The caller `_estimateInitialProcessNoiseFromData` (core.py:3621-3780) for every chain of a batch, on the resident
+ * float32 data / variance matrices (nothing is converted or masked on the host; only the sampled columns are read):
+ * same-track estimate -> pooled fallback -> median-observation-variance fallback -> clamps.  out: n_chains records.
+ * source: 0 sameTrackEB, 1 pooledEB, 2 observationVarianceFloor, 3 minQ; reason: 0 ok, 1 fallback_observation_variance,
+ * 2 fallback_min_q, 3 insufficient_transition_support (never final).  state_dim 2 = levelTrend, 1 = level. */
+typedef struct csr_qseed_cfg {
+    csr_qseed_sample_cfg sample;
+    double pad, min_q, max_q /* < 0 or non-finite: no cap */, delta_f, robust_t_nu /* NaN: default */, q_seed_prior_level;
+    int64_t min_transitions;
+    double prior_log_sd, default_t_nu;
+    int64_t grid_size;
+    int32_t state_dim, reserved;
+} csr_qseed_cfg;
+typedef struct csr_qseed_out {
+    double q_level, q_trend;                 /* diagonal of matrixQ before its float32 cast (qSeedLevelFinal / TrendFinal) */
+    double level_pre_clamp, trend_pre_clamp;
+    int32_t source, reason;
+    csr_qseed_sample_diag sample;            /* of the same-track scan */
+    csr_qseed_post post;                     /* of the estimate that was used (ok = 0: none was) */
+} csr_qseed_out;
+int csr_batch_qseed(csr_ctx *ctx, const csr_qseed_cfg *cfg, csr_qseed_out *out);
+
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */
