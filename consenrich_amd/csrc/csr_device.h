@@ -129,6 +129,34 @@ __device__ __forceinline__ double rcp_nr(double x) {
     return r;
 }
 
+// Natural logarithm for the per-bin likelihood terms (k_fwd_dstat is bound by fp64 instruction issue, and the library
+// log is ~100 of them): x = 2^e m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716; the odd
+// series to s^21 leaves a truncation error below 2e-18.  Relative error ~2e-16 (1-2 ulp), also for x -> 1 (s is formed
+// from the exactly representable m - 1).  Non-positive, non-finite and subnormal arguments take the library routine.
+__device__ __forceinline__ double log_pos(double x) {
+    if (!(x >= 2.2250738585072014e-308) || !(x <= 1.7976931348623157e308)) return log(x);
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440) {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double z = s * s;
+    double q = 1.0 / 21.0;
+    q = fma(q, z, 1.0 / 19.0);
+    q = fma(q, z, 1.0 / 17.0);
+    q = fma(q, z, 1.0 / 15.0);
+    q = fma(q, z, 1.0 / 13.0);
+    q = fma(q, z, 1.0 / 11.0);
+    q = fma(q, z, 1.0 / 9.0);
+    q = fma(q, z, 1.0 / 7.0);
+    q = fma(q, z, 1.0 / 5.0);
+    q = fma(q, z, 1.0 / 3.0);
+    const double lm = fma(2.0 * s * z, q, 2.0 * s);
+    return fma((double)e, 0.693147180559945309417232121458, lm);
+}
+
 __device__ __forceinline__ int64_t tbase(int64_t b, int B) { return ((b >> 6) * (int64_t)B) * 64 + (b & 63); }
 __device__ __forceinline__ int64_t tidx(int64_t b, int s, int B) { return tbase(b, B) + (int64_t)s * 64; }
 
@@ -198,6 +226,8 @@ struct BinStats {
 // pivot z_0 (first sample), then zbar = z_0 + A/S0 and S2c = B - A^2/S0.  The shift keeps the cancellation in B - A^2/S0
 // at (z_0 - zbar)^2 / var, i.e. a relative error of ~1e-16 * that ratio -- >= 8 digits of headroom to the 1e-5 budget
 // even for a 10^4-sigma pivot.  1/R uses v_rcp_f64 + two Newton steps (<= 1 ulp).
+// UN = sample rows loaded together (2 * UN loads in flight per thread)
+template <int UN = 8>
 __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, const float *__restrict__ munc,
                                               int64_t stride, int64_t g, int m, double pad, float bgv) {
     // bgv: background of this bin; z = data - background is formed in float32 like the reference's dataAdjusted
@@ -206,15 +236,15 @@ __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, co
     int ex = 0;
     const float *dp = data + g, *mp = munc + g;
     int j = 0;
-    for (; j + 8 <= m; j += 8) {
-        float z[8], v[8];
+    for (; j + UN <= m; j += UN) {
+        float z[UN], v[UN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
             z[u] = dp[(int64_t)(j + u) * stride] - bgv;
             v[u] = mp[(int64_t)(j + u) * stride];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
             double R = (double)v[u] + pad;
             if (R < 1.0e-12) R = 1.0e-12;
             const double w = rcp_nr(R);
@@ -256,7 +286,7 @@ __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, co
 // from every sample row (TS*4-byte contiguous segments), reduced over the m samples, transposed through LDS and
 // written as TS rows of TL*8 bytes (a full 128-B line for TL = 16).  TS*TL/256 passes of 256 threads per tile; the tile
 // is kept small (<= 35 KB of LDS) so that >= 4 waves/SIMD are resident to cover the HBM latency.
-template <int TS, int TL>
+template <int TS, int TL, int UN = 8>
 __global__ __launch_bounds__(256) void k_stats(Prm p) {
     constexpr int RP = 256 / TS;            // runs handled per pass (TS <= 256)
     constexpr int LT = 64 / TL;             // lane-tiles per wave-group
@@ -278,7 +308,7 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
             const int4 bi = p.blk[b];
             if (s0 + si < bi.y && chain_on(p, b)) {
                 const int64_t g = (int64_t)bi.x + s0 + si;
-                o = bin_stats(p.data, p.munc, p.Npad, g, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
+                o = bin_stats<UN>(p.data, p.munc, p.Npad, g, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
             }
         }
         tile[0][si][ll] = o.s0;
@@ -1454,41 +1484,61 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
         const double mD = (double)p.m;
         const double log2pi = 1.8378770664093454835606594728112;
         const bool wantNLL = (p.flags & F_NLL) != 0;
-        for (int s = sBeg; s < sEnd; ++s) {
-            const int64_t i = base + (int64_t)s * 64;
-            const double lam = (p.flags & F_LAMBDA) ? clampd((double)p.tLam[i], p.wMin, p.wMax) : 1.0;
-            double xp0, pp;
-            if (p.d == 2) {
-                double x0, x1;
-                if (s > 0) { const float2 v = p.tXf[i - 64]; x0 = v.x; x1 = v.y; }
-                else if (b > bi.z) { const float2 v = p.tXf[tidx(b - 1, p.B - 1, p.B)]; x0 = v.x; x1 = v.y; }
-                else { x0 = (double)(float)p.init; x1 = 0.0; }
-                xp0 = r32(fma(p.F01, x1, p.F00 * x0));
-                pp = p.predCompact ? (double)p.tPP[i] : (double)p.tXin[i].z;
-            } else {
-                if (s > 0) xp0 = p.tXd[i - 64];
-                else if (b > bi.z) xp0 = p.tXd[tidx(b - 1, p.B - 1, p.B)];
-                else xp0 = p.init;
-                { const float4 r = p.tXin[i]; pp = unpack_d(r.z, r.w); }
+        // DU steps at a time: their loads are issued together (the stores to tD may alias the inputs as far as the
+        // compiler knows, so a step-by-step loop keeps only one step of loads in flight per wave)
+        constexpr int DU = 4;
+        for (int s0 = sBeg; s0 < sEnd; s0 += DU) {
+            double lamv[DU], xp0v[DU], ppv[DU], s0u[DU], zb[DU], s2c[DU], slr[DU];
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                const int s = s0 + u;
+                lamv[u] = 1.0; xp0v[u] = 0.0; ppv[u] = 0.0; s0u[u] = 0.0; zb[u] = 0.0; s2c[u] = 0.0; slr[u] = 0.0;
+                if (s >= sEnd) continue;
+                const int64_t i = base + (int64_t)s * 64;
+                if (p.flags & F_LAMBDA) lamv[u] = clampd((double)p.tLam[i], p.wMin, p.wMax);
+                if (p.d == 2) {
+                    double x0, x1;
+                    if (s > 0) { const float2 v = p.tXf[i - 64]; x0 = v.x; x1 = v.y; }
+                    else if (b > bi.z) { const float2 v = p.tXf[tidx(b - 1, p.B - 1, p.B)]; x0 = v.x; x1 = v.y; }
+                    else { x0 = (double)(float)p.init; x1 = 0.0; }
+                    xp0v[u] = r32(fma(p.F01, x1, p.F00 * x0));
+                    ppv[u] = p.predCompact ? (double)p.tPP[i] : (double)p.tXin[i].z;
+                } else {
+                    if (s > 0) xp0v[u] = p.tXd[i - 64];
+                    else if (b > bi.z) xp0v[u] = p.tXd[tidx(b - 1, p.B - 1, p.B)];
+                    else xp0v[u] = p.init;
+                    { const float4 r = p.tXin[i]; ppv[u] = unpack_d(r.z, r.w); }
+                }
+                s0u[u] = p.tS0u[i];
+                zb[u] = p.tZbar[i];
+                s2c[u] = p.tS2c[i];
+                if (wantNLL) slr[u] = p.tLogR[i];
             }
-            const double S0 = lam * p.tS0u[i];
-            const double dz = p.tZbar[i] - xp0;
-            const double S1 = S0 * dz;
-            const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
-            const double is = 1.0 + pp * S0;
-            const double gl = pp / is;
-            double quad = S2 - gl * (S1 * S1);
-            if (quad < 0.0) quad = 0.0;
-            double nll = 0.0;
-            if (wantNLL) {
-                double SL = p.tLogR[i];
-                if (p.flags & F_LAMBDA) SL -= mD * log(lam);
-                nll = 0.5 * (SL + log(is) + quad + mD * log2pi);
-                sumN += nll;
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                const int s = s0 + u;
+                if (s >= sEnd) continue;
+                const int64_t i = base + (int64_t)s * 64;
+                const double lam = lamv[u], pp = ppv[u];
+                const double S0 = lam * s0u[u];
+                const double dz = zb[u] - xp0v[u];
+                const double S1 = S0 * dz;
+                const double S2 = fma(S0, dz * dz, lam * s2c[u]);
+                const double is = 1.0 + pp * S0;
+                const double gl = pp * rcp_nr(is);
+                double quad = S2 - gl * (S1 * S1);
+                if (quad < 0.0) quad = 0.0;
+                double nll = 0.0;
+                if (wantNLL) {
+                    double SL = slr[u];
+                    if (p.flags & F_LAMBDA) SL -= mD * log_pos(lam);
+                    nll = 0.5 * (SL + log_pos(is) + quad + mD * log2pi);
+                    sumN += nll;
+                }
+                const float D = (float)((wantNLL && (p.flags & F_NLL_IN_D)) ? nll : quad / mD);
+                p.tD[i] = D;
+                sumD += (double)D;
             }
-            const float D = (float)((wantNLL && (p.flags & F_NLL_IN_D)) ? nll : quad / mD);
-            p.tD[i] = D;
-            sumD += (double)D;
         }
     }
     redD[part][lane] = sumD;
@@ -1823,37 +1873,57 @@ __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xs
 }
 
 // vectorised variant for m % 4 == 0: 16-byte loads of four consecutive bins per sample row, 16-byte stores of four
-// consecutive samples of one bin.  One workgroup = 64 bins x m samples.
+// consecutive samples of one bin.  One workgroup = K * 64 bins x m samples: K independent 16-byte loads per thread and
+// sweep are in flight together (K = 1 leaves the kernel latency-bound: 2 loads per thread at m = 32).
+template <int K>
 __global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
-    extern __shared__ float tileR[];                 // [m][68]: row stride 68 floats keeps float4 rows 16-B aligned
-    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    extern __shared__ float tileR[];                 // [m][K*64+4]: the row stride keeps float4 rows 16-B aligned
+    constexpr int RS = K * 64 + 4;
+    const int64_t g0 = (int64_t)blockIdx.x * (K * 64);
     const int t = threadIdx.x;
     const int q = t & 15, r0 = t >> 4;               // q: group of 4 bins, r0: sample row within a sweep of 16
-    const int64_t g = g0 + 4 * q;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
-    float4 bg4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g + 3 < nBins) {
-        x0 = xsNat[(g + 0) * xsStride]; x1 = xsNat[(g + 1) * xsStride];
-        x2 = xsNat[(g + 2) * xsStride]; x3 = xsNat[(g + 3) * xsStride];
-        if (p.bg) bg4 = *reinterpret_cast<const float4 *>(p.bg + g);
+    float x[K][4];
+    float4 bg4[K];
+    bool ok[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int64_t g = g0 + u * 64 + 4 * q;
+        ok[u] = g + 3 < nBins;
+        bg4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f;
+        if (ok[u]) {
+            x[u][0] = xsNat[(g + 0) * xsStride]; x[u][1] = xsNat[(g + 1) * xsStride];
+            x[u][2] = xsNat[(g + 2) * xsStride]; x[u][3] = xsNat[(g + 3) * xsStride];
+            if (p.bg) bg4[u] = *reinterpret_cast<const float4 *>(p.bg + g);
+        }
     }
     for (int j = r0; j < p.m; j += 16) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g + 3 < nBins) {
-            const float4 z = *reinterpret_cast<const float4 *>(p.data + (int64_t)j * p.Npad + g);
-            v.x = (float)((double)(z.x - bg4.x) - (double)x0); v.y = (float)((double)(z.y - bg4.y) - (double)x1);
-            v.z = (float)((double)(z.z - bg4.z) - (double)x2); v.w = (float)((double)(z.w - bg4.w) - (double)x3);
+        float4 z[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            z[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) z[u] = *reinterpret_cast<const float4 *>(p.data + (int64_t)j * p.Npad + g0 + u * 64 + 4 * q);
         }
-        *reinterpret_cast<float4 *>(tileR + j * 68 + 4 * q) = v;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) {
+                v.x = (float)((double)(z[u].x - bg4[u].x) - (double)x[u][0]);
+                v.y = (float)((double)(z[u].y - bg4[u].y) - (double)x[u][1]);
+                v.z = (float)((double)(z[u].z - bg4[u].z) - (double)x[u][2]);
+                v.w = (float)((double)(z[u].w - bg4[u].w) - (double)x[u][3]);
+            }
+            *reinterpret_cast<float4 *>(tileR + j * RS + u * 64 + 4 * q) = v;
+        }
     }
     __syncthreads();
     const int m4 = p.m >> 2;
-    const int total4 = 64 * m4;
+    const int total4 = K * 64 * m4;
     for (int e = t; e < total4; e += 256) {
         const int bin = e / m4, j = (e - bin * m4) << 2;
         if (g0 + bin < nBins) {
-            const float4 o = make_float4(tileR[(j + 0) * 68 + bin], tileR[(j + 1) * 68 + bin],
-                                         tileR[(j + 2) * 68 + bin], tileR[(j + 3) * 68 + bin]);
+            const float4 o = make_float4(tileR[(j + 0) * RS + bin], tileR[(j + 1) * RS + bin],
+                                         tileR[(j + 2) * RS + bin], tileR[(j + 3) * RS + bin]);
             *reinterpret_cast<float4 *>(resid + (g0 + bin) * (int64_t)p.m + j) = o;
         }
     }

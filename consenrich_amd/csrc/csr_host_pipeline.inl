@@ -4,10 +4,10 @@
 // ---------------------------------------------------------------------------------------------------------------
 // compute
 // ---------------------------------------------------------------------------------------------------------------
-template <int TS, int TL>
+template <int TS, int TL, int UN = 8>
 static void launch_stats(csr_ctx *c, const Prm &p) {
     const int grid = (int)(c->NG * (c->B / TS) * (64 / TL));
-    hipLaunchKernelGGL((k_stats<TS, TL>), dim3(grid), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL((k_stats<TS, TL, UN>), dim3(grid), dim3(256), 0, c->stream, p);
 }
 
 extern "C" int csr_batch_stats(csr_ctx *c) {
@@ -20,6 +20,8 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
         if (ts == 0) ts = 64;
         if (c->B % ts != 0) ts = 32;
         if (ts == 128) launch_stats<128, 16>(c, p);
+        else if (ts == 64 && c->statsUnroll == 16) launch_stats<64, 16, 16>(c, p);
+        else if (ts == 64 && c->statsUnroll == 32) launch_stats<64, 16, 32>(c, p);
         else if (ts == 64) launch_stats<64, 16>(c, p);
         else launch_stats<32, 16>(c, p);
     }
@@ -143,10 +145,16 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
 
+// Join the side stream.  The per-chain sums (22 workgroups of 1024 threads, ~10 us) run on the main stream after the
+// join: left on the side stream behind the epilogue they starve for whole-CU slots while a bandwidth-bound kernel of the
+// main stream keeps the chip full (measured 0.64 ms instead of 0.01).
 static void join_side(csr_ctx *c) {
     if (c->sidePending) {
         hipStreamWaitEvent(c->stream, c->evJoin, 0);
         c->sidePending = false;
+        Scope sc(c, "chain_sums");
+        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, c->sidePrm, c->dChainFirst,
+                           c->dChainNb);
     }
 }
 
@@ -165,15 +173,17 @@ static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
         hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, st, p);
     }
     LAUNCH_CHECK("k_fwd_dstat");
+    if (side) {
+        HIPOK(hipEventRecord(c->evJoin, c->side));
+        c->sidePending = true;
+        c->sidePrm = p;                 // k_chain_sums follows on the main stream at the join
+        return 0;
+    }
     {
         Scope sc(c, "chain_sums", st);
         hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, st, p, c->dChainFirst, c->dChainNb);
     }
     LAUNCH_CHECK("k_chain_sums");
-    if (side) {
-        HIPOK(hipEventRecord(c->evJoin, c->side));
-        c->sidePending = true;
-    }
     return 0;
 }
 
@@ -492,7 +502,6 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
 // Exports may be queued behind an optimistically validated pipeline: they are re-issued by settle() if it fails.
 extern "C" int csr_batch_export(csr_ctx *c, uint32_t what) {
     CHECK(need(c));
-    join_side(c);
     if (c->pendFwd || c->pendBwd) c->pendExport |= what;
     return export_impl(c, what);
 }
@@ -529,9 +538,12 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     const int nv = d, nm = d * d;      // exported components of state vectors / covariance matrices
     ExpList L;
     memset(&L, 0, sizeof(L));
+    // The NIS/NLL track is the only export that depends on the side stream's epilogue: when that is still running it is
+    // converted last, after the (long, bandwidth-bound) residual kernel, so the epilogue leaves the critical path.
+    const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending;
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
-        CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
+        if (!lateD) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
         if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
             CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
             CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
@@ -565,13 +577,26 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(nat_array(c, CSR_ARR_XS, &xs));
         CHECK(nat_array(c, CSR_ARR_RESID, &res));
         Scope sc(c, "residuals");
-        if ((c->m & 3) == 0)
-            hipLaunchKernelGGL(k_resid_v4, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m, c->stream,
-                               c->p, xs, d, res, c->Npad);
-        else
+        if ((c->m & 3) == 0) {
+            const int K = (c->residTile == 1 || c->residTile == 2 || c->residTile == 4) ? c->residTile : 1;
+            const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
+            const dim3 grid((unsigned)((c->Npad + K * 64 - 1) / (K * 64)));
+            if (K == 4 && lds <= 65536)
+                hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, c->p, xs, d, res, c->Npad);
+            else if (K == 2 && lds <= 65536)
+                hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, c->p, xs, d, res, c->Npad);
+            else
+                hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
+                                   c->stream, c->p, xs, d, res, c->Npad);
+        } else
             hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
                                c->p, xs, d, res, c->Npad);
         LAUNCH_CHECK("k_resid");
+    }
+    if (lateD) {
+        join_side(c);
+        CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
+        CHECK(flush_export(c, L));
     }
     return 0;
 }

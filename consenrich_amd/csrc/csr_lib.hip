@@ -102,6 +102,8 @@ struct csr_ctx {
     bool adaptWarm = true;
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
     int xTolUlps = 2;
+    int statsUnroll = 8;    // sample rows loaded together by the statistics kernel (8, 16, 32)
+    int residTile = 2;      // residual kernel: 64-bin sub-tiles per workgroup (1, 2, 4); 2 measured best (0.665 vs 0.684 ms)
     int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
     // batch
     bool configured = false;
@@ -145,6 +147,7 @@ struct csr_ctx {
     int dbgForceIters = 0;
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
+    Prm sidePrm{};              // parameters of the epilogue running on the side stream (its sums follow at the join)
     uint32_t pendFlags = 0, pendExport = 0;
     bool pendWantD = false;
     const unsigned char *pendActiveF = nullptr, *pendActiveB = nullptr;
@@ -260,6 +263,8 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     c->dbgLog = getenv("CONSENRICH_AMD_DEBUG") != nullptr;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_RESID_TILE"))) c->residTile = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_STATS_UNROLL"))) c->statsUnroll = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
     if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
     return c;
