@@ -52,7 +52,11 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
         // below 2 M bins the chains are purely latency-bound (< 1 wave per SIMD): 32-bin blocks shorten every lane's walk
         // (80 + 32 instead of 80 + 64 steps; 0.436 -> 0.414 ms on a 1/8-genome shard).  Bit-exact mode keeps 64: its
         // state chain repairs one block per validation pass, shorter blocks mean more passes.
-        c->B = total >= (int64_t)24000000 ? 256 : (total >= (int64_t)2000000 ? 128 : (c->xTolUlps > 0 ? 32 : 64));
+        // 2 M .. 6 M bins (a quarter-genome shard): 64-bin blocks, 0.77 vs 0.82 ms with 128; above that 64 = 128.
+        c->B = total >= (int64_t)24000000 ? 256
+             : total >= (int64_t)6000000  ? 128
+             : total >= (int64_t)2000000  ? 64
+                                          : (c->xTolUlps > 0 ? 32 : 64);
     }
     const int B = c->B;
     int64_t off = 0, nb = 0;

@@ -540,7 +540,10 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     memset(&L, 0, sizeof(L));
     // The NIS/NLL track is the only export that depends on the side stream's epilogue: when that is still running it is
     // converted last, after the (long, bandwidth-bound) residual kernel, so the epilogue leaves the critical path.
-    const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending;
+    // (Small batches are launch-bound: there the extra conversion launch costs more than the overlap saves.)
+    const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending && (what & CSR_EXPORT_RESID) &&
+                       c->Npad >= ((int64_t)4 << 20);
+    if (!lateD) join_side(c);
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
         if (!lateD) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));

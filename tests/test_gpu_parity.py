@@ -218,10 +218,11 @@ def _full_chain(mod, d, n, m, seed=4242):
     return dict(phi=r[0], nll=r[3], xf=xf, Pf=Pf, pn=pn[: n - 1], D=D, xs=b[0], Ps=b[1], lag=b[2][: n - 1], resid=b[3])
 
 
-@pytest.mark.parametrize("d,n,m", [(2, 1000000, 4), (2, 1244783, 8), (1, 1000000, 4)])
+@pytest.mark.parametrize("d,n,m", [(2, 1000000, 4), (2, 1244783, 8), (1, 1000000, 4), (2, 2200000, 2)])
 def test_full_size_chain_matches_oracle(product, oracle, d, n, m):
     """BASELINE config sizes (1e6 x 4; chr1 @200bp x 8): the whole chain, every bin, against the CPU oracle in the
-    THROUGHPUT (2-ulp carry validation) mode.  |x| reaches ~30 here, so one float32 ulp of the level is 2e-6."""
+    THROUGHPUT (2-ulp carry validation) mode.  |x| reaches ~30 here, so one float32 ulp of the level is 2e-6.
+    (2.2e6 x 2: the automatic block length is 64 bins between 2 M and 6 M bins, 32 below.)"""
     product.set_validation(2)
     try:
         g = _full_chain(product, d, n, m)
