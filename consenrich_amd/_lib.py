@@ -118,6 +118,18 @@ class QseedOut(C.Structure):
                 ("sample", QseedSampleDiag), ("post", QseedPost)]
 
 
+class ObjectiveCfg(C.Structure):
+    _fields_ = [("nu", C.c_double), ("lam_first", C.c_double), ("lam", C.c_double),
+                ("negative_penalty_multiplier", C.c_double), ("pad", C.c_double), ("use_lambda_penalty", C.c_int32),
+                ("use_kappa_penalty", C.c_int32), ("use_lambda_weights", C.c_int32), ("use_nonnegative", C.c_int32)]
+
+
+class ObjectiveTerms(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("robust_observation_penalty", "robust_process_penalty",
+                                          "first_difference_penalty", "second_difference_penalty", "negative_penalty",
+                                          "weight_median")] + [("effective_observation_count", C.c_int64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -183,6 +195,8 @@ SYMBOLS = {
     "csr_backward_pass": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, C.c_int64, FP]),
     "csr_fixed_background_ecm": (C.c_int, [C.POINTER(Model), C.POINTER(EcmCfg), C.c_int64, C.c_int64, FP, FP, FP, FP,
                                            FP, FP, FP, FP, FP, DP, C.POINTER(EcmOut)]),
+    "csr_batch_objective_terms": (C.c_int, [C.c_void_p, C.POINTER(ObjectiveCfg), C.POINTER(ObjectiveTerms)]),
+    "csr_batch_forward_masked": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, DP, DP]),
     "csr_qseed_same_track": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), C.POINTER(QseedSampleCfg), DP, DP,
                                        DP, I64P, C.POINTER(QseedSampleDiag)]),
     "csr_qseed_pooled": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), DP, DP, DP, I64P]),

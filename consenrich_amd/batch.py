@@ -163,6 +163,26 @@ class DeviceBatch:
                                                L.dp(path)))
         return list(outs), path.reshape(nc, -1)
 
+    def forward_masked(self, flags: int, chain_mask):
+        """forward() for the chains with chain_mask[c] true only; returns (sum_d, sum_nll) (masked chains: stale)."""
+        nc = len(self.chain_lens)
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        mask = bytes(bytearray(int(bool(t)) for t in chain_mask))
+        L.check(self._lib.csr_batch_forward_masked(self._ctx, int(flags), mask, L.dp(sd), L.dp(sn)))
+        return sd, sn
+
+    def objective_terms(self, nu: float, lam_first: float, lam: float, negative_penalty_multiplier=1.0, pad=1.0e-4,
+                        use_lambda_penalty=False, use_kappa_penalty=True, use_lambda_weights=False, use_nonnegative=True):
+        """Everything of the reference's penalised objective (core.py:4418-4538) except the forward NLL, per chain, from
+        the resident variances / multipliers / current background; list of dicts."""
+        nc = len(self.chain_lens)
+        mult = float("nan") if negative_penalty_multiplier is None else float(negative_penalty_multiplier)
+        cfg = L.ObjectiveCfg(float(nu), float(lam_first), float(lam), mult, float(pad), int(use_lambda_penalty),
+                             int(use_kappa_penalty), int(use_lambda_weights), int(use_nonnegative))
+        out = (L.ObjectiveTerms * nc)()
+        L.check(self._lib.csr_batch_objective_terms(self._ctx, C.byref(cfg), out))
+        return [{k: getattr(o, k) for k, _ in L.ObjectiveTerms._fields_} for o in out]
+
     def diagnostics(self, flags: int = 0):
         """Per-interval output diagnostics (core.py:7734-7878) of the resident forward pass; results are the arrays
         sumGain0, sumGain1, effectiveQLevel, effectiveQTrend, muncTrace (download()).  flags: USE_LAMBDA / USE_KAPPA /

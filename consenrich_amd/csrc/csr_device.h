@@ -50,6 +50,7 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
+    int probeTiled;     // measurement probe only (wrong results): k_stats reads [tile][sample][64 bins] addresses
     int predCompact;    // fused forward chain: only the NIS epilogue reads the gain record, and only P00pred of it --
                         // store that float (tPP, 4 B/bin) instead of the 16-byte record
     float *tPP;
@@ -308,6 +309,10 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
             const int4 bi = p.blk[b];
             if (s0 + si < bi.y && chain_on(p, b)) {
                 const int64_t g = (int64_t)bi.x + s0 + si;
+                if (p.probeTiled) {
+                    const int64_t gt = (g >> 6) * ((int64_t)p.m << 6) + (g & 63);
+                    o = bin_stats<UN>(p.data, p.munc, 64, gt, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
+                } else
                 o = bin_stats<UN>(p.data, p.munc, p.Npad, g, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
             }
         }

@@ -14,6 +14,7 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
     CHECK(settle(c));
     Prm p = c->p;
+    p.probeTiled = getenv("CONSENRICH_AMD_PROBE_TILED") ? 1 : 0;
     {
         Scope sc(c, "stats");
         int ts = c->statsTile;
@@ -346,6 +347,21 @@ extern "C" int csr_batch_forward(csr_ctx *c, uint32_t flags, double *sum_d, doub
     CHECK(need(c));
     CHECK(settle(c));
     CHECK(forward_impl(c, flags, true, nullptr, true, false, true));
+    if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
+    return 0;
+}
+
+// chain_mask[c] == 0: chain c's resident forward results stay untouched (its sums are not updated)
+extern "C" int csr_batch_forward_masked(csr_ctx *c, uint32_t flags, const unsigned char *chain_mask, double *sum_d,
+                                        double *sum_nll) {
+    if (!chain_mask) return csr_batch_forward(c, flags, sum_d, sum_nll);
+    CHECK(need(c));
+    CHECK(settle(c));
+    const int nc = (int)c->chains.size();
+    std::vector<unsigned char> act(chain_mask, chain_mask + nc);
+    HIPOK(hipMemcpyAsync(c->dActive, act.data(), nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    CHECK(forward_impl(c, flags, true, c->dActive, true, false, false));
     if (sum_d || sum_nll) CHECK(read_sums(c, sum_d, sum_nll));
     return 0;
 }

@@ -656,6 +656,109 @@ extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// terms of the penalised objective of the outer stop rule (core.py:4418-4538) for every chain
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_batch_objective_terms(csr_ctx *c, const csr_objective_cfg *cfg, csr_objective_terms *out) {
+    CHECK(need(c));
+    if (!cfg || !out) return fail("null argument");
+    CHECK(settle(c));
+    CHECK(bg_setup(c, c->bg.ready ? c->bg.Bp : 1024));
+    csr_ctx::BgState &S = c->bg;
+    BgBatch a = S.bat;
+    const int nc = (int)c->chains.size();
+    const bool needLam = cfg->use_lambda_penalty || cfg->use_lambda_weights;
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        if (needLam) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        if (cfg->use_kappa_penalty) CHECK(add_export(c, L, CSR_ARR_KAPPA, c->p.tKap, 1, 1, 0));
+        CHECK(flush_export(c, L));
+    }
+    ObjArgs o;
+    memset(&o, 0, sizeof(o));
+    o.lamNat = needLam ? c->nat[CSR_ARR_LAMBDA] : nullptr;
+    o.kapNat = cfg->use_kappa_penalty ? c->nat[CSR_ARR_KAPPA] : nullptr;
+    o.bg = S.haveCur ? c->nat[CSR_ARR_BACKGROUND] : nullptr;
+    o.useLambdaPenalty = cfg->use_lambda_penalty ? 1 : 0;
+    o.useKappaPenalty = cfg->use_kappa_penalty ? 1 : 0;
+    o.useLambdaWeights = cfg->use_lambda_weights ? 1 : 0;
+    o.pad = cfg->pad; o.wMin = c->mdl.w_min; o.wMax = c->mdl.w_max;
+    o.maskedHalf = 0.5 * (double)1.0e30f;
+    const bool negActive = cfg->use_nonnegative && std::isfinite(cfg->negative_penalty_multiplier) &&
+                           cfg->negative_penalty_multiplier > 0.0;
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t q = need_; need_ += (b + 255) / 256 * 256; return q; };
+    const size_t oPart = take(8 * 6 * (size_t)a.NW), oOut = take(8 * 6 * (size_t)nc), oW = take(negActive ? 8 * (size_t)c->Npad : 8);
+    CHECK(c->qsBuf.reserve(need_));
+    char *base = (char *)c->qsBuf.ptr;
+    o.part = (double *)(base + oPart); o.chainOut = (double *)(base + oOut);
+    o.w64 = negActive ? (double *)(base + oW) : nullptr;
+    const int gridW = (a.NW + 3) / 4;
+    {
+        Scope sc(c, "objective_terms");
+        hipLaunchKernelGGL(k_obj_wave, dim3(gridW), dim3(256), 0, c->stream, c->p, a, o);
+        hipLaunchKernelGGL(k_obj_fold, dim3(nc), dim3(64), 0, c->stream, a, o);
+    }
+    LAUNCH_CHECK("k_obj_wave");
+    std::vector<double> t(6 * (size_t)nc);
+    HIPOK(hipMemcpyAsync(t.data(), o.chainOut, 8 * 6 * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> scale(nc, 1.0);
+    if (negActive) {      // median of the positive float64 weights (core.py:4437-4446), same selection passes as the update
+        a.w = o.w64;
+        auto wave_pass = [&](int what, int bit) {
+            hipLaunchKernelGGL(k_bg_wave_pass, dim3(gridW), dim3(256), 0, c->stream, c->p, a, what, bit,
+                               (const unsigned char *)nullptr);
+            hipLaunchKernelGGL(k_bg_wave_fold, dim3(nc), dim3(64), 0, c->stream, a, what, bit);
+        };
+        wave_pass(0, 0);
+        std::vector<double> cs(5 * (size_t)nc);
+        HIPOK(hipMemcpyAsync(cs.data(), a.chainSum, 8 * 5 * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        std::vector<long long> rank(2 * (size_t)nc, -1);
+        bool any = false;
+        for (int i = 0; i < nc; ++i) {
+            const long long sup = (long long)cs[5 * i + 1];       // entries > 0 (NaN / inf: see below)
+            if (sup <= 0) continue;
+            rank[2 * i] = (sup - 1) / 2;
+            rank[2 * i + 1] = sup / 2;
+            any = true;
+        }
+        if (any) {
+            HIPOK(hipMemcpyAsync(S.dSelRank, rank.data(), 8 * 2 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemsetAsync(a.selAns, 0, 8 * 2 * (size_t)nc, c->stream));
+            {
+                Scope sc(c, "objective_median");
+                for (int bit = 62; bit >= 0; --bit) wave_pass(1, bit);
+            }
+            LAUNCH_CHECK("objective median");
+            std::vector<double> mid(2 * (size_t)nc, 0.0);
+            HIPOK(hipMemcpyAsync(mid.data(), a.selAns, 8 * 2 * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(wait_stream(c));
+            for (int i = 0; i < nc; ++i) {
+                if (rank[2 * i] < 0) continue;
+                double sc = 0.5 * (mid[2 * i] + mid[2 * i + 1]);
+                if (!std::isfinite(sc) || sc <= 0.0) sc = 1.0;
+                scale[i] = sc;
+            }
+        }
+    } else {
+        HIPOK(wait_stream(c));
+    }
+    for (int i = 0; i < nc; ++i) {
+        csr_objective_terms &r = out[i];
+        const double *q = &t[6 * (size_t)i];
+        r.robust_observation_penalty = cfg->use_lambda_penalty ? 0.5 * cfg->nu * q[0] : 0.0;
+        r.robust_process_penalty = cfg->use_kappa_penalty ? 0.5 * cfg->nu * q[1] : 0.0;
+        r.first_difference_penalty = 0.5 * cfg->lam_first * q[2];
+        r.second_difference_penalty = 0.5 * cfg->lam * q[3];
+        r.weight_median = scale[i];
+        r.negative_penalty = negActive ? 0.5 * (cfg->negative_penalty_multiplier * scale[i]) * q[4] : 0.0;
+        r.effective_observation_count = std::max<int64_t>(1, (int64_t)q[5]);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
 // ---------------------------------------------------------------------------------------------------------------
 static int fold_stage(csr_ctx *c, size_t bytes, char **base) {

@@ -7,6 +7,7 @@
 #include "csr_writers.h"
 #include "csr_folds.h"
 #include "csr_qseed.h"
+#include "csr_objective.h"
 
 #include <algorithm>
 #include <cfloat>

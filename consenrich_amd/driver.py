@@ -9,16 +9,23 @@ Per outer pass, for the chains still iterating (chromosomes are independent fits
   3. `DeviceBatch.background_update()` -- weight / rhs tracks from the ORIGINAL data and the smoothed level, conditioning
      guard, pentadiagonal solve, asymmetric IRLS seeded with the current background (core.py:5064-5136);
   4. shift test: weighted RMS shift <= rtol * max(proposal RMS, reference RMS, 1) (core.py:5199-5243);
-  5. `DeviceBatch.background_apply(take=...)`; a chain stops when it was shift-stable with a converged inner ECM for
-     `patience` consecutive passes after `min_outer` passes (core.py:5244-5376).
+  5. `DeviceBatch.background_apply(take=...)`: the proposal is adopted (core.py:5243-5247);
+  6. penalised objective of the adopted background with the phase's multipliers (`_scorePenalizedObjective`,
+     core.py:4418-4538): `stats()` + `forward_masked(RETURN_NLL | multipliers)` give the forward NLL of data - background
+     (the statistics are the ones the next ECM phase starts from, so only the forward pass is extra, as in the
+     reference), `objective_terms()` the robust-precision, roughness and negative-part penalties and the effective
+     observation count; objective-stable when the per-cell change is within outer_nll_rtol * max(|cur|, |prev|, 1)
+     (`_recordOuterObjective`, core.py:4750-4830);
+  7. a chain stops when it was shift-stable AND objective-stable with a converged inner ECM for `patience` consecutive
+     passes after `min_outer` passes (core.py:5252-5376).
 
-The reference's stop rule additionally requires its penalised objective to be stable (`_recordOuterObjective`,
-core.py:4750-4830: one more forward-NLL pass per outer pass).  That term is not reproduced -- `consenrich.core` cannot be
-imported in the build image to pin it -- so this driver (and its CPU twin oracle/driver.py, which the tests compare it
-with) uses the two criteria above; everything the passes COMPUTE is the reference's arithmetic.
+Steps 6-7 restate pure-Python code of `consenrich.core`, which cannot be imported in the build image: they are checked
+against the CPU twin (oracle/driver.py) and a NumPy restatement of the formulas, not against reference outputs ("parity
+unpinned" for this part).  Everything the passes COMPUTE with natives is the reference's arithmetic.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
@@ -42,6 +49,8 @@ class FitConfig:
     outer_passes: int = 32
     min_outer: int = 3
     shift_rtol: float = 5.0e-3
+    outer_nll_rtol: float = 5.0e-5               # ECM_outerNLLRtol, constants.py:281
+    pad: float = 1.0e-4                          # the Python-float pad of the objective's weight track (core.py:4506)
     patience: int = 2
 
 
@@ -53,6 +62,7 @@ class ChainFit:
     nll: List[float] = field(default_factory=list)
     shift: List[float] = field(default_factory=list)
     irls_passes: List[int] = field(default_factory=list)
+    objective: List[dict] = field(default_factory=list)       # per pass: the reference's objective diagnostics
 
 
 def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
@@ -64,8 +74,12 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
     stable = [0] * nc
     for c in range(nc):
         batch.set_background(c, None)
+    prev_obj = [float("nan")] * nc
+    fwd_flags = L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
+    have_stats = False
     for p in range(cfg.outer_passes):
-        batch.stats()
+        if not have_stats:
+            batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
                             use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, chain_mask=active)
         for c in range(nc):
@@ -83,6 +97,14 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
         # proposal is applied: applying a background invalidates the resident fit, the exported arrays stay downloadable
         batch.export(L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
         take = list(active)
+        batch.background_apply(take)            # the proposal of a pass is always adopted (core.py:5243)
+        # penalised objective of the adopted background (core.py:5248-5251)
+        batch.stats()
+        have_stats = True
+        _, fnll = batch.forward_masked(fwd_flags, take)
+        terms = batch.objective_terms(cfg.nu, cfg.penalties[0], cfg.penalties[1], cfg.neg_multiplier, pad=cfg.pad,
+                                      use_lambda_penalty=cfg.use_lambda, use_kappa_penalty=cfg.use_kappa,
+                                      use_lambda_weights=cfg.use_lambda, use_nonnegative=cfg.use_nonnegative)
         for c in range(nc):
             if not active[c]:
                 continue
@@ -90,12 +112,21 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
             scale = max(o["proposal_rms"], o["reference_rms"], 1.0)
             fits[c].shift.append(float(o["shift_rms"]))
             fits[c].irls_passes.append(int(o["passes"]))
+            t = terms[c]
+            obj = (float(fnll[c]) + t["robust_observation_penalty"] + t["robust_process_penalty"]
+                   + (t["first_difference_penalty"] + t["second_difference_penalty"]) + t["negative_penalty"])
+            cur = obj / t["effective_observation_count"]
+            obj_stable = bool(math.isfinite(prev_obj[c]) and math.isfinite(cur)
+                              and abs(cur - prev_obj[c]) <= cfg.outer_nll_rtol * max(abs(cur), abs(prev_obj[c]), 1.0))
+            prev_obj[c] = cur
+            fits[c].objective.append(dict(t, forward_nll=float(fnll[c]), penalized_objective=obj,
+                                          penalized_objective_per_cell=cur, stable=obj_stable))
             inner_ok = bool(outs[c].converged) or bool(outs[c].skipped == 1)
-            stable[c] = stable[c] + 1 if (o["shift_rms"] <= cfg.shift_rtol * scale and inner_ok) else 0
+            ok = o["shift_rms"] <= cfg.shift_rtol * scale and obj_stable and inner_ok
+            stable[c] = stable[c] + 1 if ok else 0
             if p + 1 >= cfg.min_outer and stable[c] >= cfg.patience:
                 fits[c].converged = True
                 active[c] = False
-        batch.background_apply(take)            # the proposal of a pass is always adopted (core.py:5243)
         if not any(active):
             break
     if not cfg.fit_background:

@@ -288,6 +288,26 @@ int csr_batch_background_apply(csr_ctx *ctx, const unsigned char *take);
 /* H2D a background track for one chain (NULL: zeros). */
 int csr_batch_set_background(csr_ctx *ctx, int32_t chain, const float *background);
 
+/* ---- terms of the penalised objective of the outer stop rule (core.py:4418-4538) ---------------------------
+ * For every chain, from the resident variances, multipliers and CURRENT background: robust precision penalties
+ * 0.5 nu sum(x - log x) (core.py:3161-3179; kappa skips the first bin), roughness penalties 0.5 lam sum d^2
+ * (core.py:3182-3204), negative-part penalty 0.5 mult median(positive weights) sum min(bg,0)^2 (core.py:4431-4463; float64
+ * weight track sum_j clip(lambda)/max(munc+pad,1e-8)), effective observation count (core.py:2981-2986).  The caller adds
+ * the forward NLL of (data - background) (csr_batch_stats + csr_batch_forward_masked) and divides by the count. */
+typedef struct csr_objective_cfg {
+    double nu, lam_first, lam, negative_penalty_multiplier, pad;
+    int32_t use_lambda_penalty, use_kappa_penalty, use_lambda_weights, use_nonnegative;
+} csr_objective_cfg;
+typedef struct csr_objective_terms {
+    double robust_observation_penalty, robust_process_penalty, first_difference_penalty, second_difference_penalty,
+        negative_penalty, weight_median;
+    int64_t effective_observation_count;
+} csr_objective_terms;
+int csr_batch_objective_terms(csr_ctx *ctx, const csr_objective_cfg *cfg, csr_objective_terms *out);
+/* csr_batch_forward for the chains with chain_mask[c] != 0 only (NULL: all); the others keep their resident results. */
+int csr_batch_forward_masked(csr_ctx *ctx, uint32_t flags, const unsigned char *chain_mask, double *sum_d,
+                             double *sum_nll);
+
 /* ---- track writer ------------------------------------------------------------------------------
  * bedGraph text of one track, byte for byte what the reference emits (consenrich.py:9797-9805: pandas to_csv with
  * sep="\t", header=False, index=False, float_format="%.4f", lineterminator="\n"; NaN -> empty field, +-inf -> inf/-inf).

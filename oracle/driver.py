@@ -7,12 +7,17 @@ Per chromosome and outer pass (core.py:4860-5390):
   3. weight / rhs tracks from the ORIGINAL data and the smoothed level                       core.py:5064-5083
   4. solveZeroCenteredBackground(..., initialBackground = current background)               core.py:5124-5136
   5. weighted RMS shift, proposal / reference RMS, tolerance = rtol * max(RMS..., 1)         core.py:5199-5243
-  6. background := proposal; stop when shift-stable and inner ECM converged for `patience`
-     consecutive passes after `min_outer` passes                                            core.py:5244-5376
+  6. background := proposal                                                                  core.py:5243-5247
+  7. penalised objective of the adopted background with the current multipliers              core.py:4418-4538, 4750-4830
+     = forward NLL + robust precision penalties (core.py:3161-3179) + roughness penalties (core.py:3182-3204)
+       + negative-part penalty, per effective observation (core.py:2981-2986); stable when its per-cell change is within
+       outer_nll_rtol * max(|current|, |previous|, 1)
+  8. stop when shift-stable AND objective-stable AND inner ECM converged for `patience` consecutive passes after
+     `min_outer` passes                                                                      core.py:5252-5376
 
-NOT reproduced (documented in DESIGN.md): the penalised-objective stability term of the reference's stop rule
-(`_recordOuterObjective`, core.py:4750-4830, an extra forward-NLL pass per outer pass) -- `consenrich.core` cannot be
-imported here to pin it, so both drivers use the two criteria above.  Never imported by ``consenrich_amd``.
+Steps 7-8 restate pure-Python code of `consenrich.core`, which cannot be imported here: that part is
+"parity unpinned" -- checked against the formulas' own NumPy restatement in the tests, not against reference outputs.
+Never imported by ``consenrich_amd``.
 """
 from __future__ import annotations
 
@@ -22,6 +27,50 @@ from . import background as bgo
 from . import oracle as orc
 
 
+MASKED_HALF = 0.5 * float(np.float32(1.0e30))      # constants.py:387, core.py:2983-2985
+
+
+def penalized_objective(forward_nll, munc, background, lam, kap, cfg):
+    """core.py:4484-4538 given the forward NLL of (data - background): dict with the reference's keys."""
+    nu = float(cfg["nu"])
+    tiny = float(np.finfo(np.float64).tiny)
+    obs_pen = proc_pen = 0.0
+    if cfg["use_lambda"] and lam is not None:                                  # core.py:3171-3173
+        v = np.maximum(np.asarray(lam, np.float64), tiny)
+        obs_pen = float(0.5 * nu * np.sum(v - np.log(v)))
+    if cfg["use_kappa"] and kap is not None:                                   # core.py:3174-3178
+        v = np.maximum(np.asarray(kap, np.float64), tiny)
+        if v.size > 1:
+            v = v[1:]
+        proc_pen = float(0.5 * nu * np.sum(v - np.log(v)))
+    bg = np.asarray(background, np.float64).reshape(-1)
+    lam_first, lam_second = cfg["penalties"]
+    first = 0.5 * float(lam_first) * float(np.dot(np.diff(bg), np.diff(bg))) if bg.size >= 2 else 0.0
+    second = 0.5 * float(lam_second) * float(np.dot(np.diff(bg, n=2), np.diff(bg, n=2))) if bg.size >= 3 else 0.0
+    neg = 0.0
+    mult = cfg["neg_multiplier"]
+    if cfg["use_nonnegative"] and mult is not None and mult > 0.0:             # core.py:4078-4082, 4431-4463
+        w = np.zeros(bg.size)
+        prec = None if lam is None else np.clip(np.asarray(lam, np.float64).reshape(-1), *cfg["lambda_bounds"])
+        for row in np.asarray(munc):
+            inv = 1.0 / np.maximum(np.asarray(row, np.float64) + float(cfg["pad"]), 1.0e-8)
+            if prec is not None:
+                inv *= prec
+            w += inv
+        pos = w[np.isfinite(w) & (w > 0.0)]
+        scale = float(np.median(pos)) if pos.size else 1.0
+        if not np.isfinite(scale) or scale <= 0.0:
+            scale = 1.0
+        neg = 0.5 * float(mult * scale) * float(np.sum(np.minimum(bg, 0.0) ** 2, dtype=np.float64))
+    m64 = np.asarray(munc, np.float64)
+    count = int(max(1, np.count_nonzero(np.isfinite(m64) & (m64 < MASKED_HALF))))
+    obj = float(forward_nll + obs_pen + proc_pen + (first + second) + neg)
+    return {"forward_nll": float(forward_nll), "robust_observation_penalty": obs_pen, "robust_process_penalty": proc_pen,
+            "background_first_difference_penalty": first, "background_second_difference_penalty": second,
+            "background_negative_penalty": neg, "penalized_objective": obj, "penalized_objective_per_cell": obj / count,
+            "effective_observation_count": count}
+
+
 def fit_chain(data, munc, cfg):
     data = np.ascontiguousarray(data, np.float32)
     munc = np.ascontiguousarray(munc, np.float32)
@@ -29,7 +78,9 @@ def fit_chain(data, munc, cfg):
     d = cfg["state_dim"]
     bg = np.zeros(n, np.float32)
     lam = kap = None
-    hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "converged": False}
+    hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "objective": [], "converged": False}
+    prev_obj = float("nan")
+    fwd = orc.cforwardPass if d == 2 else orc.cforwardPassLevel
     lam_first, lam2 = cfg["penalties"]
     stable = 0
     bm = (np.arange(n) // cfg["block_len_intervals"]).astype(np.int32)
@@ -65,7 +116,24 @@ def fit_chain(data, munc, cfg):
         hist["shift"].append(shift)
         hist["irls_passes"].append(int(info["passes"]))
         bg = nxt
-        if shift <= cfg["shift_rtol"] * scale and bool(diag["converged"]):
+        # penalised objective of the adopted background (core.py:4465-4483: forward NLL of data - background with the
+        # phase's multipliers)
+        adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)
+        fkw = dict(matrixData=adj, matrixPluginMuncInit=munc, matrixQ0=kw["matrixQ0"], intervalToBlockMap=bm,
+                   blockCount=kw["blockCount"], stateInit=cfg["state_init"], stateCovarInit=cfg["state_covar_init"],
+                   pad=cfg["pad"], returnNLL=True, lambdaExp=lam, processPrecExp=kap if cfg["use_kappa"] else None,
+                   ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
+                   obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
+                   procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1])
+        if d == 2:
+            fkw["matrixF"] = kw["matrixF"]
+        obj = penalized_objective(float(fwd(**fkw)[3]), munc, bg, lam, kap, cfg)
+        cur = obj["penalized_objective_per_cell"]
+        obj_stable = bool(np.isfinite(prev_obj) and np.isfinite(cur)
+                          and abs(cur - prev_obj) <= cfg["outer_nll_rtol"] * max(abs(cur), abs(prev_obj), 1.0))
+        prev_obj = cur
+        hist["objective"].append(obj)
+        if shift <= cfg["shift_rtol"] * scale and obj_stable and bool(diag["converged"]):
             stable += 1
         else:
             stable = 0

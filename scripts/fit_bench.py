@@ -24,4 +24,6 @@ print(json.dumps({"workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {
                   "outer_passes": [f.passes for f in fits], "converged": [f.converged for f in fits],
                   "ecm_iterations_total_over_chains": ecm_total, "ecm_iters_first_chain": fits[0].ecm_iters,
                   "shift_first_chain": [round(x, 6) for x in fits[0].shift],
+                  "objective_per_cell_first_chain": [round(o["penalized_objective_per_cell"], 7) for o in fits[0].objective],
+                  "objective_stable_first_chain": [o["stable"] for o in fits[0].objective],
                   "kernel_ms": {k: round(v[1], 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])[:10]}}))

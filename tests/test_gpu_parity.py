@@ -865,7 +865,8 @@ def test_device_resident_alternation_matches_cpu_twin(product, oracle):
                 penalties=pen, ecm_iters=cfg.ecm_iters, ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu,
                 use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, fit_background=True, zero_center=False,
                 use_nonnegative=True, neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes,
-                min_outer=cfg.min_outer, shift_rtol=cfg.shift_rtol, patience=cfg.patience)
+                min_outer=cfg.min_outer, shift_rtol=cfg.shift_rtol, patience=cfg.patience,
+                outer_nll_rtol=cfg.outer_nll_rtol)
     with DeviceBatch(0, x_tol_ulps=0) as b:
         b.configure(mp, m, n_list)
         for c, (data, munc) in enumerate(ins):
@@ -881,6 +882,18 @@ def test_device_resident_alternation_matches_cpu_twin(product, oracle):
         assert f.ecm_iters == ref["ecm_iters"] and f.irls_passes == ref["irls_passes"], (c, f.ecm_iters, ref["ecm_iters"])
         np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-6)
         np.testing.assert_allclose(f.shift, ref["shift"], rtol=1e-3, atol=1e-7)
+        # penalised objective of every pass (core.py:4418-4538): integer count exact, sums to the background's tolerance
+        assert len(f.objective) == len(ref["objective"])
+        for og, orf in zip(f.objective, ref["objective"]):
+            assert og["effective_observation_count"] == orf["effective_observation_count"]
+            assert og["forward_nll"] == pytest.approx(orf["forward_nll"], rel=1e-6)
+            assert og["robust_process_penalty"] == pytest.approx(orf["robust_process_penalty"], rel=1e-5)
+            assert og["robust_observation_penalty"] == orf["robust_observation_penalty"] == 0.0
+            for k_g, k_r in (("first_difference_penalty", "background_first_difference_penalty"),
+                             ("second_difference_penalty", "background_second_difference_penalty"),
+                             ("negative_penalty", "background_negative_penalty")):
+                assert og[k_g] == pytest.approx(orf[k_r], rel=2e-3, abs=1e-9), (c, k_g)
+            assert og["penalized_objective_per_cell"] == pytest.approx(orf["penalized_objective_per_cell"], rel=1e-6)
         scale = max(float(np.abs(ref["background"]).max()), 1e-3)
         assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
         lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)

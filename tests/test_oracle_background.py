@@ -140,3 +140,34 @@ def test_background_irls_penalises_negative_parts():
     soft, info = bgo.solve_background(w, r, 40, 2.0, use_nonnegative=True, multiplier=4.0, return_info=True)
     assert info["passes"] >= 1 and (plain < 0).any()
     assert np.minimum(soft, 0).sum() > np.minimum(plain, 0).sum()          # negative mass shrinks, softly
+
+
+def test_penalized_objective_known_answers():
+    """oracle/driver.py `penalized_objective` (core.py:4418-4538, 3161-3204, 2981-2986) on inputs whose terms are known
+    in closed form"""
+    from oracle import driver as odrv
+
+    n, m = 11, 3
+    munc = np.full((m, n), 0.25, np.float32)
+    munc[1, 4] = np.float32(1.0e30)                       # masked cell: not an effective observation
+    bg = (0.5 * np.arange(n) - 1.0).astype(np.float32)    # linear: second differences vanish; two negative bins (-1, -0.5)
+    cfg = dict(nu=8.0, use_lambda=True, use_kappa=True, penalties=(3.0, 7.0), neg_multiplier=2.0, use_nonnegative=True,
+               lambda_bounds=(0.25, 4.0), pad=1.0e-4)
+    lam = np.ones(n, np.float32)
+    kap = np.full(n, np.float32(np.e))
+    o = odrv.penalized_objective(100.0, munc, bg, lam, kap, cfg)
+    assert o["effective_observation_count"] == m * n - 1
+    assert o["robust_observation_penalty"] == pytest.approx(0.5 * 8.0 * n * 1.0)                 # x - log x at x = 1
+    assert o["robust_process_penalty"] == pytest.approx(0.5 * 8.0 * (n - 1) * (np.e - 1.0), rel=1e-6)   # first bin skipped
+    assert o["background_first_difference_penalty"] == pytest.approx(0.5 * 3.0 * (n - 1) * 0.25)
+    assert o["background_second_difference_penalty"] == pytest.approx(0.0, abs=1e-12)
+    w_full = 3.0 / (0.25 + 1.0e-4)                        # median bin: all three tracks unmasked
+    assert o["background_negative_penalty"] == pytest.approx(0.5 * 2.0 * w_full * (1.0 + 0.25), rel=1e-6)
+    total = 100.0 + sum(o[k] for k in ("robust_observation_penalty", "robust_process_penalty",
+                                       "background_first_difference_penalty", "background_second_difference_penalty",
+                                       "background_negative_penalty"))
+    assert o["penalized_objective"] == pytest.approx(total) and o["penalized_objective_per_cell"] == pytest.approx(total / 32)
+    cfg["use_nonnegative"] = False
+    cfg["use_lambda"] = False
+    o2 = odrv.penalized_objective(100.0, munc, bg, lam, None, cfg)
+    assert o2["background_negative_penalty"] == 0.0 and o2["robust_observation_penalty"] == 0.0 and o2["robust_process_penalty"] == 0.0
