@@ -2051,15 +2051,16 @@ __global__ __launch_bounds__(256) void k_diag_natural(Prm p, DiagArgs a) {
     }
     double qs = 1.0;
     if (a.qs && k > 0) qs = fmax((double)a.qs[g], tiny);
-    double Q00 = p.Q00 * qs, Q01 = p.Q01 * qs, Q10 = p.Q10 * qs, Q11 = p.Q11 * qs;
+    // only the first column of the predicted covariance (pred00, pred10) is needed: Q01 never enters
+    double Q00 = p.Q00 * qs, Q10 = p.Q10 * qs, Q11 = p.Q11 * qs;
     if (a.kap) {
         const double kp = fmax(clampd((double)a.kap[g], p.kMin, p.kMax), tiny);
-        Q00 /= kp; Q01 /= kp; Q10 /= kp; Q11 /= kp;
+        Q00 /= kp; Q10 /= kp; Q11 /= kp;
     } else if (a.pn && k > 0) {
         const float *q = a.pn + (g - 1) * dd;
         if (d == 2) {
             const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3)) { Q00 = q0; Q01 = q1; Q10 = q2; Q11 = q3; }
+            if (isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3)) { Q00 = q0; Q10 = q2; Q11 = q3; }
         } else {
             const double q0 = q[0];
             if (isfinite(q0)) Q00 = q0;

@@ -151,8 +151,8 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     p.chainSumNLL = p.chainSumD + n_chains;
     for (unsigned int &v : c->lastCnt) v = 0;
     for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
-        if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
-    if (c->hMail) hipHostFree(c->hMail);
+        if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
+    if (c->hMail) (void)hipHostFree(c->hMail);
     c->hMail = nullptr;
     HIPOK(hipHostMalloc((void **)&c->hMail, c->mailBytes));
     memset(c->hMail, 0, c->mailBytes);

@@ -151,7 +151,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
 // main stream keeps the chip full (measured 0.64 ms instead of 0.01).
 static void join_side(csr_ctx *c) {
     if (c->sidePending) {
-        hipStreamWaitEvent(c->stream, c->evJoin, 0);
+        (void)hipStreamWaitEvent(c->stream, c->evJoin, 0);
         c->sidePending = false;
         Scope sc(c, "chain_sums");
         hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, c->sidePrm, c->dChainFirst,

@@ -148,16 +148,19 @@ extern "C" int csr_expected_transition_residual_sums(int32_t state_dim, int64_t 
     const int d = state_dim;
     double *dxs = nullptr, *dPs = nullptr, *dlag = nullptr, *dpart = nullptr;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 512);
-    auto cleanup = [&]() { hipFree(dxs); hipFree(dPs); hipFree(dlag); hipFree(dpart); };
+    auto cleanup = [&]() { (void)hipFree(dxs); (void)hipFree(dPs); (void)hipFree(dlag); (void)hipFree(dpart); };
     if (hipMalloc((void **)&dxs, sizeof(double) * n * d) != hipSuccess || hipMalloc((void **)&dPs, sizeof(double) * n * d * d) != hipSuccess ||
         hipMalloc((void **)&dlag, sizeof(double) * (n - 1) * d * d) != hipSuccess ||
         hipMalloc((void **)&dpart, sizeof(double) * 2 * grid) != hipSuccess) {
         cleanup();
         return fail("hipMalloc failed in transition sums");
     }
-    hipMemcpyAsync(dxs, xs, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(dPs, Ps, sizeof(double) * n * d * d, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(dlag, lag, sizeof(double) * (n - 1) * d * d, hipMemcpyHostToDevice, c->stream);
+    if (hipMemcpyAsync(dxs, xs, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(dPs, Ps, sizeof(double) * n * d * d, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(dlag, lag, sizeof(double) * (n - 1) * d * d, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        cleanup();
+        return fail("hipMemcpyAsync (transition sums inputs) failed");
+    }
     {
         Scope sc(c, "transition_sums");
         hipLaunchKernelGGL(k_tsums, dim3(grid), dim3(256), 0, c->stream, d, n, dxs, dPs, dlag, d == 2 ? F[0] : 1.0,

@@ -76,7 +76,7 @@ struct DevBuf {
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (ptr) hipFree(ptr);
+        if (ptr) (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 8 + 256;
@@ -196,7 +196,7 @@ static int dalloc(csr_ctx *c, T **ptr, int64_t count) {
 }
 
 static void free_batch(csr_ctx *c) {
-    for (void *q : c->allocs) hipFree(q);
+    for (void *q : c->allocs) (void)hipFree(q);
     c->allocs.clear();
     c->configured = false;
     c->statsValid = c->haveFwd = c->haveBwd = false;
@@ -273,23 +273,23 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
 
 extern "C" void csr_destroy(csr_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    if (c->side) hipStreamSynchronize(c->side);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     free_batch(c);
     for (auto &kv : c->prof)
         for (auto &pr : kv.second.pending) {
-            hipEventDestroy(pr.first);
-            hipEventDestroy(pr.second);
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
         }
-    for (hipEvent_t ev : c->eventPool) hipEventDestroy(ev);
+    for (hipEvent_t ev : c->eventPool) (void)hipEventDestroy(ev);
     for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf})
-        if (b->ptr) { hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
-    if (c->hMail) hipHostFree(c->hMail);
-    if (c->evFork) hipEventDestroy(c->evFork);
-    if (c->evJoin) hipEventDestroy(c->evJoin);
-    if (c->side) hipStreamDestroy(c->side);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
+    if (c->hMail) (void)hipHostFree(c->hMail);
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -336,7 +336,7 @@ static hipEvent_t get_event(csr_ctx *c) {
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 struct Scope {
@@ -349,20 +349,20 @@ struct Scope {
             pe = &c->prof[name];
             a = get_event(c);
             b = get_event(c);
-            hipEventRecord(a, st);
+            (void)hipEventRecord(a, st);
         }
     }
     ~Scope() {
         if (pe) {
-            hipEventRecord(b, st);
+            (void)hipEventRecord(b, st);
             pe->pending.emplace_back(a, b);
             pe->launches++;
         }
     }
 };
 static void prof_collect(csr_ctx *c) {
-    hipStreamSynchronize(c->stream);
-    if (c->side) hipStreamSynchronize(c->side);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto &kv : c->prof) {
         for (auto &pr : kv.second.pending) {
             float ms = 0.f;
