@@ -146,10 +146,9 @@ def main() -> int:
     what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 
     def step():
-        batch.stats()
-        batch.forward_backward(flags, want_sums=False)
-        batch.export(what)
-        batch.sums()                    # phiHat / NLL per chain: the step's one host synchronisation
+        # statistics + forward (store, NLL) + backward + export of every track + residuals + per-chain phiHat / NLL
+        # read-back (the step's one host synchronisation), as one C-ABI call
+        batch.step(flags, what)
 
     def fence():
         if dist is not None:

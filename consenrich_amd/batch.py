@@ -163,6 +163,16 @@ class DeviceBatch:
                                                L.dp(path)))
         return list(outs), path.reshape(nc, -1)
 
+    def step(self, flags: int = L.RETURN_NLL, what: int = 0, want_sums: bool = True):
+        """stats() + forward_backward(flags) + export(what) + sums() in one C-ABI call (same launches, same cost)."""
+        if not want_sums:
+            L.check(self._lib.csr_batch_step(self._ctx, int(flags), int(what), None, None))
+            return None, None
+        nc = len(self.chain_lens)
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        L.check(self._lib.csr_batch_step(self._ctx, int(flags), int(what), L.dp(sd), L.dp(sn)))
+        return sd, sn
+
     def forward_masked(self, flags: int, chain_mask):
         """forward() for the chains with chain_mask[c] true only; returns (sum_d, sum_nll) (masked chains: stale)."""
         nc = len(self.chain_lens)

@@ -14,7 +14,10 @@ b = DeviceBatch(0, block_len=B)
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
-    b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
+    if os.environ.get("SPLIT_CALLS"):
+        b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
+    else:
+        b.step(L.RETURN_NLL, what)
 cfgs = [tuple(map(int, c.split(','))) for c in os.environ.get('CFGS', '256,256,128').split(';')]
 for cfg in cfgs:
     b.set_tuning(0, *cfg)
