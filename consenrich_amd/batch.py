@@ -97,6 +97,25 @@ class DeviceBatch:
         mdl = model.to_c()
         L.check(self._lib.csr_batch_set_model(self._ctx, C.byref(mdl)))
 
+    def set_chain_q(self, q_list):
+        """Per-chain base process noise: one (2,2) (or (1,1) for the level model) matrix per chain, values taken as
+        float32 like the reference's matrixQ0; None = the model's Q0 for every chain again."""
+        if q_list is None:
+            L.check(self._lib.csr_batch_set_chain_q(self._ctx, None))
+            return
+        if len(q_list) != len(self.chain_lens):
+            raise ValueError("one Q0 per chain")
+        flat = np.zeros((len(q_list), 4))
+        for i, q in enumerate(q_list):
+            q = np.asarray(q, np.float32).astype(np.float64)
+            if q.shape == (1, 1):
+                flat[i, 0] = q[0, 0]
+            elif q.shape == (2, 2):
+                flat[i] = q.reshape(-1)
+            else:
+                raise ValueError("Q0 must be (2,2) or (1,1)")
+        L.check(self._lib.csr_batch_set_chain_q(self._ctx, L.dp(flat)))
+
     def set_tuning(self, block_len=0, warm_p=-1, warm_x=-1, warm_b=-1):
         L.check(self._lib.csr_set_tuning(self._ctx, int(block_len), int(warm_p), int(warm_x), int(warm_b)))
 

@@ -67,6 +67,7 @@ struct Prm {
     // block table: x = natural index of first bin, y = length, z = first block of chain, w = last block of chain
     const int4 *blk;
     const int *blkChain;
+    const double *chainQ;   // per chain: Q00 Q01 Q10 Q11 (row-major base process noise) or null = the model's Q0 for all
     const unsigned char *chainActive;   // nullptr = all chains active
 
     // natural inputs
@@ -163,6 +164,31 @@ __device__ __forceinline__ int64_t tidx(int64_t b, int s, int B) { return tbase(
 
 __device__ __forceinline__ bool chain_on(const Prm &p, int64_t b) {
     return p.chainActive == nullptr || p.chainActive[p.blkChain[b]] != 0;
+}
+
+// Per-chain base process noise (csr_batch_set_chain_q: every chromosome is seeded with its own Q0, core.py:5667): the
+// kernels that use Q work on a per-lane copy of the parameter block whose Q fields come from the lane's chain.  A lane
+// only ever walks blocks of ONE chain (warm-up included), so the copy is made once per kernel.
+__device__ __forceinline__ Prm chain_model(const Prm &p, int chain) {
+    Prm q = p;
+    if (p.chainQ != nullptr) {
+        const double *t = p.chainQ + 4 * (int64_t)chain;
+        q.Q00 = t[0]; q.Q01 = t[1]; q.Q10 = t[2]; q.Q11 = t[3];
+        q.qDiag = 0.5 * (t[0] + t[3]);
+    }
+    return q;
+}
+__device__ __forceinline__ Prm lane_model(const Prm &p, int64_t b) {
+    return chain_model(p, p.chainQ != nullptr ? p.blkChain[b < p.NB ? b : p.NB - 1] : 0);
+}
+// The serial chain kernels get the per-lane copy only in their PCQ instantiation (launched when a per-chain table is
+// set): with it the Q fields live in vector registers (12 more VGPRs in the fused forward chain) and the constant-Q
+// arithmetic the compiler otherwise folds into scalar code runs per lane; the default instantiation is the same
+// machine code as without the feature (same register counts).
+template <bool PCQ>
+__device__ __forceinline__ Prm lane_model_if(const Prm &p, int64_t b) {
+    if constexpr (PCQ) return lane_model(p, b);
+    else return p;
 }
 
 __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
@@ -358,6 +384,7 @@ __device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) 
 #define CSR_U_B 4
 #endif
 struct FwdPTrend {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
@@ -461,6 +488,7 @@ struct FwdPTrend {
 
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
@@ -524,6 +552,7 @@ struct FwdPLevel {
 
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
 struct FwdXTrend {
+    static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool FWD = true;
@@ -593,6 +622,7 @@ struct FwdXTrend {
 
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
+    static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = true;
@@ -657,6 +687,7 @@ struct FwdXLevel {
 // two (one fixed launch/drain cost, no gain-record round trip through HBM for the state update).  The arithmetic is the
 // split chains' own (advance() / step() above are called as they are), so the results are the same numbers.
 struct FwdTrendFused {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT = false;
     static constexpr bool NATOUT_FWD = true;   // main phase can also emit xf / Pf in the reference layout (walk_nat_fwd)
     static constexpr bool DMA = false;
@@ -704,6 +735,7 @@ struct FwdTrendFused {
     }
 };
 struct FwdLevelFused {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
@@ -781,6 +813,7 @@ __device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, floa
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
 struct BwdTrend {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = true;     // main phase can emit the reference layout through LDS tiles (walk_nat)
     static constexpr bool DMA = false;
@@ -920,6 +953,7 @@ struct BwdTrend {
 
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
+    static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
@@ -1250,9 +1284,10 @@ __device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::C
 // NAT = true: separate instantiation whose main phase writes the reference layout through LDS tiles (walk_nat*); the
 // plain one stays as lean as before (the tile walkers cost ~50-100 VGPRs and slowed the ECM sweeps by 25 % when both
 // paths lived in one kernel).
-template <class CH, bool NAT = false>
-__global__ __launch_bounds__(64) void k_chain_spec(Prm p) {
+template <class CH, bool NAT = false, bool PCQ = false>
+__global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const Prm p = lane_model_if<PCQ>(p_, b);
     const bool live = b < p.NB && chain_on(p, b);
     int4 bi = make_int4(0, 0, 0, 0);
     if (b < p.NB) bi = p.blk[b];
@@ -1388,7 +1423,7 @@ __device__ __forceinline__ void dma_phase(const Prm &p, typename CH::Carry &c, u
 }
 
 template <class CH>
-__global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {
+__global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state chains only: they never read Q
     extern __shared__ unsigned ringMem[];
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
@@ -1425,9 +1460,10 @@ __global__ __launch_bounds__(64) void k_probe(Prm p) {
 // Validation / fix-up pass: a block whose recorded carry-in differs from its neighbour's current carry-out is re-run
 // from that carry.  Iterated (ping-pong outCur/outNext) until no block re-runs: the fixed point is the sequential
 // recursion.  which = 0: read A write B; 1: read B write A.
-template <class CH, bool NAT = false>
-__global__ __launch_bounds__(64) void k_chain_fix(Prm p, int which) {
+template <class CH, bool NAT = false, bool PCQ = false>
+__global__ __launch_bounds__(64) void k_chain_fix(Prm p_, int which) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const Prm p = lane_model_if<PCQ>(p_, b);
     const bool live = b < p.NB && chain_on(p, b);
     using Carry = typename CH::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
@@ -1624,14 +1660,15 @@ __global__ __launch_bounds__(256) void k_estep_lambda(Prm p) {
 }
 
 // kappa (pyx:8244-8298 with MAT2 helpers pyx:4123-4175; level pyx:7496-7521); also produces lag (needed anyway)
-__global__ __launch_bounds__(256) void k_estep_kappa(Prm p) {
+__global__ __launch_bounds__(256) void k_estep_kappa(Prm p_) {
     const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int l = (int)(slot & 63);
     const int64_t row = slot >> 6;
-    const int64_t G = row / p.B;
-    const int s = (int)(row % p.B);
+    const int64_t G = row / p_.B;
+    const int s = (int)(row % p_.B);
     const int64_t b = G * 64 + l;
-    if (b >= p.NB || !chain_on(p, b)) return;
+    if (b >= p_.NB || !chain_on(p_, b)) return;
+    const Prm p = lane_model(p_, b);
     const int4 bi = p.blk[b];
     if (s >= bi.y) return;
     if (s == 0 && b == bi.z) p.tKap[slot] = 1.0f;     // processPrecExp[0] = 1 (pyx:8245)
@@ -1658,10 +1695,11 @@ __global__ __launch_bounds__(256) void k_estep_kappa(Prm p) {
 // sequential fallback with adaptive process noise (pyx:510-527 / 688-705): D[k] feeds back into Q[k+1], so the
 // chain cannot be cut; one lane per chain runs the fused step.  Off by default in the reference (constants.py:272).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fwd_apn(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
+__global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= p.nchains) return;
-    if (p.chainActive != nullptr && !p.chainActive[c]) return;
+    if (c >= p_.nchains) return;
+    if (p_.chainActive != nullptr && !p_.chainActive[c]) return;
+    const Prm p = chain_model(p_, c);
     const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
     const double mD = (double)p.m;
     const double log2pi = 1.8378770664093454835606594728112;
@@ -1828,10 +1866,12 @@ __device__ __forceinline__ void export_tile(const Prm &p, const ExpDesc &d, floa
                 const int64_t g = (int64_t)bi.x + s;
                 const float *q = tile + si * RS + l * E;
                 vecN o;
-                if constexpr (N == 1) o = fill ? d.cval[0] : q[0];
+                // constant fill = the base process noise; with per-chain Q0 it is the chain's
+                const double *cq = (fill && p.chainQ != nullptr) ? p.chainQ + 4 * (int64_t)p.blkChain[b] : nullptr;
+                if constexpr (N == 1) o = fill ? (cq ? (float)cq[0] : d.cval[0]) : q[0];
                 else {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) o[k] = fill ? d.cval[k] : q[k];
+                    for (int k = 0; k < N; ++k) o[k] = fill ? (cq ? (float)cq[k] : d.cval[k]) : q[k];
                 }
                 *reinterpret_cast<vecN *>(d.dst + g * N) = o;
             }
@@ -2023,9 +2063,9 @@ struct DiagArgs {
     const int64_t *chainOff, *chainLen;
     int nchains, pad_;
 };
-__global__ __launch_bounds__(256) void k_diag_natural(Prm p, DiagArgs a) {
+__global__ __launch_bounds__(256) void k_diag_natural(Prm p_, DiagArgs a) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= p.Npad) return;
+    if (g >= p_.Npad) return;
     int lo = 0, hi = a.nchains - 1;          // chain whose [off, off + padded len) holds g
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -2033,7 +2073,8 @@ __global__ __launch_bounds__(256) void k_diag_natural(Prm p, DiagArgs a) {
     }
     const int64_t k = g - a.chainOff[lo];
     if (k >= a.chainLen[lo]) return;
-    if (p.chainActive != nullptr && !p.chainActive[lo]) return;
+    if (p_.chainActive != nullptr && !p_.chainActive[lo]) return;
+    const Prm p = chain_model(p_, lo);
     const double tiny = 2.2250738585072014e-308;
     const int d = p.d, dd = d * d;
     double lam = 1.0;

@@ -32,6 +32,33 @@ extern "C" int csr_batch_set_model(csr_ctx *c, const csr_model *mdl) {
     return 0;
 }
 
+// Per-chain base process noise: q = n_chains x 4 doubles (row-major Q0 of every chain, float32 values widened like
+// csr_model.Q0) or NULL = every chain uses the model's Q0 again.  The reference seeds Q0 per chromosome (core.py:5667).
+extern "C" int csr_batch_set_chain_q(csr_ctx *c, const double *q) {
+    if (!c) return fail("null argument");
+    if (!c->configured) return fail("batch not configured");
+    CHECK(ctx_select(c));
+    CHECK(settle(c));
+    const int nc = (int)c->chains.size();
+    if (q == nullptr) {
+        c->p.chainQ = nullptr;
+    } else {
+        std::vector<double> h(q, q + 4 * (size_t)nc);
+        for (int i = 0; i < nc; ++i) {
+            double *t = &h[4 * (size_t)i];
+            for (int k = 0; k < 4; ++k)
+                if (!std::isfinite(t[k])) return fail("chain %d: Q0 must be finite", i);
+            if (c->mdl.state_dim == 1) t[1] = t[2] = t[3] = 0.0;          // level model: only Q00 exists (fill_model)
+        }
+        if (!c->dChainQ) CHECK(dalloc(c, &c->dChainQ, 4 * (int64_t)nc));
+        HIPOK(hipMemcpyAsync(c->dChainQ, h.data(), 8 * h.size(), hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        c->p.chainQ = c->dChainQ;
+    }
+    c->haveFwd = c->haveBwd = false;
+    return 0;
+}
+
 extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, int32_t n_chains,
                                    const int64_t *chain_len) {
     if (!c || !mdl || !chain_len) return fail("null argument");

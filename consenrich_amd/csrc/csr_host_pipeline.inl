@@ -88,6 +88,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
         HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
     }
+    const bool pcq = CH::USES_Q && p.chainQ != nullptr;      // per-chain base process noise: per-lane model copy
     {
         Scope sc(c, name);
         if constexpr (CH::DMA) {
@@ -99,11 +100,15 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             bool launched = false;
             if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
                 if (p.natOut) {
-                    hipLaunchKernelGGL((k_chain_spec<CH, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    if (pcq) hipLaunchKernelGGL((k_chain_spec<CH, true, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    else hipLaunchKernelGGL((k_chain_spec<CH, true, false>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
                     launched = true;
                 }
             }
-            if (!launched) hipLaunchKernelGGL((k_chain_spec<CH, false>), dim3(grid), dim3(64), 0, c->stream, p);
+            if (!launched) {
+                if (pcq) hipLaunchKernelGGL((k_chain_spec<CH, false, true>), dim3(grid), dim3(64), 0, c->stream, p);
+                else hipLaunchKernelGGL((k_chain_spec<CH, false, false>), dim3(grid), dim3(64), 0, c->stream, p);
+            }
         }
     }
     LAUNCH_CHECK(name);
@@ -122,11 +127,15 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             bool launched = false;
             if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
                 if (p.natOut) {
-                    hipLaunchKernelGGL((k_chain_fix<CH, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                    if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, true, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                    else hipLaunchKernelGGL((k_chain_fix<CH, true, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
                     launched = true;
                 }
             }
-            if (!launched) hipLaunchKernelGGL((k_chain_fix<CH, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+            if (!launched) {
+                if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, false, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                else hipLaunchKernelGGL((k_chain_fix<CH, false, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+            }
             c->rs.fix_launches++;
             which ^= 1;
         }

@@ -148,6 +148,7 @@ struct csr_ctx {
     int dbgForceIters = 0;
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
+    double *dChainQ = nullptr;  // per-chain base process noise (csr_batch_set_chain_q), freed with the batch
     Prm sidePrm{};              // parameters of the epilogue running on the side stream (its sums follow at the join)
     uint32_t pendFlags = 0, pendExport = 0;
     bool pendWantD = false;
@@ -203,6 +204,7 @@ static void free_batch(csr_ctx *c) {
     c->pendFwd = c->pendBwd = c->sidePending = false;
     c->pendExport = 0;
     c->dMail = nullptr;
+    c->dChainQ = nullptr;
     c->bg = csr_ctx::BgState{};
     c->dActive = nullptr;
     for (auto &n : c->nat) n = nullptr;

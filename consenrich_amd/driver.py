@@ -1,7 +1,9 @@
 """Device-resident counterpart of the reference's outer alternation (`runConsenrich`, core.py:4860-5390):
 fixed-background ECM phase <-> background update, for a whole batch of chromosomes on one GPU.
 
-Per outer pass, for the chains still iterating (chromosomes are independent fits and stop independently):
+With `seed_q`, every chromosome first gets its own base process noise from its data (`DeviceBatch.qseed` +
+`set_chain_q`; the reference's fixedDiagonal calibration, core.py:5667-5686).  Then, per outer pass, for the chains still
+iterating (chromosomes are independent fits and stop independently):
   1. `DeviceBatch.stats()` -- the current background is subtracted from the data in float32 inside the statistics
      kernel (= the reference's `dataAdjusted`, core.py:3253-3256);
   2. `DeviceBatch.ecm(chain_mask=...)` -- the multipliers of the previous pass are resident, i.e. the warm start the
@@ -49,6 +51,11 @@ class FitConfig:
     outer_passes: int = 32
     min_outer: int = 3
     shift_rtol: float = 5.0e-3
+    seed_q: bool = False                         # per-chromosome Q0 from the data (core.py:5667, fixedDiagonal calibration)
+    min_q: float = 1.0e-6                        # constants.py:147-149
+    max_q: float = 1000.0
+    delta_f: float = 1.0
+    q_seed_prior_level: float = 1.0e-5
     outer_nll_rtol: float = 5.0e-5               # ECM_outerNLLRtol, constants.py:281
     pad: float = 1.0e-4                          # the Python-float pad of the objective's weight track (core.py:4506)
     patience: int = 2
@@ -63,6 +70,8 @@ class ChainFit:
     shift: List[float] = field(default_factory=list)
     irls_passes: List[int] = field(default_factory=list)
     objective: List[dict] = field(default_factory=list)       # per pass: the reference's objective diagnostics
+    q0: object = None                                         # seeded base process noise (float32 (2,2)) if seed_q
+    q_seed: dict = field(default_factory=dict)                # its diagnostics (core.py:3751-3779)
 
 
 def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
@@ -74,6 +83,13 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
     stable = [0] * nc
     for c in range(nc):
         batch.set_background(c, None)
+    if cfg.seed_q:
+        # matrixQ0 of every chromosome from its own data (core.py:5667-5686), on the resident matrices
+        seeds = batch.qseed(pad=cfg.pad, stateModel="levelTrend" if batch.d == 2 else "level", minQ=cfg.min_q,
+                            maxQ=cfg.max_q, deltaF=cfg.delta_f, robustTNu=cfg.nu, qSeedPriorLevel=cfg.q_seed_prior_level)
+        batch.set_chain_q([q[: batch.d, : batch.d] for q, _ in seeds])
+        for c in range(nc):
+            fits[c].q0, fits[c].q_seed = seeds[c]
     prev_obj = [float("nan")] * nc
     fwd_flags = L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
     have_stats = False

@@ -150,6 +150,10 @@ int csr_batch_configure(csr_ctx *ctx, const csr_model *mdl, int64_t m, int32_t n
                         const int64_t *chain_len);
 /* Replace the model parameters (same state_dim) without reallocating or re-uploading. */
 int csr_batch_set_model(csr_ctx *ctx, const csr_model *mdl);
+/* Per-chain base process noise: q = n_chains x 4 doubles (row-major Q0 per chain, float32 values widened) or NULL = the
+ * model's Q0 for every chain.  The reference seeds Q0 per chromosome (core.py:5667, csr_batch_qseed); F and the other
+ * model parameters stay batch-wide. */
+int csr_batch_set_chain_q(csr_ctx *ctx, const double *q);
 /* H2D one chain's (m,n_c) C-order matrices. */
 int csr_batch_upload(csr_ctx *ctx, int32_t chain, const float *data, const float *munc);
 /* H2D optional per-bin multipliers (any may be NULL = leave as is).  After csr_batch_configure all multipliers are 1. */

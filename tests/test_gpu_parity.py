@@ -1053,3 +1053,122 @@ def test_folds_as_extra_chains_of_a_batch(product, oracle):
             b2.export(L.EXPORT_SMOOTH)
             assert np.array_equal(xs[1 + f], b2.download(0, "xs"))
     assert not np.array_equal(xs[0], xs[1])
+
+
+@pytest.mark.parametrize("d", [2, 1])
+def test_per_chain_process_noise(product, oracle, d):
+    """csr_batch_set_chain_q: every chain of a batch with its own base process noise (the reference seeds Q0 per
+    chromosome, core.py:5667).  Forward + smoother + diagnostics + the ECM loop of every chain against the oracle run with
+    THAT chain's Q0, in both validation modes; clearing it restores the model's Q0."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [5000, 1300, 64, 700, 1], 4
+    qs = [np.diag([1e-3, 1e-4]), np.asarray([[4e-2, 1e-3], [1e-3, 2e-3]]), np.diag([1e-5, 1e-5]), np.diag([0.3, 1e-6]),
+          np.diag([7e-4, 7e-4])]
+    qs = [q.astype(np.float32)[:d, :d] for q in qs]
+    F = np.asarray(cases.F_TREND, np.float32)
+    sets = [cases.synth(n, m, 8100 + i, mask_frac=0.02) for i, n in enumerate(n_list)]
+
+    def ref_fb(c):
+        n, (d_, v_) = n_list[c], sets[c]
+        xf, Pf, pn = (np.zeros((n, d), np.float32), np.zeros((n, d, d), np.float32), np.zeros((n, d, d), np.float32))
+        D = np.zeros(n, np.float32)
+        kw = dict(matrixData=d_, matrixPluginMuncInit=v_, matrixQ0=qs[c] if d == 2 else np.asarray([[qs[c][0, 0], 0], [0, 1]], np.float32),
+                  intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0, stateCovarInit=1000.0,
+                  stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn, vectorD=D, returnNLL=True)
+        if d == 2:
+            r = oracle.cforwardPass(matrixF=F, **kw)
+            bw = oracle.cbackwardPass(matrixData=d_, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+        else:
+            r = oracle.cforwardPassLevel(**kw)
+            bw = oracle.cbackwardPassLevel(matrixData=d_, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+        return r[3], dict(D=D, xf=xf, Pf=Pf, pnoise=pn[: n - 1], xs=bw[0], Ps=bw[1], lag=bw[2][: n - 1], resid=bw[3])
+
+    refs = [ref_fb(c) for c in range(len(n_list))]
+    for xtol in (0, 2):
+        with DeviceBatch(0, x_tol_ulps=xtol) as b:
+            b.configure(ModelParams(state_dim=d), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            b.set_chain_q(qs)
+            sd, sn = b.step(L.RETURN_NLL, L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+            for c in range(len(n_list)):
+                assert sn[c] == pytest.approx(refs[c][0], rel=1e-8, abs=1e-8), (xtol, c)
+                for name, ref in refs[c][1].items():
+                    got = b.download(c, name)
+                    if xtol == 0 and name in ("xf", "Pf", "xs", "Ps", "lag", "pnoise"):
+                        # bit-identical up to rare fp64-ulp ties (and the cancellation-prone first smoothed bins)
+                        assert np.sum(got != ref) <= max(2, 1e-3 * got.size), (c, name)
+                    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL, err_msg=f"xtol {xtol} chain {c} {name}")
+            if d == 2 and xtol == 0:
+                # ECM with per-chain Q0: kappa E-step weights by the chain's Q0^-1 (pyx:8244-8298)
+                b.stats()
+                outs, _ = b.ecm(max_iters=8, inner_iters=3, rtol=1e-5, use_lambda=False, use_kappa=True)
+                b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT)
+                for c in (0, 1, 3):
+                    n, (d_, v_) = n_list[c], sets[c]
+                    r = oracle.cfixedBackgroundECM(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=qs[c],
+                                                   intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                                   stateCovarInit=1000.0, ECM_fixedBackgroundIters=8,
+                                                   ECM_fixedBackgroundRtol=1e-5, t_innerIters=3,
+                                                   ECM_useObsPrecisionReweighting=False,
+                                                   procPrecisionMultiplierMin=5e-3, procPrecisionMultiplierMax=5e3,
+                                                   returnIntermediates=True, logIterations=False)
+                    assert int(outs[c].iters_done) == r[0] and outs[c].final_nll == pytest.approx(r[1], rel=1e-8), c
+                    np.testing.assert_allclose(b.download(c, "xs"), r[2], rtol=RTOL, atol=ATOL)
+                    close_mostly(b.download(c, "kappa"), r[7], frac=2e-2, cap=5e-2, msg=f"kappa chain {c}")
+                # clearing the table restores the model's Q0 for every chain
+                b.set_chain_q(None)
+                b.stats()
+                _, sn2 = b.step(L.RETURN_NLL, 0)
+                d_, v_ = sets[1]
+                n = n_list[1]
+                r = oracle.cforwardPass(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F,
+                                        matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+                                        intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                        stateCovarInit=1000.0, returnNLL=True)
+                assert sn2[1] == pytest.approx(r[3], rel=1e-8)
+
+
+def test_alternation_with_per_chromosome_seeded_process_noise(product, oracle):
+    """fit_batch(seed_q=True): Q0 of every chromosome from its own data on the device (core.py:5667), then the outer
+    alternation with per-chain Q0 -- against the CPU twin run per chromosome with the oracle's seed for that chromosome."""
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.driver import FitConfig, fit_batch
+    from oracle import background as bgo
+    from oracle import driver as odrv
+    from oracle import qseed as oq
+
+    n_list, m = [2500, 900], 4
+    mp = ModelParams(state_dim=2)
+    ins = _bg_batch_fixture(n_list, m, 6200, bg_amp=0.3)
+    ins = [(d_ * np.float32(1.0 + 2.0 * i), v_) for i, (d_, v_) in enumerate(ins)]       # different dynamics per chain
+    pen = bgo.penalties(40, 2.0)
+    cfg = FitConfig(penalties=pen, ecm_iters=5, ecm_rtol=1e-4, inner_iters=3, outer_passes=4, min_outer=2, patience=1,
+                    shift_rtol=2e-2, neg_multiplier=2.0, seed_q=True)
+    with DeviceBatch(0, x_tol_ulps=0) as b:
+        b.configure(mp, m, n_list)
+        for c, (data, munc) in enumerate(ins):
+            b.upload(c, data, munc)
+        fits = fit_batch(b, cfg)
+        got = [dict(bg=b.download(c, "background"), xs=b.download(c, "xs")) for c in range(len(n_list))]
+    assert not np.array_equal(fits[0].q0, fits[1].q0)
+    for c, (data, munc) in enumerate(ins):
+        Q, diag = oq.estimate_initial_process_noise(oq, matrixData=data, matrixMunc=munc, pad=cfg.pad, stateModel="levelTrend",
+                                                    minQ=cfg.min_q, maxQ=cfg.max_q, deltaF=cfg.delta_f, robustTNu=cfg.nu)
+        assert np.array_equal(fits[c].q0, Q) and fits[c].q_seed["qSeedSource"] == diag["qSeedSource"]
+        ocfg = dict(state_dim=2, F=mp.F, Q0=Q, state_init=mp.state_init, state_covar_init=mp.state_covar_init, pad=mp.pad,
+                    lambda_bounds=mp.lambda_bounds, kappa_bounds=mp.kappa_bounds, block_len_intervals=500, penalties=pen,
+                    ecm_iters=cfg.ecm_iters, ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu,
+                    use_lambda=False, use_kappa=True, fit_background=True, zero_center=False, use_nonnegative=True,
+                    neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes, min_outer=cfg.min_outer,
+                    shift_rtol=cfg.shift_rtol, patience=cfg.patience, outer_nll_rtol=cfg.outer_nll_rtol)
+        ref = odrv.fit_chain(data, munc, ocfg)
+        f = fits[c]
+        assert f.passes == ref["passes"] and f.converged == ref["converged"] and f.ecm_iters == ref["ecm_iters"], (c, f, ref["passes"])
+        np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-6)
+        scale = max(float(np.abs(ref["background"]).max()), 1e-3)
+        assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
+        lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
+        assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
