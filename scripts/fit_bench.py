@@ -15,12 +15,14 @@ lengths = hg38_chain_lengths(200)
 b = DeviceBatch(0)
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 cfg = FitConfig(penalties=bg_cases.penalties(750, 128.0), ecm_iters=int(os.environ.get("ECM_ITERS", "50")), ecm_rtol=1e-6,
-                inner_iters=5, outer_passes=int(os.environ.get("OUTER", "8")), min_outer=3, patience=2, shift_rtol=5e-3)
+                inner_iters=5, outer_passes=int(os.environ.get("OUTER", "8")), min_outer=3, patience=2, shift_rtol=5e-3,
+                seed_q=bool(os.environ.get("SEED_Q")))
 b.synchronize(); b.profile(True)
 t = time.perf_counter(); fits = fit_batch(b, cfg); b.synchronize(); wall = time.perf_counter() - t
 kt = b.kernel_times(); b.profile(False)
 ecm_total = sum(sum(f.ecm_iters) for f in fits)
-print(json.dumps({"workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {sum(lengths)} bins", "wall_s": round(wall, 3),
+print(json.dumps({"seed_q": cfg.seed_q, "q0_first_chain": None if fits[0].q0 is None else [float(fits[0].q0[0, 0]), float(fits[0].q0[1, 1])],
+                  "workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {sum(lengths)} bins", "wall_s": round(wall, 3),
                   "outer_passes": [f.passes for f in fits], "converged": [f.converged for f in fits],
                   "ecm_iterations_total_over_chains": ecm_total, "ecm_iters_first_chain": fits[0].ecm_iters,
                   "shift_first_chain": [round(x, 6) for x in fits[0].shift],
