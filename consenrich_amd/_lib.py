@@ -195,6 +195,7 @@ SYMBOLS = {
     "csr_backward_pass": (C.c_int, [C.POINTER(Model), C.c_int64, C.c_int64, FP, FP, FP, FP, FP, FP, FP, C.c_int64, FP]),
     "csr_fixed_background_ecm": (C.c_int, [C.POINTER(Model), C.POINTER(EcmCfg), C.c_int64, C.c_int64, FP, FP, FP, FP,
                                            FP, FP, FP, FP, FP, DP, C.POINTER(EcmOut)]),
+    "csr_batch_download_inputs": (C.c_int, [C.c_void_p, C.c_int32, FP, FP]),
     "csr_batch_set_chain_q": (C.c_int, [C.c_void_p, DP]),
     "csr_batch_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, DP, DP]),
     "csr_batch_objective_terms": (C.c_int, [C.c_void_p, C.POINTER(ObjectiveCfg), C.POINTER(ObjectiveTerms)]),

@@ -136,6 +136,13 @@ class DeviceBatch:
     def synthesize(self, seed: int):
         L.check(self._lib.csr_batch_synthesize(self._ctx, int(seed)))
 
+    def download_inputs(self, chain: int):
+        """(data, munc) of one chain as resident on the device, (m, n) float32 each."""
+        shape = (self.m, self.chain_lens[chain])
+        data, munc = np.empty(shape, np.float32), np.empty(shape, np.float32)
+        L.check(self._lib.csr_batch_download_inputs(self._ctx, int(chain), L.fp(data), L.fp(munc)))
+        return data, munc
+
     # -- compute -------------------------------------------------------------------------------------------------
     def stats(self):
         L.check(self._lib.csr_batch_stats(self._ctx))

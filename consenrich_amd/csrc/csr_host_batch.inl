@@ -217,6 +217,23 @@ extern "C" int csr_batch_upload(csr_ctx *c, int32_t chain, const float *data, co
     return 0;
 }
 
+// D2H of a chain's resident inputs ((m, n) float32 each, like csr_batch_upload takes them): lets a caller check what a
+// device-side generator (csr_batch_synthesize) or fold builder (csr_batch_make_fold) put there.
+extern "C" int csr_batch_download_inputs(csr_ctx *c, int32_t chain, float *data, float *munc) {
+    CHECK(need(c));
+    CHECK(settle(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    const ChainInfo &ci = c->chains[chain];
+    if (data)
+        HIPOK(hipMemcpy2DAsync(data, sizeof(float) * ci.n, c->p.data + ci.off, sizeof(float) * c->Npad, sizeof(float) * ci.n,
+                               (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
+    if (munc)
+        HIPOK(hipMemcpy2DAsync(munc, sizeof(float) * ci.n, c->p.munc + ci.off, sizeof(float) * c->Npad, sizeof(float) * ci.n,
+                               (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 static int grid_slots(csr_ctx *c) { return (int)((c->TN + 255) / 256); }
 
 static int64_t arr_comps(csr_ctx *c, int id);

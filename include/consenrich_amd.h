@@ -161,6 +161,8 @@ int csr_batch_upload_multipliers(csr_ctx *ctx, int32_t chain, const float *lambd
                                  const float *qscale);
 /* Fill every chain with the SURVEY 8(d) synthetic recipe directly in HBM (counter-based RNG). */
 int csr_batch_synthesize(csr_ctx *ctx, uint64_t seed);
+/* D2H of one chain's resident inputs, (m, n) float32 each (either pointer may be NULL). */
+int csr_batch_download_inputs(csr_ctx *ctx, int32_t chain, float *data, float *munc);
 
 /* a1: per-bin sufficient statistics of (data, munc, pad); must precede forward/ECM after any upload. */
 int csr_batch_stats(csr_ctx *ctx);

@@ -1172,3 +1172,46 @@ def test_alternation_with_per_chromosome_seeded_process_noise(product, oracle):
         assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
         lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
         assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
+
+
+def test_bench_workload_matches_oracle(product, oracle):
+    """The exact workload bench.py times -- hg38 autosomes @200 bp x 32 samples, device-synthesised inputs (seed 1234),
+    one csr_batch_step in the throughput mode -- checked against the CPU oracle on the inputs read back from the device:
+    NLL of every chromosome, and every output array of the longest and the two shortest chromosomes."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.sharding import hg38_chain_lengths
+
+    lengths = hg38_chain_lengths(200)
+    m = 32
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    with DeviceBatch(0) as b:
+        b.configure(ModelParams(state_dim=2), m, lengths)
+        b.synthesize(1234)
+        sd, sn = b.step(L.RETURN_NLL, L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+        full = (0, 20, 21)
+        for c, n in enumerate(lengths):
+            d_, v_ = b.download_inputs(c)
+            assert np.all(np.isfinite(d_)) and np.all(v_ > 0)
+            store = c in full
+            xf = np.zeros((n, 2), np.float32) if store else None
+            Pf = np.zeros((n, 2, 2), np.float32) if store else None
+            pn = np.zeros((n, 2, 2), np.float32) if store else None
+            D = np.zeros(n, np.float32)
+            r = oracle.cforwardPass(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=Q0,
+                                    intervalToBlockMap=(np.arange(n) // 500).astype(np.int32), blockCount=(n + 499) // 500,
+                                    stateInit=0.0, stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf,
+                                    pNoiseForward=pn, vectorD=D, returnNLL=True)
+            assert sn[c] == pytest.approx(r[3], rel=1e-8), c
+            assert sd[c] / n == pytest.approx(r[0], rel=1e-5), c
+            if not store:
+                continue
+            bw = oracle.cbackwardPass(matrixData=d_, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+            lvl = np.maximum(np.abs(bw[0][:, :1].astype(np.float64)), 1.0)
+            for name, ref in (("xf", xf), ("xs", bw[0])):
+                assert np.all(np.abs(b.download(c, name).astype(np.float64) - ref) <= RTOL * lvl + ATOL), (c, name)
+            for name, ref in (("Pf", Pf), ("pnoise", pn[: n - 1]), ("Ps", bw[1]), ("lag", bw[2][: n - 1])):
+                np.testing.assert_allclose(b.download(c, name), ref, rtol=RTOL, atol=ATOL, err_msg=f"chain {c} {name}")
+            assert np.all(np.abs(b.download(c, "resid").astype(np.float64) - bw[3]) <= RTOL * lvl + ATOL), c
+            close_mostly(b.download(c, "D"), D, frac=1e-2, cap=5e-4, msg=f"D chain {c}")
