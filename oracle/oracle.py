@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libconsenrich_oracle.so")
+_LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "libconsenrich_oracle.so")   # ORACLE_LIB: sanitizer build
 
 
 class _Model(C.Structure):
