@@ -203,3 +203,22 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     sizes = [int(v) for v in fields[5:11]]
     assert sizes == [C.sizeof(L.Model), C.sizeof(L.EcmCfg), C.sizeof(L.EcmOut), C.sizeof(L.BgCfg), C.sizeof(L.BgOut),
                      C.sizeof(L.RunStats)]
+
+
+def test_qseed_posterior_host_tail_matches_reference_golden_vectors():
+    """csr_qseed_posterior is host arithmetic inside the product library (no device call): the grid posterior of the Q0
+    seed (pyx:1905-2146) against the golden vectors of the compiled reference, here on the CPU."""
+    import os
+
+    import numpy as np
+
+    import qseed_cases as qc
+    from consenrich_amd import qseed
+
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    for case in qc.native_cases():
+        if case["kind"] != "post":
+            continue
+        with np.load(os.path.join(golden, case["name"] + ".npz")) as z:
+            gold = {k: z[k] for k in z.files}
+        qc.same(qc.run_native(qseed, case), gold, rtol=1e-12)
