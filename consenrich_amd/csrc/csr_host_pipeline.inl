@@ -577,8 +577,22 @@ static int export_impl(csr_ctx *c, uint32_t what) {
             CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
         }
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
+        if (constQ && p.chainQ == nullptr) {
+            // one Q0 for every bin of every chain: a streaming fill (rows past a chain's n-1 are padding nobody reads)
+            float *dst;
+            CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));
+            const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
+            Scope sc(c, "export_natural");
+            if (nm == 4)
+                hipLaunchKernelGGL(k_fill_rows<4>, dim3(grid), dim3(256), 0, c->stream, dst, c->Npad, (float)p.Q00,
+                                   (float)p.Q01, (float)p.Q10, (float)p.Q11);
+            else
+                hipLaunchKernelGGL(k_fill_rows<1>, dim3(grid), dim3(256), 0, c->stream, dst, c->Npad, (float)p.Q00, 0.f, 0.f,
+                                   0.f);
+        } else {
         CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
-        if (constQ) {
+        }
+        if (constQ && p.chainQ != nullptr) {
             ExpDesc &e = L.d[L.count - 1];
             e.cval[0] = (float)p.Q00;
             e.cval[1] = d == 2 ? (float)p.Q01 : 0.f;
