@@ -18,6 +18,8 @@ sweeps = iters * (inner + 1)      # forward passes; backward passes = iters*inne
 print(f"GPU ECM: {iters} iters x ({inner} fwd+bwd+E + 1 NLL fwd) over {sum(lengths)} bins x {m}: {dt*1e3:.1f} ms "
       f"-> {dt*1e3/iters:.2f} ms/iter, {sum(lengths)*iters*inner/dt/1e9:.2f} G bin-sweeps/s (fwd+bwd+E-step)")
 print({k: (v[0], round(v[1], 2)) for k, v in kt.items()})
+rs = b.run_stats()
+print("run stats:", {k: rs[k] for k in ("reruns_p", "reruns_x", "reruns_b", "pipeline_redos", "warm_p", "block_len")})
 if os.environ.get("CPU", "1") == "1":
     import cases
     from oracle import oracle as orc
