@@ -222,3 +222,39 @@ def test_qseed_posterior_host_tail_matches_reference_golden_vectors():
         with np.load(os.path.join(golden, case["name"] + ".npz")) as z:
             gold = {k: z[k] for k in z.files}
         qc.same(qc.run_native(qseed, case), gold, rtol=1e-12)
+
+
+def test_qseed_mirror_argument_validation_without_a_gpu():
+    """the Python-level validation of the Q0-seed natives (pyx:1532-1546, 1977-1996) happens before any device call"""
+    import math
+
+    import numpy as np
+    import pytest
+
+    from consenrich_amd import cconsenrich as amd
+
+    data, act = np.zeros((2, 9)), np.ones((2, 9), bool)
+    with pytest.raises(ValueError, match="signalPanelSize must be nonnegative"):
+        amd.cEstimateSameTrackProcessNoiseTransitions(data, np.ones((2, 9)), act, 0.95, 20.0, 0, 32000, -1)
+    with pytest.raises(ValueError, match=r"precisionCapQuantile must be in \[0, 1\]"):
+        amd.cEstimateSameTrackProcessNoiseTransitions(data, np.ones((2, 9)), act, 1.5, 20.0)
+    with pytest.raises(ValueError, match="precisionCapMultiplier must be positive"):
+        amd.cEstimateSameTrackProcessNoiseTransitions(data, np.ones((2, 9)), act, 0.95, 0.0)
+    with pytest.raises(ValueError, match="obsVar shape must match matrixData"):
+        amd.cEstimateSameTrackProcessNoiseTransitions(data, np.ones((2, 8)), act, 0.95, 20.0)
+    with pytest.raises(ValueError, match="matrixData must be a 2D array"):
+        amd.cEstimatePooledProcessNoiseTransitions(np.zeros(9), np.ones(9), np.ones(9, bool))
+    empty = amd.cEstimateSameTrackProcessNoiseTransitions(np.zeros((2, 1)), np.ones((2, 1)), np.ones((2, 1), bool), 0.95, 20.0)
+    assert empty[0].size == 0 and math.isnan(empty[3]["precisionCap"])
+    assert all(a.size == 0 for a in amd.cEstimatePooledProcessNoiseTransitions(np.zeros((2, 1)), np.ones((2, 1)), np.ones((2, 1), bool)))
+    one = np.ones(8)
+    tail = (1.0e-5, 8, math.log(4.0), 8.0, 64)
+    for kwargs, msg in (((one, one[:3], one, 1e-5, 1.0, 8.0, "s") + tail, "same length"),
+                        ((one, one, one, 0.0, 1.0, 8.0, "s") + tail, "qFloor must be positive finite"),
+                        ((one, one, one, 1e-5, -1.0, 8.0, "s") + tail, "qCap must be positive or infinite"),
+                        ((one, one, one, 1e-5, 1.0, 8.0, "s", 1e-5, 0, math.log(4.0), 8.0, 64), "minTransitions must be positive"),
+                        ((one, one, one, 1e-5, 1.0, 8.0, "s", 1e-5, 8, math.log(4.0), 8.0, 0), "gridSize must be positive")):
+        with pytest.raises(ValueError, match=msg):
+            amd.cQSeedPosteriorFromTransitions(*kwargs)
+    with pytest.raises(ValueError, match="samplingVariances must be nonnegative finite"):     # data-dependent, host tail
+        amd.cQSeedPosteriorFromTransitions(one, -one, one, 1e-5, 1.0, 8.0, "s", *tail)
