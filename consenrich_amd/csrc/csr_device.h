@@ -582,7 +582,7 @@ struct FwdXTrend {
         dma4(z, slot + 256);
         dma4(z + 4, slot + 320);
     }
-    __device__ static __forceinline__ In dma_read(const unsigned *slot, int lane) {
+    __device__ static __forceinline__ In dma_read(const Prm &, const unsigned *slot, int lane) {
         const uint4 r = lds_rd128(slot + lane * 4);
         const unsigned w0 = lds_rd32(slot + 256 + lane), w1 = lds_rd32(slot + 320 + lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -650,7 +650,7 @@ struct FwdXLevel {
         in.pp = unpack_d(r.z, r.w);
         return in;
     }
-    __device__ static __forceinline__ In dma_read(const unsigned *slot, int lane) {
+    __device__ static __forceinline__ In dma_read(const Prm &, const unsigned *slot, int lane) {
         const uint4 r = lds_rd128(slot + lane * 4);
         const unsigned w0 = lds_rd32(slot + 256 + lane), w1 = lds_rd32(slot + 320 + lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -734,6 +734,57 @@ struct FwdTrendFused {
         FwdXTrend::step<STORE>(p, c.X, xin, b, s, i, bfirst);
     }
 };
+// LDS-DMA variant of the fused forward chain (k_chain_spec_dma).  PMC on the plain kernel: the wavefront is parked on
+// s_waitcnt 62-66 % of its cycles and issues only 27-30 % -- with loads AND stores in flight hipcc waits vmcnt(0) for
+// every register-prefetched batch, i.e. also for the store acknowledgements of the previous batch.  Through the ring the
+// inputs arrive in LDS DMA_L steps ahead under a counted wait that younger stores only make more conservative.
+// Rows of a slot (64 lanes x 4 bytes each): s0u lo / hi, zbar lo / hi [, lambda, kappa, qScale when MULT].
+template <int MULT>      // 0: no per-bin multipliers; 1: kappa only (the reference's default ECM); 2: lambda, kappa, qScale
+struct FwdTrendFusedDma : FwdTrendFused {
+    static constexpr bool DMA = true;
+    static constexpr bool NATOUT_FWD = false;
+    static constexpr int NW = MULT == 0 ? 4 : (MULT == 1 ? 5 : 7), ND = NW;
+    __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
+        const char *a = reinterpret_cast<const char *>(p.tS0u + i);
+        const char *z = reinterpret_cast<const char *>(p.tZbar + i);
+        dma4(a, slot);
+        dma4(a + 4, slot + 64);
+        dma4(z, slot + 128);
+        dma4(z + 4, slot + 192);
+        if constexpr (MULT == 1) dma4(p.tKap + i, slot + 256);
+        if constexpr (MULT == 2) {
+            // a multiplier that is switched off is fetched from a valid dummy address (ND must not depend on flags)
+            const float *d = reinterpret_cast<const float *>(p.tZbar + i);
+            dma4((p.flags & F_LAMBDA) ? p.tLam + i : d, slot + 256);
+            dma4((p.flags & F_KAPPA) ? p.tKap + i : d, slot + 320);
+            dma4((p.flags & F_QSCALE) ? p.tQs + i : d, slot + 384);
+        }
+    }
+    __device__ static __forceinline__ In dma_read(const Prm &p, const unsigned *slot, int lane) {
+        const unsigned a0 = lds_rd32(slot + lane), a1 = lds_rd32(slot + 64 + lane);
+        const unsigned z0 = lds_rd32(slot + 128 + lane), z1 = lds_rd32(slot + 192 + lane);
+        unsigned l = 0, k = 0, q = 0;
+        if constexpr (MULT == 1) k = lds_rd32(slot + 256 + lane);
+        if constexpr (MULT == 2) {
+            l = lds_rd32(slot + 256 + lane);
+            k = lds_rd32(slot + 320 + lane);
+            q = lds_rd32(slot + 384 + lane);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        In in;
+        in.s0u = words2double(a0, a1);
+        in.zbar = words2double(z0, z1);
+        in.lam = in.kap = in.qs = 1.0f;       // the values FwdPTrend::load delivers: 1 when a multiplier is switched off
+        if constexpr (MULT == 1) in.kap = __uint_as_float(k);
+        if constexpr (MULT == 2) {
+            if (p.flags & F_LAMBDA) in.lam = __uint_as_float(l);
+            if (p.flags & F_KAPPA) in.kap = __uint_as_float(k);
+            if (p.flags & F_QSCALE) in.qs = __uint_as_float(q);
+        }
+        return in;
+    }
+};
+
 struct FwdLevelFused {
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
@@ -1410,7 +1461,7 @@ __device__ __forceinline__ void dma_phase(const Prm &p, typename CH::Carry &c, u
     for (; t < tEnd; ++t) {
         if (t + DMA_L <= T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_L - 1) * ND) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        typename CH::In in = CH::dma_read(ring + (t % DMA_R) * (CH::NW * 64), lane);
+        typename CH::In in = CH::dma_read(p, ring + (t % DMA_R) * (CH::NW * 64), lane);
         __builtin_amdgcn_sched_barrier(0);
         if (t + DMA_L < T) {
             CH::dma_issue(p, iss.idx, ring + ((t + DMA_L) % DMA_R) * (CH::NW * 64));

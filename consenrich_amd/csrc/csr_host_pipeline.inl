@@ -98,8 +98,24 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
             bool launched = false;
+            if constexpr (std::is_same<CH, FwdTrendFused>::value) {
+                // ECM sweeps and other passes without reference-layout outputs: inputs through the LDS-DMA ring
+                if (c->useDmaFused && !p.natOut && !pcq) {
+                    const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
+                    if (mm == 0)
+                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 4 * 64, c->stream, p);
+                    else if (mm == F_KAPPA)
+                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<1>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 5 * 64, c->stream, p);
+                    else
+                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<2>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 7 * 64, c->stream, p);
+                    launched = true;
+                }
+            }
             if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
-                if (p.natOut) {
+                if (!launched && p.natOut) {
                     if (pcq) hipLaunchKernelGGL((k_chain_spec<CH, true, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
                     else hipLaunchKernelGGL((k_chain_spec<CH, true, false>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
                     launched = true;
