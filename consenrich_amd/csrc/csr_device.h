@@ -75,8 +75,8 @@ struct Prm {
     const float *munc;
 
     // blocked per-bin statistics (a1)
-    double *tS0u;       // sum_j 1/R_j
-    double *tZbar;      // weighted mean of z
+    double2 *tSZ;       // .x = S0u = sum_j 1/R_j, .y = zbar = weighted mean of z: one 16-byte record per bin (one load /
+                        // one LDS-DMA instruction per step of the serial chains instead of two / four)
     double *tS2c;       // sum_j (z_j - zbar)^2 / R_j
     double *tLogR;      // sum_j log R_j
     // blocked multipliers
@@ -354,8 +354,7 @@ __global__ __launch_bounds__(256) void k_stats(Prm p) {
         const int idx = it * 256 + t;
         const int row = idx / TL, ll = idx % TL;
         const int64_t o = rowBase + (int64_t)row * 64 + ll;
-        p.tS0u[o] = tile[0][row][ll];
-        p.tZbar[o] = tile[1][row][ll];
+        p.tSZ[o] = make_double2(tile[0][row][ll], tile[1][row][ll]);
         p.tS2c[o] = tile[2][row][ll];
         p.tLogR[o] = tile[3][row][ll];
     }
@@ -402,7 +401,7 @@ struct FwdPTrend {
     };
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
-        in.s0u = p.tS0u[i];
+        in.s0u = p.tSZ[i].x;
         in.lam = (p.flags & F_LAMBDA) ? p.tLam[i] : 1.0f;
         in.kap = (p.flags & F_KAPPA) ? p.tKap[i] : 1.0f;
         in.qs = (p.flags & F_QSCALE) ? p.tQs[i] : 1.0f;
@@ -567,7 +566,7 @@ struct FwdXTrend {
     };
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
-        in.zbar = p.tZbar[i];
+        in.zbar = p.tSZ[i].y;
         const float4 r = p.tXin[i];
         in.gs = unpack_d(r.x, r.y);
         in.cp = make_float2(r.z, r.w);
@@ -577,7 +576,7 @@ struct FwdXTrend {
     static constexpr bool DMA = true;
     static constexpr int NW = 6, ND = 3;
     __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
-        const char *z = reinterpret_cast<const char *>(p.tZbar + i);
+        const char *z = reinterpret_cast<const char *>(p.tSZ + i) + 8;
         dma16(p.tXin + i, slot);
         dma4(z, slot + 256);
         dma4(z + 4, slot + 320);
@@ -628,7 +627,7 @@ struct FwdXLevel {
     static constexpr bool DMA = true;
     static constexpr int NW = 6, ND = 3;
     __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
-        const char *z = reinterpret_cast<const char *>(p.tZbar + i);
+        const char *z = reinterpret_cast<const char *>(p.tSZ + i) + 8;
         dma16(p.tXin + i, slot);
         dma4(z, slot + 256);
         dma4(z + 4, slot + 320);
@@ -644,7 +643,7 @@ struct FwdXLevel {
     };
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
-        in.zbar = p.tZbar[i];
+        in.zbar = p.tSZ[i].y;
         const float4 r = p.tXin[i];
         in.gs = unpack_d(r.x, r.y);
         in.pp = unpack_d(r.z, r.w);
@@ -708,7 +707,7 @@ struct FwdTrendFused {
         const FwdPTrend::In a = FwdPTrend::load(p, i, bq, s, len);
         In in;
         in.s0u = a.s0u; in.lam = a.lam; in.kap = a.kap; in.qs = a.qs;
-        in.zbar = p.tZbar[i];
+        in.zbar = p.tSZ[i].y;
         return in;
     }
     __device__ static __forceinline__ Carry init_true(const Prm &p) {
@@ -743,26 +742,21 @@ template <int MULT>      // 0: no per-bin multipliers; 1: kappa only (the refere
 struct FwdTrendFusedDma : FwdTrendFused {
     static constexpr bool DMA = true;
     static constexpr bool NATOUT_FWD = false;
-    static constexpr int NW = MULT == 0 ? 4 : (MULT == 1 ? 5 : 7), ND = NW;
+    // slot: [lane][4 words] = the (S0u, zbar) record in one 16-byte DMA, then one 64-word row per multiplier
+    static constexpr int NW = MULT == 0 ? 4 : (MULT == 1 ? 5 : 7), ND = MULT == 0 ? 1 : (MULT == 1 ? 2 : 4);
     __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
-        const char *a = reinterpret_cast<const char *>(p.tS0u + i);
-        const char *z = reinterpret_cast<const char *>(p.tZbar + i);
-        dma4(a, slot);
-        dma4(a + 4, slot + 64);
-        dma4(z, slot + 128);
-        dma4(z + 4, slot + 192);
+        dma16(p.tSZ + i, slot);
         if constexpr (MULT == 1) dma4(p.tKap + i, slot + 256);
         if constexpr (MULT == 2) {
             // a multiplier that is switched off is fetched from a valid dummy address (ND must not depend on flags)
-            const float *d = reinterpret_cast<const float *>(p.tZbar + i);
+            const float *d = reinterpret_cast<const float *>(p.tSZ + i);
             dma4((p.flags & F_LAMBDA) ? p.tLam + i : d, slot + 256);
             dma4((p.flags & F_KAPPA) ? p.tKap + i : d, slot + 320);
             dma4((p.flags & F_QSCALE) ? p.tQs + i : d, slot + 384);
         }
     }
     __device__ static __forceinline__ In dma_read(const Prm &p, const unsigned *slot, int lane) {
-        const unsigned a0 = lds_rd32(slot + lane), a1 = lds_rd32(slot + 64 + lane);
-        const unsigned z0 = lds_rd32(slot + 128 + lane), z1 = lds_rd32(slot + 192 + lane);
+        const uint4 r = lds_rd128(slot + lane * 4);
         unsigned l = 0, k = 0, q = 0;
         if constexpr (MULT == 1) k = lds_rd32(slot + 256 + lane);
         if constexpr (MULT == 2) {
@@ -772,8 +766,8 @@ struct FwdTrendFusedDma : FwdTrendFused {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         In in;
-        in.s0u = words2double(a0, a1);
-        in.zbar = words2double(z0, z1);
+        in.s0u = words2double(r.x, r.y);
+        in.zbar = words2double(r.z, r.w);
         in.lam = in.kap = in.qs = 1.0f;       // the values FwdPTrend::load delivers: 1 when a multiplier is switched off
         if constexpr (MULT == 1) in.kap = __uint_as_float(k);
         if constexpr (MULT == 2) {
@@ -1601,8 +1595,7 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
                     else xp0v[u] = p.init;
                     { const float4 r = p.tXin[i]; ppv[u] = unpack_d(r.z, r.w); }
                 }
-                s0u[u] = p.tS0u[i];
-                zb[u] = p.tZbar[i];
+                { const double2 sz = p.tSZ[i]; s0u[u] = sz.x; zb[u] = sz.y; }
                 s2c[u] = p.tS2c[i];
                 if (wantNLL) slr[u] = p.tLogR[i];
             }
@@ -1701,8 +1694,9 @@ __global__ __launch_bounds__(256) void k_estep_lambda(Prm p) {
     if (s >= bi.y) return;
     double p00 = (double)p.tPs[slot].x;
     if (p00 < 0.0) p00 = 0.0;
-    const double s0u = p.tS0u[slot];
-    const double dz = p.tZbar[slot] - (double)p.tXs[slot].x;
+    const double2 sz = p.tSZ[slot];
+    const double s0u = sz.x;
+    const double dz = sz.y - (double)p.tXs[slot].x;
     const double u2 = fma(p00, s0u, fma(s0u, dz * dz, p.tS2c[slot]));
     double w = (p.nu + (double)p.m) / (p.nu + u2);
     if (w < p.wMin) w = p.wMin;
@@ -1770,7 +1764,8 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
             const double lam = (p.flags & F_LAMBDA) ? clampd((double)p.tLam[i], p.wMin, p.wMax) : 1.0;
             const double qs = (p.flags & F_QSCALE) ? (double)p.tQs[i] : apn;
             const double qf = qs / kap;
-            const double S0 = lam * p.tS0u[i];
+            const double2 sz = p.tSZ[i];
+            const double S0 = lam * sz.x;
             double pp, xp0, quad, is, Qd;
             if (p.d == 2) {
                 const double Q00 = qf * p.Q00, Q01 = qf * p.Q01, Q10 = qf * p.Q10, Q11 = qf * p.Q11;
@@ -1786,7 +1781,7 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
                 pp = a00;
                 xp0 = xq0;
                 is = 1.0 + a00 * S0;
-                const double dz = p.tZbar[i] - xq0;
+                const double dz = sz.y - xq0;
                 const double S1 = S0 * dz;
                 const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
                 quad = S2 - (a00 / is) * (S1 * S1);
@@ -1811,7 +1806,7 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
                 pp = pl;
                 xp0 = xl;
                 is = 1.0 + pl * S0;
-                const double dz = p.tZbar[i] - xl;
+                const double dz = sz.y - xl;
                 const double S1 = S0 * dz;
                 const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
                 quad = S2 - (pl / is) * (S1 * S1);

@@ -155,7 +155,7 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     p.data = dd; p.munc = dm;
 
     const int64_t T = c->TN;
-    CHECK(dalloc(c, &p.tS0u, T)); CHECK(dalloc(c, &p.tZbar, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
+    CHECK(dalloc(c, &p.tSZ, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
     CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
     CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
     CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T)); CHECK(dalloc(c, &p.tPP, T));

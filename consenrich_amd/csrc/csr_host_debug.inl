@@ -37,7 +37,7 @@ extern "C" int csr_debug_read(csr_ctx *c, int buf, void *dst, int64_t bytes) {
         case 1: src = c->p.carryOutA; break;
         case 2: src = c->p.carryOutB; break;
         case 3: src = c->p.tPf; break;
-        case 4: src = c->p.tS0u; break;
+        case 4: src = c->p.tSZ; break;          // (S0u, zbar) records
         default: return fail("bad debug buffer");
     }
     HIPOK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
