@@ -236,7 +236,7 @@ __device__ __forceinline__ double words2double(unsigned lo, unsigned hi) {
 }
 
 constexpr int DMA_L = 8;      // steps in flight
-constexpr int DMA_R = 10;     // ring slots (> DMA_L)
+constexpr int DMA_R = 9;      // ring slots (> DMA_L: the slot a step refills is the one the previous step finished reading)
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1251,9 +1251,14 @@ __device__ __forceinline__ void walk_nat_direct(const Prm &p, typename CH::Carry
 // Forward counterpart of walk_nat for the fused forward chain: the blocked stores stay (the smoother reads them), and the
 // filtered state / covariance are ALSO written in the reference layout through the same LDS tiles, so the export pass
 // has nothing left to convert but D.  natXs / natPs point at the natural xf / Pf arrays here.
-template <class CH>
+struct NatTilesFwd {                    // the forward walker's share of NatTiles (no lag tile): 13 KB
+    float4 ps[8][65];
+    float2 xs[8][65];
+    int gbase[64], len[64];
+};
+template <class CH, class TT = NatTiles>
 __device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
-                                             int64_t bfirst, int gbase, NatTiles &T) {
+                                             int64_t bfirst, int gbase, TT &T) {
     const int lane = threadIdx.x;
     const int B = p.B;
     const int64_t base = tbase(bq, B);
@@ -1493,6 +1498,40 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state cha
     if (live) cin[b] = c;
     dma_phase<CH, true>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, T, T);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (live) cout[b] = c;
+}
+
+// Hybrid for the fused forward chain WITH reference-layout outputs: the warm-up (no stores: 38 % of a lane's steps at genome
+// scale, 71 % on a 1/8-genome shard) runs through the LDS-DMA ring, the main phase is the tile walker of k_chain_spec
+// (plain loads: its ~5 stores per step could not be told apart from the DMA by a counted wait).  The ring is drained
+// before the main phase, so the tile walker's barriers and LDS reads see no DMA in flight.
+template <class DCH>
+__global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dynMemW[];
+    unsigned *ringMem = dynMemW;
+    NatTilesFwd &tiles = *reinterpret_cast<NatTilesFwd *>(dynMemW + DMA_R * DCH::NW * 64);
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    const int lastLen = p.B;
+    typename DCH::Carry c = DCH::init_cold(p);
+    typename DCH::Carry *cin = reinterpret_cast<typename DCH::Carry *>(p.carryIn);
+    typename DCH::Carry *cout = reinterpret_cast<typename DCH::Carry *>(p.carryOutA);
+    const int W = p.warm;
+    LaneCursor<true> cons, iss;
+    cons.init(p, W, b, live, bi, lastLen);
+    iss.init(p, W, b, live, bi, lastLen);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // block-table loads retired before the ring starts
+    for (int t0 = 0; t0 < DMA_L && t0 < W; ++t0) {
+        DCH::dma_issue(p, iss.idx, ringMem + (t0 % DMA_R) * (DCH::NW * 64));
+        iss.next(p, b, live, bi, lastLen);
+    }
+    int t = 0;
+    dma_phase<DCH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, W);     // T = W: nothing fetched beyond
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (live) cin[b] = c;
+    walk_nat_fwd<FwdTrendFused, NatTilesFwd>(p, c, b, bi.y, live, bi.z, bi.x, tiles);
     if (live) cout[b] = c;
 }
 

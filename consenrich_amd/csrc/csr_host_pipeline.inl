@@ -100,7 +100,21 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             bool launched = false;
             if constexpr (std::is_same<CH, FwdTrendFused>::value) {
                 // ECM sweeps and other passes without reference-layout outputs: inputs through the LDS-DMA ring
-                if (c->useDmaFused && !p.natOut && !pcq) {
+                if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0) {
+                    // reference-layout outputs: ring for the warm-up only, tile walker for the main phase
+                    const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
+                    const size_t tl = sizeof(NatTilesFwd);
+                    if (mm == 0)
+                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 4 * 64 + tl, c->stream, p);
+                    else if (mm == F_KAPPA)
+                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<1>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 5 * 64 + tl, c->stream, p);
+                    else
+                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<2>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 7 * 64 + tl, c->stream, p);
+                    launched = true;
+                } else if (c->useDmaFused && !p.natOut && !pcq) {
                     const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
                     if (mm == 0)
                         hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),

@@ -102,6 +102,7 @@ struct csr_ctx {
     int *lastFwdWindow = nullptr;   // ... of the last forward stage launched (a failed settle widens that one)
     bool Bfixed = false;
     bool adaptWarm = true;
+    bool useDmaWarm = true;    // ... and, with reference-layout outputs, for its warm-up phase
     bool useDmaFused = true;   // fused forward chain without reference-layout outputs: LDS-DMA ring
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
     int xTolUlps = 2;
@@ -271,6 +272,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_RESID_TILE"))) c->residTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_STATS_UNROLL"))) c->statsUnroll = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA_FUSED"))) c->useDmaFused = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_DMA_WARM"))) c->useDmaWarm = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
     if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
     return c;
