@@ -997,6 +997,36 @@ struct BwdTrend {
 };
 
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
+// LDS-DMA inputs of the smoother chain (used for its warm-up phase, k_chain_spec_dmawarm_natbwd): the filtered
+// covariance in one 16-byte DMA ([lane][4] words), the filtered state as two 4-byte rows, the stored process noise in
+// one more 16-byte DMA when it varies per bin (QARR).
+template <bool QARR>
+struct BwdTrendDma : BwdTrend {
+    static constexpr bool DMA = true;
+    static constexpr bool NATOUT = false;
+    static constexpr int NW = QARR ? 10 : 6, ND = QARR ? 4 : 3;
+    __device__ static __forceinline__ void dma_issue(const Prm &p, int64_t i, unsigned *slot) {
+        const char *x = reinterpret_cast<const char *>(p.tXf + i);
+        dma16(p.tPf + i, slot);
+        dma4(x, slot + 256);
+        dma4(x + 4, slot + 320);
+        if constexpr (QARR) dma16(p.tQ + i, slot + 384);
+    }
+    __device__ static __forceinline__ In dma_read(const Prm &p, const unsigned *slot, int lane) {
+        const uint4 f = lds_rd128(slot + lane * 4);
+        const unsigned x0 = lds_rd32(slot + 256 + lane), x1 = lds_rd32(slot + 320 + lane);
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (QARR) q = lds_rd128(slot + 384 + lane * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        In in;
+        in.xf = make_float2(__uint_as_float(x0), __uint_as_float(x1));
+        in.pf = make_float4(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z), __uint_as_float(f.w));
+        if constexpr (QARR) in.q = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+        else in.q = make_float4((float)p.Q00, (float)p.Q01, (float)p.Q10, (float)p.Q11);
+        return in;
+    }
+};
+
 struct BwdLevel {
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
@@ -1532,6 +1562,40 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (live) cin[b] = c;
     walk_nat_fwd<FwdTrendFused, NatTilesFwd>(p, c, b, bi.y, live, bi.z, bi.x, tiles);
+    if (live) cout[b] = c;
+}
+
+// Same hybrid for the smoother chain (warm-up blocks b+q .. b+1 walked downwards through the ring, tile walker for the
+// lane's own block).  Ring + tiles need 35 KB of LDS per wavefront, i.e. 4 wavefronts per CU: used for batches of at
+// most 1024 wave-groups (the shards of a multi-GPU run), where it is the warm-up that dominates a lane's walk.
+template <class DCH>
+__global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dynMemB[];
+    unsigned *ringMem = dynMemB;
+    NatTiles &tiles = *reinterpret_cast<NatTiles *>(dynMemB + DMA_R * DCH::NW * 64);
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    int lastLen = p.B;
+    if (live) lastLen = p.blk[bi.w].y;
+    typename DCH::Carry c = DCH::init_cold(p);
+    typename DCH::Carry *cin = reinterpret_cast<typename DCH::Carry *>(p.carryIn);
+    typename DCH::Carry *cout = reinterpret_cast<typename DCH::Carry *>(p.carryOutA);
+    const int W = p.warm;
+    LaneCursor<false> cons, iss;
+    cons.init(p, W, b, live, bi, lastLen);
+    iss.init(p, W, b, live, bi, lastLen);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int t0 = 0; t0 < DMA_L && t0 < W; ++t0) {
+        DCH::dma_issue(p, iss.idx, ringMem + (t0 % DMA_R) * (DCH::NW * 64));
+        iss.next(p, b, live, bi, lastLen);
+    }
+    int t = 0;
+    dma_phase<DCH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, W);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (live) cin[b] = c;
+    walk_nat<BwdTrend>(p, c, b, bi.y, live, b == bi.w, bi.x, tiles);
     if (live) cout[b] = c;
 }
 

@@ -128,6 +128,19 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                     launched = true;
                 }
             }
+            if constexpr (std::is_same<CH, BwdTrend>::value) {
+                // smoother with reference-layout outputs on a small batch (a multi-GPU shard): warm-up through the ring
+                // (32-bin blocks: measured slower, 0.063 vs 0.057 ms -- the ring's fill and drain weigh more than they hide)
+                if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->NG <= 1024 && c->B >= 64) {
+                    if (p.qFromMult)
+                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<false>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 6 * 64 + sizeof(NatTiles), c->stream, p);
+                    else
+                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<true>>, dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 10 * 64 + sizeof(NatTiles), c->stream, p);
+                    launched = true;
+                }
+            }
             if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
                 if (!launched && p.natOut) {
                     if (pcq) hipLaunchKernelGGL((k_chain_spec<CH, true, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
