@@ -1539,7 +1539,8 @@ template <class DCH>
 __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
     extern __shared__ __attribute__((aligned(16))) unsigned dynMemW[];
     unsigned *ringMem = dynMemW;
-    NatTilesFwd &tiles = *reinterpret_cast<NatTilesFwd *>(dynMemW + DMA_R * DCH::NW * 64);
+    // the tiles OVERLAY the ring: it is drained before the main phase starts (same LDS footprint as the plain kernel)
+    NatTilesFwd &tiles = *reinterpret_cast<NatTilesFwd *>(dynMemW);
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
     int4 bi = make_int4(0, 0, 0, 0);
@@ -1566,13 +1567,13 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
 }
 
 // Same hybrid for the smoother chain (warm-up blocks b+q .. b+1 walked downwards through the ring, tile walker for the
-// lane's own block).  Ring + tiles need 35 KB of LDS per wavefront, i.e. 4 wavefronts per CU: used for batches of at
-// most 1024 wave-groups (the shards of a multi-GPU run), where it is the warm-up that dominates a lane's walk.
+// lane's own block).  Ring and tiles share the same LDS (the ring is drained first), so the footprint is the plain
+// kernel's.
 template <class DCH>
 __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
     extern __shared__ __attribute__((aligned(16))) unsigned dynMemB[];
     unsigned *ringMem = dynMemB;
-    NatTiles &tiles = *reinterpret_cast<NatTiles *>(dynMemB + DMA_R * DCH::NW * 64);
+    NatTiles &tiles = *reinterpret_cast<NatTiles *>(dynMemB);      // overlays the (drained) ring
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
     int4 bi = make_int4(0, 0, 0, 0);

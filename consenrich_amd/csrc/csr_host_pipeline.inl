@@ -106,13 +106,13 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                     const size_t tl = sizeof(NatTilesFwd);
                     if (mm == 0)
                         hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),
-                                           sizeof(unsigned) * DMA_R * 4 * 64 + tl, c->stream, p);
+                                           std::max(sizeof(unsigned) * DMA_R * 4 * 64, tl), c->stream, p);
                     else if (mm == F_KAPPA)
                         hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<1>>, dim3(grid), dim3(64),
-                                           sizeof(unsigned) * DMA_R * 5 * 64 + tl, c->stream, p);
+                                           std::max(sizeof(unsigned) * DMA_R * 5 * 64, tl), c->stream, p);
                     else
                         hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<2>>, dim3(grid), dim3(64),
-                                           sizeof(unsigned) * DMA_R * 7 * 64 + tl, c->stream, p);
+                                           std::max(sizeof(unsigned) * DMA_R * 7 * 64, tl), c->stream, p);
                     launched = true;
                 } else if (c->useDmaFused && !p.natOut && !pcq) {
                     const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
@@ -129,15 +129,15 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                 }
             }
             if constexpr (std::is_same<CH, BwdTrend>::value) {
-                // smoother with reference-layout outputs on a small batch (a multi-GPU shard): warm-up through the ring
+                // smoother with reference-layout outputs: warm-up through the ring
                 // (32-bin blocks: measured slower, 0.063 vs 0.057 ms -- the ring's fill and drain weigh more than they hide)
-                if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->NG <= 1024 && c->B >= 64) {
+                if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->B >= 64) {
                     if (p.qFromMult)
                         hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<false>>, dim3(grid), dim3(64),
-                                           sizeof(unsigned) * DMA_R * 6 * 64 + sizeof(NatTiles), c->stream, p);
+                                           std::max(sizeof(unsigned) * DMA_R * 6 * 64, sizeof(NatTiles)), c->stream, p);
                     else
                         hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<true>>, dim3(grid), dim3(64),
-                                           sizeof(unsigned) * DMA_R * 10 * 64 + sizeof(NatTiles), c->stream, p);
+                                           std::max(sizeof(unsigned) * DMA_R * 10 * 64, sizeof(NatTiles)), c->stream, p);
                     launched = true;
                 }
             }
