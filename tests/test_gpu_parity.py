@@ -1219,3 +1219,74 @@ def test_bench_workload_matches_oracle(product, oracle):
                 np.testing.assert_allclose(b.download(c, name), ref, rtol=RTOL, atol=ATOL, err_msg=f"chain {c} {name}")
             assert np.all(np.abs(b.download(c, "resid").astype(np.float64) - bw[3]) <= RTOL * lvl + ATOL), c
             close_mostly(b.download(c, "D"), D, frac=1e-2, cap=5e-4, msg=f"D chain {c}")
+
+
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+@pytest.mark.parametrize("flags_name", ["plain", "kappa", "all"])
+@pytest.mark.parametrize("block_len", [32, 64, 128])
+def test_lds_dma_paths_agree_with_the_plain_kernels(product, block_len, flags_name, xtol):
+    """The LDS-DMA ring only changes HOW a chain's inputs reach the recursion (global_load_lds + counted waits instead of
+    register prefetch).  In exact mode the results do not depend on the speculation at all: every output must equal the
+    plain kernels' bit for bit (smoother warm-up hybrid, state-chain ring).  In the 2-ulp mode a lane whose chain starts
+    inside its window begins at the window's edge through the ring and at the chain start in the plain kernel -- two
+    valid speculations -- so the outputs agree to the mode's tolerance.  Ragged chains (partial blocks, chain starts /
+    ends inside warm-up windows, one-bin chains), constant and per-bin multipliers, forward with reference-layout outputs
+    (warm-up hybrid) and ECM sweeps (whole walk through the ring)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    rng = np.random.default_rng(77 + block_len)
+    n_list = [int(v) for v in np.concatenate([[1, 2, 31, 33, 63, 65, 127, 129, 300], rng.integers(1, 4000, 40)])]
+    m = 3
+    sets = [cases.synth(n, m, 9100 + i, mask_frac=0.02) for i, n in enumerate(n_list)]
+    mult = {c: (np.exp(rng.normal(0, 0.3, n)).astype(np.float32), np.exp(rng.normal(0, 1.0, n)).astype(np.float32),
+                np.exp(rng.normal(0, 0.2, n)).astype(np.float32)) for c, n in enumerate(n_list)}
+    flags = {"plain": 0, "kappa": L.USE_KAPPA, "all": L.USE_KAPPA | L.USE_LAMBDA | L.USE_QSCALE}[flags_name]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+
+    def run(dma):
+        env = {k: ("1" if dma else "0") for k in ("CONSENRICH_AMD_DMA_WARM", "CONSENRICH_AMD_DMA_FUSED", "CONSENRICH_AMD_DMA")}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with DeviceBatch(0, block_len=block_len, x_tol_ulps=xtol) as b:     # switches are read at context creation
+                b.configure(ModelParams(state_dim=2), m, n_list)
+                for c, (d_, v_) in enumerate(sets):
+                    b.upload(c, d_, v_)
+                    if flags:
+                        b.upload_multipliers(c, *mult[c])
+                b.stats()
+                sd, sn = b.forward_backward(L.RETURN_NLL | flags)                  # reference-layout outputs: warm-up hybrid
+                b.export(what)
+                out = {(c, k): b.download(c, k) for c in range(len(n_list)) for k in ("D", "xf", "Pf", "xs", "Ps", "lag", "resid")}
+                outs, _ = b.ecm(max_iters=2, inner_iters=2, rtol=0.0, use_lambda=bool(flags & L.USE_LAMBDA), use_kappa=True)
+                b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT)                           # ECM sweeps: whole walk through the ring
+                for c in range(len(n_list)):
+                    out[(c, "ecm_xs")] = b.download(c, "xs")
+                    out[(c, "ecm_kappa")] = b.download(c, "kappa")
+                return sn.copy(), np.asarray([o.final_nll for o in outs]), out
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    sn_a, nll_a, out_a = run(True)
+    sn_b, nll_b, out_b = run(False)
+    if xtol == 0:
+        assert np.array_equal(sn_a, sn_b) and np.array_equal(nll_a, nll_b)
+        for key in out_a:
+            assert np.array_equal(out_a[key], out_b[key], equal_nan=True), key
+        return
+    np.testing.assert_allclose(sn_a, sn_b, rtol=1e-7)
+    np.testing.assert_allclose(nll_a, nll_b, rtol=1e-6)
+    for (c, k), a in out_a.items():
+        b_ = out_b[(c, k)]
+        if k in ("D", "ecm_kappa"):
+            close_mostly(a, b_, frac=2e-2, cap=5e-2, msg=f"{k} chain {c}")
+        elif k in ("xf", "xs", "ecm_xs", "resid"):
+            lvl = np.maximum(np.abs(out_b[(c, "xs" if k != "ecm_xs" else "ecm_xs")][:, :1].astype(np.float64)), 1.0)
+            assert np.all(np.abs(a.astype(np.float64) - b_) <= 2 * RTOL * lvl + ATOL), (c, k)
+        else:
+            np.testing.assert_allclose(a, b_, rtol=2 * RTOL, atol=ATOL, err_msg=f"{k} chain {c}")
