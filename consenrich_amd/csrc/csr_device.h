@@ -996,7 +996,6 @@ struct BwdTrend {
     }
 };
 
-// ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 // LDS-DMA inputs of the smoother chain (used for its warm-up phase, k_chain_spec_dmawarm_natbwd): the filtered
 // covariance in one 16-byte DMA ([lane][4] words), the filtered state as two 4-byte rows, the stored process noise in
 // one more 16-byte DMA when it varies per bin (QARR).
@@ -1027,6 +1026,7 @@ struct BwdTrendDma : BwdTrend {
     }
 };
 
+// ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
