@@ -8,6 +8,9 @@ from consenrich_amd.batch import DeviceBatch, ModelParams
 from consenrich_amd.sharding import hg38_chain_lengths
 m = int(os.environ.get("M", "32")); iters = int(os.environ.get("ITERS", "4")); inner = 5
 lengths = hg38_chain_lengths(200)
+if os.environ.get("SHARD"):      # "8:0" = the contigs rank 0 of 8 would own
+    from consenrich_amd.sharding import lpt_assign
+    w, r = map(int, os.environ["SHARD"].split(":")); lengths = [lengths[i] for i in lpt_assign(lengths, w)[r]]
 b = DeviceBatch(0); b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234); b.stats(); b.synchronize()
 for rep in range(2):
     b.profile(True); t = time.perf_counter()
