@@ -81,6 +81,8 @@ struct Prm {
     double *tLogR;      // sum_j log R_j
     // blocked multipliers
     float *tLam, *tKap, *tQs;
+    float *tKapOut;     // where the smoother's fused kappa E-step writes (the ECM loop ping-pongs scratch buffers so that a
+                        // sweep never overwrites the kappa its own forward pass was run with; == tKap outside that loop)
     // forward covariance chain outputs
     // gain record of the forward covariance chain, one 16-byte element per bin (one load / one LDS-DMA per step):
     //   trend: { double gs = S0/innovScale ; float P00pred ; float P10pred }
@@ -980,10 +982,10 @@ struct BwdTrend {
                 if (o.hasLag) {
                     const int64_t nx = (s + 1 < p.B) ? i + 64 : tidx(b + 1, 0, p.B);
                     const float qs = (p.flags & F_QSCALE) ? p.tQs[nx] : 1.0f;
-                    p.tKap[nx] = estep_kappa_trend(p, o.xs, o.ps, make_float2(nextBin.x0, nextBin.x1),
-                                                   make_float4(nextBin.p00, nextBin.p01, nextBin.p10, nextBin.p11), o.lag, qs);
+                    p.tKapOut[nx] = estep_kappa_trend(p, o.xs, o.ps, make_float2(nextBin.x0, nextBin.x1),
+                                                      make_float4(nextBin.p00, nextBin.p01, nextBin.p10, nextBin.p11), o.lag, qs);
                 }
-                if (s == 0 && b == bfirst) p.tKap[i] = 1.0f;      // processPrecExp[0] = 1 (pyx:8245)
+                if (s == 0 && b == bfirst) p.tKapOut[i] = 1.0f;   // processPrecExp[0] = 1 (pyx:8245)
             }
             if (p.storeMoments) {
                 if (o.hasLag) p.tLag[i] = o.lag;
@@ -1971,6 +1973,17 @@ __global__ __launch_bounds__(256) void k_import_f32(Prm p, const float *nat, int
     if (s >= bi.y) return;
     const int64_t g = (int64_t)bi.x + s;
     dst[slot * dstStride + dstComp] = nat[g * ncomp + comp];
+}
+
+// blocked -> blocked copy of a per-bin float array, active chains only (ECM: the kappa of a validated iteration becomes
+// the resident one; chains that are masked out keep theirs)
+__global__ __launch_bounds__(256) void k_copy_active_f32(Prm p, const float *src, float *dst) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t G = (slot >> 6) / p.B;
+    const int64_t b = G * 64 + l;
+    if (b >= p.NB || !chain_on(p, b)) return;
+    dst[slot] = src[slot];
 }
 
 // blocked -> natural for a list of arrays in ONE launch: a workgroup owns a (wave-group, 32-step) tile, reads 32

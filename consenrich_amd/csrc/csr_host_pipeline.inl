@@ -246,6 +246,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
+    if (c->kapIn) p.tKap = c->kapIn;                                  // ECM sweep: the kappa of the previous sweep's E-step
     p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
     defer = defer && c->deferEnabled;
     c->fwdNat = false;
@@ -313,6 +314,8 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     p.chainActive = active;
     p.estepKappa = estep != 0 ? 1 : 0;
     p.storeMoments = estep == 2 ? 0 : 1;
+    if (c->kapIn) p.tKap = c->kapIn;
+    p.tKapOut = c->kapOut ? c->kapOut : p.tKap;
     c->pendEstep = estep;
     natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
     if (natOut) {
@@ -341,14 +344,10 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
 // blocks in its single validation pass, its results -- and everything computed from them -- are not yet the fixed
 // point: the pipeline is re-run synchronously from that stage and the stage goes back to synchronous validation
 // until a clean pass re-arms it.  After settle() the mailbox mirror holds the current per-chain sums.
-static int settle(csr_ctx *c) {
-    join_side(c);
-    if (!c->pendFwd && !c->pendBwd) return 0;
-    CHECK(read_mail(c, c->mailBytes));
-    const bool pf = c->pendFwd, pb = c->pendBwd;
-    const uint32_t pe = c->pendExport;
-    c->pendFwd = c->pendBwd = false;
-    c->pendExport = 0;
+// Consumes the stage counters of the mailbox mirror (which the caller has just refreshed).  Returns the first stage whose
+// single optimistic validation pass re-ran blocks (-1: none did); such a stage goes back to synchronous validation and
+// gets a wider window.
+static int check_stages(csr_ctx *c) {
     int firstFail = -1;
     for (int stg = ST_P; stg <= ST_B; ++stg) {
         const unsigned int fresh = take_fresh(c, stg);
@@ -367,6 +366,18 @@ static int settle(csr_ctx *c) {
         if (firstFail < 0) firstFail = stg;
         if (c->dbgLog) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
     }
+    return firstFail;
+}
+
+static int settle(csr_ctx *c) {
+    join_side(c);
+    if (!c->pendFwd && !c->pendBwd) return 0;
+    CHECK(read_mail(c, c->mailBytes));
+    const bool pf = c->pendFwd, pb = c->pendBwd;
+    const uint32_t pe = c->pendExport;
+    c->pendFwd = c->pendBwd = false;
+    c->pendExport = 0;
+    const int firstFail = check_stages(c);
     if (firstFail < 0) return 0;
     c->rs.pipeline_redos += 1;     // pipelines re-run after a failed optimistic validation
     if (firstFail <= ST_X && pf) {
@@ -494,37 +505,89 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
         for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5 && !masked(i)) ? 1 : 0;
         CHECK(push_active());
         bool fwdFresh = false;   // forward results already match the current multipliers
-        for (int64_t it = 0; it < cfg->max_iters; ++it) {
+        // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments of bins k
+        // and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself; only the last inner
+        // sweep's moments can become the result of this iteration, the others are not even stored.
+        const bool fusedE = c->fuseEstep && cfg->use_kappa && !cfg->use_lambda && !cfg->use_apn && c->mdl.state_dim == 2;
+        if (fusedE) {
+            // The fused E-step must not overwrite the kappa its own sweep's forward pass ran with: were that pass's
+            // deferred validation to fail, its re-run would read the NEXT sweep's kappa (one E-step ahead of pyx:8222-8300).
+            // Sweeps therefore ping-pong two scratch buffers; the resident kappa changes only when an iteration is validated.
+            for (float *&q : c->kapScratch)
+                if (!q) CHECK(dalloc(c, &q, c->TN));
+        }
+        // One ECM iteration (pyx:8156-8300) as launches only: t_inner x [forward, smoother + kappa E-step] + NLL forward.
+        // Returns the buffer holding the iteration's final kappa (nullptr: no sweep ran, the resident one is unchanged).
+        float *iterKappa = nullptr;
+        auto launch_iteration = [&](bool defer, bool skipFirstForward) -> int {
+            float *cur = nullptr;                   // nullptr = the resident kappa (the one this iteration starts from)
             for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
-                if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
-                fwdFresh = false;
-                // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments
-                // of bins k and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself;
-                // only the last inner sweep's moments can become the result of this iteration, the others are not
-                // even stored
-                const bool fusedE = c->fuseEstep && cfg->use_kappa && !cfg->use_lambda && c->mdl.state_dim == 2;
-                const int es = !fusedE ? 0 : (inner + 1 == cfg->inner_iters ? 1 : 2);
-                CHECK(backward_impl(c, true, c->dActive, true, false, es));
-                CHECK(settle(c));          // the next sweep (or the E-step kernels) consume validated results
-                Prm p = c->p;
-                p.flags = fl;
-                p.chainActive = c->dActive;
-                if (cfg->use_lambda) {
-                    Scope sc(c, "estep_lambda");
-                    hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
-                    LAUNCH_CHECK("k_estep_lambda");
-                }
-                if (cfg->use_kappa && !fusedE) {
-                    Scope sc(c, "estep_kappa");
-                    hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
-                    LAUNCH_CHECK("k_estep_kappa");
-                }
+                c->kapIn = cur;
+                if (!(inner == 0 && skipFirstForward)) CHECK(forward_impl(c, fl, false, c->dActive, defer));
+                c->kapOut = c->kapScratch[inner & 1];
+                CHECK(backward_impl(c, true, c->dActive, defer, false, inner + 1 == cfg->inner_iters ? 1 : 2));
+                cur = c->kapOut;
+                c->kapOut = nullptr;
             }
-            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));      // pyx:8300
+            c->kapIn = cur;
+            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, defer));      // pyx:8300
+            c->kapIn = nullptr;
+            iterKappa = cur;
+            return 0;
+        };
+        const double *mailSums = reinterpret_cast<const double *>(c->hMail + 16);
+        for (int64_t it = 0; it < cfg->max_iters; ++it) {
+            if (fusedE) {
+                // ONE settle point per iteration: every stage of every sweep is validated optimistically; if any of them
+                // re-ran blocks, the whole iteration is replayed with synchronous validation from the kappa it started with
+                // (still resident: it is replaced only below, once the iteration stands).
+                const bool defer = c->deferIteration && c->deferEnabled;
+                CHECK(launch_iteration(defer, fwdFresh));
+                CHECK(read_mail(c, c->mailBytes));
+                const bool hadPending = c->pendFwd || c->pendBwd;
+                c->pendFwd = c->pendBwd = false;
+                c->pendExport = 0;
+                if (hadPending && check_stages(c) >= 0) {
+                    c->rs.pipeline_redos += 1;
+                    CHECK(launch_iteration(false, false));
+                    CHECK(read_mail(c, c->mailBytes));
+                    c->pendFwd = c->pendBwd = false;
+                    for (int stg = ST_P; stg <= ST_B; ++stg) (void)take_fresh(c, stg);
+                }
+                if (iterKappa) {      // the iteration's kappa becomes the resident one (for the chains of this iteration)
+                    Prm p = c->p;
+                    p.chainActive = c->dActive;
+                    Scope sc(c, "ecm_commit_kappa");
+                    hipLaunchKernelGGL(k_copy_active_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, iterKappa, c->p.tKap);
+                    LAUNCH_CHECK("k_copy_active_f32");
+                }
+                for (int i = 0; i < nc; ++i) nll[i] = mailSums[nc + i];
+            } else {
+                for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
+                    if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
+                    fwdFresh = false;
+                    CHECK(backward_impl(c, true, c->dActive, true, false, 0));
+                    CHECK(settle(c));          // the E-step kernels consume validated results and update in place
+                    Prm p = c->p;
+                    p.flags = fl;
+                    p.chainActive = c->dActive;
+                    if (cfg->use_lambda) {
+                        Scope sc(c, "estep_lambda");
+                        hipLaunchKernelGGL(k_estep_lambda, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                        LAUNCH_CHECK("k_estep_lambda");
+                    }
+                    if (cfg->use_kappa) {
+                        Scope sc(c, "estep_kappa");
+                        hipLaunchKernelGGL(k_estep_kappa, dim3(grid_slots(c)), dim3(256), 0, c->stream, p);
+                        LAUNCH_CHECK("k_estep_kappa");
+                    }
+                }
+                CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));      // pyx:8300
+                CHECK(read_sums(c, nullptr, nll.data()));
+            }
             // the multipliers do not change until the next E-step: the next sweep may reuse this forward pass,
             // unless adaptive process noise made it depend on returnNLL-independent state only (it does not)
             fwdFresh = (cfg->inner_iters > 0);
-            CHECK(read_sums(c, nullptr, nll.data()));
             bool anyLeft = false, changed = false;
             for (int i = 0; i < nc; ++i) {
                 if (!act[i]) continue;

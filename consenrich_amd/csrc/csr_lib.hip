@@ -152,6 +152,12 @@ struct csr_ctx {
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
     double *dChainQ = nullptr;  // per-chain base process noise (csr_batch_set_chain_q), freed with the batch
+    // ECM with the kappa E-step inside the smoother: a sweep's smoother writes kappa into a scratch buffer (kapOut), the next
+    // sweep's forward pass reads it (kapIn); the resident tKap only changes when a whole iteration has been validated
+    // (nullptr = the resident array).  Allocated on first use, freed with the batch.
+    float *kapScratch[2] = {nullptr, nullptr};
+    float *kapIn = nullptr, *kapOut = nullptr;
+    bool deferIteration = true; // ECM (fused E-step): one settle point per iteration, replay on a failed validation
     Prm sidePrm{};              // parameters of the epilogue running on the side stream (its sums follow at the join)
     uint32_t pendFlags = 0, pendExport = 0;
     bool pendWantD = false;
@@ -208,6 +214,8 @@ static void free_batch(csr_ctx *c) {
     c->pendExport = 0;
     c->dMail = nullptr;
     c->dChainQ = nullptr;
+    c->kapScratch[0] = c->kapScratch[1] = nullptr;
+    c->kapIn = c->kapOut = nullptr;
     c->bg = csr_ctx::BgState{};
     c->dActive = nullptr;
     for (auto &n : c->nat) n = nullptr;
@@ -262,6 +270,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE_ESTEP"))) c->fuseEstep = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_DEFER_ITER"))) c->deferIteration = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
     c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
     c->dbgProbe = getenv("CONSENRICH_AMD_PROBE") != nullptr;

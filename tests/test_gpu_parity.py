@@ -344,6 +344,50 @@ def test_batch_ecm_lockstep_equals_per_chain_calls(product):
     assert len(iters) >= 2      # the chains really stop at different iterations
 
 
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+def test_ecm_with_failed_optimistic_validations_follows_the_reference_sequence(product, oracle, xtol, monkeypatch):
+    """The fused kappa E-step writes the kappa of the NEXT sweep while the forward pass of THIS sweep may still have to be
+    re-run (deferred validation).  With deliberately short windows every iteration of the loop fails its optimistic
+    validation and is replayed; iteration count, NLL path, kappa and the smoothed moments must still be the reference
+    sequence (pyx:8156-8300) -- a sweep reading the kappa of its own E-step would run one E-step ahead."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    monkeypatch.setenv("CONSENRICH_AMD_WARM_FM", "16")      # window of the fused forward chain with per-bin kappa
+    n_list, m = [6000, 2500], 5
+    sets = [cases.synth(n, m, 3300 + i, outlier_frac=0.02) for i, n in enumerate(n_list)]
+    with DeviceBatch(0, block_len=32, warm=(16, 16, 16), x_tol_ulps=xtol) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        for c, (d_, v_) in enumerate(sets):
+            b.upload(c, d_, v_)
+        b.stats()
+        outs, paths = b.ecm(max_iters=8, inner_iters=3, rtol=1e-7, use_lambda=False, use_kappa=True)
+        b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT)
+        got = [(int(o.iters_done), paths[c], b.download(c, "xs"), b.download(c, "Ps"), b.download(c, "kappa"))
+               for c, o in enumerate(outs)]
+        rs = b.run_stats()
+    assert rs["pipeline_redos"] >= 1 and (rs["reruns_p"] + rs["reruns_x"] + rs["reruns_b"]) > 0, rs
+    for c, (d_, v_) in enumerate(sets):
+        n = n_list[c]
+        r = oracle.cfixedBackgroundECM(matrixData=d_, matrixPluginMuncInit=v_, matrixF=np.asarray(cases.F_TREND, np.float32),
+                                       matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+                                       intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                       stateCovarInit=1000.0, ECM_fixedBackgroundIters=8, ECM_fixedBackgroundRtol=1e-7,
+                                       ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=True,
+                                       procPrecisionMultiplierMin=5e-3, procPrecisionMultiplierMax=5e3, t_innerIters=3,
+                                       returnIntermediates=True, returnDiagnostics=True, trackOptimizationPath=True,
+                                       logIterations=False)
+        assert got[c][0] == r[0], (c, got[c][0], r[0])
+        np.testing.assert_allclose(got[c][1][: r[0]], r[8]["optimization_path"], rtol=1e-9 if xtol == 0 else 5e-8)
+        scale = np.abs(r[2]).max(axis=1, keepdims=True)
+        assert np.all(np.abs(got[c][2].astype(np.float64) - r[2]) <= RTOL * scale + ATOL)
+        np.testing.assert_allclose(got[c][3], r[3], rtol=RTOL, atol=ATOL)
+        if xtol == 0:
+            np.testing.assert_allclose(got[c][4], r[7], rtol=RTOL, atol=ATOL)
+        else:
+            close_mostly(got[c][4], r[7], frac=2e-2, cap=5e-2, msg="kappa")
+
+
 def test_exact_mode_on_a_chromosome_sized_chain(product):
     """Bit-exact sequential semantics at chr21 size: default blocks (speculative) == one block per chain."""
     n = 233550
