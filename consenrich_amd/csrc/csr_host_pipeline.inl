@@ -20,7 +20,14 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
         int ts = c->statsTile;
         if (ts == 0) ts = 64;
         if (c->B % ts != 0) ts = 32;
-        if (ts == 128) launch_stats<128, 16>(c, p);
+        if (c->statsWide && (ts == 64 || ts == 32)) {
+            // 16-byte loads, four bins per thread
+            const int grid = (int)(c->NG * (c->B / ts) * (ts == 64 ? 4 : 2));
+            if (ts == 64 && c->statsWideUnroll == 8) hipLaunchKernelGGL((k_stats_v4<64, 8>), dim3(grid), dim3(256), 0, c->stream, p);
+            else if (ts == 64 && c->statsWideUnroll == 2) hipLaunchKernelGGL((k_stats_v4<64, 2>), dim3(grid), dim3(256), 0, c->stream, p);
+            else if (ts == 64) hipLaunchKernelGGL((k_stats_v4<64, 4>), dim3(grid), dim3(256), 0, c->stream, p);
+            else hipLaunchKernelGGL((k_stats_v4<32, 4>), dim3(grid), dim3(256), 0, c->stream, p);
+        } else if (ts == 128) launch_stats<128, 16>(c, p);
         else if (ts == 64 && c->statsUnroll == 16) launch_stats<64, 16, 16>(c, p);
         else if (ts == 64 && c->statsUnroll == 32) launch_stats<64, 16, 32>(c, p);
         else if (ts == 64) launch_stats<64, 16>(c, p);

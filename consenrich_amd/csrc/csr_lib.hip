@@ -106,6 +106,8 @@ struct csr_ctx {
     bool useDmaFused = true;   // fused forward chain without reference-layout outputs: LDS-DMA ring
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
     int xTolUlps = 2;
+    bool statsWide = true;  // statistics kernel with 16-byte loads (four bins per thread)
+    int statsWideUnroll = 4;    // ... sample rows it loads together (2, 4, 8)
     int statsUnroll = 8;    // sample rows loaded together by the statistics kernel (8, 16, 32)
     int residTile = 2;      // residual kernel: 64-bin sub-tiles per workgroup (1, 2, 4); 2 measured best (0.665 vs 0.684 ms)
     int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
@@ -280,6 +282,8 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_RESID_TILE"))) c->residTile = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_STATS_UNROLL"))) c->statsUnroll = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_STATS_WIDE"))) c->statsWide = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_STATS_WIDE_UNROLL"))) c->statsWideUnroll = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DMA_FUSED"))) c->useDmaFused = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DMA_WARM"))) c->useDmaWarm = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
