@@ -21,6 +21,7 @@ USE_LAMBDA, USE_KAPPA, USE_QSCALE, USE_APN, RETURN_NLL, NLL_IN_D = (1 << i for i
  ARR_SUMGAIN0, ARR_SUMGAIN1, ARR_EFFQ_LEVEL, ARR_EFFQ_TREND, ARR_MUNCTRACE, ARR_BACKGROUND, ARR_BACKGROUND_NEXT,
  ARR_COUNT) = range(19)
 BG_OK, BG_NO_SUPPORT, BG_BAD_PIVOT, BG_UNRELIABLE, BG_NONFINITE = range(5)
+BG_INIT_FROM_CURRENT, BG_ZERO_STATE = 1, 2
 EXPORT_FORWARD, EXPORT_SMOOTH, EXPORT_RESID, EXPORT_MULT = 1, 2, 4, 8
 
 

@@ -228,16 +228,18 @@ class DeviceBatch:
     # -- background update between ECM phases -----------------------------------------------------
     def background_update(self, lam_first: float, lam: float, zero_center=False, use_nonnegative=True,
                           negative_penalty_multiplier=1.0, use_lambda=False, use_initial=True, max_passes=5,
-                          block_len=0, raise_on_error=True):
+                          block_len=0, raise_on_error=True, zero_state=False):
         """core.py:5064-5137 + 8085-8378 for every chain, device-resident: weight / rhs tracks from the original data,
         munc and the smoothed level, conditioning guard, pentadiagonal solve with the asymmetric-IRLS wrapper.  The
         proposal is the array "background_next"; returns one dict per chain.  Errors the reference raises
         (pivot modification, float64 reliability, non-finite solution) raise RuntimeError here unless
-        raise_on_error=False."""
+        raise_on_error=False.  zero_state=True is the reference's background warm start from the weighted data
+        (`_estimateBackgroundWarmStart`, core.py:2809-2910: residual = data, no fit needs to be resident)."""
         nc = len(self.chain_lens)
         cfg = L.BgCfg(float(lam_first), float(lam),
                       float("nan") if negative_penalty_multiplier is None else float(negative_penalty_multiplier),
-                      int(bool(zero_center)), int(bool(use_nonnegative)), int(bool(use_lambda)), int(bool(use_initial)),
+                      int(bool(zero_center)), int(bool(use_nonnegative)), int(bool(use_lambda)),
+                      (L.BG_INIT_FROM_CURRENT if use_initial else 0) | (L.BG_ZERO_STATE if zero_state else 0),
                       int(max_passes), int(block_len))
         outs = (L.BgOut * nc)()
         L.check(self._lib.csr_batch_background_update(self._ctx, C.byref(cfg), outs))

@@ -473,7 +473,7 @@ struct BgBatch {
     int nchains, useLambda;
     float padf, wMinf, wMaxf;
     const float *lamNat;                // natural lambda (exported) or null
-    const float *xsNat;                 // natural smoothed state (Npad, d), level = component 0
+    const float *xsNat;                 // natural smoothed state (Npad, d), level = component 0; null = identically zero
     int xsStride;
     double *w, *rhs, *wAdj, *sol;
     unsigned long long *selAns;         // per chain x 2: order statistic being built bit by bit
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_bg_batch_stats(Prm p, BgBatch a) {
     if (c >= 0 && g - a.chainOff[c] < a.chainLen[c]) {
         float lam = 1.f;
         if (a.useLambda) lam = fminf(fmaxf(a.lamNat[g], a.wMinf), a.wMaxf);
-        const float xs0 = a.xsNat[g * a.xsStride];
+        const float xs0 = a.xsNat ? a.xsNat[g * a.xsStride] : 0.0f;      // null: background warm start (core.py:2857)
         for (int j = 0; j < p.m; ++j) {
             float iv = __fdiv_rn(1.0f, fmaxf(p.munc[(int64_t)j * p.Npad + g] + a.padf, 1.0e-8f));
             if (a.useLambda) iv *= lam;

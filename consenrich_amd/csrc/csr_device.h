@@ -59,6 +59,7 @@ struct Prm {
     int storeMoments;   // 0: inner ECM sweeps whose smoothed moments nobody reads are not stored at all
     int natOut;         // smoother (levelTrend): 1 = write xs / Ps / lag straight into the reference-layout arrays below
     float *natXs, *natPs, *natLag;
+    float *natD;        // NIS/NLL epilogue: non-null = write D in the reference layout (through an LDS tile) instead of tD
     const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
     int qFromMult;      // smoother: 1 = process noise is the constant float32(Q0) (internal forward pass without
                         //           kappa / qScale / APN), 0 = read the stored / imported pNoise array tQ
@@ -1787,14 +1788,21 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p_, int which) {
 
 // NIS / NLL per bin (pyx:458-475) from the stored predicted covariance, the previous filtered state and the bin
 // statistics; per-block partial sums give deterministic sumD / sumNLL.
+template <bool NATD>
 __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
     __shared__ double redD[4][64], redN[4][64];
+    // NATD: D leaves the kernel in the reference layout -- the workgroup's 64 blocks x B steps are staged in LDS
+    // ([lane][B + 1] floats, dynamic) and written as one contiguous run of B floats per block; no tD, no export pass
+    extern __shared__ float dTile[];
+    __shared__ int dBase[64], dLen[64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * 64 + lane;
     const bool live = b < p.NB && chain_on(p, b);
     double sumD = 0.0, sumN = 0.0;
+    if (NATD && part == 0) { dBase[lane] = 0; dLen[lane] = 0; }
     if (live) {
         const int4 bi = p.blk[b];
+        if (NATD && part == 0) { dBase[lane] = bi.x; dLen[lane] = bi.y; }
         const int64_t base = tbase(b, p.B);
         const int q4 = p.B >> 2;
         const int sBeg = part * q4;
@@ -1853,7 +1861,8 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
                     sumN += nll;
                 }
                 const float D = (float)((wantNLL && (p.flags & F_NLL_IN_D)) ? nll : quad / mD);
-                p.tD[i] = D;
+                if constexpr (NATD) dTile[lane * (p.B + 1) + s] = D;
+                else p.tD[i] = D;
                 sumD += (double)D;
             }
         }
@@ -1864,6 +1873,13 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
     if (part == 0 && live) {
         p.blkSumD[b] = ((redD[0][lane] + redD[1][lane]) + redD[2][lane]) + redD[3][lane];
         p.blkSumNLL[b] = ((redN[0][lane] + redN[1][lane]) + redN[2][lane]) + redN[3][lane];
+    }
+    if constexpr (NATD) {
+        const int total = 64 * p.B;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int L = e / p.B, st = e - L * p.B;
+            if (st < dLen[L]) p.natD[(int64_t)dBase[L] + st] = dTile[L * (p.B + 1) + st];
+        }
     }
 }
 

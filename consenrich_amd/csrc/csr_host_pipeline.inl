@@ -230,7 +230,8 @@ static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
     }
     {
         Scope sc(c, "fwd_dstat", st);
-        hipLaunchKernelGGL(k_fwd_dstat, dim3((int)c->NG), dim3(256), 0, st, p);
+        if (p.natD) hipLaunchKernelGGL(k_fwd_dstat<true>, dim3((int)c->NG), dim3(256), sizeof(float) * 64 * (c->B + 1), st, p);
+        else hipLaunchKernelGGL(k_fwd_dstat<false>, dim3((int)c->NG), dim3(256), 0, st, p);
     }
     LAUNCH_CHECK("k_fwd_dstat");
     if (side) {
@@ -257,6 +258,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
     defer = defer && c->deferEnabled;
     c->fwdNat = false;
+    c->dNat = false;
     c->pendFwdNat = natOut;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
@@ -295,6 +297,20 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
         } else {
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+        }
+        if (wantD && natOut && c->natOutEnabled && c->natOutD) {        // D straight into the reference layout
+            const size_t tileBytes = sizeof(float) * 64 * (size_t)(c->B + 1);
+            bool ok = true;
+            if (tileBytes > 48 * 1024 && !c->dstatLdsRaised) {      // 256-bin blocks: 65.8 KB of dynamic LDS
+                ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_dstat<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileBytes) == hipSuccess;
+                (void)hipGetLastError();
+                c->dstatLdsRaised = ok;
+            }
+            if (ok) {
+                CHECK(nat_array(c, CSR_ARR_D, &p.natD));
+                c->dNat = true;
+            }
         }
         if (wantD) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
         if (dP || dX) {
@@ -679,12 +695,12 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     // The NIS/NLL track is the only export that depends on the side stream's epilogue: when that is still running it is
     // converted last, after the (long, bandwidth-bound) residual kernel, so the epilogue leaves the critical path.
     // (Small batches are launch-bound: there the extra conversion launch costs more than the overlap saves.)
-    const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending && (what & CSR_EXPORT_RESID) &&
+    const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending && (what & CSR_EXPORT_RESID) && !c->dNat &&
                        c->Npad >= ((int64_t)4 << 20);
     if (!lateD) join_side(c);
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
-        if (!lateD) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
+        if (!lateD && !c->dNat) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));   // dNat: the epilogue wrote it already
         if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
             CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
             CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));

@@ -349,7 +349,10 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     CHECK(need(c));
     if (!cfg || !out) return fail("null argument");
     CHECK(settle(c));
-    if (!c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
+    // use_initial bit 1 (CSR_BG_ZERO_STATE): the warm start of `_estimateBackgroundWarmStart` (core.py:2809-2910) -- the
+    // weighted data themselves are smoothed (residual = data, i.e. a smoothed level of zero), no fit needs to be resident
+    const bool zeroState = (cfg->use_initial & CSR_BG_ZERO_STATE) != 0;
+    if (!zeroState && !c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
     if (!std::isfinite(cfg->lam_first) || cfg->lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
     if (!std::isfinite(cfg->lam) || cfg->lam < 0.0) return fail("lam must be finite and nonnegative");
     int Bp = cfg->block_len > 0 ? cfg->block_len : 1024;
@@ -364,11 +367,11 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+        if (!zeroState && !c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
         if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
         CHECK(flush_export(c, L));
     }
-    a.xsNat = c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
+    a.xsNat = zeroState ? nullptr : c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
     a.useLambda = cfg->use_lambda ? 1 : 0;
     a.lamNat = cfg->use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr;
     a.padf = (float)c->mdl.pad; a.wMinf = (float)c->mdl.w_min; a.wMaxf = (float)c->mdl.w_max;
@@ -442,7 +445,7 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     HIPOK(hipMemcpyAsync(S.dHasSup, sup.data(), nc, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemcpyAsync(S.dPen, pen.data(), 8 * nc, hipMemcpyHostToDevice, c->stream));
     // first solve (core.py:8306-8324)
-    const bool useInit = irls && cfg->use_initial;
+    const bool useInit = irls && (cfg->use_initial & CSR_BG_INIT_FROM_CURRENT) != 0;
     if (useInit) {
         hipLaunchKernelGGL(k_bg_mask, dim3(gridN), dim3(256), 0, c->stream, p, a, 0);
         for (int i = 0; i < nc; ++i) prevValid[i] = 1;

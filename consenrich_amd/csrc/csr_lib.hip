@@ -123,6 +123,9 @@ struct csr_ctx {
                                 // block-transposed copies are stale; nothing but the ECM E-steps reads those)
     bool pendNatOut = false;
     bool fwdNat = false, pendFwdNat = false;   // the last forward pass wrote xf / Pf in the reference layout too
+    bool dNat = false;          // ... and its NIS/NLL epilogue wrote D there (nothing left to convert)
+    bool natOutD = true;        // CONSENRICH_AMD_NATOUT_D=0: D through tD + the export pass
+    bool dstatLdsRaised = false;
     int pendEstep = 0;
     bool fuseEstep = true;      // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
@@ -271,6 +274,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_NATOUT_D"))) c->natOutD = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE_ESTEP"))) c->fuseEstep = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DEFER_ITER"))) c->deferIteration = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }

@@ -1,35 +1,49 @@
-"""Device-resident counterpart of the reference's outer alternation (`runConsenrich`, core.py:4860-5390):
-fixed-background ECM phase <-> background update, for a whole batch of chromosomes on one GPU.
+"""Device-resident counterpart of the reference's estimator orchestration (`runConsenrich`,
+core.py:3861-6142) for a whole batch of chromosomes on one GPU.
 
-With `seed_q`, every chromosome first gets its own base process noise from its data (`DeviceBatch.qseed` +
-`set_chain_q`; the reference's fixedDiagonal calibration, core.py:5667-5686).  Then, per outer pass, for the chains still
-iterating (chromosomes are independent fits and stop independently):
-  1. `DeviceBatch.stats()` -- the current background is subtracted from the data in float32 inside the statistics
-     kernel (= the reference's `dataAdjusted`, core.py:3253-3256);
-  2. `DeviceBatch.ecm(chain_mask=...)` -- the multipliers of the previous pass are resident, i.e. the warm start the
-     reference passes as lambdaExpInit / processPrecExpInit (core.py:3257-3290);
-  3. `DeviceBatch.background_update()` -- weight / rhs tracks from the ORIGINAL data and the smoothed level, conditioning
-     guard, pentadiagonal solve, asymmetric IRLS seeded with the current background (core.py:5064-5136);
-  4. shift test: weighted RMS shift <= rtol * max(proposal RMS, reference RMS, 1) (core.py:5199-5243);
-  5. `DeviceBatch.background_apply(take=...)`: the proposal is adopted (core.py:5243-5247);
-  6. penalised objective of the adopted background with the phase's multipliers (`_scorePenalizedObjective`,
-     core.py:4418-4538): `stats()` + `forward_masked(RETURN_NLL | multipliers)` give the forward NLL of data - background
-     (the statistics are the ones the next ECM phase starts from, so only the forward pass is extra, as in the
-     reference), `objective_terms()` the robust-precision, roughness and negative-part penalties and the effective
-     observation count; objective-stable when the per-cell change is within outer_nll_rtol * max(|cur|, |prev|, 1)
-     (`_recordOuterObjective`, core.py:4750-4830);
-  7. a chain stops when it was shift-stable AND objective-stable with a converged inner ECM for `patience` consecutive
-     passes after `min_outer` passes (core.py:5252-5376).
+`run_consenrich_batch` composes, in the reference's order:
 
-Steps 6-7 restate pure-Python code of `consenrich.core`, which cannot be imported in the build image: they are checked
+  0. [seed_q] every chromosome's base process noise from its own data (`DeviceBatch.qseed` + `set_chain_q`; the
+     reference's fixedDiagonal calibration, core.py:5667-5686);
+  1. background warm start from the weighted data (`_estimateBackgroundWarmStart`, core.py:4663-4690, 2809-2910) when the
+     background is fitted and no initial background is given;
+  2. the outer alternation `fit_batch` (core.py:4860-5376), per pass and for the chains still iterating (chromosomes are
+     independent fits and stop independently):
+       a. `stats()` -- the current background is subtracted from the data in float32 inside the statistics kernel
+          (= the reference's `dataAdjusted`, core.py:3253-3256);
+       b. `ecm(chain_mask=...)` -- the multipliers of the previous pass are resident, i.e. the warm start the reference
+          passes as lambdaExpInit / processPrecExpInit (core.py:3257-3290);
+       c. `background_update()` -- weight / rhs tracks from the ORIGINAL data and the smoothed level, conditioning guard,
+          pentadiagonal solve, asymmetric IRLS seeded with the current background (core.py:5064-5136);
+       d. shift test: weighted RMS shift <= rtol * max(proposal RMS, reference RMS, 1) (core.py:5199-5243);
+       e. `background_apply(take=...)`: the proposal is adopted (core.py:5243-5247);
+       f. penalised objective of the adopted background with the phase's multipliers (`_scorePenalizedObjective`,
+          core.py:4418-4538): `stats()` + `forward_masked(RETURN_NLL | multipliers)` give the forward NLL of
+          data - background, `objective_terms()` the robust-precision, roughness and negative-part penalties and the
+          effective observation count; objective-stable when the per-cell change is within
+          outer_nll_rtol * max(|cur|, |prev|, 1) (`_recordOuterObjective`, core.py:4750-4830);
+       g. a chain stops when it was shift-stable AND objective-stable with a converged inner ECM for `patience`
+          consecutive passes after `min_outer` passes (core.py:5252-5376);
+  3. the FINAL fixed-background ECM phase with the converged background and warm-started multipliers, all chains
+     (core.py:5385-5440);
+  4. the FINAL store-all forward / backward pass on data - background with the final multipliers
+     (`_runForwardBackward`, core.py:5560-5600, 4207-4336: returnNLL, NIS in D): THE tracks the reference returns and its
+     CLI writes come from this pass;
+  5. the return tuple of core.py:6126-6142 per chromosome: (stateSmoothed (n,2), stateCovarSmoothed (n,2,2),
+     postFitResiduals (n,m), NIS (n,), intervalToBlockMap[, background][, precision diagnostics]); the level model's
+     arrays are zero-padded to the levelTrend shapes (core.py:4178-4192, 6004-6006).
+
+Steps 2f-2g restate pure-Python code of `consenrich.core`, which cannot be imported in the build image: they are checked
 against the CPU twin (oracle/driver.py) and a NumPy restatement of the formulas, not against reference outputs ("parity
-unpinned" for this part).  Everything the passes COMPUTE with natives is the reference's arithmetic.
+unpinned" for that glue).  Everything the passes COMPUTE with natives is the reference's arithmetic.
 """
 from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import List, Tuple
+from typing import List, Optional, Tuple
+
+import numpy as np
 
 from . import _lib as L
 from .batch import DeviceBatch
@@ -59,6 +73,7 @@ class FitConfig:
     outer_nll_rtol: float = 5.0e-5               # ECM_outerNLLRtol, constants.py:281
     pad: float = 1.0e-4                          # the Python-float pad of the objective's weight track (core.py:4506)
     patience: int = 2
+    background_warm_start: bool = False          # step 1 (run_consenrich_batch sets it when no initial background is given)
 
 
 @dataclass
@@ -72,17 +87,26 @@ class ChainFit:
     objective: List[dict] = field(default_factory=list)       # per pass: the reference's objective diagnostics
     q0: object = None                                         # seeded base process noise (float32 (2,2)) if seed_q
     q_seed: dict = field(default_factory=dict)                # its diagnostics (core.py:3751-3779)
+    warm_start_passes: Optional[int] = None                   # IRLS passes of the background warm start
+    final_ecm_iters: Optional[int] = None                     # final fixed-background ECM phase (core.py:5403)
+    final_ecm_nll: Optional[float] = None
+    final_ecm_converged: Optional[bool] = None
+    final_nll: Optional[float] = None                         # sumNLL of the final forward pass (core.py:5583)
+    final_forward_nis: Optional[float] = None                 # mean NIS of the final forward pass (core.py:5824)
 
 
-def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
-    """Runs the alternation on a configured batch with data uploaded.  Afterwards download(): "xs", "Ps", "lag", "resid",
-    "lambda", "kappa" (fit of the last ECM phase of each chain) and "background"."""
+def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False) -> List[ChainFit]:
+    """Steps 0-2 (the alternation loop, core.py:4860-5376) on a configured batch with data uploaded.  The fit that is
+    resident afterwards is the one of each chain's last in-loop ECM phase against the background of THAT phase -- the
+    reference never returns it: `run_consenrich_batch` continues with the final phases.  keep_background: start from the
+    background that is resident (an initial background uploaded with set_background) instead of zeros."""
     nc = len(batch.chain_lens)
     fits = [ChainFit() for _ in range(nc)]
     active = [True] * nc
     stable = [0] * nc
-    for c in range(nc):
-        batch.set_background(c, None)
+    if not keep_background:
+        for c in range(nc):
+            batch.set_background(c, None)
     if cfg.seed_q:
         # matrixQ0 of every chromosome from its own data (core.py:5667-5686), on the resident matrices
         seeds = batch.qseed(pad=cfg.pad, stateModel="levelTrend" if batch.d == 2 else "level", minQ=cfg.min_q,
@@ -90,6 +114,15 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
         batch.set_chain_q([q[: batch.d, : batch.d] for q, _ in seeds])
         for c in range(nc):
             fits[c].q0, fits[c].q_seed = seeds[c]
+    if cfg.fit_background and cfg.background_warm_start and not keep_background:
+        # core.py:4663-4690: asymmetric-IRLS (or plain) solve of the weighted data themselves, no initial background
+        info = batch.background_update(cfg.penalties[0], cfg.penalties[1], zero_center=cfg.zero_center,
+                                       use_nonnegative=cfg.use_nonnegative,
+                                       negative_penalty_multiplier=cfg.neg_multiplier, use_lambda=False,
+                                       use_initial=False, zero_state=True)
+        batch.background_apply(None)
+        for c in range(nc):
+            fits[c].warm_start_passes = int(info[c]["passes"])
     prev_obj = [float("nan")] * nc
     fwd_flags = L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
     have_stats = False
@@ -109,9 +142,6 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
                                        use_nonnegative=cfg.use_nonnegative,
                                        negative_penalty_multiplier=cfg.neg_multiplier, use_lambda=cfg.use_lambda,
                                        use_initial=True)
-        # natural-layout copies of this pass's fit (smoothed moments, residuals, multipliers) are taken before the
-        # proposal is applied: applying a background invalidates the resident fit, the exported arrays stay downloadable
-        batch.export(L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
         take = list(active)
         batch.background_apply(take)            # the proposal of a pass is always adopted (core.py:5243)
         # penalised objective of the adopted background (core.py:5248-5251)
@@ -145,8 +175,102 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig) -> List[ChainFit]:
                 active[c] = False
         if not any(active):
             break
-    if not cfg.fit_background:
-        batch.export(L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
-    # like the reference's loop, the returned fit is the one of the last ECM phase and "background" the last adopted
-    # proposal; call stats() before any further pass so that the statistics see the final background
     return fits
+
+
+def precision_diagnostics(batch: DeviceBatch, cfg: FitConfig, chain: int, q0, stateModel: str) -> dict:
+    """The reference's `returnPrecisionDiagnostics` dict (core.py:6040-6121) of one chain from the resident final pass:
+    ten per-interval float32 tracks (core.py:7734-7878; `DeviceBatch.diagnostics` must have run) + multipliers + Q0."""
+    n = batch.chain_lens[chain]
+    d = batch.d
+    q0 = np.asarray(q0, np.float32)
+    base_level = np.full(n, float(q0[0, 0]))
+    base_trend = np.full(n, float(q0[1, 1])) if d == 2 else np.zeros(n)
+    ones = np.ones(n)                                       # processQScaleFinal = ones (core.py:5688)
+    tracks = {
+        "baseQLevel": base_level.astype(np.float32), "baseQTrend": base_trend.astype(np.float32),
+        "preKappaQLevel": (base_level * ones).astype(np.float32),
+        "preKappaQTrend": (base_trend * ones).astype(np.float32),
+        "processQScale": ones.astype(np.float32),
+    }
+    for name in ("sumGain0", "sumGain1", "effectiveQLevel", "effectiveQTrend", "muncTrace"):
+        tracks[name] = batch.download(chain, name)
+    return {
+        "precision_track_diagnostics": True,
+        "state_model": stateModel,
+        "ECM_useAPN": False,
+        "process_precision_reweighting_requested": bool(cfg.use_kappa),
+        "process_precision_reweighting_effective": bool(cfg.use_kappa),
+        "process_precision_reweighting_disabled_by_apn": False,
+        "lambdaExp": batch.download(chain, "lambda") if cfg.use_lambda else None,
+        "processPrecExp": batch.download(chain, "kappa") if cfg.use_kappa else None,
+        "matrixQ0": q0,
+        "outputTracks": tracks,
+    }
+
+
+def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_intervals: int, model_q0=None,
+                         initial_background=None, return_background: bool = True,
+                         return_precision_diagnostics: bool = True, download: bool = True):
+    """Steps 0-5 of the module docstring.  Returns (fits, results): `fits` the per-chain history, `results` one tuple per
+    chain in the reference's order (core.py:6126-6142 with returnScales=True): (stateSmoothed (n,2) float32,
+    stateCovarSmoothed (n,2,2), postFitResiduals (n,m), NIS (n,), intervalToBlockMap (n,) int32[, background (n,)]
+    [, precision diagnostics dict]).  download=False leaves everything on the device (results = None): the final pass's
+    arrays are resident and exported (`DeviceBatch.download`, `bedgraph_bytes`, `device_array`).
+
+    model_q0: the batch-wide matrixQ0 (2,2) used when cfg.seed_q is False (for the diagnostics dict; default: the
+    reference's 1e-4 fixed diagonal is NOT assumed -- pass what the batch was configured with).
+    initial_background: optional list of per-chain float32 tracks (the reference's `initialBackground`); None = background
+    warm start from the weighted data when the background is fitted (core.py:4663), zeros otherwise."""
+    nc = len(batch.chain_lens)
+    d = batch.d
+    cfg = FitConfig(**{**cfg.__dict__})
+    if initial_background is not None:
+        for c in range(nc):
+            batch.set_background(c, initial_background[c])
+        cfg.background_warm_start = False
+    else:
+        cfg.background_warm_start = bool(cfg.fit_background)
+    fits = fit_batch(batch, cfg, keep_background=initial_background is not None)
+
+    mult_flags = (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
+    if cfg.fit_background:
+        # final fixed-background ECM phase (core.py:5385-5440): every chain, converged background, warm-started multipliers
+        batch.stats()
+        outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
+                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa)
+        for c in range(nc):
+            fits[c].final_ecm_iters = int(outs[c].iters_done)
+            fits[c].final_ecm_nll = float(outs[c].final_nll)
+            fits[c].final_ecm_converged = bool(outs[c].converged) or bool(outs[c].skipped == 1)
+    # final store-all forward / backward on data - background with the final multipliers (core.py:5560-5600).  The
+    # statistics of the final background are resident (the ECM phase above or, without a background fit, the loop's)
+    sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags)
+    batch.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
+    if return_precision_diagnostics:
+        batch.diagnostics(mult_flags)
+    for c in range(nc):
+        fits[c].final_nll = float(sum_nll[c])
+        fits[c].final_forward_nis = float(sum_d[c]) / float(batch.chain_lens[c])      # phiHat = sumD / n (pyx:6627)
+    if not download:
+        return fits, None
+    state_model = "levelTrend" if d == 2 else "level"
+    results = []
+    for c in range(nc):
+        n = batch.chain_lens[c]
+        xs, ps = batch.download(c, "xs"), batch.download(c, "Ps")
+        if d == 1:                              # _padLevelStateArray / _padLevelCovarArray (core.py:4178-4192)
+            xs2, ps2 = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+            xs2[:, 0], ps2[:, 0, 0] = xs[:, 0], ps[:, 0, 0]
+            xs, ps = xs2, ps2
+        block_map = (np.arange(n, dtype=np.int64) // max(int(block_len_intervals), 1)).astype(np.int32)   # core.py:4105-4114
+        res = [xs, ps, batch.download(c, "resid"), batch.download(c, "D"), block_map]
+        if return_background:
+            res.append(batch.download(c, "background"))
+        if return_precision_diagnostics:
+            q0 = fits[c].q0 if fits[c].q0 is not None else model_q0
+            if q0 is None:
+                raise ValueError("model_q0 is required for the precision diagnostics when cfg.seed_q is False")
+            res.append(precision_diagnostics(batch, cfg, c, q0, state_model))
+        results.append(tuple(res))
+    return fits, results

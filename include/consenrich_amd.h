@@ -275,10 +275,14 @@ typedef struct csr_bg_cfg {
     int32_t zero_center;                /* fitParams.ECM_zeroCenterBackground */
     int32_t use_nonnegative;            /* fitParams.useNonnegativeBackground */
     int32_t use_lambda;                 /* multiply 1/max(munc+pad,1e-8) by clip(lambda) (core.py:5065-5074) */
-    int32_t use_initial;                /* seed the first solve with the current background's negative mask */
+    int32_t use_initial;                /* bit 0 (CSR_BG_INIT_FROM_CURRENT): seed the first solve with the current background's
+                                           negative mask (initialBackground, core.py:8306-8316); bit 1 (CSR_BG_ZERO_STATE):
+                                           the smoothed level is taken as zero -- the background warm start from the weighted
+                                           data, core.py:2809-2910 `_estimateBackgroundWarmStart` (no fit needs to be resident) */
     int32_t max_passes;                 /* reference: 5 */
     int32_t block_len;                  /* partition size of the solver, 0 = default */
 } csr_bg_cfg;
+enum { CSR_BG_INIT_FROM_CURRENT = 1, CSR_BG_ZERO_STATE = 2 };
 enum { CSR_BG_OK = 0, CSR_BG_NO_SUPPORT = 1, CSR_BG_BAD_PIVOT = 2, CSR_BG_UNRELIABLE = 3, CSR_BG_NONFINITE = 4 };
 typedef struct csr_bg_out {
     int64_t support;                    /* bins with positive weight */

@@ -71,12 +71,12 @@ def penalized_objective(forward_nll, munc, background, lam, kap, cfg):
             "effective_observation_count": count}
 
 
-def fit_chain(data, munc, cfg):
+def fit_chain(data, munc, cfg, initial_background=None):
     data = np.ascontiguousarray(data, np.float32)
     munc = np.ascontiguousarray(munc, np.float32)
     m, n = data.shape
     d = cfg["state_dim"]
-    bg = np.zeros(n, np.float32)
+    bg = np.zeros(n, np.float32) if initial_background is None else np.ascontiguousarray(initial_background, np.float32).copy()
     lam = kap = None
     hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "objective": [], "converged": False}
     prev_obj = float("nan")
@@ -142,4 +142,70 @@ def fit_chain(data, munc, cfg):
             break
     iters, nll, xs, Ps, lag, res, lam, kap, diag = out
     hist.update(passes=len(hist["ecm_iters"]), background=bg, xs=xs, Ps=Ps, resid=res, lam=lam, kap=kap)
+    return hist
+
+
+def background_warm_start(data, munc, cfg):
+    """core.py:2809-2910 `_estimateBackgroundWarmStart` (called at core.py:4663 when the background is fitted and no initial
+    background is given): the background solve of the weighted DATA (residual = data, float32 inverse variances, no
+    observation precision unless an initial lambda is supplied, no initial background)."""
+    w, r, _, _ = bgo.weight_rhs_tracks(data, munc, np.zeros(np.asarray(data).shape[1], np.float32), np.float32(cfg["pad"]))
+    out, info = bgo.solve_background(w, r, 0, zero_center=cfg["zero_center"], use_nonnegative=cfg["use_nonnegative"],
+                                     multiplier=cfg["neg_multiplier"], initial=None, penalties_override=cfg["penalties"],
+                                     return_info=True)
+    return np.ascontiguousarray(out, np.float32), int(info["passes"])
+
+
+def run_consenrich_chain(data, munc, cfg, initial_background=None):
+    """The whole `runConsenrich` composition for one chromosome (module docstring of consenrich_amd/driver.py, steps 1-5):
+    background warm start -> alternation loop -> FINAL fixed-background ECM phase (core.py:5385-5440) -> FINAL store-all
+    forward / backward on data - background with the final multipliers (core.py:5560-5600, 4207-4336) -> the pieces of the
+    return tuple (core.py:6126-6142).  Natives: the oracle's; glue: restated ("parity unpinned", see the header)."""
+    data = np.ascontiguousarray(data, np.float32)
+    munc = np.ascontiguousarray(munc, np.float32)
+    m, n = data.shape
+    d = cfg["state_dim"]
+    warm_passes = None
+    bg0 = initial_background
+    if bg0 is None and cfg["fit_background"]:
+        bg0, warm_passes = background_warm_start(data, munc, cfg)
+    hist = fit_chain(data, munc, cfg, initial_background=bg0)
+    bg, lam, kap = hist["background"], hist["lam"], hist["kap"]
+    bm = (np.arange(n, dtype=np.int32) // cfg["block_len_intervals"]).astype(np.int32)
+    Q0 = np.asarray(cfg["Q0"], np.float32)
+    common = dict(matrixQ0=Q0, intervalToBlockMap=bm, blockCount=int(bm.max()) + 1, stateInit=cfg["state_init"],
+                  stateCovarInit=cfg["state_covar_init"], pad=cfg["pad"],
+                  ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
+                  obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
+                  procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1])
+    if d == 2:
+        common["matrixF"] = np.asarray(cfg["F"], np.float32)
+    adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)
+    final = {}
+    if cfg["fit_background"]:
+        ecm = orc.cfixedBackgroundECM if d == 2 else orc.cfixedBackgroundECMLevel
+        out = ecm(matrixData=adj, matrixPluginMuncInit=munc, lambdaExpInit=lam, processPrecExpInit=kap,
+                  ECM_fixedBackgroundIters=cfg["ecm_iters"], ECM_fixedBackgroundRtol=cfg["ecm_rtol"],
+                  t_innerIters=cfg["inner_iters"], ECM_robustTNu=cfg["nu"], returnIntermediates=True,
+                  returnDiagnostics=True, logIterations=False, **common)
+        iters, nll, _xs, _Ps, _lag, _res, lam, kap, diag = out
+        final = dict(final_ecm_iters=int(iters), final_ecm_nll=float(nll), final_ecm_converged=bool(diag["converged"]))
+    xf, Pf, pn = np.empty((n, d), np.float32), np.empty((n, d, d), np.float32), np.empty((n, d, d), np.float32)
+    D = np.empty(n, np.float32)
+    fwd = orc.cforwardPass if d == 2 else orc.cforwardPassLevel
+    phi, _, D, nll = fwd(matrixData=adj, matrixPluginMuncInit=munc, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                         vectorD=D, returnNLL=True, storeNLLInD=False, lambdaExp=lam if cfg["use_lambda"] else None,
+                         processPrecExp=kap if cfg["use_kappa"] else None, processQScale=np.ones(n, np.float32), **common)
+    bkw = dict(matrixData=adj, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+    if d == 2:
+        bkw["matrixF"] = common["matrixF"]
+    xs, Ps, lag, res = (orc.cbackwardPass if d == 2 else orc.cbackwardPassLevel)(**bkw)
+    if d == 1:          # _padLevelStateArray / _padLevelCovarArray (core.py:4178-4192)
+        xs2, Ps2 = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+        xs2[:, 0], Ps2[:, 0, 0] = xs[:, 0], Ps[:, 0, 0]
+        xs, Ps = xs2, Ps2
+    hist.update(final, warm_start_passes=warm_passes, final_nll=float(nll), final_forward_nis=float(phi),
+                out_xs=np.asarray(xs, np.float32), out_Ps=np.asarray(Ps, np.float32), out_resid=np.asarray(res, np.float32),
+                out_NIS=np.asarray(D, np.float32), out_block_map=bm, out_background=bg, out_lam=lam, out_kap=kap,
+                out_Pf=Pf, out_pn=pn)
     return hist

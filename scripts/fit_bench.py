@@ -1,5 +1,7 @@
 """Whole-genome device-resident fit (SURVEY a12 counterpart, consenrich_amd/driver.py): hg38 autosomes @200bp x 32 synthetic
-samples, outer alternation of fixed-background ECM phases and background updates, everything resident in HBM.
+samples: background warm start, outer alternation of fixed-background ECM phases and background updates, final
+fixed-background ECM phase, final forward/backward pass + per-interval diagnostics (run_consenrich_batch, download=False),
+everything resident in HBM.
 Reports wall time, per-chromosome pass / iteration counts and the kernel-time breakdown."""
 import sys, os, time, json
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests", "golden"))
@@ -7,7 +9,7 @@ import numpy as np
 import bg_cases
 from consenrich_amd import _lib as L
 from consenrich_amd.batch import DeviceBatch, ModelParams
-from consenrich_amd.driver import FitConfig, fit_batch
+from consenrich_amd.driver import FitConfig, run_consenrich_batch
 from consenrich_amd.sharding import hg38_chain_lengths
 
 m = int(os.environ.get("M", "32"))
@@ -18,13 +20,14 @@ cfg = FitConfig(penalties=bg_cases.penalties(750, 128.0), ecm_iters=int(os.envir
                 inner_iters=5, outer_passes=int(os.environ.get("OUTER", "8")), min_outer=3, patience=2, shift_rtol=5e-3,
                 seed_q=bool(os.environ.get("SEED_Q")))
 b.synchronize(); b.profile(True)
-t = time.perf_counter(); fits = fit_batch(b, cfg); b.synchronize(); wall = time.perf_counter() - t
+t = time.perf_counter(); fits, _ = run_consenrich_batch(b, cfg, block_len_intervals=750, download=False); b.synchronize(); wall = time.perf_counter() - t
 kt = b.kernel_times(); b.profile(False)
 ecm_total = sum(sum(f.ecm_iters) for f in fits)
 print(json.dumps({"seed_q": cfg.seed_q, "q0_first_chain": None if fits[0].q0 is None else [float(fits[0].q0[0, 0]), float(fits[0].q0[1, 1])],
                   "workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {sum(lengths)} bins", "wall_s": round(wall, 3),
                   "outer_passes": [f.passes for f in fits], "converged": [f.converged for f in fits],
                   "ecm_iterations_total_over_chains": ecm_total, "ecm_iters_first_chain": fits[0].ecm_iters,
+                  "final_ecm_iters": [f.final_ecm_iters for f in fits], "final_nll_first_chain": fits[0].final_nll,
                   "shift_first_chain": [round(x, 6) for x in fits[0].shift],
                   "objective_per_cell_first_chain": [round(o["penalized_objective_per_cell"], 7) for o in fits[0].objective],
                   "objective_stable_first_chain": [o["stable"] for o in fits[0].objective],

@@ -887,42 +887,85 @@ print("rccl gather ok")
     assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stderr[-2000:]
 
 
+def _twin_cfg(mp, cfg, pen, Q0=None):
+    return dict(state_dim=mp.state_dim, F=mp.F, Q0=mp.Q0 if Q0 is None else Q0, state_init=mp.state_init,
+                state_covar_init=mp.state_covar_init, pad=mp.pad, lambda_bounds=mp.lambda_bounds,
+                kappa_bounds=mp.kappa_bounds, block_len_intervals=500, penalties=pen, ecm_iters=cfg.ecm_iters,
+                ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu, use_lambda=cfg.use_lambda,
+                use_kappa=cfg.use_kappa, fit_background=cfg.fit_background, zero_center=False, use_nonnegative=True,
+                neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes, min_outer=cfg.min_outer,
+                shift_rtol=cfg.shift_rtol, patience=cfg.patience, outer_nll_rtol=cfg.outer_nll_rtol)
+
+
+def _check_run_result(res, ref, fit, m, worst, tag):
+    """The reference's return tuple (core.py:6126-6142) against the CPU twin's composition; `worst` collects the measured
+    worst relative errors (printed by the caller)."""
+    xs, Ps, resid, nis, block_map, bg, diag = res
+    n = xs.shape[0]
+    assert xs.shape == (n, 2) and Ps.shape == (n, 2, 2) and resid.shape == (n, m) and nis.shape == (n,)     # test_core.py:4059-4063
+    assert all(a.dtype == np.float32 for a in (xs, Ps, resid, nis, bg)) and block_map.dtype == np.int32
+    assert np.array_equal(block_map, ref["out_block_map"])
+    for a in (xs, Ps, resid, nis, bg):
+        assert np.all(np.isfinite(a))
+    assert fit.final_ecm_iters == ref["final_ecm_iters"] and fit.final_ecm_converged == ref["final_ecm_converged"], tag
+    assert fit.final_nll == pytest.approx(ref["final_nll"], rel=1e-6)
+    assert fit.final_forward_nis == pytest.approx(float(np.mean(nis.astype(np.float64))), rel=1e-6)         # test_core.py:4085
+    assert fit.final_forward_nis == pytest.approx(ref["final_forward_nis"], rel=1e-4)
+    scale = max(float(np.abs(ref["out_background"]).max()), 1e-3)
+    e_bg = float(np.abs(bg - ref["out_background"]).max()) / scale
+    lvl = np.maximum(np.abs(ref["out_xs"][:, :1]).astype(np.float64), 1.0)
+    e_xs = float((np.abs(xs.astype(np.float64) - ref["out_xs"]) / lvl).max())
+    e_ps = float((np.abs(Ps.astype(np.float64) - ref["out_Ps"]) / (np.abs(ref["out_Ps"]) + ATOL / RTOL)).max())
+    e_res = float((np.abs(resid.astype(np.float64) - ref["out_resid"]) / lvl).max())
+    worst.update({f"{tag}:bg": e_bg, f"{tag}:xs": e_xs, f"{tag}:Ps": e_ps, f"{tag}:resid": e_res})
+    assert e_bg <= 2e-5 and e_xs <= 1e-4 and e_ps <= 1e-4 and e_res <= 1e-4, (tag, e_bg, e_xs, e_ps, e_res)
+    close_mostly(nis, ref["out_NIS"], frac=2e-2, cap=5e-2, msg=f"NIS {tag}")
+    close_mostly(diag["processPrecExp"], ref["out_kap"], frac=2e-2, cap=5e-2, msg=f"kappa {tag}")
+    tracks = diag["outputTracks"]
+    assert tuple(sorted(tracks)) == ("baseQLevel", "baseQTrend", "effectiveQLevel", "effectiveQTrend", "muncTrace",
+                                     "preKappaQLevel", "preKappaQTrend", "processQScale", "sumGain0", "sumGain1")   # test_core.py:4066-4077
+    assert all(np.asarray(t).shape == (n,) and np.asarray(t).dtype == np.float32 for t in tracks.values())
+    assert diag["precision_track_diagnostics"] is True
+
+
 @pytest.mark.parametrize("use_lambda", [False, True], ids=["kappa", "kappa+lambda"])
-def test_device_resident_alternation_matches_cpu_twin(product, oracle, use_lambda):
-    """SURVEY a12 counterpart: several outer passes of [ECM phase with warm-started multipliers <-> background update ->
-    apply], all device-resident, against the same alternation composed from the oracle's natives on the host.
-    Chromosomes stop independently (chain masks).  Exact-mode validation keeps the discrete decisions (ECM iteration
+def test_run_consenrich_batch_matches_cpu_twin(product, oracle, use_lambda):
+    """`run_consenrich_batch` = background warm start -> outer alternation [ECM phase with warm-started
+    multipliers <-> background update -> apply -> penalised objective] -> FINAL fixed-background ECM -> FINAL store-all
+    forward/backward -> the reference's return tuple, all device-resident, against the same composition of the oracle's
+    natives on the host (oracle/driver.py).  Chromosomes stop independently (chain masks) and the tuple of every chromosome
+    comes from ITS final pass, whatever the others did.  Exact-mode validation keeps the discrete decisions (ECM iteration
     counts, IRLS passes, stop pass) identical."""
-    from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
-    from consenrich_amd.driver import FitConfig, fit_batch
+    from consenrich_amd.driver import FitConfig, run_consenrich_batch
     from oracle import background as bgo
+    from oracle import diagnostics as odiag
     from oracle import driver as odrv
 
-    n_list, m = [3000, 1200, 500], 4
+    n_list, m = [3000, 1200, 500, 2200], 4
     mp = ModelParams(state_dim=2)
     ins = _bg_batch_fixture(n_list, m, 5100, bg_amp=0.4)
+    # a chromosome with a stronger, rougher background keeps iterating after the others have stopped
+    ins[3] = (ins[3][0] + (0.8 * np.sin(np.arange(n_list[3]) / 60.0) ** 2).astype(np.float32)[None, :], ins[3][1])
     pen = bgo.penalties(40, 2.0)
-    cfg = FitConfig(penalties=pen, ecm_iters=6, ecm_rtol=1e-4, inner_iters=3, outer_passes=6, min_outer=2, patience=1,
+    cfg = FitConfig(penalties=pen, ecm_iters=6, ecm_rtol=1e-4, inner_iters=3, outer_passes=8, min_outer=2, patience=1,
                     shift_rtol=2e-2, neg_multiplier=2.0, use_lambda=use_lambda)
-    ocfg = dict(state_dim=2, F=mp.F, Q0=mp.Q0, state_init=mp.state_init, state_covar_init=mp.state_covar_init,
-                pad=mp.pad, lambda_bounds=mp.lambda_bounds, kappa_bounds=mp.kappa_bounds, block_len_intervals=500,
-                penalties=pen, ecm_iters=cfg.ecm_iters, ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu,
-                use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, fit_background=True, zero_center=False,
-                use_nonnegative=True, neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes,
-                min_outer=cfg.min_outer, shift_rtol=cfg.shift_rtol, patience=cfg.patience,
-                outer_nll_rtol=cfg.outer_nll_rtol)
+    ocfg = _twin_cfg(mp, cfg, pen)
     with DeviceBatch(0, x_tol_ulps=0) as b:
         b.configure(mp, m, n_list)
         for c, (data, munc) in enumerate(ins):
             b.upload(c, data, munc)
-        fits = fit_batch(b, cfg)
-        got = [dict(bg=b.download(c, "background"), xs=b.download(c, "xs"), kap=b.download(c, "kappa"))
-               for c in range(len(n_list))]
-    assert len({f.passes for f in fits}) >= 1
+        fits, results = run_consenrich_batch(b, cfg, block_len_intervals=500, model_q0=np.asarray(mp.Q0, np.float32))
+        # the f3 writer emits the state / uncertainty tracks of THAT final pass (consenrich.py:9476, 9797-9805)
+        text_state = b.bedgraph_bytes(1, "xs", "chrT", 0, 25, end_cap=25 * n_list[1] - 7, transform="round4")
+        text_unc = b.bedgraph_bytes(1, "Ps", "chrT", 0, 25, end_cap=25 * n_list[1] - 7, transform="sqrt")
+    worst = {}
+    refs = []
     for c, (data, munc) in enumerate(ins):
-        ref = odrv.fit_chain(data, munc, ocfg)
+        ref = odrv.run_consenrich_chain(data, munc, ocfg)
+        refs.append(ref)
         f = fits[c]
+        assert f.warm_start_passes == ref["warm_start_passes"]
         assert f.passes == ref["passes"] and f.converged == ref["converged"], (c, f, ref["passes"])
         assert f.ecm_iters == ref["ecm_iters"] and f.irls_passes == ref["irls_passes"], (c, f.ecm_iters, ref["ecm_iters"])
         np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-6)
@@ -942,11 +985,30 @@ def test_device_resident_alternation_matches_cpu_twin(product, oracle, use_lambd
                              ("negative_penalty", "background_negative_penalty")):
                 assert og[k_g] == pytest.approx(orf[k_r], rel=2e-3, abs=1e-9), (c, k_g)
             assert og["penalized_objective_per_cell"] == pytest.approx(orf["penalized_objective_per_cell"], rel=1e-6)
-        scale = max(float(np.abs(ref["background"]).max()), 1e-3)
-        assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
-        lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
-        assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
-        close_mostly(got[c]["kap"], ref["kap"], frac=2e-2, cap=5e-2, msg=f"kappa chain {c}")
+        _check_run_result(results[c], ref, f, m, worst, f"chain{c}")
+        # the ten per-interval diagnostic tracks against the NumPy restatement of core.py:7734-7878 on the twin's final pass
+        want = odiag.output_diagnostic_tracks(
+            stateCovarForward=ref["out_Pf"], matrixMunc=munc, matrixQ0=np.asarray(mp.Q0, np.float32),
+            matrixF=np.asarray(mp.F, np.float32), stateCovarInit=mp.state_covar_init, state_dim=2,
+            lambdaExp=ref["out_lam"] if use_lambda else None, processPrecExp=ref["out_kap"],
+            processQScale=np.ones(n_list[c], np.float32), pNoiseForward=ref["out_pn"], pad=mp.pad,
+            obsPrecisionMultiplierMin=mp.lambda_bounds[0], obsPrecisionMultiplierMax=mp.lambda_bounds[1],
+            procPrecisionMultiplierMin=mp.kappa_bounds[0], procPrecisionMultiplierMax=mp.kappa_bounds[1])
+        for k, v in want.items():
+            if k in ("effectiveQLevel", "effectiveQTrend", "sumGain0", "sumGain1"):     # carry 1/kappa
+                close_mostly(results[c][6]["outputTracks"][k], v, frac=2e-2, cap=5e-2, msg=f"{k} chain {c}")
+            else:
+                np.testing.assert_allclose(results[c][6]["outputTracks"][k], v, rtol=1e-4, atol=ATOL, err_msg=k)
+    print("run_consenrich_batch worst relative errors:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+    assert len({f.passes for f in fits}) >= 2, [f.passes for f in fits]     # chromosomes really stop at different passes
+    # bedGraph of chromosome 1 = the reference's writer on ITS final tracks (a chain that stopped before the others)
+    from oracle import writers as ow
+
+    x1, p1 = results[1][0], results[1][1]
+    starts = np.arange(n_list[1], dtype=np.int64) * 25
+    ends = np.minimum(starts + 25, 25 * n_list[1] - 7)
+    assert text_state == ow.bedgraph_bytes("chrT", starts, ends, np.round(x1[:, 0], 4))
+    assert text_unc == ow.bedgraph_bytes("chrT", starts, ends, np.sqrt(p1[:, 0, 0]))
 
 
 def test_whole_genome_batch_matches_oracle_config3(product, oracle):
@@ -1183,7 +1245,7 @@ def test_alternation_with_per_chromosome_seeded_process_noise(product, oracle):
     """fit_batch(seed_q=True): Q0 of every chromosome from its own data on the device (core.py:5667), then the outer
     alternation with per-chain Q0 -- against the CPU twin run per chromosome with the oracle's seed for that chromosome."""
     from consenrich_amd.batch import DeviceBatch, ModelParams
-    from consenrich_amd.driver import FitConfig, fit_batch
+    from consenrich_amd.driver import FitConfig, run_consenrich_batch
     from oracle import background as bgo
     from oracle import driver as odrv
     from oracle import qseed as oq
@@ -1199,27 +1261,20 @@ def test_alternation_with_per_chromosome_seeded_process_noise(product, oracle):
         b.configure(mp, m, n_list)
         for c, (data, munc) in enumerate(ins):
             b.upload(c, data, munc)
-        fits = fit_batch(b, cfg)
-        got = [dict(bg=b.download(c, "background"), xs=b.download(c, "xs")) for c in range(len(n_list))]
+        fits, results = run_consenrich_batch(b, cfg, block_len_intervals=500)
     assert not np.array_equal(fits[0].q0, fits[1].q0)
+    worst = {}
     for c, (data, munc) in enumerate(ins):
         Q, diag = oq.estimate_initial_process_noise(oq, matrixData=data, matrixMunc=munc, pad=cfg.pad, stateModel="levelTrend",
                                                     minQ=cfg.min_q, maxQ=cfg.max_q, deltaF=cfg.delta_f, robustTNu=cfg.nu)
         assert np.array_equal(fits[c].q0, Q) and fits[c].q_seed["qSeedSource"] == diag["qSeedSource"]
-        ocfg = dict(state_dim=2, F=mp.F, Q0=Q, state_init=mp.state_init, state_covar_init=mp.state_covar_init, pad=mp.pad,
-                    lambda_bounds=mp.lambda_bounds, kappa_bounds=mp.kappa_bounds, block_len_intervals=500, penalties=pen,
-                    ecm_iters=cfg.ecm_iters, ecm_rtol=cfg.ecm_rtol, inner_iters=cfg.inner_iters, nu=cfg.nu,
-                    use_lambda=False, use_kappa=True, fit_background=True, zero_center=False, use_nonnegative=True,
-                    neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes, min_outer=cfg.min_outer,
-                    shift_rtol=cfg.shift_rtol, patience=cfg.patience, outer_nll_rtol=cfg.outer_nll_rtol)
-        ref = odrv.fit_chain(data, munc, ocfg)
+        ref = odrv.run_consenrich_chain(data, munc, _twin_cfg(mp, cfg, pen, Q0=Q))
         f = fits[c]
         assert f.passes == ref["passes"] and f.converged == ref["converged"] and f.ecm_iters == ref["ecm_iters"], (c, f, ref["passes"])
         np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-6)
-        scale = max(float(np.abs(ref["background"]).max()), 1e-3)
-        assert float(np.abs(got[c]["bg"] - ref["background"]).max()) <= 2e-5 * scale
-        lvl = np.abs(ref["xs"][:, :1]).astype(np.float64)
-        assert np.all(np.abs(got[c]["xs"].astype(np.float64) - ref["xs"]) <= 1e-4 * np.maximum(lvl, 1.0) + ATOL)
+        _check_run_result(results[c], ref, f, m, worst, f"chain{c}")
+        assert np.array_equal(results[c][6]["matrixQ0"], Q)
+    print("seeded run_consenrich_batch worst relative errors:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
 
 
 def test_bench_workload_matches_oracle(product, oracle):
