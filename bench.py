@@ -9,16 +9,21 @@ Workload (BASELINE.json metric "genomic bins/sec (forward+backward pass), hg38 2
 22 synthetic chains with the hg38 autosome bin counts at 200 bp (14 375 018 bins), m = 32 samples, levelTrend model,
 SURVEY 8(d) parameters.  One STEP = one full pass of the hot path over every chain the rank owns, inputs already
 resident in HBM:  per-bin sufficient statistics of (data, munc)  ->  forward filter (store, NLL)  ->  RTS smoother
-->  lag-one covariances  ->  export of D, xf, Pf, pNoise, xs, Ps, lagCov to the reference layouts  ->  residuals (n, m).
+->  lag-one covariances  ->  D, xf, Pf, pNoise, xs, Ps, lagCov in the reference layouts  ->  residuals (n, m).
 With N > 1 the chains are LPT-sharded over the ranks (strong scaling: the genome is fixed); there is no data-path
 collective -- the one RCCL call is the final track gather, done once after the timed region and reported separately.
-torch is used only for the process group / barrier / device-wide synchronize required by the contract.
+
+No PyTorch: the launcher (`python -m torch.distributed.run`) only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in
+the environment; the barrier and the max-over-ranks of the timed region are RCCL all-reduces on the library's stream
+(consenrich_amd.sharding.RcclComm -> csr_comm_* in libconsenrich_amd.so, librccl dlopen'ed there), the rendezvous of the
+128-byte RCCL id is a file on the node.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -28,6 +33,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")     # PMC pass of THIS workload (scripts/pmc_traffic.py)
 
 
 def b_alg(m: int) -> int:
@@ -40,6 +46,7 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
     return {
         "stats": 8.0 * m,                       # data + munc read once
         "residuals": 4.0 * m,                   # (n, m) residual write
+        "fwd_chain": 16.0 + 16.0 + 16.0 + 8.0,  # lambda/kappa/qscale/blockMap in, Pf + pNoise + xf out (fused chain)
         "fwd_cov_chain": 16.0 + 16.0 + 16.0,    # lambda/kappa/qscale/blockMap in, Pf + pNoise out
         "fwd_state_chain": 8.0,                 # xf out
         "fwd_dstat": 4.0,                       # D out
@@ -48,15 +55,56 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
     }.get(name, 0.0)
 
 
-def cpu_baseline(m: int, max_seconds: float = 30.0):
-    """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload."""
+class FileComm:
+    """Control-plane fallback over files on the node (barrier and max only): used to agree on whether RCCL is usable on
+    every rank, and in its place if it is not -- so that a broken RCCL installation costs the gather, not the measurement."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world, self.k = rank, world, 0
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        self.dir = os.path.join(base, f"consenrich_amd_fc_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+        os.makedirs(self.dir, exist_ok=True)
+
+    def allreduce_max(self, value: float, timeout_s: float = 600.0) -> float:
+        self.k += 1
+        mine = os.path.join(self.dir, f"{self.k}_{self.rank}")
+        with open(mine + ".tmp", "w") as fh:
+            fh.write(repr(float(value)))
+        os.replace(mine + ".tmp", mine)
+        vals, deadline = [], time.monotonic() + timeout_s
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"{self.k}_{r}")
+            while True:
+                try:
+                    with open(path) as fh:
+                        vals.append(float(fh.read()))
+                    break
+                except (FileNotFoundError, ValueError):
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} never reached barrier {self.k}")
+                    time.sleep(0.0005)
+        return max(vals)
+
+    def barrier(self):
+        self.allreduce_max(0.0)
+
+    def close(self):
+        self.barrier()
+        if self.rank == 0:
+            time.sleep(0.2)
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def cpu_baseline(m: int, max_seconds: float = 15.0):
+    """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload: a chr1-sized chain.
+    (scripts/cpu_port_vs_reference.py, build container only: the port runs within 3 % of the compiled reference.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import cases
     from consenrich_amd.sharding import hg38_chain_lengths
     from oracle import oracle as orc
 
     orc.lib()
-    n = hg38_chain_lengths(200)[20]   # chr21-sized chain: 233 550 bins
+    n = hg38_chain_lengths(200)[0]    # chr1-sized chain: 1 244 783 bins
     data, munc = cases.synth(n, m, 21)
     F = np.asarray(cases.F_TREND, np.float32)
     Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
@@ -75,7 +123,7 @@ def cpu_baseline(m: int, max_seconds: float = 30.0):
 
     one()  # warm-up (first-touch page faults)
     best, spent, reps = float("inf"), 0.0, 0
-    while reps < 400 and spent < min(max_seconds, 12.0):
+    while reps < 400 and spent < max_seconds:
         t = time.perf_counter()
         one()
         dt = time.perf_counter() - t
@@ -84,7 +132,7 @@ def cpu_baseline(m: int, max_seconds: float = 30.0):
         reps += 1
     return {
         "value": n / best, "unit": "genomic bins/s", "cores": 1, "kind": "port",
-        "sample": f"oracle C port (forward store+NLL, backward+residuals), 1 thread, chr21-sized chain "
+        "sample": f"oracle C port (forward store+NLL, backward+residuals), 1 thread, chr1-sized chain "
                   f"({n} bins x {m} samples), best of {reps} passes after warm-up ({spent:.1f} s of CPU work)",
     }
 
@@ -96,86 +144,84 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--bin-bp", type=int, default=200)
+    ap.add_argument("--q0", default="1e-3,1e-4", help="diagonal of the base process noise Q0 (long-memory regime: 1e-5,1e-6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-mode and ECM measurements")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (no RCCL: file barrier)")
     args = ap.parse_args()
-
-    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.same_device:
-        local_rank = 0
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N > 1 must be launched through torch.distributed.run", file=sys.stderr)
-            return 2
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one process per GPU)", file=sys.stderr)
+        return 2
 
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
-    from consenrich_amd.sharding import gather_tracks, hg38_chain_lengths, lpt_assign
+    from consenrich_amd.sharding import RcclComm, hg38_chain_lengths, lpt_assign
 
     m = args.samples
+    q00, q11 = (float(v) for v in args.q0.split(","))
     lengths = hg38_chain_lengths(args.bin_bp)
     total_bins = int(sum(lengths))
     mine = lpt_assign(lengths, world)[rank]
     my_lens = [lengths[i] for i in mine]
 
-    model = ModelParams(state_dim=2)
+    model = ModelParams(state_dim=2, Q0=((q00, 0.0), (0.0, q11)))
     batch = DeviceBatch(local_rank)
+    comm, comm_kind, comm_note, fc = None, "none", None, None
+    if world > 1:
+        fc = FileComm(rank, world)
+        probe_ok = 0.0
+        if args.same_device:
+            probe_ok, comm_note = 1.0, "same-device rehearsal: RCCL refuses two ranks on one GPU"
+        else:
+            import ctypes
+
+            if L.lib().csr_comm_unique_id(ctypes.create_string_buffer(128)) != 0:      # RCCL loads and sees this device?
+                probe_ok, comm_note = 1.0, f"rank {rank}: {L.last_error()}"
+        if fc.allreduce_max(probe_ok) == 0.0:
+            comm, comm_kind = RcclComm(batch, world, rank), "rccl"
+        else:
+            comm, comm_kind = fc, "file"
+            comm_note = comm_note or "RCCL unusable on another rank"
     batch.configure(model, m, my_lens)
     batch.synthesize(seed=1234 + rank)
     flags = L.RETURN_NLL
     what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 
-    def step():
-        # statistics + forward (store, NLL) + backward + export of every track + residuals + per-chain phiHat / NLL
-        # read-back (the step's one host synchronisation), as one C-ABI call
-        batch.step(flags, what)
+    def fence(b=batch):
+        # device-wide synchronize of this rank, then the barrier over all ranks (an RCCL all-reduce on the library's
+        # stream + stream synchronisation), then nothing is in flight anywhere
+        b.synchronize()
+        if comm is not None:
+            comm.barrier()
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        batch.synchronize()
-        torch.cuda.synchronize()
+    def max_over_ranks(v: float) -> float:
+        return comm.allreduce_max(v) if comm is not None else v
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(b, fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        fence(b)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence(b)
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # statistics + forward (store, NLL) + backward + every track in the reference layout + residuals + per-chain phiHat /
+    # NLL read-back (the step's one host synchronisation), as one C-ABI call
+    elapsed = timed(batch, lambda: batch.step(flags, what), args.warmup, args.steps)
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = total_bins * args.steps / elapsed
 
     # per-kernel durations: HIP events on the library's stream, separate (untimed) pass of the same steps
     batch.profile(True)
     for _ in range(args.steps):
-        step()
+        batch.step(flags, what)
     times = batch.kernel_times()
     batch.profile(False)
     rs = batch.run_stats()
@@ -183,7 +229,7 @@ def main() -> int:
     per_kernel = {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1), "ms_per_step": v[1] / max(args.steps, 1)}
                   for k, v in times.items()}
     # dominant kernel = the longest one ON THE CRITICAL PATH: the NIS/NLL epilogue runs on the side stream underneath the
-    # smoother / export / residual kernels (its event-measured duration is stretched by that overlap), so it never is
+    # smoother / residual kernels (its event-measured duration is stretched by that overlap), so it never is
     critical = {k: v for k, v in per_kernel.items() if k != "fwd_dstat"} or per_kernel
     dom = max(critical, key=lambda k: critical[k]["ms_per_step"]) if critical else None
     roofline = None
@@ -191,38 +237,67 @@ def main() -> int:
         alg_bytes = kernel_alg_bytes(dom, m, 2) * my_bins
         avg_s = per_kernel[dom]["avg_ms"] * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        traffic, traffic_source = None, None
+        pmc_path = os.path.join(ROOT, TRAFFIC_FILE)
         # the committed PMC pass was taken on the default workload at N = 1; it does not describe other shapes / shards
-        if os.path.exists(pmc_path) and world == 1 and m == 32 and args.bin_bp == 200:
+        if os.path.exists(pmc_path) and world == 1 and m == 32 and args.bin_bp == 200 and args.q0 == "1e-3,1e-4":
             try:
                 with open(pmc_path) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_source = f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes of this " \
+                                 "command; not measured in this run)"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_bin": kernel_alg_bytes(dom, m, 2), "bins_per_launch": my_bins,
                     "avg_launch_ms": per_kernel[dom]["avg_ms"]}
 
-    gather_ms, gather_note = None, None
-    if dist is not None and not args.no_gather:
-        # final track gather (state + uncertainty): once per job, RCCL all_gather over xGMI, not part of `value`.
-        # It runs after the timed region; a failure here must not cost the measurement its JSON line.
+    extras = {}
+    if not args.no_extras:
+        # (1) the ECM loop -- what real runs execute: 5 x [forward, smoother + kappa E-step] + 1 NLL forward
+        ecm_iters, inner = 3, 5
+        batch.stats()
+
+        def ecm_once():
+            batch.ecm(max_iters=ecm_iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
+
+        e = timed(batch, ecm_once, 1, 2) / 2.0
+        rs_ecm = batch.run_stats()
+        extras["ecm"] = {"ms_per_iter": 1000.0 * e / ecm_iters, "iters": ecm_iters, "inner_sweeps": inner,
+                         "bin_sweeps_per_s": total_bins * ecm_iters * inner / e,
+                         "pipeline_redos": rs_ecm["pipeline_redos"] - rs["pipeline_redos"],
+                         "note": "per ECM iteration over all chains: 5 x (forward + smoother + kappa E-step) + 1 NLL "
+                                 "forward; bin_sweeps = forward+backward+E-step sweeps"}
+        # (2) the same step in the bit-exact validation mode (k = 0: results == the sequential recursion; the mode the
+        # reference-shaped drop-in callables default to)
+        ex = DeviceBatch(local_rank, x_tol_ulps=0)
+        ex.configure(model, m, my_lens)
+        ex.synthesize(seed=1234 + rank)
+        ex_steps = max(1, min(args.steps, 3))
+        ee = timed(ex, lambda: ex.step(flags, what), 1, ex_steps)
+        rx = ex.run_stats()
+        extras["exact_mode"] = {"x_tol_ulps": 0, "ms_per_step": 1000.0 * ee / ex_steps, "value": total_bins * ex_steps / ee,
+                                "unit": "genomic bins/s", "steps": ex_steps, "block_len": rx["block_len"],
+                                "warm_bins": [rx["warm_p"], rx["warm_x"], rx["warm_b"]],
+                                "reruns": [rx["reruns_p"], rx["reruns_x"], rx["reruns_b"]],
+                                "fix_launches": rx["fix_launches"]}
+        ex.close()
+
+    gather_ms, gather_note = None, comm_note
+    if comm_kind == "rccl" and not args.no_gather:
+        # final track gather (state + its variance): once per job, packed on the device from the exported arrays and
+        # all-gathered over RCCL / xGMI; not part of `value`.  A failure here must not cost the measurement its JSON line.
         try:
-            xs_tracks = {}
-            for ci, gi in enumerate(mine):
-                xs = batch.download(ci, "xs")[:, :1]
-                ps = np.sqrt(np.maximum(batch.download(ci, "Ps")[:, 0, 0:1], 0.0))
-                xs_tracks[gi] = np.concatenate([xs, ps], axis=1)
+            batch.step(flags, what)
             fence()
             tg = time.perf_counter()
-            gathered = gather_tracks(xs_tracks, lengths, 2,
-                                     device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+            gathered = comm.gather_batch_tracks(lengths, to_host=True)
             fence()
-            gather_ms = 1000.0 * (time.perf_counter() - tg)
-            if rank == 0 and not (gathered is not None and all(g.shape == (lengths[i], 2) for i, g in enumerate(gathered))):
-                gather_note = "gathered tracks have unexpected shapes"
+            gather_ms = 1000.0 * max_over_ranks(time.perf_counter() - tg)
+            if rank == 0 and not all(g is not None and g.shape == (lengths[i], 2) and np.all(np.isfinite(g))
+                                     for i, g in enumerate(gathered)):
+                gather_note = "gathered tracks have unexpected shapes / values"
         except Exception as exc:        # noqa: BLE001
             gather_note = f"gather failed: {exc!r}"
 
@@ -231,12 +306,14 @@ def main() -> int:
             "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples",
             "value": value, "unit": "genomic bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64 arithmetic on f32 storage", "data": "synthetic",
             "config": {
                 "workload": f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
-                            "stats + forward(store,NLL) + RTS backward + lagCov + export + residuals, levelTrend",
-                "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"],
+                            "stats + forward(store,NLL) + RTS backward + lagCov + reference-layout tracks + residuals, "
+                            "levelTrend",
+                "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"], "q0_diag": [q00, q11],
                 "warm_bins": [rs["warm_p"], rs["warm_x"], rs["warm_b"]], "x_tol_ulps": rs["x_tol_ulps"],
+                "comm": comm_kind,
             },
             "roofline": roofline,
             "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": value * b_alg(m) / 1e9,
@@ -244,18 +321,23 @@ def main() -> int:
                               "frac": value * b_alg(m) / 1e9 / (HBM_PEAK_GBS * world)},
             "kernels_rank0": per_kernel,
             "speculation": {"blocks": rs["blocks"], "reruns_cov": rs["reruns_p"], "reruns_state": rs["reruns_x"],
-                            "reruns_bwd": rs["reruns_b"], "fix_launches": rs["fix_launches"]},
+                            "reruns_bwd": rs["reruns_b"], "fix_launches": rs["fix_launches"],
+                            "pipeline_redos": rs["pipeline_redos"]},
             "gather_ms": gather_ms,
         }
+        out.update(extras)
         if gather_note:
             out["gather_note"] = gather_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m)
         print(json.dumps(out))
+    if comm is not None:
+        comm.barrier()
+        if comm is not fc:
+            comm.close()
+    if fc is not None:
+        fc.close()
     batch.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 

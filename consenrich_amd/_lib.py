@@ -206,6 +206,14 @@ SYMBOLS = {
     "csr_qseed_pooled": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), DP, DP, DP, I64P]),
     "csr_qseed_posterior": (C.c_int, [C.c_int64, DP, DP, DP, C.POINTER(QseedPostCfg), C.POINTER(QseedPost)]),
     "csr_batch_qseed": (C.c_int, [C.c_void_p, C.POINTER(QseedCfg), C.POINTER(QseedOut)]),
+    "csr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "csr_comm_create": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "csr_comm_destroy": (None, [C.c_void_p]),
+    "csr_comm_world": (C.c_int, [C.c_void_p]),
+    "csr_comm_rank": (C.c_int, [C.c_void_p]),
+    "csr_comm_allreduce_max": (C.c_int, [C.c_void_p, DP]),
+    "csr_comm_barrier": (C.c_int, [C.c_void_p]),
+    "csr_batch_gather_tracks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, FP]),
     "csr_expected_transition_residual_sums": (C.c_int, [C.c_int32, C.c_int64, DP, DP, DP, DP, DP, DP, I64P]),
 }
 

@@ -697,7 +697,9 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     // (Small batches are launch-bound: there the extra conversion launch costs more than the overlap saves.)
     const bool lateD = (what & CSR_EXPORT_FORWARD) && c->sidePending && (what & CSR_EXPORT_RESID) && !c->dNat &&
                        c->Npad >= ((int64_t)4 << 20);
-    if (!lateD) join_side(c);
+    // dNat: the epilogue writes D in the reference layout itself -- nothing in this export depends on the side stream; it
+    // is joined at the next settle point (sums, download, device_array, synchronize)
+    if (!lateD && !c->dNat) join_side(c);
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
         if (!lateD && !c->dNat) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));   // dNat: the epilogue wrote it already

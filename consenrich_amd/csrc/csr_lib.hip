@@ -347,6 +347,7 @@ extern "C" int csr_synchronize(csr_ctx *c) {
     CHECK(ctx_select(c));
     if (c->configured) CHECK(settle(c));
     HIPOK(hipStreamSynchronize(c->stream));
+    HIPOK(hipDeviceSynchronize());      // side stream, other contexts of this process: nothing is in flight on the device
     return 0;
 }
 
@@ -449,3 +450,4 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
 #include "csr_host_rows.inl"
 #include "csr_host_qseed.inl"
 #include "csr_host_debug.inl"
+#include "csr_host_comm.inl"

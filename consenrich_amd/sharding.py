@@ -2,13 +2,19 @@
 
 Chromosomes/contigs are fully independent fits (reference: sequential loop consenrich.py:8809, no cross-chromosome
 state inside runConsenrich), so the path shards with NO data-path collective: every rank fits its own chains with its
-own DeviceBatch.  The only communication is the final gather of the per-bin output tracks, done once per job with
-torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
-torch is imported lazily and only here / in bench.py: it is plumbing for the process group, not part of the product.
+own DeviceBatch.  The only communication is the final gather of the per-bin output tracks, done once per job over RCCL /
+xGMI: `RcclComm` binds the library's csr_comm_* entry points (RCCL itself is dlopen'ed by libconsenrich_amd.so) -- the
+tracks are packed on the device straight from the exported arrays and all-gathered, no host bounce, NO PyTorch.  The
+rendezvous (rank 0's 128-byte unique id) goes through a file on the node, keyed by the launcher's MASTER_PORT and process id.
+The host-side bookkeeping (ownership, packed layout, re-assembly in genome order) is transport-agnostic (`pack_layout`,
+`unpack_gathered`, `gather_tracks`) and is what the world-size-2 CPU test drives over gloo.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+import ctypes as C
+import os
+import time
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -50,40 +56,142 @@ def shard_bound(lengths: Sequence[int], world_size: int) -> float:
     return float(sum(int(v) for v in lengths)) / float(makespan)
 
 
-def gather_tracks(local: Dict[int, np.ndarray], lengths: Sequence[int], row_width: int, group=None, device=None):
-    """Final track gather: every rank contributes {chain index: float32 array (n_c, row_width)} for the chains it
-    owns; rank 0 returns the genome-ordered list of arrays (others return None).
+def pack_layout(lengths: Sequence[int], world_size: int):
+    """(owned, share, cap): chains of every rank, bins of every rank, and the per-rank capacity (bins) of the gather buffers."""
+    owned = lpt_assign(lengths, world_size)
+    share = [sum(int(lengths[i]) for i in v) for v in owned]
+    return owned, share, max(max(share), 1)
 
-    One padded all_gather of a flat float32 buffer per call (uneven shards are padded to the largest rank's share);
-    there is no all-reduce and no exchange inside the estimator.
-    """
-    import torch
-    import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    owned = lpt_assign(lengths, world)
-    share = [sum(int(lengths[i]) for i in v) * row_width for v in owned]
-    cap = max(max(share), 1)
-    dev = torch.device(device) if device is not None else torch.device("cpu")
-    send = torch.zeros(cap, dtype=torch.float32, device=dev)
+def unpack_gathered(buf: np.ndarray, lengths: Sequence[int], world_size: int, row_width: int) -> List[np.ndarray]:
+    """Re-assembles genome order from the gathered buffer (world, cap * row_width): rank r's chains follow each other,
+    unpadded, from the start of row r."""
+    owned, _share, cap = pack_layout(lengths, world_size)
+    buf = np.asarray(buf, np.float32).reshape(world_size, cap * row_width)
+    out: List[np.ndarray] = [None] * len(lengths)  # type: ignore[list-item]
+    for r in range(world_size):
+        pos = 0
+        for i in owned[r]:
+            cnt = int(lengths[i]) * row_width
+            out[i] = buf[r, pos:pos + cnt].reshape(int(lengths[i]), row_width).copy()
+            pos += cnt
+    return out
+
+
+def gather_tracks(local: Dict[int, np.ndarray], lengths: Sequence[int], row_width: int, transport):
+    """Host-array form of the final gather over any transport with `rank`, `world` and
+    `all_gather(send: float32 (cap * row_width,)) -> float32 (world, cap * row_width)`: every rank contributes
+    {chain index: float32 (n_c, row_width)} for the chains it owns; rank 0 returns the genome-ordered list (others None).
+    (The product's multi-GPU path is RcclComm.gather_batch_tracks: same layout, packed on the device.)"""
+    world, rank = int(transport.world), int(transport.rank)
+    owned, _share, cap = pack_layout(lengths, world)
+    send = np.zeros(cap * row_width, np.float32)
     pos = 0
     for i in owned[rank]:
         arr = np.ascontiguousarray(local[i], dtype=np.float32).reshape(-1)
         if arr.size != int(lengths[i]) * row_width:
             raise ValueError(f"chain {i}: expected {int(lengths[i]) * row_width} values, got {arr.size}")
-        send[pos:pos + arr.size] = torch.from_numpy(arr).to(dev)
+        send[pos:pos + arr.size] = arr
         pos += arr.size
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    recv = transport.all_gather(send)
     if rank != 0:
         return None
-    out: List[np.ndarray] = [None] * len(lengths)  # type: ignore[list-item]
-    for r in range(world):
-        buf = recv[r].cpu().numpy()
-        pos = 0
-        for i in owned[r]:
-            cnt = int(lengths[i]) * row_width
-            out[i] = buf[pos:pos + cnt].reshape(int(lengths[i]), row_width).copy()
-            pos += cnt
-    return out
+    return unpack_gathered(recv, lengths, world, row_width)
+
+
+def _rendezvous_path() -> str:
+    """One file per job on the node: the launcher's port + its process id (every rank of a node is a child of the same
+    launcher process: `python -m torch.distributed.run`, mpirun, a shell loop ...); CONSENRICH_AMD_RDZV_FILE overrides."""
+    explicit = os.environ.get("CONSENRICH_AMD_RDZV_FILE")
+    if explicit:
+        return explicit
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    return os.path.join(base, f"consenrich_amd_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+
+
+def exchange_unique_id(rank: int, make_id, path: str, timeout_s: float = 300.0) -> bytes:
+    """Rank 0 creates the 128-byte id and publishes it atomically at `path`; every other rank polls for it."""
+    if rank == 0:
+        raw = make_id()
+        if len(raw) != 128:
+            raise ValueError("the unique id must have 128 bytes")
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(raw)
+        os.replace(tmp, path)           # atomic: a reader sees all 128 bytes or no file
+        return raw
+    deadline = time.monotonic() + timeout_s
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                raw = fh.read()
+            if len(raw) == 128:
+                return raw
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
+        time.sleep(0.01)
+
+
+class RcclComm:
+    """One RCCL communicator per rank, on the device of a DeviceBatch's context.  Single node (xGMI)."""
+
+    def __init__(self, batch, world: Optional[int] = None, rank: Optional[int] = None, timeout_s: float = 300.0):
+        from . import _lib as L
+
+        self._L = L
+        self._lib = L.lib()
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self._batch = batch
+        self._path = _rendezvous_path() if self.world > 1 else None
+        def make_id() -> bytes:
+            uid = C.create_string_buffer(128)
+            L.check(self._lib.csr_comm_unique_id(uid))
+            return uid.raw
+
+        raw = make_id() if self.world == 1 else exchange_unique_id(self.rank, make_id, self._path, timeout_s)
+        uid = C.create_string_buffer(raw, 128)
+        self._comm = self._lib.csr_comm_create(batch._ctx, uid, self.world, self.rank)
+        if not self._comm:
+            raise L.ConsenrichAMDError(L.last_error())
+        self.barrier()                              # every rank has read the id: rank 0 may remove the file
+        if self.rank == 0 and self._path:
+            try:
+                os.unlink(self._path)
+            except OSError:
+                pass
+
+    def barrier(self):
+        self._L.check(self._lib.csr_comm_barrier(self._comm))
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        self._L.check(self._lib.csr_comm_allreduce_max(self._comm, C.byref(v)))
+        return float(v.value)
+
+    def gather_batch_tracks(self, lengths: Sequence[int], to_host: bool = True):
+        """Final gather of (smoothed level, its variance) of every chromosome: the batch's exported xs / Ps are packed on the
+        device and all-gathered over RCCL; with to_host the gathered buffer is copied to the host and rank 0 returns the
+        genome-ordered list of float32 (n_c, 2) arrays (other ranks, or to_host=False: None).  `lengths`: bins of ALL
+        chromosomes of the genome, in genome order (this rank's batch holds the ones lpt_assign gives it, ascending)."""
+        owned, share, cap = pack_layout(lengths, self.world)
+        if [int(lengths[i]) for i in owned[self.rank]] != [int(v) for v in self._batch.chain_lens]:
+            raise ValueError("the batch does not hold the chains lpt_assign gives this rank")
+        host = np.empty((self.world, cap * 2), np.float32) if to_host else None
+        self._L.check(self._lib.csr_batch_gather_tracks(self._batch._ctx, self._comm, int(cap), self._L.fp(host)))
+        if not to_host or self.rank != 0:
+            return None
+        return unpack_gathered(host, lengths, self.world, 2)
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.csr_comm_destroy(self._comm)
+            self._comm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -417,6 +417,28 @@ typedef struct csr_qseed_out {
 } csr_qseed_out;
 int csr_batch_qseed(csr_ctx *ctx, const csr_qseed_cfg *cfg, csr_qseed_out *out);
 
+/* ---- the one collective of the path -- final track gather over RCCL / xGMI ----------------------------------
+ * The reference fits chromosomes in a sequential loop of one process (consenrich.py:8809) and has no communication at all;
+ * here contigs are sharded over the GPUs of a node (one process and one csr_ctx per GPU, no data-path collective) and the
+ * per-bin output tracks are gathered ONCE at the end.  RCCL is bound at run time (dlopen librccl.so.1): only these entry
+ * points need it.  No PyTorch: rank 0 creates the 128-byte unique id, the caller's launcher distributes it (bench.py: a file
+ * on the node), every rank creates its communicator on its context's device. */
+typedef struct csr_comm csr_comm;
+int csr_comm_unique_id(char *id128);                       /* ncclGetUniqueId; 128 bytes */
+csr_comm *csr_comm_create(csr_ctx *ctx, const char *id128, int32_t world, int32_t rank);     /* NULL on failure */
+void csr_comm_destroy(csr_comm *comm);
+int csr_comm_world(csr_comm *comm);
+int csr_comm_rank(csr_comm *comm);
+/* *value := max over ranks (ncclAllReduce on the library's stream + stream synchronisation: also a barrier that completes
+ * only when every rank's queue is drained). */
+int csr_comm_allreduce_max(csr_comm *comm, double *value);
+int csr_comm_barrier(csr_comm *comm);
+/* (smoothed level xs[:,0], its variance Ps[:,0,0]) of every bin of the rank's chains, packed chain after chain on the device
+ * straight from the exported arrays (CSR_EXPORT_SMOOTH; no host bounce), then ncclAllGather: every rank ends with
+ * world x cap_bins (level, variance) pairs; rank r's chains start at pair r * cap_bins.  cap_bins = max over ranks of the
+ * rank's total bins (same value on every rank).  host_out: world * cap_bins * 2 floats, or NULL. */
+int csr_batch_gather_tracks(csr_ctx *ctx, csr_comm *comm, int64_t cap_bins, float *host_out);
+
 typedef struct csr_run_stats {
     int64_t blocks;             /* speculative blocks in the batch */
     int64_t fix_launches;       /* validation/fix-up kernel launches so far */
