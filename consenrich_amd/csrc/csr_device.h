@@ -107,6 +107,7 @@ struct Prm {
     void *carryOutA;    // ping
     void *carryOutB;    // pong
     unsigned int *rerunCount;
+    unsigned int *rerunCountPass;   // counter of THIS validation pass (deferred validation launches 1-4 passes and checks the last)
 };
 
 enum : uint32_t {
@@ -1779,6 +1780,7 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p_, int which) {
     if (rerun) {
         onxt[b] = c;
         atomicAdd(p.rerunCount, 1u);
+        atomicAdd(p.rerunCountPass, 1u);
     }
 }
 

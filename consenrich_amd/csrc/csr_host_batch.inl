@@ -173,13 +173,16 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));
     HIPOK(hipMemsetAsync(p.tD, 0, sizeof(float) * T, c->stream));
     CHECK(dalloc(c, &p.blkSumD, nb)); CHECK(dalloc(c, &p.blkSumNLL, nb));
-    c->mailBytes = 16 + sizeof(double) * 2 * (size_t)n_chains;
+    c->mailBytes = MAIL_HDR + sizeof(double) * 2 * (size_t)n_chains;
     CHECK(dalloc(c, &c->dMail, (int64_t)c->mailBytes));
     HIPOK(hipMemsetAsync(c->dMail, 0, c->mailBytes, c->stream));
     p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail);
-    p.chainSumD = reinterpret_cast<double *>(c->dMail + 16);
+    p.rerunCountPass = reinterpret_cast<unsigned int *>(c->dMail) + MAIL_DUMMY;
+    p.chainSumD = reinterpret_cast<double *>(c->dMail + MAIL_HDR);
     p.chainSumNLL = p.chainSumD + n_chains;
     for (unsigned int &v : c->lastCnt) v = 0;
+    for (int &v : c->nPasses) v = 1;
+    for (int &v : c->cleanRuns) v = 0;
     for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf})
         if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) (void)hipHostFree(c->hMail);

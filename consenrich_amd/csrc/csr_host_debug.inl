@@ -23,7 +23,7 @@ extern "C" int csr_debug_chain_step(csr_ctx *c, int kind, int op, int which, uin
         if (kind == 2) hipLaunchKernelGGL(k_chain_fix<BwdTrend>, dim3(grid), dim3(64), 0, c->stream, p, which);
     }
     LAUNCH_CHECK("debug chain step");
-    CHECK(read_mail(c, 16));
+    CHECK(read_mail(c, MAIL_HDR));
     const unsigned int fresh = take_fresh(c, ST_DEBUG);
     if (count) *count = fresh;
     c->haveFwd = true;

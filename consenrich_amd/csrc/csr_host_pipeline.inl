@@ -164,6 +164,35 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     LAUNCH_CHECK(name);
     if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
     int which = 0;
+    unsigned int *const cnt = reinterpret_cast<unsigned int *>(c->dMail);
+    auto launch_fix = [&](unsigned int *passCounter) {
+        Scope sc(c, fixName);
+        p.rerunCountPass = passCounter;
+        bool launched = false;
+        if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
+            if (p.natOut) {
+                if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, true, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                else hipLaunchKernelGGL((k_chain_fix<CH, true, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+                launched = true;
+            }
+        }
+        if (!launched) {
+            if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, false, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
+            else hipLaunchKernelGGL((k_chain_fix<CH, false, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
+        }
+        c->rs.fix_launches++;
+        which ^= 1;
+    };
+    if (defer) {
+        // optimistic: nPasses validation passes back to back, no host round trip; the stage stands iff the last one re-ran
+        // nothing (checked at the next settle point through its own counter)
+        p.debugForce = c->dbgFence ? 2 : 0;
+        const int np = std::max(1, std::min(MAX_DEFER_PASSES, c->nPasses[stage]));
+        for (int j = 0; j < np; ++j) launch_fix(cnt + MAIL_PASS0 + 4 * stage + j);
+        LAUNCH_CHECK(fixName);
+        c->launchedPasses[stage] = np;
+        return 0;
+    }
     // Validation passes are launched in bursts once the first one has re-run blocks: a correction travels one block per
     // pass (bit-exact state chains need hundreds of passes), and reading the counter after every pass costs a host round
     // trip each.  A burst whose passes re-ran nothing at all is the fixed point (a pass without re-runs copies the
@@ -172,30 +201,19 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
         p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
         if (c->dbgFence) p.debugForce |= 2;
-        for (int rep = 0; rep < burst; ++rep) {
-            Scope sc(c, fixName);
-            bool launched = false;
-            if constexpr (CH::NATOUT || CH::NATOUT_FWD) {
-                if (p.natOut) {
-                    if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, true, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
-                    else hipLaunchKernelGGL((k_chain_fix<CH, true, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
-                    launched = true;
-                }
-            }
-            if (!launched) {
-                if (pcq) hipLaunchKernelGGL((k_chain_fix<CH, false, true>), dim3(grid), dim3(64), 0, c->stream, p, which);
-                else hipLaunchKernelGGL((k_chain_fix<CH, false, false>), dim3(grid), dim3(64), 0, c->stream, p, which);
-            }
-            c->rs.fix_launches++;
-            which ^= 1;
-        }
+        for (int rep = 0; rep < burst; ++rep) launch_fix(cnt + MAIL_DUMMY);
         LAUNCH_CHECK(fixName);
-        if (defer) return 0;
-        CHECK(read_mail(c, 16));
+        CHECK(read_mail(c, MAIL_HDR));
         const unsigned int fresh = take_fresh(c, stage);
         if (c->dbgLog) fprintf(stderr, "[csr] %s iter %lld reruns %u\n", fixName, (long long)it, fresh);
         if (fresh == 0) {
-            if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) c->optimistic[stage] = true;
+            // re-arm optimistic launches after a few clean synchronous runs in a row (a stage that fails every other time
+            // would otherwise pay a pipeline replay every other time)
+            if (it == 0 && (stage != ST_X || c->xTolUlps > 0)) {
+                if (++c->cleanRuns[stage] >= 4 || c->nPasses[stage] < MAX_DEFER_PASSES) c->optimistic[stage] = true;
+            } else if (it > 0) {
+                c->cleanRuns[stage] = 0;
+            }
             return 0;
         }
         stage_reruns(c, stage) += fresh;
@@ -374,20 +392,34 @@ static int check_stages(csr_ctx *c) {
     int firstFail = -1;
     for (int stg = ST_P; stg <= ST_B; ++stg) {
         const unsigned int fresh = take_fresh(c, stg);
-        if (fresh == 0) continue;
+        unsigned int pass[MAX_DEFER_PASSES];
+        for (int j = 0; j < MAX_DEFER_PASSES; ++j) pass[j] = take_fresh(c, MAIL_PASS0 + 4 * stg + j);
+        const int np = c->launchedPasses[stg];
+        if (fresh == 0) {
+            // a long clean streak lets an extra confirmation pass go again
+            if (np > 1 && ++c->cleanRuns[stg] >= 64) { c->nPasses[stg] = np - 1; c->cleanRuns[stg] = 0; }
+            continue;
+        }
         stage_reruns(c, stg) += fresh;
-        c->optimistic[stg] = false;
+        c->cleanRuns[stg] = 0;
         int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow : stage_warm(c, stg);
-        grow_warm(c, wstage, fresh);
-        // a failed optimistic validation costs a whole pipeline: widen that stage's window by half (up to 4x the mode's
-        // default; beyond that the data simply has long memory and synchronous validation is the right mode)
+        grow_warm(c, wstage, pass[0]);
+        const bool stands = np >= 1 && pass[np - 1] == 0;      // the last validation pass re-ran nothing: a fixed point
+        if (c->dbgLog)
+            fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks (passes %u %u %u %u of %d) -> %s\n", stg, fresh, pass[0],
+                    pass[1], pass[2], pass[3], np, stands ? "stands" : "replay");
+        if (stands) continue;
+        // failed: one more confirmation pass next time; at the limit the stage goes back to synchronous validation until a
+        // few clean runs re-arm it, and its window widens by half (up to 4x the mode's default; beyond that the data simply
+        // has long memory and repairing the few failing blocks is cheaper than a longer walk for every block)
+        if (c->nPasses[stg] < MAX_DEFER_PASSES) c->nPasses[stg] += 1;
+        else c->optimistic[stg] = false;
         if (c->adaptWarm) {
             int &w = wstage;
             const int cap = 4 * (c->xTolUlps > 0 ? 80 : 256);
             if (w < cap) w = std::min(cap, (w + w / 2 + 15) / 16 * 16);
         }
         if (firstFail < 0) firstFail = stg;
-        if (c->dbgLog) fprintf(stderr, "[csr] settle: stage %d re-ran %u blocks\n", stg, fresh);
     }
     return firstFail;
 }
@@ -423,7 +455,7 @@ static int read_sums(csr_ctx *c, double *sum_d, double *sum_nll) {
     const bool pending = c->pendFwd || c->pendBwd;
     CHECK(settle(c));
     if (!pending) CHECK(read_mail(c, c->mailBytes));
-    const double *hs = reinterpret_cast<const double *>(c->hMail + 16);
+    const double *hs = reinterpret_cast<const double *>(c->hMail + MAIL_HDR);
     if (sum_d) memcpy(sum_d, hs, sizeof(double) * nc);
     if (sum_nll) memcpy(sum_nll, hs + nc, sizeof(double) * nc);
     return 0;
@@ -558,7 +590,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             iterKappa = cur;
             return 0;
         };
-        const double *mailSums = reinterpret_cast<const double *>(c->hMail + 16);
+        const double *mailSums = reinterpret_cast<const double *>(c->hMail + MAIL_HDR);
         for (int64_t it = 0; it < cfg->max_iters; ++it) {
             if (fusedE) {
                 // ONE settle point per iteration: every stage of every sweep is validated optimistically; if any of them

@@ -58,6 +58,9 @@ extern "C" int csr_device_count(void) {
 // ---------------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------------
+constexpr size_t MAIL_HDR = 80;     // 20 x u32 counters
+constexpr int MAIL_PASS0 = 4, MAIL_DUMMY = 16, MAX_DEFER_PASSES = 4;
+
 struct ChainInfo {
     int64_t n;      // bins
     int64_t off;    // natural offset (multiple of 64)
@@ -138,11 +141,18 @@ struct csr_ctx {
     unsigned char *dActive = nullptr;
     float *dLatent = nullptr;
     float *nat[CSR_ARR_COUNT] = {nullptr};
-    // mailbox: [4 x u32 monotonic re-run counters (covariance, state, smoother, debug) | sumD[nchains] | sumNLL[nchains]]
-    // in device memory, mirrored into pinned host memory with ONE copy per settle point
+    // mailbox: [20 x u32 monotonic re-run counters: 0-3 cumulative per stage (covariance, state, smoother, debug), 4-15 per
+    // stage and validation-pass index, 16 scratch | sumD[nchains] | sumNLL[nchains]] in device memory, mirrored into pinned
+    // host memory with ONE copy per settle point
     char *dMail = nullptr, *hMail = nullptr;
     size_t mailBytes = 0;
-    unsigned int lastCnt[4] = {0, 0, 0, 0};
+    unsigned int lastCnt[20] = {0};
+    // deferred validation launches nPasses[stage] validation passes back to back; the stage stands iff the LAST of them
+    // re-ran nothing (then it was a fixed point).  Isolated speculation failures -- the normal case when the data has a
+    // longer memory than the window (small Q0) -- are repaired by pass 1 and confirmed by pass 2 without a pipeline replay.
+    int nPasses[3] = {1, 1, 1};
+    int cleanRuns[3] = {0, 0, 0};
+    int launchedPasses[3] = {1, 1, 1};
     // deferred validation: a stage whose last synchronous run needed no re-run is launched optimistically (speculative
     // pass + one validation pass, no host round trip); the counters are checked at the next settle point and the
     // pipeline is re-run synchronously from the first stage that did re-run blocks.
