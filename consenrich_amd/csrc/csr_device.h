@@ -63,6 +63,14 @@ struct Prm {
     const float *bg;    // natural (Npad) current background, subtracted from the data in float32 (core.py:3253); may be null
     int qFromMult;      // smoother: 1 = process noise is the constant float32(Q0) (internal forward pass without
                         //           kappa / qScale / APN), 0 = read the stored / imported pNoise array tQ
+    int qFromKappa;     // ECM sweeps with a DIAGONAL base process noise (the reference's default, core.py:4198-4205): the
+                        // forward pass stores only the two diagonal float32 entries of pNoise (tQ2, 8 B instead of 16; the
+                        // off-diagonal ones are float32(qf * 0) = 0) and the smoother reads them through the *Q2 policies.
+                        // (Rebuilding Q in the smoother from kappa, or from the stored scalar qScale / kappa, saves more bytes
+                        // but was measured SLOWER: 0.28 -> 0.35 / 0.32 ms per sweep -- that chain is bound by instruction
+                        // issue, an IEEE division or even four multiply + convert pairs per step cost more than the bytes.)
+    float2 *tQ2;
+    int storePP;        // fused forward chain: 0 = the predicted level variance is not stored (no NIS/NLL epilogue follows)
     int xTolUlps;       // forward state chain validation: 0 = bitwise, k = accept a carry-in within k float32 ulps
 
     // block table: x = natural index of first bin, y = length, z = first block of chain, w = last block of chain
@@ -603,11 +611,14 @@ struct FwdPTrend {
         gout.p00 = (float)a00;
         gout.p10 = (float)a10;
         if constexpr (STORE) {
-            if (p.predCompact) p.tPP[i] = (float)a00;
+            if (p.predCompact) { if (p.storePP) p.tPP[i] = (float)a00; }
             else p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
             p.tPf[i] = make_float4(c.c00, c.c01, c.c01, c.c11);
             // pNoiseForward[k-1] = Q used to reach k (pyx:504-508): shifted store, skipped at the chain's first bin
-            if (!p.qFromMult) {     // constant float32(Q0) otherwise: neither stored nor read back (smoother, export)
+            if (p.qFromKappa) {
+                if (s > 0) p.tQ2[i - 64] = make_float2((float)Q00, (float)Q11);
+                else if (b > bfirst) p.tQ2[tidx(b - 1, p.B - 1, p.B)] = make_float2((float)Q00, (float)Q11);
+            } else if (!p.qFromMult) {     // constant float32(Q0) otherwise: neither stored nor read back (smoother, export)
                 if (s > 0) p.tQ[i - 64] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
                 else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q00, (float)Q01, (float)Q10, (float)Q11);
             }
@@ -671,7 +682,10 @@ struct FwdPLevel {
         if constexpr (STORE) {
             p.tXin[i] = pack_gain_level(gG, pp);
             p.tPf[i] = make_float4((float)c.p, 0.f, 0.f, 0.f);
-            if (!p.qFromMult) {
+            if (p.qFromKappa) {
+                if (s > 0) p.tQ2[i - 64] = make_float2((float)Q, 0.f);
+                else if (b > bfirst) p.tQ2[tidx(b - 1, p.B - 1, p.B)] = make_float2((float)Q, 0.f);
+            } else if (!p.qFromMult) {
                 if (s > 0) p.tQ[i - 64] = make_float4((float)Q, 0.f, 0.f, 0.f);
                 else if (b > bfirst) p.tQ[tidx(b - 1, p.B - 1, p.B)] = make_float4((float)Q, 0.f, 0.f, 0.f);
             }
@@ -1126,6 +1140,19 @@ struct BwdTrend {
     }
 };
 
+// ECM sweeps, diagonal base process noise: pNoise arrives as its two diagonal entries (Prm::tQ2)
+struct BwdTrendQ2 : BwdTrend {
+    static constexpr bool NATOUT = false;    // ECM sweeps never write the reference layout
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
+        In in;
+        in.xf = p.tXf[i];
+        in.pf = p.tPf[i];
+        const float2 q = p.tQ2[i];
+        in.q = make_float4(q.x, 0.f, 0.f, q.y);
+        return in;
+    }
+};
+
 // LDS-DMA inputs of the smoother chain (used for its warm-up phase, k_chain_spec_dmawarm_natbwd): the filtered
 // covariance in one 16-byte DMA ([lane][4] words), the filtered state as two 4-byte rows, the stored process noise in
 // one more 16-byte DMA when it varies per bin (QARR).
@@ -1212,6 +1239,16 @@ struct BwdLevel {
             p.tXs[i] = make_float2(c.x, 0.f);
             p.tPs[i] = make_float4(c.ps, 0.f, 0.f, 0.f);
         }
+    }
+};
+
+struct BwdLevelQ2 : BwdLevel {
+    __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
+        In in;
+        in.xf = p.tXf[i].x;
+        in.pf = p.tPf[i].x;
+        in.q = p.tQ2[i].x;
+        return in;
     }
 };
 

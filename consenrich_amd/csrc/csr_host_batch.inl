@@ -17,6 +17,8 @@ static void fill_model(csr_ctx *c) {
     p.apnScale = m.apn_scale; p.apnPC = m.apn_pc;
     p.qDiag = 0.5 * (m.Q0[0] + m.Q0[3]);
     p.nu = 8.0;
+    c->modelQDiagonal = p.Q01 == 0.0 && p.Q10 == 0.0;
+    c->qDiagonal = c->modelQDiagonal && (p.chainQ == nullptr || c->chainQDiagonal);
 }
 
 extern "C" int csr_batch_set_model(csr_ctx *c, const csr_model *mdl) {
@@ -42,6 +44,7 @@ extern "C" int csr_batch_set_chain_q(csr_ctx *c, const double *q) {
     const int nc = (int)c->chains.size();
     if (q == nullptr) {
         c->p.chainQ = nullptr;
+        c->qDiagonal = c->modelQDiagonal;
     } else {
         std::vector<double> h(q, q + 4 * (size_t)nc);
         for (int i = 0; i < nc; ++i) {
@@ -54,6 +57,10 @@ extern "C" int csr_batch_set_chain_q(csr_ctx *c, const double *q) {
         HIPOK(hipMemcpyAsync(c->dChainQ, h.data(), 8 * h.size(), hipMemcpyHostToDevice, c->stream));
         HIPOK(hipStreamSynchronize(c->stream));
         c->p.chainQ = c->dChainQ;
+        c->chainQDiagonal = true;
+        for (int i = 0; i < nc; ++i)
+            if (h[4 * (size_t)i + 1] != 0.0 || h[4 * (size_t)i + 2] != 0.0) c->chainQDiagonal = false;
+        c->qDiagonal = c->chainQDiagonal;       // with a per-chain table the model's Q0 is not used
     }
     c->haveFwd = c->haveBwd = false;
     return 0;
@@ -156,20 +163,25 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
 
     const int64_t T = c->TN;
     CHECK(dalloc(c, &p.tSZ, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
-    CHECK(dalloc(c, &p.tLam, T)); CHECK(dalloc(c, &p.tKap, T)); CHECK(dalloc(c, &p.tQs, T));
+    // (+ one padding wave-group: the smoother's look-ahead at the multipliers of bin k+1 may touch the slot after the batch's
+    // last block, csr_device.h BwdTrend::load)
+    const int64_t TP = T + (int64_t)B * 64;
+    CHECK(dalloc(c, &p.tLam, TP)); CHECK(dalloc(c, &p.tKap, TP)); CHECK(dalloc(c, &p.tQs, TP));
     p.tKapOut = p.tKap;
+    p.storePP = 1;
     c->kapScratch[0] = c->kapScratch[1] = nullptr;
     c->kapIn = c->kapOut = nullptr;
-    CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T));
+    CHECK(dalloc(c, &p.tXin, T)); CHECK(dalloc(c, &p.tPf, T)); CHECK(dalloc(c, &p.tQ, T)); CHECK(dalloc(c, &p.tQ2, T));
     CHECK(dalloc(c, &p.tXf, T)); CHECK(dalloc(c, &p.tD, T)); CHECK(dalloc(c, &p.tPP, T));
     CHECK(dalloc(c, &p.tXs, T)); CHECK(dalloc(c, &p.tPs, T)); CHECK(dalloc(c, &p.tLag, T));
     if (mdl->state_dim == 1) { CHECK(dalloc(c, &p.tXd, T)); }
     // multipliers default to 1 (the reference's cold start, pyx:7901/7914) until csr_batch_upload_multipliers
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tLam, 0x3f800000, (size_t)T, c->stream));
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tKap, 0x3f800000, (size_t)T, c->stream));
-    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tQs, 0x3f800000, (size_t)T, c->stream));
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tLam, 0x3f800000, (size_t)TP, c->stream));
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tKap, 0x3f800000, (size_t)TP, c->stream));
+    HIPOK(hipMemsetD32Async((hipDeviceptr_t)p.tQs, 0x3f800000, (size_t)TP, c->stream));
     // defined contents for slots no kernel writes (pNoise/lag tails, padding)
     HIPOK(hipMemsetAsync(p.tQ, 0, sizeof(float4) * T, c->stream));
+    HIPOK(hipMemsetAsync(p.tQ2, 0, sizeof(float2) * T, c->stream));
     HIPOK(hipMemsetAsync(p.tLag, 0, sizeof(float4) * T, c->stream));
     HIPOK(hipMemsetAsync(p.tD, 0, sizeof(float) * T, c->stream));
     CHECK(dalloc(c, &p.blkSumD, nb)); CHECK(dalloc(c, &p.blkSumNLL, nb));

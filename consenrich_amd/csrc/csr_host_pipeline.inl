@@ -274,6 +274,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     p.chainActive = active;
     if (c->kapIn) p.tKap = c->kapIn;                                  // ECM sweep: the kappa of the previous sweep's E-step
     p.qFromMult = (flags & (F_APN | F_QSCALE | F_KAPPA)) ? 0 : 1;     // constant process noise: pNoise is not stored
+    // inner ECM sweeps: only the smoother reads this pass's pNoise (diagonal base process noise: its two diagonal entries,
+    // 8 B instead of 16) and nobody its predicted variance (no NIS/NLL epilogue)
+    p.qFromKappa = (c->sweepSkipQ && !p.qFromMult && !(flags & F_APN) && c->qDiagonal) ? 1 : 0;
+    p.storePP = (wantD || !c->sweepSkipQ) ? 1 : 0;
+    c->fwdQCompact = p.qFromKappa != 0;
     defer = defer && c->deferEnabled;
     c->fwdNat = false;
     c->dNat = false;
@@ -357,6 +362,7 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     p.storeMoments = estep == 2 ? 0 : 1;
     if (c->kapIn) p.tKap = c->kapIn;
     p.tKapOut = c->kapOut ? c->kapOut : p.tKap;
+    p.qFromKappa = c->fwdQCompact ? 1 : 0;       // the resident forward pass stored qf instead of pNoise
     c->pendEstep = estep;
     natOut = natOut && c->natOutEnabled && c->mdl.state_dim == 2;
     if (natOut) {
@@ -371,7 +377,12 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
     const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
-    if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    if (p.qFromKappa && !natOut) {
+        if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrendQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+        else CHECK(run_chain<BwdLevelQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    } else if (p.qFromKappa) {
+        return fail("internal: compact process noise is only produced by ECM sweeps (no reference-layout outputs)");
+    } else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     if (dB) {
         c->pendBwd = true;
@@ -560,6 +571,10 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
         for (int i = 0; i < nc; ++i) act[i] = (c->chains[i].n > 5 && !masked(i)) ? 1 : 0;
         CHECK(push_active());
         bool fwdFresh = false;   // forward results already match the current multipliers
+        struct SweepStateReset {     // also on the error paths
+            csr_ctx *c;
+            ~SweepStateReset() { c->sweepSkipQ = false; c->kapIn = c->kapOut = nullptr; }
+        } sweepStateReset{c};
         // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments of bins k
         // and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself; only the last inner
         // sweep's moments can become the result of this iteration, the others are not even stored.
@@ -569,7 +584,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             // deferred validation to fail, its re-run would read the NEXT sweep's kappa (one E-step ahead of pyx:8222-8300).
             // Sweeps therefore ping-pong two scratch buffers; the resident kappa changes only when an iteration is validated.
             for (float *&q : c->kapScratch)
-                if (!q) CHECK(dalloc(c, &q, c->TN));
+                if (!q) CHECK(dalloc(c, &q, c->TN + (int64_t)c->B * 64));      // + the look-ahead padding group
         }
         // One ECM iteration (pyx:8156-8300) as launches only: t_inner x [forward, smoother + kappa E-step] + NLL forward.
         // Returns the buffer holding the iteration's final kappa (nullptr: no sweep ran, the resident one is unchanged).
@@ -578,15 +593,17 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             float *cur = nullptr;                   // nullptr = the resident kappa (the one this iteration starts from)
             for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
                 c->kapIn = cur;
+                c->sweepSkipQ = true;
                 if (!(inner == 0 && skipFirstForward)) CHECK(forward_impl(c, fl, false, c->dActive, defer));
+                c->sweepSkipQ = false;
                 c->kapOut = c->kapScratch[inner & 1];
                 CHECK(backward_impl(c, true, c->dActive, defer, false, inner + 1 == cfg->inner_iters ? 1 : 2));
                 cur = c->kapOut;
                 c->kapOut = nullptr;
             }
             c->kapIn = cur;
-            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, defer));      // pyx:8300
-            c->kapIn = nullptr;
+            CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, defer));      // pyx:8300 (stores everything: it is the
+            c->kapIn = nullptr;                                               // forward pass that stays resident)
             iterKappa = cur;
             return 0;
         };
@@ -619,10 +636,12 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
                 for (int i = 0; i < nc; ++i) nll[i] = mailSums[nc + i];
             } else {
                 for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
+                    c->sweepSkipQ = true;
                     if (!fwdFresh) CHECK(forward_impl(c, fl, false, c->dActive, true));
                     fwdFresh = false;
                     CHECK(backward_impl(c, true, c->dActive, true, false, 0));
                     CHECK(settle(c));          // the E-step kernels consume validated results and update in place
+                    c->sweepSkipQ = false;
                     Prm p = c->p;
                     p.flags = fl;
                     p.chainActive = c->dActive;
@@ -676,6 +695,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             out[i].final_nll = st[i].prev;
         }
     }
+    c->sweepSkipQ = false;
     c->fwdFlags = fl;
     c->haveFwd = c->haveBwd = true;
     return 0;

@@ -95,6 +95,7 @@ extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, con
     if (n > 1) CHECK(import_nat(c, pnoise, d * d, n - 1, 0, (float *)c->p.tQ, 4));
     c->haveFwd = true;
     c->fwdInternal = false;
+    c->fwdQCompact = false;
     c->fwdFlags = 0;
     CHECK(backward_impl(c, true, nullptr));
     CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));

@@ -173,6 +173,10 @@ struct csr_ctx {
     float *kapScratch[2] = {nullptr, nullptr};
     float *kapIn = nullptr, *kapOut = nullptr;
     bool deferIteration = true; // ECM (fused E-step): one settle point per iteration, replay on a failed validation
+    bool sweepSkipQ = false;    // the forward pass being launched is an inner ECM sweep (Prm::qFromKappa, storePP)
+    bool fwdQCompact = false;   // the resident forward pass stored the diagonal of pNoise (tQ2) instead of pNoise (tQ)
+    bool qDiagonal = true;      // the base process noise in use (model's, or every chain's) is diagonal
+    bool modelQDiagonal = true, chainQDiagonal = true;
     Prm sidePrm{};              // parameters of the epilogue running on the side stream (its sums follow at the join)
     uint32_t pendFlags = 0, pendExport = 0;
     bool pendWantD = false;
