@@ -1767,6 +1767,120 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
     if (live) cout[b] = c;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bit-exact state chain, levelTrend (validation mode k = 0).  Two float32-rounded trajectories that start one ulp apart
+// stay one ulp apart for 10^2..10^5 bins, so speculation never coalesces BITWISE: the fix-up iteration of k_chain_fix
+// degenerates into a front that moves one block per pass (hg38 x 32: ~1600 passes, 18 M block re-runs, 100 ms per forward
+// pass).  The exact recursion is inherently sequential per chain -- so run it that way, but as cheaply as the hardware
+// allows: ONE wavefront per chain; its 64 lanes fetch the gain / statistic records of the next 64 bins (one record per
+// lane), the recursion itself runs on wave-uniform values (v_readlane of the record of bin j, the same FwdXTrend::step as
+// everywhere else), results are collected with v_writelane and stored 64 bins at a time.  The dependent path per bin is
+// ~9 fp64 instructions (~35 ns): a chromosome takes (bins x 35 ns) -- 45 ms for chr1 at 200 bp -- instead of 100 ms, and
+// all chains of the batch run concurrently.  The covariance chain (short memory, validates bitwise with a 256-bin window)
+// and the smoother stay speculative.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rl64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
+    return words2double(lo, hi);
+}
+__device__ __forceinline__ float rl32(float v, int lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+// UNITF: F = [[1, f], [0, 1]] (what the reference's constructMatrixF always builds, core.py:2164-2176): 1 * x and
+// 0 * x + x are exact, so the predicted trend is the filtered trend itself and the predicted level one fma -- the same bits
+// as the general expression with five instructions less on an issue-bound wave (one wave per SIMD: every VALU instruction
+// costs >= 4 cycles whether or not it is on the dependent path).
+template <bool UNITF>
+__global__ __launch_bounds__(64) void k_state_seq_trend(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
+    const int c = blockIdx.x;
+    if (p.chainActive != nullptr && !p.chainActive[c]) return;
+    const int lane = threadIdx.x;
+    const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
+    const int B = p.B;
+    const int64_t n = (nb - 1) * (int64_t)B + p.blk[b0 + nb - 1].y;       // bins of this chain
+    FwdXTrend::Carry cx = FwdXTrend::init_true(p);
+    // records of bins [k0, k0 + 64): lane j holds bin k0 + j
+    auto slot = [&](int64_t k) -> int64_t {         // k < 2^31 (batch size limit): 32-bit division
+        const int ki = (int)k, q = ki / B;
+        return tidx(b0 + q, ki - q * B, B);
+    };
+    // The records of a batch go through LDS: the recursion reads them back with two wave-uniform 16-byte LDS loads per bin
+    // (broadcast, issued bins ahead by the scheduler) instead of eight v_readlane -- on a wave that is bound by instruction
+    // issue that is 6 of 23 instructions per bin.
+    __shared__ double4 rec[2][64];               // {gs, zbar, (double)P00pred, (double)P10pred} of the bins of a batch
+    double4 cur = make_double4(0.0, 0.0, 0.0, 0.0);
+    auto fetch = [&](int64_t k0, double4 &r4) {
+        const int64_t k = k0 + lane;
+        if (k < n) {
+            const int64_t i = slot(k);
+            const float4 r = p.tXin[i];
+            r4 = make_double4(unpack_d(r.x, r.y), p.tSZ[i].y, (double)r.z, (double)r.w);    // widened here, 64 bins at a time
+        }
+    };
+    auto one = [&](const double4 &r4) {
+        const double g = r4.x, z = r4.y, a = r4.z, b = r4.w;
+        if constexpr (UNITF) {
+            const double x0 = (double)cx.x0, x1 = (double)cx.x1;
+            const double xp0 = r32(fma(p.F01, x1, x0));     // == r32(fma(F01, x1, 1 * x0)); xp1 == r32(fma(1, x1, 0 * x0)) == x1
+            const double dl = g * (z - xp0);
+            cx.x0 = (float)fma(a, dl, xp0);
+            cx.x1 = (float)fma(b, dl, x1);
+        } else {
+            FwdXTrend::In in;
+            in.gs = g; in.zbar = z;
+            in.cp = make_float2((float)a, (float)b);        // exact round trip of float32 values
+            FwdXTrend::step<false>(p, cx, in, 0, 0, 0, 0);
+        }
+    };
+    // results of a batch: every bin's (x0, x1) is written to LDS by the whole wavefront (same address, same value: one
+    // instruction) and picked up lane-wise after the batch -- collecting them in registers costs four instructions per bin
+    __shared__ float2 outb[64];
+    fetch(0, cur);
+    int buf = 0;
+    for (int64_t k0 = 0; k0 < n; k0 += 64, buf ^= 1) {
+        rec[buf][lane] = cur;
+        __syncthreads();                                    // one wavefront: a waitcnt, no cross-wave barrier cost
+        double4 nxt = make_double4(0.0, 0.0, 0.0, 0.0);
+        fetch(k0 + 64, nxt);                                // in flight while this batch's recursion runs
+        const int cnt = (int)((n - k0 < 64) ? (n - k0) : 64);
+        const double4 *rb = rec[buf];
+        if (cnt == 64) {
+            // groups of four bins: the records of the next group are requested before this group's recursion starts
+            double4 ra[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ra[u] = rb[u];
+#pragma unroll
+            for (int j0 = 0; j0 < 64; j0 += 4) {
+                double4 rn[4];
+                if (j0 + 4 < 64) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rn[u] = rb[j0 + 4 + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    one(ra[u]);
+                    outb[j0 + u] = make_float2(cx.x0, cx.x1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ra[u] = rn[u];
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < cnt; ++j) {
+                one(rb[j]);
+                outb[j] = make_float2(cx.x0, cx.x1);
+            }
+        }
+        __syncthreads();
+        if (k0 + lane < n) p.tXf[slot(k0 + lane)] = outb[lane];
+        cur = nxt;
+    }
+}
+
 // diagnostic: a near-empty kernel (used to attribute kernel-boundary costs when profiling)
 __global__ __launch_bounds__(64) void k_probe(Prm p) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;

@@ -292,14 +292,16 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     } else {
         bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
         // Fused chain (tolerant mode).  Its state recursion warms up on SPECULATIVE gains (the split state chain reads the
-        // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) it needs about covariance-window +
-        // state-window bins: with the plain 80-bin window 9 of 24 optimistic validations failed there (6.3 ms per ECM
-        // iteration), with 160 bins none (3.6 ms; split chains 4.3 ms).  Constant multipliers: 80 bins, zero re-runs.
+        // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) a few blocks need about covariance-window +
+        // state-window bins.  Round 1 ran every block with a 160-bin window for them (a failed validation cost a whole
+        // pipeline).  With up to four confirmation passes per stage (check_stages) the few blocks that need more are simply
+        // repaired: the window starts 16 bins above the plain one (96: ECM iteration 3.01 -> 2.85 ms at genome scale, 1.02 ->
+        // 0.88 ms on a 1/8-genome shard) and widens itself like the others when many blocks fail.
         if (c->fuseFwd && c->xTolUlps > 0) {
             // one stage (counter of the covariance stage; the window covers the state chain's needs too)
             const bool mult = (flags & (F_KAPPA | F_LAMBDA | F_QSCALE)) != 0;
             if (c->warmP < c->warmX) c->warmP = c->warmX;
-            if (c->warmFM < 2 * c->warmP && !c->pinFM) c->warmFM = 2 * c->warmP;
+            if (c->warmFM < c->warmP + 16 && !c->pinFM) c->warmFM = c->warmP + 16;
             c->fwdWindow = mult ? &c->warmFM : &c->warmP;
             dX = false;
             p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
@@ -315,7 +317,25 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             c->fwdWindow = nullptr;
         } else if (c->mdl.state_dim == 2) {
             c->lastFwdWindow = nullptr;
+            const bool seqX = c->xTolUlps == 0 && c->seqState;
+            // (the sequential state chain below costs tens of milliseconds: its gains are validated first -- one host
+            // round trip -- rather than optimistically)
+            if (seqX) dP = false;
             CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            if (seqX) {
+                // bit-exact mode: the state recursion cannot be validated speculatively in reasonable time (see
+                // k_state_seq_trend) -- one wavefront per chain runs it sequentially on the validated gains
+                Scope sc(c, "fwd_state_seq");
+                const bool unitF = p.F00 == 1.0 && p.F10 == 0.0 && p.F11 == 1.0;
+                if (unitF)
+                    hipLaunchKernelGGL(k_state_seq_trend<true>, dim3((unsigned)c->chains.size()), dim3(64), 0, c->stream, p,
+                                       c->dChainFirst, c->dChainNb);
+                else
+                    hipLaunchKernelGGL(k_state_seq_trend<false>, dim3((unsigned)c->chains.size()), dim3(64), 0, c->stream, p,
+                                       c->dChainFirst, c->dChainNb);
+                LAUNCH_CHECK("k_state_seq_trend");
+                dX = false;
+            } else
             CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         } else {
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));

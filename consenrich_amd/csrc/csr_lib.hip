@@ -100,7 +100,7 @@ struct csr_ctx {
     // coalescence of float32-rounded trajectories needs ~4x the window that k-ulp agreement does.
     int warmP = 256, warmX = 256, warmB = 128;
     bool pinP = false, pinX = false, pinB = false, pinFM = false;
-    int warmFM = 160;           // fused forward chain with per-bin multipliers
+    int warmFM = 96;            // fused forward chain with per-bin multipliers (see forward_impl)
     int *fwdWindow = nullptr;   // window variable of the forward stage being launched (see stage_warm)
     int *lastFwdWindow = nullptr;   // ... of the last forward stage launched (a failed settle widens that one)
     bool Bfixed = false;
@@ -159,6 +159,7 @@ struct csr_ctx {
     bool deferEnabled = true;
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    bool seqState = true;       // bit-exact validation, levelTrend: sequential state chain (CONSENRICH_AMD_SEQ_STATE=0: speculative)
     bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
     bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
     // debugging switches, read once from the environment at creation (never on the launch path)
@@ -286,6 +287,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_D"))) c->natOutD = atoi(e) != 0;
