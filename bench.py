@@ -283,6 +283,20 @@ def main() -> int:
                                 "reruns": [rx["reruns_p"], rx["reruns_x"], rx["reruns_b"]],
                                 "fix_launches": rx["fix_launches"]}
         ex.close()
+        # (3) the same step with the delete-block calibration folds of every chromosome as extra chains of the batch
+        # (uncertainty.py:1370-1419: folds = 2 independent refits per chromosome, constants.py:437; DeviceBatch.make_fold):
+        # what fills an under-occupied shard -- the latency-bound chain kernels take about as long for 3x the chains
+        folds = 2
+        fb = DeviceBatch(local_rank)
+        fb.configure(model, m, [n for n in my_lens for _ in range(folds + 1)])
+        fb.synthesize(seed=4321 + rank)
+        ef = timed(fb, lambda: fb.step(flags, what), 1, max(1, min(args.steps, 5)))
+        fsteps = max(1, min(args.steps, 5))
+        extras["with_calibration_folds"] = {"folds": folds, "ms_per_step": 1000.0 * ef / fsteps,
+                                            "value": total_bins * (folds + 1) * fsteps / ef, "unit": "genomic bins/s",
+                                            "note": "every chromosome three times in the batch (fit + 2 fold refits, "
+                                                    "synthetic data of the same shape); bins of all refits counted"}
+        fb.close()
 
     gather_ms, gather_note = None, comm_note
     if comm_kind == "rccl" and not args.no_gather:

@@ -280,15 +280,6 @@ static int64_t arr_comps_impl(csr_ctx *c, int id) {
 
 static int64_t arr_comps(csr_ctx *c, int id) { return arr_comps_impl(c, id); }
 
-static int import_vec(csr_ctx *c, int chain, const float *host, float *blocked) {
-    // stage through the natural scratch of CSR_ARR_D (1 comp) then scatter into the blocked array
-    float *scr;
-    CHECK(nat_array(c, CSR_ARR_D, &scr));
-    const ChainInfo &ci = c->chains[chain];
-    HIPOK(hipMemcpyAsync(scr + ci.off, host, sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
-    return 0;
-}
-
 extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const float *lambda, const float *kappa,
                                             const float *qscale) {
     CHECK(need(c));
@@ -296,20 +287,21 @@ extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const flo
     if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
     const float *src[3] = {lambda, kappa, qscale};
     float *dst[3] = {c->p.tLam, c->p.tKap, c->p.tQs};
-    float *scr;
-    CHECK(nat_array(c, CSR_ARR_D, &scr));
-    // restrict the scatter to this chain so other chains' multipliers stay untouched
+    // staged through a scratch buffer of its own (the exported arrays stay what the last export made them)
+    CHECK(c->stageBuf.reserve(sizeof(float) * (size_t)c->Npad));
+    float *scr = reinterpret_cast<float *>(c->stageBuf.ptr);
+    // the scatter is restricted to this chain (k_import_f32 skips inactive chains): the others keep their multipliers
     std::vector<unsigned char> act(c->chains.size(), 0);
     act[chain] = 1;
     HIPOK(hipMemcpyAsync(c->dActive, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
+    const ChainInfo &ci = c->chains[chain];
     for (int k = 0; k < 3; ++k) {
         if (!src[k]) continue;
-        CHECK(import_vec(c, chain, src[k], dst[k]));
+        HIPOK(hipMemcpyAsync(scr + ci.off, src[k], sizeof(float) * ci.n, hipMemcpyHostToDevice, c->stream));
         Prm p = c->p;
         p.chainActive = c->dActive;
         {
             Scope sc(c, "import_f32");
-            // k_import_f32 ignores chainActive; use the export-style guard by launching the guarded variant below
             hipLaunchKernelGGL(k_import_f32, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, scr, 1, 0, dst[k], 1, 0);
         }
         LAUNCH_CHECK("k_import_f32");

@@ -12,6 +12,7 @@ static csr_ctx *g_default = nullptr;
 static std::recursive_mutex g_defaultMutex;
 #define DEFAULT_CTX_GUARD std::lock_guard<std::recursive_mutex> guard_(g_defaultMutex)
 static csr_ctx *default_ctx() {
+    DEFAULT_CTX_GUARD;          // creation is serialised too (csr_set_validation(NULL) / csr_profile_enable(NULL) come here unlocked)
     if (!g_default) {
         int dev = 0;
         if (const char *e = getenv("CONSENRICH_AMD_DEVICE")) dev = atoi(e);

@@ -195,6 +195,7 @@ struct csr_ctx {
         long long *dSelRank = nullptr;
     } bg;
     DevBuf qsBuf;                       // Q0-seed work space
+    DevBuf stageBuf;                    // host -> device staging of per-bin vectors (csr_batch_upload_multipliers)
     DevBuf bgBuf, wrBuf, textBuf;       // host-buffer background solver / bedGraph writer work space (this device)
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -323,7 +324,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
             (void)hipEventDestroy(pr.second);
         }
     for (hipEvent_t ev : c->eventPool) (void)hipEventDestroy(ev);
-    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf})
+    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf, &c->stageBuf})
         if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) (void)hipHostFree(c->hMail);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
