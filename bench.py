@@ -171,7 +171,7 @@ def main() -> int:
 
     model = ModelParams(state_dim=2, Q0=((q00, 0.0), (0.0, q11)))
     batch = DeviceBatch(local_rank)
-    comm, comm_kind, comm_note, fc = None, "none", None, None
+    comm, comm_kind, comm_note, fc, rccl_hung = None, "none", None, None, False
     if world > 1:
         fc = FileComm(rank, world)
         probe_ok = 0.0
@@ -182,8 +182,31 @@ def main() -> int:
 
             if L.lib().csr_comm_unique_id(ctypes.create_string_buffer(128)) != 0:      # RCCL loads and sees this device?
                 probe_ok, comm_note = 1.0, f"rank {rank}: {L.last_error()}"
+        rccl_hung = False
         if fc.allreduce_max(probe_ok) == 0.0:
-            comm, comm_kind = RcclComm(batch, world, rank), "rccl"
+            # communicator creation is a collective: run it under a watchdog so that a bootstrap that never completes on this
+            # node costs the gather, not the measurement (the ranks then agree, through the files, to use the file barrier)
+            import threading
+
+            box = {}
+
+            def make():
+                try:
+                    box["comm"] = RcclComm(batch, world, rank)
+                except Exception as exc:        # noqa: BLE001
+                    box["err"] = repr(exc)
+
+            th = threading.Thread(target=make, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("CONSENRICH_AMD_RCCL_TIMEOUT", "240")))
+            mine_ok = "comm" in box
+            if fc.allreduce_max(0.0 if mine_ok else 1.0) == 0.0:
+                comm, comm_kind = box["comm"], "rccl"
+            else:
+                comm, comm_kind = fc, "file"
+                rccl_hung = th.is_alive()
+                comm_note = f"rank {rank}: RCCL communicator not created ({box.get('err', 'timeout')})" if not mine_ok \
+                    else "RCCL communicator not created on another rank"
         else:
             comm, comm_kind = fc, "file"
             comm_note = comm_note or "RCCL unusable on another rank"
@@ -351,6 +374,9 @@ def main() -> int:
             comm.close()
     if fc is not None:
         fc.close()
+    if rccl_hung:               # a thread is still stuck inside ncclCommInitRank: do not wait for it at interpreter exit
+        sys.stdout.flush()
+        os._exit(0)
     batch.close()
     return 0
 
