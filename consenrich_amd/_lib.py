@@ -131,6 +131,11 @@ class ObjectiveTerms(C.Structure):
                                           "weight_median")] + [("effective_observation_count", C.c_int64)]
 
 
+class BwSummary(C.Structure):
+    _fields_ = [("bases_covered", C.c_int64), ("non_finite", C.c_int64), ("min_val", C.c_double), ("max_val", C.c_double),
+                ("sum_data", C.c_double), ("sum_squares", C.c_double)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -171,6 +176,10 @@ SYMBOLS = {
                                         C.c_char_p, C.c_int64]),
     "csr_batch_format_bedgraph": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
                                               C.c_int64, C.c_int64, C.c_char_p, C.c_int64]),
+    "csr_batch_bigwig_sections": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int64,
+                                              C.c_int64, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.POINTER(BwSummary)]),
+    "csr_batch_bigwig_zoom": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int64,
+                                          C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64]),
     "csr_observation_total_information": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), DP,
                                                     C.c_double, C.c_double, DP]),
     "csr_fold_mask_and_information": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32), I64P, I64P,

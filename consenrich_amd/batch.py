@@ -284,6 +284,42 @@ class DeviceBatch:
             raise L.ConsenrichAMDError(L.last_error() or "bedGraph writer size mismatch")
         return buf.raw
 
+    def bigwig_track(self, chain: int, name: str, chrom_id: int, start0: int, step: int, end_cap: int = 0, comp: int = 0,
+                     transform=None, zoom_bases=()):
+        """The fixed-record body of a bigWig file for component `comp` of an exported array of one chain, formatted on the
+        device (io.py:530-790 is the reference's pyBigWig conversion of its bedGraph): data sections + total summary + one
+        set of reduction records per entry of `zoom_bases` (bases per record, multiples of `step`).  Values = float32 of the
+        "%.4f" text of the (transformed) track value, i.e. what the reference's file holds.  Returns a
+        consenrich_amd.bigwig.TrackPiece for `bigwig.write_bigwig`."""
+        from . import bigwig as BW
+
+        t = {None: 0, "none": 0, "round4": 1, "sqrt": 2}[transform]
+        f = self._lib.csr_batch_bigwig_sections
+        args = (self._ctx, int(chain), _ARR[name], int(comp), t, int(chrom_id), int(start0), int(step), int(end_cap))
+        size = f(*args, BW.ITEMS_PER_SECTION, None, 0, None)
+        if size < 0:
+            raise L.ConsenrichAMDError(L.last_error())
+        buf = C.create_string_buffer(int(size))
+        summ = L.BwSummary()
+        if f(*args, BW.ITEMS_PER_SECTION, buf, int(size), C.byref(summ)) != size:
+            raise L.ConsenrichAMDError(L.last_error() or "bigWig sections size mismatch")
+        if summ.non_finite:
+            raise ValueError(f"Non-finite bedGraph value in chain {chain} ({summ.non_finite} intervals)")     # io.py:713-716
+        zooms = {}
+        for zb in zoom_bases:
+            if int(zb) % int(step):
+                raise ValueError("zoom levels must be multiples of the interval step")
+            g = self._lib.csr_batch_bigwig_zoom
+            zsize = g(*args, int(zb) // int(step), None, 0)
+            if zsize < 0:
+                raise L.ConsenrichAMDError(L.last_error())
+            zbuf = C.create_string_buffer(int(zsize))
+            if g(*args, int(zb) // int(step), zbuf, int(zsize)) != zsize:
+                raise L.ConsenrichAMDError(L.last_error() or "bigWig zoom size mismatch")
+            zooms[int(zb)] = zbuf.raw
+        return BW.TrackPiece(int(chrom_id), buf.raw, self.chain_lens[chain], int(summ.bases_covered), float(summ.min_val),
+                             float(summ.max_val), float(summ.sum_data), float(summ.sum_squares), zooms)
+
     def make_fold(self, src: int, dst: int, block_len: int, fold: int, block_fold, reps_count, reps, pad: float,
                   rho: float = 0.0, masked_variance: float = 1.0e30):
         """Delete-block calibration fold as an extra chain (uncertainty.py:1370-1419, cuncertainty.pyx:160-305): chain `dst`

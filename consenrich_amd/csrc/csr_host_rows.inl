@@ -659,6 +659,91 @@ extern "C" int64_t csr_batch_format_bedgraph(csr_ctx *c, int32_t chain, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// SURVEY 8(f) rank 3, bigWig (io.py:530-760): data sections, total summary and zoom records of one track of one chain
+// ---------------------------------------------------------------------------------------------------------------
+static int bw_args(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp, int32_t transform, int64_t start0, int64_t step,
+                   int64_t end_cap, BwArgs &a) {
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (array_id < 0 || array_id >= CSR_ARR_COUNT || array_id == CSR_ARR_RESID) return fail("bad array id");
+    if (!c->nat[array_id]) return fail("array %d was not exported", array_id);
+    const int64_t per = arr_comps(c, array_id);
+    if (comp < 0 || comp >= per) return fail("component out of range");
+    if (transform < 0 || transform > 2) return fail("bad transform");
+    if (step <= 0 || start0 < 0) return fail("bigWig intervals need start0 >= 0 and step > 0");
+    const ChainInfo &ci = c->chains[chain];
+    const int64_t lastEnd = (end_cap > 0) ? std::min<int64_t>(start0 + ci.n * step, end_cap) : start0 + ci.n * step;
+    if (lastEnd > (int64_t)0xffffffffll) return fail("bigWig coordinates are 32-bit");
+    if (end_cap > 0 && end_cap <= start0 + (ci.n - 1) * step) return fail("end_cap leaves an empty last interval");
+    memset(&a, 0, sizeof(a));
+    a.g.n = ci.n; a.g.transform = transform; a.g.start0 = start0; a.g.step = step; a.g.endCap = end_cap;
+    a.g.values = c->nat[array_id] + ci.off * per; a.g.stride = (int)per; a.g.comp = comp;
+    return 0;
+}
+
+extern "C" int64_t csr_batch_bigwig_sections(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp, int32_t transform,
+                                             uint32_t chrom_id, int64_t start0, int64_t step, int64_t end_cap,
+                                             int32_t items_per_section, unsigned char *out, int64_t out_capacity,
+                                             csr_bw_summary *total) {
+    if (need(c) != 0 || settle(c) != 0) return -1;
+    if (items_per_section <= 0 || items_per_section > 65535) { fail("items_per_section must be in 1..65535"); return -1; }
+    BwArgs a;
+    if (bw_args(c, chain, array_id, comp, transform, start0, step, end_cap, a) != 0) return -1;
+    const int64_t n = a.g.n, nsec = (n + items_per_section - 1) / items_per_section;
+    const int64_t bytes = nsec * 24 + n * 12;
+    if (!out) return bytes;
+    if (out_capacity < bytes) { fail("bigWig sections: output buffer too small"); return -1; }
+    const int64_t grid = (n + 255) / 256;
+    const size_t full = (size_t)nsec * (24 + 12 * (size_t)items_per_section);      // the device image pads the last section
+    if (c->wrBuf.reserve(full + 256 + sizeof(double) * 6 * (size_t)grid) != 0) return -1;
+    a.chromId = chrom_id; a.itemsPerSection = items_per_section;
+    a.out = (unsigned char *)c->wrBuf.ptr;
+    a.part = (double *)((char *)c->wrBuf.ptr + (full + 255) / 256 * 256);
+    {
+        Scope sc(c, "bigwig_sections");
+        hipLaunchKernelGGL(k_bw_sections, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess) { fail("bigWig sections launch failed"); return -1; }
+    std::vector<double> part(6 * (size_t)grid);
+    if (hipMemcpyAsync(out, a.out, (size_t)bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(part.data(), a.part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { fail("bigWig sections: copy failed"); return -1; }
+    csr_bw_summary t;
+    memset(&t, 0, sizeof(t));
+    t.min_val = INFINITY; t.max_val = -INFINITY;
+    double bad = 0.0, bases = 0.0;
+    for (int64_t g = 0; g < grid; ++g) {            // fixed order: deterministic
+        bases += part[6 * g]; t.min_val = std::fmin(t.min_val, part[6 * g + 1]); t.max_val = std::fmax(t.max_val, part[6 * g + 2]);
+        t.sum_data += part[6 * g + 3]; t.sum_squares += part[6 * g + 4]; bad += part[6 * g + 5];
+    }
+    t.bases_covered = (int64_t)bases;
+    t.non_finite = (int64_t)bad;
+    if (total) *total = t;
+    return bytes;
+}
+
+extern "C" int64_t csr_batch_bigwig_zoom(csr_ctx *c, int32_t chain, int32_t array_id, int32_t comp, int32_t transform,
+                                         uint32_t chrom_id, int64_t start0, int64_t step, int64_t end_cap,
+                                         int64_t bins_per_record, unsigned char *out, int64_t out_capacity) {
+    if (need(c) != 0 || settle(c) != 0) return -1;
+    if (bins_per_record <= 0) { fail("bins_per_record must be positive"); return -1; }
+    BwArgs a;
+    if (bw_args(c, chain, array_id, comp, transform, start0, step, end_cap, a) != 0) return -1;
+    const int64_t nrec = (a.g.n + bins_per_record - 1) / bins_per_record, bytes = nrec * 32;
+    if (!out) return bytes;
+    if (out_capacity < bytes) { fail("bigWig zoom: output buffer too small"); return -1; }
+    if (c->wrBuf.reserve((size_t)bytes + 256) != 0) return -1;
+    a.chromId = chrom_id; a.binsPerRecord = bins_per_record; a.out = (unsigned char *)c->wrBuf.ptr;
+    {
+        Scope sc(c, "bigwig_zoom");
+        hipLaunchKernelGGL(k_bw_zoom, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, a, nrec);
+    }
+    if (hipGetLastError() != hipSuccess) { fail("bigWig zoom launch failed"); return -1; }
+    if (hipMemcpyAsync(out, a.out, (size_t)bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { fail("bigWig zoom: copy failed"); return -1; }
+    return bytes;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // terms of the penalised objective of the outer stop rule (core.py:4418-4538) for every chain
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int csr_batch_objective_terms(csr_ctx *c, const csr_objective_cfg *cfg, csr_objective_terms *out) {

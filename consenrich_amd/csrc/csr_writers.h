@@ -208,4 +208,93 @@ __global__ __launch_bounds__(256) void k_bgw_write(BgwArgs a) {
     o[n++] = '\n';
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bigWig (io.py:530-760: the reference converts its bedGraph files with pyBigWig).  The body of a bigWig file is byte
+// work with fixed record sizes, produced here straight from the resident track: the data sections (24-byte header + 12-byte
+// bedGraph items, Kent et al. 2010, file format supplement) and the reduction records a file needs (total summary, zoom
+// levels).  The values are the ones the reference's file holds: it writes `"%.4f" % v` to the bedGraph and parses that text
+// back (io.py:707), so an item is float32(R / 10^4) with R = the round-half-even integer of v * 10^4 (same exact integer
+// arithmetic as bgw_format_value).  Assembly (chromosome tree, R-tree index, optional zlib of every block, headers) is
+// O(sections) host work in consenrich_amd/writers.py.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bgw_text4_value(float v) {      // value of the decimal text "%.4f" % v, as float32
+    if (!isfinite(v)) return v;
+    const double t = fabs((double)v) * 10000.0;                   // exact
+    const double r = rint(t) / 10000.0;                           // correctly rounded quotient = strtod of the text
+    return (float)((__float_as_uint(v) >> 31) ? -r : r);
+}
+struct BwArgs {
+    BgwArgs g;                  // track, intervals (fixed step or explicit), transform
+    unsigned int chromId;
+    int itemsPerSection;
+    int64_t binsPerRecord;      // zoom: consecutive rows per reduction record
+    unsigned char *out;         // sections / zoom records
+    double *part;               // per-workgroup partial summaries: [bases, min, max, sum, sumSq, nonFinite] x gridDim
+};
+// one thread per item; the first thread of a section also writes its header
+__global__ __launch_bounds__(256) void k_bw_sections(BwArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double bases = 0.0, mn = INFINITY, mx = -INFINITY, sm = 0.0, sq = 0.0, bad = 0.0;
+    if (k < a.g.n) {
+        int64_t s, e;
+        bgw_interval(a.g, k, s, e);
+        const float v = bgw_text4_value(bgw_value(a.g, k));
+        const int64_t sec = k / a.itemsPerSection, j = k - sec * a.itemsPerSection;
+        unsigned int *o = reinterpret_cast<unsigned int *>(a.out + sec * (24 + 12 * (int64_t)a.itemsPerSection) + 24 + 12 * j);
+        o[0] = (unsigned int)s; o[1] = (unsigned int)e; o[2] = __float_as_uint(v);
+        if (j == 0) {
+            const int64_t last = (sec + 1) * a.itemsPerSection < a.g.n ? (sec + 1) * a.itemsPerSection - 1 : a.g.n - 1;
+            int64_t s2, e2;
+            bgw_interval(a.g, last, s2, e2);
+            unsigned int *h = reinterpret_cast<unsigned int *>(a.out + sec * (24 + 12 * (int64_t)a.itemsPerSection));
+            h[0] = a.chromId; h[1] = (unsigned int)s; h[2] = (unsigned int)e2; h[3] = 0u; h[4] = 0u;
+            h[5] = 1u | ((unsigned int)(last - k + 1) << 16);      // type 1 (bedGraph), reserved 0, itemCount (u16)
+        }
+        if (isfinite(v)) {
+            const double w = (double)(e - s), dv = (double)v;
+            bases = w; mn = dv; mx = dv; sm = dv * w; sq = dv * dv * w;
+        } else bad = 1.0;
+    }
+    __shared__ double sh[6][256];
+    sh[0][threadIdx.x] = bases; sh[1][threadIdx.x] = mn; sh[2][threadIdx.x] = mx;
+    sh[3][threadIdx.x] = sm; sh[4][threadIdx.x] = sq; sh[5][threadIdx.x] = bad;
+    __syncthreads();
+    for (int wd = 128; wd > 0; wd >>= 1) {
+        if ((int)threadIdx.x < wd) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + wd];
+            sh[1][threadIdx.x] = fmin(sh[1][threadIdx.x], sh[1][threadIdx.x + wd]);
+            sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + wd]);
+            sh[3][threadIdx.x] += sh[3][threadIdx.x + wd];
+            sh[4][threadIdx.x] += sh[4][threadIdx.x + wd];
+            sh[5][threadIdx.x] += sh[5][threadIdx.x + wd];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 6; ++q) a.part[(int64_t)blockIdx.x * 6 + q] = sh[q][0];
+}
+// zoom level: one thread per reduction record of binsPerRecord consecutive rows -> (chromId, start, end, validCount, min,
+// max, sum, sumSquares), 32 bytes (bbiSummaryOnDisk); sums over BASES in double, stored as float32
+__global__ __launch_bounds__(256) void k_bw_zoom(BwArgs a, int64_t nrec) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const int64_t k0 = r * a.binsPerRecord, k1 = (k0 + a.binsPerRecord < a.g.n) ? k0 + a.binsPerRecord : a.g.n;
+    double mn = INFINITY, mx = -INFINITY, sm = 0.0, sq = 0.0;
+    int64_t valid = 0, s0 = 0, e1 = 0;
+    for (int64_t k = k0; k < k1; ++k) {
+        int64_t s, e;
+        bgw_interval(a.g, k, s, e);
+        if (k == k0) s0 = s;
+        e1 = e;
+        const double dv = (double)bgw_text4_value(bgw_value(a.g, k)), w = (double)(e - s);
+        valid += e - s;
+        mn = fmin(mn, dv); mx = fmax(mx, dv); sm += dv * w; sq += dv * dv * w;
+    }
+    unsigned int *o = reinterpret_cast<unsigned int *>(a.out + r * 32);
+    o[0] = a.chromId; o[1] = (unsigned int)s0; o[2] = (unsigned int)e1; o[3] = (unsigned int)valid;
+    o[4] = __float_as_uint((float)mn); o[5] = __float_as_uint((float)mx);
+    o[6] = __float_as_uint((float)sm); o[7] = __float_as_uint((float)sq);
+}
+
 }  // namespace csr

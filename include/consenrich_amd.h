@@ -338,6 +338,29 @@ int64_t csr_batch_format_bedgraph(csr_ctx *ctx, int32_t chain, int32_t array_id,
                                   const char *chrom, int64_t start0, int64_t step, int64_t end_cap, char *out,
                                   int64_t out_capacity);
 
+/* bigWig (io.py:530 `convertBedGraphToBigWig`, io.py:633-760 `_convertBedGraphToBigWigPyBigWig`: the reference converts its
+ * bedGraph files with pyBigWig).  The fixed-record body of a bigWig file (Kent et al. 2010, BigWig/BigBed file format) for one
+ * track of one chain, formatted on the device from the exported array like csr_batch_format_bedgraph:
+ *   csr_batch_bigwig_sections  the UNCOMPRESSED data sections, back to back: 24-byte header (chromId, chromStart, chromEnd,
+ *                              itemStep 0, itemSpan 0, type 1 = bedGraph, reserved, itemCount) + 12-byte items (start, end,
+ *                              float32 value), items_per_section items each (the last one fewer), + the total summary;
+ *   csr_batch_bigwig_zoom      reduction records of bins_per_record consecutive intervals (32 bytes: chromId, start, end,
+ *                              validCount, min, max, sum, sumSquares as float32) for one zoom level.
+ * An item's value is what the reference's file holds: float32 of the decimal text "%.4f" of the (transformed) track value --
+ * pyBigWig receives the values parsed back from the bedGraph rows.  Both return the byte count (call with out = NULL to size
+ * the buffer), negative on error.  Chromosome tree, R-tree index, zlib of the blocks and the headers are O(sections) host
+ * work (consenrich_amd/writers.py). */
+typedef struct csr_bw_summary {
+    int64_t bases_covered, non_finite;      /* non_finite: items whose value is NaN / inf (the reference refuses such rows) */
+    double min_val, max_val, sum_data, sum_squares;
+} csr_bw_summary;
+int64_t csr_batch_bigwig_sections(csr_ctx *ctx, int32_t chain, int32_t array_id, int32_t comp, int32_t transform,
+                                  uint32_t chrom_id, int64_t start0, int64_t step, int64_t end_cap, int32_t items_per_section,
+                                  unsigned char *out, int64_t out_capacity, csr_bw_summary *total);
+int64_t csr_batch_bigwig_zoom(csr_ctx *ctx, int32_t chain, int32_t array_id, int32_t comp, int32_t transform,
+                              uint32_t chrom_id, int64_t start0, int64_t step, int64_t end_cap, int64_t bins_per_record,
+                              unsigned char *out, int64_t out_capacity);
+
 /* ---- natives of the delete-block uncertainty calibration (cuncertainty.pyx) -------------------
  * csr_observation_total_information = cobservationTotalInformation (pyx:97-157); csr_fold_mask_and_information =
  * cmakeFoldMaskAndInformation (pyx:160-305) after its argument validation.  munc is float32 (munc_is_f64 = 0) or float64,
