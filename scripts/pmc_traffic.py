@@ -1,4 +1,4 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-launch HBM byte counts (profiles/r01_pmc_traffic.json).
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-launch HBM byte counts (profiles/rNN_pmc_traffic.json).
 
 Per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB-like units of
 1024 B per count?  -> they are reported in kilobytes; collected in SEPARATE passes (TCC slots: FETCH 3, WRITE 2);
@@ -12,7 +12,8 @@ import json
 import sys
 
 SHORT = {"k_stats": "stats", "k_resid": "residuals", "k_export_tiled": "export_natural", "FwdTrendFused": "fwd_chain", "FwdPTrend": "fwd_cov_chain",
-         "FwdXTrend": "fwd_state_chain", "BwdTrend": "bwd_chain", "k_fwd_dstat": "fwd_dstat", "k_bwd_lag": "bwd_lagcov"}
+         "FwdXTrend": "fwd_state_chain", "BwdTrend": "bwd_chain", "k_fwd_dstat": "fwd_dstat", "k_bwd_lag": "bwd_lagcov", "k_fill_rows": "pnoise_fill",
+         "k_copy_active": "ecm_commit_kappa"}
 
 
 def short(name):
