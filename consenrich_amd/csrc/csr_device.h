@@ -520,7 +520,16 @@ __device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) 
 #ifndef CSR_U_B
 #define CSR_U_B 4
 #endif
-struct FwdPTrend {
+enum { FAM_OTHER = 0, FAM_FWD_FUSED = 1, FAM_BWD_TREND = 2 };      // what run_chain dispatches its LDS-DMA variants on
+
+// UF ("unit F"): F = [[1, f], [0, 1]] -- what the reference's constructMatrixF always builds (core.py:2164-2176).  1 * x and
+// 0 * x + y are exact, so the UF instances drop those operations and produce THE SAME BITS with fewer dependent-issue
+// instructions (8 of ~75 in the fused forward step, 17 of ~110 in the smoother step): the latency-bound chains of small
+// batches (8-GPU shards, ECM sweeps) are a count of exactly those instructions.  The general instances stay for any other F.
+template <bool UF>
+struct FwdPTrendT {
+    static constexpr bool UNITF = UF;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -585,14 +594,24 @@ struct FwdPTrend {
         const double Q00 = qf * p.Q00, Q01 = qf * p.Q01, Q10 = qf * p.Q10, Q11 = qf * p.Q11;
         const double c00 = (double)c.c00, c01 = (double)c.c01, c11 = (double)c.c11;
         // F P F^T + Q, rounded to float32 (pyx:417-430); the carry is symmetric (c10 == c01)
-        const double t00 = fma(p.F01, c01, p.F00 * c00);
-        const double t01 = fma(p.F01, c11, p.F00 * c01);
-        const double t10 = fma(p.F11, c01, p.F10 * c00);
-        const double t11 = fma(p.F11, c11, p.F10 * c01);
-        const double a00 = r32(fma(t01, p.F01, fma(t00, p.F00, Q00)));
-        const double a01 = r32(fma(t01, p.F11, fma(t00, p.F10, Q01)));
-        const double a10 = r32(fma(t11, p.F01, fma(t10, p.F00, Q10)));
-        const double a11 = r32(fma(t11, p.F11, fma(t10, p.F10, Q11)));
+        double a00, a01, a10, a11;
+        if constexpr (UF) {
+            const double t00 = fma(p.F01, c01, c00);          // fma(F01, c01, 1 * c00)
+            const double t01 = fma(p.F01, c11, c01);
+            a00 = r32(fma(t01, p.F01, t00 + Q00));            // fma(t00, 1, Q00) == t00 + Q00 (one rounding)
+            a01 = r32(t01 + Q01);                             // fma(t01, 1, fma(t00, 0, Q01))
+            a10 = r32(fma(c11, p.F01, c01 + Q10));            // t11 == c11, t10 == c01
+            a11 = r32(c11 + Q11);
+        } else {
+            const double t00 = fma(p.F01, c01, p.F00 * c00);
+            const double t01 = fma(p.F01, c11, p.F00 * c01);
+            const double t10 = fma(p.F11, c01, p.F10 * c00);
+            const double t11 = fma(p.F11, c11, p.F10 * c01);
+            a00 = r32(fma(t01, p.F01, fma(t00, p.F00, Q00)));
+            a01 = r32(fma(t01, p.F11, fma(t00, p.F10, Q01)));
+            a10 = r32(fma(t11, p.F01, fma(t10, p.F00, Q10)));
+            a11 = r32(fma(t11, p.F11, fma(t10, p.F10, Q11)));
+        }
         // collapsed measurement update (pyx:458, 481-495)
         const double S0 = lam * in.s0u;
         const double is = fma(a00, S0, 1.0);
@@ -626,8 +645,12 @@ struct FwdPTrend {
     }
 };
 
+using FwdPTrend = FwdPTrendT<false>;
+
 // ---- forward covariance chain, level (pyx:613-633, 655, 676-680); carries stay in double ----------------------
 struct FwdPLevel {
+    static constexpr bool UNITF = false;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -694,7 +717,10 @@ struct FwdPLevel {
 };
 
 // ---- forward state chain, levelTrend (pyx:403-406, 477-479) --------------------------------------------------
-struct FwdXTrend {
+template <bool UF>
+struct FwdXTrendT {
+    static constexpr bool UNITF = UF;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -754,8 +780,14 @@ struct FwdXTrend {
     template <bool STORE>
     __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
         const double x0 = (double)c.x0, x1 = (double)c.x1;
-        const double xp0 = r32(fma(p.F01, x1, p.F00 * x0));
-        const double xp1 = r32(fma(p.F11, x1, p.F10 * x0));
+        double xp0, xp1;
+        if constexpr (UF) {
+            xp0 = r32(fma(p.F01, x1, x0));
+            xp1 = x1;                                         // r32(fma(1, x1, 0 * x0)) of a float32 value
+        } else {
+            xp0 = r32(fma(p.F01, x1, p.F00 * x0));
+            xp1 = r32(fma(p.F11, x1, p.F10 * x0));
+        }
         const double dl = in.gs * (in.zbar - xp0);            // S1/innovScale with S1 = S0 (zbar - x)
         c.x0 = (float)fma((double)in.cp.x, dl, xp0);
         c.x1 = (float)fma((double)in.cp.y, dl, xp1);
@@ -763,8 +795,12 @@ struct FwdXTrend {
     }
 };
 
+using FwdXTrend = FwdXTrendT<false>;
+
 // ---- forward state chain, level (pyx:673-674); double carry ---------------------------------------------------
 struct FwdXLevel {
+    static constexpr bool UNITF = false;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -829,7 +865,12 @@ struct FwdXLevel {
 // With k-ulp validation both chains need the same ~80-bin window and a single validation pass, so one kernel replaces
 // two (one fixed launch/drain cost, no gain-record round trip through HBM for the state update).  The arithmetic is the
 // split chains' own (advance() / step() above are called as they are), so the results are the same numbers.
-struct FwdTrendFused {
+template <bool UF>
+struct FwdTrendFusedT {
+    static constexpr bool UNITF = UF;
+    static constexpr int FAMILY = FAM_FWD_FUSED;
+    using PT = FwdPTrendT<UF>;
+    using XT = FwdXTrendT<UF>;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT = false;
     static constexpr bool NATOUT_FWD = true;   // main phase can also emit xf / Pf in the reference layout (walk_nat_fwd)
@@ -839,8 +880,8 @@ struct FwdTrendFused {
     static constexpr bool PINGPONG = false;
     static constexpr int U = CSR_U_P;
     struct Carry {
-        FwdPTrend::Carry P;
-        FwdXTrend::Carry X;
+        typename PT::Carry P;
+        typename XT::Carry X;
         float pad_[2];
     };
     struct In {
@@ -848,7 +889,7 @@ struct FwdTrendFused {
         float lam, kap, qs;
     };
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
-        const FwdPTrend::In a = FwdPTrend::load(p, i, bq, s, len);
+        const typename PT::In a = PT::load(p, i, bq, s, len);
         In in;
         in.s0u = a.s0u; in.lam = a.lam; in.kap = a.kap; in.qs = a.qs;
         in.zbar = p.tSZ[i].y;
@@ -856,34 +897,37 @@ struct FwdTrendFused {
     }
     __device__ static __forceinline__ Carry init_true(const Prm &p) {
         Carry c;
-        c.P = FwdPTrend::init_true(p);
-        c.X = FwdXTrend::init_true(p);
+        c.P = PT::init_true(p);
+        c.X = XT::init_true(p);
         c.pad_[0] = c.pad_[1] = 0.f;
         return c;
     }
     __device__ static __forceinline__ Carry init_cold(const Prm &p) { return init_true(p); }
     __device__ static __forceinline__ bool same(const Prm &p, const Carry &a, const Carry &b) {
-        return FwdPTrend::same(p, a.P, b.P) & FwdXTrend::same(p, a.X, b.X);
+        return PT::same(p, a.P, b.P) & XT::same(p, a.X, b.X);
     }
     template <bool STORE>
     __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i,
                                                 int64_t bfirst) {
-        FwdPTrend::Gain g;
-        FwdPTrend::advance<STORE>(p, c.P, in, b, s, i, bfirst, g);
-        FwdXTrend::In xin;
+        typename PT::Gain g;
+        PT::template advance<STORE>(p, c.P, in, b, s, i, bfirst, g);
+        typename XT::In xin;
         xin.zbar = in.zbar;
         xin.gs = g.gs;
         xin.cp = make_float2(g.p00, g.p10);
-        FwdXTrend::step<STORE>(p, c.X, xin, b, s, i, bfirst);
+        XT::template step<STORE>(p, c.X, xin, b, s, i, bfirst);
     }
 };
+using FwdTrendFused = FwdTrendFusedT<false>;
 // LDS-DMA variant of the fused forward chain (k_chain_spec_dma).  PMC on the plain kernel: the wavefront is parked on
 // s_waitcnt 62-66 % of its cycles and issues only 27-30 % -- with loads AND stores in flight hipcc waits vmcnt(0) for
 // every register-prefetched batch, i.e. also for the store acknowledgements of the previous batch.  Through the ring the
 // inputs arrive in LDS DMA_L steps ahead under a counted wait that younger stores only make more conservative.
 // Rows of a slot (64 lanes x 4 bytes each): s0u lo / hi, zbar lo / hi [, lambda, kappa, qScale when MULT].
-template <int MULT>      // 0: no per-bin multipliers; 1: kappa only (the reference's default ECM); 2: lambda, kappa, qScale
-struct FwdTrendFusedDma : FwdTrendFused {
+template <int MULT, bool UF = false>      // MULT 0: no per-bin multipliers; 1: kappa only (the reference's default ECM); 2: all three
+struct FwdTrendFusedDma : FwdTrendFusedT<UF> {
+    using Plain = FwdTrendFusedT<UF>;         // the register-prefetch policy with the same arithmetic (tile walker)
+    using In = typename Plain::In;
     static constexpr bool DMA = true;
     static constexpr bool NATOUT_FWD = false;
     // slot: [lane][4 words] = the (S0u, zbar) record in one 16-byte DMA, then one 64-word row per multiplier
@@ -924,6 +968,8 @@ struct FwdTrendFusedDma : FwdTrendFused {
 };
 
 struct FwdLevelFused {
+    static constexpr bool UNITF = false;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -960,6 +1006,7 @@ struct FwdLevelFused {
 
 // kappa E-step of one transition k -> k+1 (pyx:8244-8298 with the MAT2 helpers pyx:4123-4175) from the float32 smoothed
 // moments of both bins and the lag-one covariance; qsNext = qScale[k+1] (1 if unused)
+template <bool UF = false>
 __device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, float4 pk, float2 ya, float4 pk1, float4 lg,
                                                    float qsNext) {
     const double x0 = xa.x, x1 = xa.y, y0 = ya.x, y1 = ya.y;
@@ -971,20 +1018,40 @@ __device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, floa
     const double xy00 = (double)lg.x + x0 * y0, xy01 = (double)lg.y + x0 * y1;
     const double xy10 = (double)lg.z + x1 * y0, xy11 = (double)lg.w + x1 * y1;
     // yx = xy^T, Ft = F^T : ww = yy - yx Ft - F xy + (F xx) Ft
-    double w00 = yy00 - (xy00 * f00 + xy10 * f01);
-    double w01 = yy01 - (xy00 * f10 + xy10 * f11);
-    double w10 = yy10 - (xy01 * f00 + xy11 * f01);
-    double w11 = yy11 - (xy01 * f10 + xy11 * f11);
-    w00 -= (f00 * xy00 + f01 * xy10);
-    w01 -= (f00 * xy01 + f01 * xy11);
-    w10 -= (f10 * xy00 + f11 * xy10);
-    w11 -= (f10 * xy01 + f11 * xy11);
-    const double g00 = f00 * xx00 + f01 * xx10, g01 = f00 * xx01 + f01 * xx11;
-    const double g10 = f10 * xx00 + f11 * xx10, g11 = f10 * xx01 + f11 * xx11;
-    w00 += (g00 * f00 + g01 * f01);
-    w01 += (g00 * f10 + g01 * f11);
-    w10 += (g10 * f00 + g11 * f01);
-    w11 += (g10 * f10 + g11 * f11);
+    double w00, w01, w10, w11;
+    if constexpr (UF) {
+        // F = [[1, f], [0, 1]]: products with 1 are the operand, products with 0 vanish from the sums (x * 0 + y == y) --
+        // every remaining operation is the general expression's, in its order
+        w00 = yy00 - (xy00 + xy10 * f01);
+        w01 = yy01 - xy10;
+        w10 = yy10 - (xy01 + xy11 * f01);
+        w11 = yy11 - xy11;
+        w00 -= (xy00 + f01 * xy10);
+        w01 -= (xy01 + f01 * xy11);
+        w10 -= xy10;
+        w11 -= xy11;
+        const double g00 = xx00 + f01 * xx10, g01 = xx01 + f01 * xx11;
+        const double g10 = xx10, g11 = xx11;
+        w00 += (g00 + g01 * f01);
+        w01 += g01;
+        w10 += (g10 + g11 * f01);
+        w11 += g11;
+    } else {
+        w00 = yy00 - (xy00 * f00 + xy10 * f01);
+        w01 = yy01 - (xy00 * f10 + xy10 * f11);
+        w10 = yy10 - (xy01 * f00 + xy11 * f01);
+        w11 = yy11 - (xy01 * f10 + xy11 * f11);
+        w00 -= (f00 * xy00 + f01 * xy10);
+        w01 -= (f00 * xy01 + f01 * xy11);
+        w10 -= (f10 * xy00 + f11 * xy10);
+        w11 -= (f10 * xy01 + f11 * xy11);
+        const double g00 = f00 * xx00 + f01 * xx10, g01 = f00 * xx01 + f01 * xx11;
+        const double g10 = f10 * xx00 + f11 * xx10, g11 = f10 * xx01 + f11 * xx11;
+        w00 += (g00 * f00 + g01 * f01);
+        w01 += (g00 * f10 + g01 * f11);
+        w10 += (g10 * f00 + g11 * f01);
+        w11 += (g10 * f10 + g11 * f11);
+    }
     if (w00 < 0.0) w00 = 0.0;
     if (w11 < 0.0) w11 = 0.0;
     const double det = p.Q00 * p.Q11 - p.Q01 * p.Q10;
@@ -1001,7 +1068,10 @@ __device__ __forceinline__ float estep_kappa_trend(const Prm &p, float2 xa, floa
 // ---- backward RTS chain, levelTrend (pyx:6758-6822) ------------------------------------------------------------
 // J and PPred depend only on filtered quantities of bin k (off the dependent path); the carries are the float32
 // smoothed state/covariance of bin k+1, exactly what the reference re-reads from its output arrays.
-struct BwdTrend {
+template <bool UF>
+struct BwdTrendT {
+    static constexpr bool UNITF = UF;
+    static constexpr int FAMILY = FAM_BWD_TREND;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = true;     // main phase can emit the reference layout through LDS tiles (walk_nat)
@@ -1049,21 +1119,36 @@ struct BwdTrend {
     __device__ static __forceinline__ Gain gain(const Prm &p, const float4 &pf, const float4 &q) {
         Gain g;
         const double f00 = pf.x, f01 = pf.y, f10 = pf.z, f11 = pf.w;
-        const double a00 = fma(p.F01, f10, p.F00 * f00);      // F Pf
-        const double a01 = fma(p.F01, f11, p.F00 * f01);
-        const double a10 = fma(p.F11, f10, p.F10 * f00);
-        const double a11 = fma(p.F11, f11, p.F10 * f01);
-        g.pp00 = fma(a01, p.F01, fma(a00, p.F00, (double)q.x));
-        g.pp01 = fma(a01, p.F11, fma(a00, p.F10, (double)q.y));
-        g.pp10 = fma(a11, p.F01, fma(a10, p.F00, (double)q.z));
-        g.pp11 = fma(a11, p.F11, fma(a10, p.F10, (double)q.w));
+        if constexpr (UF) {
+            const double a00 = fma(p.F01, f10, f00), a01 = fma(p.F01, f11, f01);      // F Pf with F = [[1, f], [0, 1]]: a10 = f10, a11 = f11
+            g.pp00 = fma(a01, p.F01, a00 + (double)q.x);
+            g.pp01 = a01 + (double)q.y;
+            g.pp10 = fma(f11, p.F01, f10 + (double)q.z);
+            g.pp11 = f11 + (double)q.w;
+        } else {
+            const double a00 = fma(p.F01, f10, p.F00 * f00);      // F Pf
+            const double a01 = fma(p.F01, f11, p.F00 * f01);
+            const double a10 = fma(p.F11, f10, p.F10 * f00);
+            const double a11 = fma(p.F11, f11, p.F10 * f01);
+            g.pp00 = fma(a01, p.F01, fma(a00, p.F00, (double)q.x));
+            g.pp01 = fma(a01, p.F11, fma(a00, p.F10, (double)q.y));
+            g.pp10 = fma(a11, p.F01, fma(a10, p.F00, (double)q.z));
+            g.pp11 = fma(a11, p.F11, fma(a10, p.F10, (double)q.w));
+        }
         const double det = fma(g.pp00, g.pp11, -(g.pp01 * g.pp10));   // unguarded, pyx:6780
         const double rd = rcp_nr(det);
         const double v00 = g.pp11 * rd, v01 = -g.pp01 * rd, v10 = -g.pp10 * rd, v11 = g.pp00 * rd;
-        g.c00 = fma(f01, p.F01, f00 * p.F00);                 // Pf F^T
-        g.c01 = fma(f01, p.F11, f00 * p.F10);
-        g.c10 = fma(f11, p.F01, f10 * p.F00);
-        g.c11 = fma(f11, p.F11, f10 * p.F10);
+        if constexpr (UF) {
+            g.c00 = fma(f01, p.F01, f00);                     // Pf F^T
+            g.c01 = f01;
+            g.c10 = fma(f11, p.F01, f10);
+            g.c11 = f11;
+        } else {
+            g.c00 = fma(f01, p.F01, f00 * p.F00);             // Pf F^T
+            g.c01 = fma(f01, p.F11, f00 * p.F10);
+            g.c10 = fma(f11, p.F01, f10 * p.F00);
+            g.c11 = fma(f11, p.F11, f10 * p.F10);
+        }
         g.J00 = fma(g.c01, v10, g.c00 * v00);
         g.J01 = fma(g.c01, v11, g.c00 * v01);
         g.J10 = fma(g.c11, v10, g.c10 * v00);
@@ -1085,8 +1170,8 @@ struct BwdTrend {
         } else {
             const Gain g = gain(p, in.pf, in.q);
             const double xf0 = in.xf.x, xf1 = in.xf.y;
-            const double dx0 = (double)c.x0 - fma(p.F01, xf1, p.F00 * xf0);
-            const double dx1 = (double)c.x1 - fma(p.F11, xf1, p.F10 * xf0);
+            const double dx0 = (double)c.x0 - (UF ? fma(p.F01, xf1, xf0) : fma(p.F01, xf1, p.F00 * xf0));
+            const double dx1 = (double)c.x1 - (UF ? xf1 : fma(p.F11, xf1, p.F10 * xf0));
             const double d00 = (double)c.p00 - g.pp00, d01 = (double)c.p01 - g.pp01;
             const double d10 = (double)c.p10 - g.pp10, d11 = (double)c.p11 - g.pp11;
             const double r00 = fma(d01, g.J01, d00 * g.J00);
@@ -1124,7 +1209,7 @@ struct BwdTrend {
                 if (o.hasLag) {
                     const int64_t nx = (s + 1 < p.B) ? i + 64 : tidx(b + 1, 0, p.B);
                     const float qs = (p.flags & F_QSCALE) ? p.tQs[nx] : 1.0f;
-                    p.tKapOut[nx] = estep_kappa_trend(p, o.xs, o.ps, make_float2(nextBin.x0, nextBin.x1),
+                    p.tKapOut[nx] = estep_kappa_trend<UF>(p, o.xs, o.ps, make_float2(nextBin.x0, nextBin.x1),
                                                       make_float4(nextBin.p00, nextBin.p01, nextBin.p10, nextBin.p11), o.lag, qs);
                 }
                 if (s == 0 && b == bfirst) p.tKapOut[i] = 1.0f;   // processPrecExp[0] = 1 (pyx:8245)
@@ -1140,8 +1225,13 @@ struct BwdTrend {
     }
 };
 
+using BwdTrend = BwdTrendT<false>;
+
 // ECM sweeps, diagonal base process noise: pNoise arrives as its two diagonal entries (Prm::tQ2)
-struct BwdTrendQ2 : BwdTrend {
+template <bool UF>
+struct BwdTrendQ2T : BwdTrendT<UF> {
+    using In = typename BwdTrendT<UF>::In;
+    static constexpr int FAMILY = FAM_OTHER;  // no LDS-DMA variant
     static constexpr bool NATOUT = false;    // ECM sweeps never write the reference layout
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
@@ -1156,8 +1246,12 @@ struct BwdTrendQ2 : BwdTrend {
 // LDS-DMA inputs of the smoother chain (used for its warm-up phase, k_chain_spec_dmawarm_natbwd): the filtered
 // covariance in one 16-byte DMA ([lane][4] words), the filtered state as two 4-byte rows, the stored process noise in
 // one more 16-byte DMA when it varies per bin (QARR).
-template <bool QARR>
-struct BwdTrendDma : BwdTrend {
+using BwdTrendQ2 = BwdTrendQ2T<false>;
+
+template <bool QARR, bool UF = false>
+struct BwdTrendDma : BwdTrendT<UF> {
+    using Plain = BwdTrendT<UF>;
+    using In = typename Plain::In;
     static constexpr bool DMA = true;
     static constexpr bool NATOUT = false;
     static constexpr int NW = QARR ? 10 : 6, ND = QARR ? 4 : 3;
@@ -1185,6 +1279,8 @@ struct BwdTrendDma : BwdTrend {
 
 // ---- backward RTS chain, level (pyx:7125-7140) -----------------------------------------------------------------
 struct BwdLevel {
+    static constexpr bool UNITF = false;
+    static constexpr int FAMILY = FAM_OTHER;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -1729,7 +1825,7 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
     dma_phase<DCH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, W);     // T = W: nothing fetched beyond
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (live) cin[b] = c;
-    walk_nat_fwd<FwdTrendFused, NatTilesFwd>(p, c, b, bi.y, live, bi.z, bi.x, tiles);
+    walk_nat_fwd<typename DCH::Plain, NatTilesFwd>(p, c, b, bi.y, live, bi.z, bi.x, tiles);
     if (live) cout[b] = c;
 }
 
@@ -1763,7 +1859,7 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
     dma_phase<DCH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, W);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (live) cin[b] = c;
-    walk_nat<BwdTrend>(p, c, b, bi.y, live, b == bi.w, bi.x, tiles);
+    walk_nat<typename DCH::Plain>(p, c, b, bi.y, live, b == bi.w, bi.x, tiles);
     if (live) cout[b] = c;
 }
 

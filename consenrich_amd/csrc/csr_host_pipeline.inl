@@ -79,6 +79,11 @@ static int64_t &stage_reruns(csr_ctx *c, int stage) {
     return stage == ST_P ? c->rs.reruns_p : (stage == ST_X ? c->rs.reruns_x : c->rs.reruns_b);
 }
 
+// F = [[1, f], [0, 1]] (constructMatrixF, core.py:2164-2176): the UF instances of the levelTrend policies (csr_device.h)
+static bool unit_f(const csr_ctx *c, const Prm &p) {
+    return c->unitFEnabled && p.F00 == 1.0 && p.F10 == 0.0 && p.F11 == 1.0;
+}
+
 // Speculative pass + validation/fix-up.  defer = true: launch the speculative pass and ONE validation pass and return
 // without a host round trip (the stage's monotonic counter is checked at the next settle point); otherwise iterate
 // validation passes to the fixed point here.
@@ -105,45 +110,45 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
             bool launched = false;
-            if constexpr (std::is_same<CH, FwdTrendFused>::value) {
+            if constexpr (CH::FAMILY == FAM_FWD_FUSED) {
                 // ECM sweeps and other passes without reference-layout outputs: inputs through the LDS-DMA ring
                 if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0) {
                     // reference-layout outputs: ring for the warm-up only, tile walker for the main phase
                     const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
                     const size_t tl = sizeof(NatTilesFwd);
                     if (mm == 0)
-                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<0, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 4 * 64, tl), c->stream, p);
                     else if (mm == F_KAPPA)
-                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<1>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<1, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 5 * 64, tl), c->stream, p);
                     else
-                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<2>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<2, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 7 * 64, tl), c->stream, p);
                     launched = true;
                 } else if (c->useDmaFused && !p.natOut && !pcq) {
                     const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
                     if (mm == 0)
-                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<0>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dma<FwdTrendFusedDma<0, CH::UNITF>>), dim3(grid), dim3(64),
                                            sizeof(unsigned) * DMA_R * 4 * 64, c->stream, p);
                     else if (mm == F_KAPPA)
-                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<1>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dma<FwdTrendFusedDma<1, CH::UNITF>>), dim3(grid), dim3(64),
                                            sizeof(unsigned) * DMA_R * 5 * 64, c->stream, p);
                     else
-                        hipLaunchKernelGGL(k_chain_spec_dma<FwdTrendFusedDma<2>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dma<FwdTrendFusedDma<2, CH::UNITF>>), dim3(grid), dim3(64),
                                            sizeof(unsigned) * DMA_R * 7 * 64, c->stream, p);
                     launched = true;
                 }
             }
-            if constexpr (std::is_same<CH, BwdTrend>::value) {
+            if constexpr (CH::FAMILY == FAM_BWD_TREND) {
                 // smoother with reference-layout outputs: warm-up through the ring
                 // (32-bin blocks: measured slower, 0.063 vs 0.057 ms -- the ring's fill and drain weigh more than they hide)
                 if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->B >= 64) {
                     if (p.qFromMult)
-                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<false>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dmawarm_natbwd<BwdTrendDma<false, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 6 * 64, sizeof(NatTiles)), c->stream, p);
                     else
-                        hipLaunchKernelGGL(k_chain_spec_dmawarm_natbwd<BwdTrendDma<true>>, dim3(grid), dim3(64),
+                        hipLaunchKernelGGL((k_chain_spec_dmawarm_natbwd<BwdTrendDma<true, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 10 * 64, sizeof(NatTiles)), c->stream, p);
                     launched = true;
                 }
@@ -311,7 +316,8 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 p.natOut = 1;
                 c->fwdNat = true;
             }
-            if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<FwdTrendFusedT<true>>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            else if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             c->lastFwdWindow = c->fwdWindow;
             c->fwdWindow = nullptr;
@@ -321,13 +327,13 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             // (the sequential state chain below costs tens of milliseconds: its gains are validated first -- one host
             // round trip -- rather than optimistically)
             if (seqX) dP = false;
-            CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            if (unit_f(c, p)) CHECK(run_chain<FwdPTrendT<true>>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            else CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             if (seqX) {
                 // bit-exact mode: the state recursion cannot be validated speculatively in reasonable time (see
                 // k_state_seq_trend) -- one wavefront per chain runs it sequentially on the validated gains
                 Scope sc(c, "fwd_state_seq");
-                const bool unitF = p.F00 == 1.0 && p.F10 == 0.0 && p.F11 == 1.0;
-                if (unitF)
+                if (p.F00 == 1.0 && p.F10 == 0.0 && p.F11 == 1.0)
                     hipLaunchKernelGGL(k_state_seq_trend<true>, dim3((unsigned)c->chains.size()), dim3(64), 0, c->stream, p,
                                        c->dChainFirst, c->dChainNb);
                 else
@@ -336,7 +342,8 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 LAUNCH_CHECK("k_state_seq_trend");
                 dX = false;
             } else
-            CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+            if (unit_f(c, p)) CHECK(run_chain<FwdXTrendT<true>>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+            else CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         } else {
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
@@ -398,11 +405,13 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
     const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
     if (p.qFromKappa && !natOut) {
-        if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrendQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+        if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<BwdTrendQ2T<true>>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+        else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrendQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
         else CHECK(run_chain<BwdLevelQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     } else if (p.qFromKappa) {
         return fail("internal: compact process noise is only produced by ECM sweeps (no reference-layout outputs)");
-    } else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    } else if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<BwdTrendT<true>>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     if (dB) {
         c->pendBwd = true;

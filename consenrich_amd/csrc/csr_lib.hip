@@ -159,6 +159,7 @@ struct csr_ctx {
     bool deferEnabled = true;
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    bool unitFEnabled = true;   // CONSENRICH_AMD_UNITF=0: the general-F instances of the levelTrend chains even for F = [[1, f], [0, 1]]
     bool seqState = true;       // bit-exact validation, levelTrend: sequential state chain (CONSENRICH_AMD_SEQ_STATE=0: speculative)
     bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
     bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
@@ -289,6 +290,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_D"))) c->natOutD = atoi(e) != 0;

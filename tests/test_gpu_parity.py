@@ -177,6 +177,44 @@ def test_fused_forward_chain_with_failed_optimistic_validation(product, d):
             assert fused["stats"]["reruns_x"] == 0 or not fusing       # no separate state stage in the fused path
 
 
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+def test_unit_f_instances_equal_the_general_ones_bit_for_bit(product, monkeypatch, xtol):
+    """F = [[1, f], [0, 1]] (what the reference's constructMatrixF always builds) runs specialised instances of the levelTrend
+    chain policies that drop the multiplications by 1 and 0 -- exact operations, so every output must carry the same bits
+    as the general-F instances (CONSENRICH_AMD_UNITF=0): forward / backward with all multipliers, and an ECM run (fused kappa
+    E-step, compact pNoise) incl. its kappa."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list = [5000, 37, 1, 12345, 64, 65]
+
+    def ecm_run():
+        out = {}
+        with DeviceBatch(0, x_tol_ulps=xtol) as b:
+            b.configure(ModelParams(state_dim=2), 4, n_list)
+            for c, n in enumerate(n_list):
+                b.upload(c, *cases.synth(n, 4, 700 + c, mask_frac=0.02, outlier_frac=0.01))
+            b.stats()
+            outs, paths = b.ecm(max_iters=4, inner_iters=3, rtol=0.0, use_lambda=False, use_kappa=True)
+            b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT | L.EXPORT_FORWARD)
+            for c in range(len(n_list)):
+                for name in ("xs", "Ps", "lag", "kappa", "xf", "Pf", "pnoise", "D"):
+                    out[(c, name)] = b.download(c, name)
+            out["paths"] = paths
+        return out
+
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CONSENRICH_AMD_UNITF", flag)
+        runs[flag] = (_run_batch(64, (-1, -1, -1), 2, n_list, 4, 100, xtol=xtol, fused=True), ecm_run())
+    for part in (0, 1):
+        a, b_ = runs["1"][part], runs["0"][part]
+        for key, val in a.items():
+            if key == "stats":
+                continue
+            assert np.array_equal(np.asarray(val), np.asarray(b_[key])), (part, key)
+
+
 def test_ulp_tolerant_validation_stays_within_parity_budget(product, monkeypatch):
     """(The bit-exact runs use the SPECULATIVE state chain here, CONSENRICH_AMD_SEQ_STATE=0 -- the production exact mode runs
     that chain sequentially, one wavefront per chromosome -- so that the re-run counts of the two validation modes can be
