@@ -1,173 +1,79 @@
 // csr_host_qseed.inl -- part of csr_lib.hip: SURVEY 8(f) rank 4, the initial process-noise (Q0) seed
 // (cconsenrich.pyx:1441-2146, caller core.py:3621-3780).  Device: csr_qseed.h (gather + per-transition reductions over the
-// sampled columns of the resident matrices).  Host, below: the bounded tail in the reference's operation order -- two
-// quantiles of the precision sample, the stable ordering of the signal levels, the grid posterior.
+// sampled columns of the resident matrices) and csr_qseed_post.h (order statistics of the precision sample by bitwise
+// bisection; weighted quantiles by bitonic sort; the grid posterior).  Host, below: orchestration, the compaction of the
+// selected transitions in scan order and the stable ordering of the signal levels for the 2048-transition panel.
 
 // ---------------------------------------------------------------------------------------------------------------
 // host tail
 // ---------------------------------------------------------------------------------------------------------------
-static double qs_linear_quantile(std::vector<double> buf, double q) {      // pyx:1257-1291 (by value: works on a copy)
-    const int64_t n = (int64_t)buf.size();
-    if (n <= 0) return NAN;
-    double pos;
-    if (q <= 0.0) pos = 0.0;
-    else if (q >= 1.0) pos = (double)(n - 1);
-    else pos = q * (double)(n - 1);
-    const int64_t lo = (int64_t)std::floor(pos);
-    int64_t hi = lo + 1;
-    if (hi >= n) hi = n - 1;
-    const double frac = pos - (double)lo;
-    std::nth_element(buf.begin(), buf.begin() + lo, buf.end());
-    const double lowVal = buf[lo];
-    if (hi == lo) return lowVal;
-    const double highVal = *std::min_element(buf.begin() + hi, buf.end());   // the (lo+1)-th order statistic
-    return lowVal + frac * (highVal - lowVal);
-}
 static void qs_stable_argsort(const double *v, int64_t n, std::vector<int64_t> &idx) {   // np.argsort(kind="mergesort")
     idx.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [v](int64_t a, int64_t b) { return v[a] < v[b]; });
 }
-static double qs_weighted_quantile(const double *values, const double *weights, int64_t n, double quantile) {   // pyx:1294-1344
-    if (n <= 0) return NAN;
-    std::vector<int64_t> order;
-    qs_stable_argsort(values, n, order);
-    double total = 0.0;
-    for (int64_t i = 0; i < n; ++i) total += weights[order[i]];
-    if (!(total > 0.0)) return NAN;
-    double target;
-    if (quantile <= 0.0) target = 0.0;
-    else if (quantile >= 1.0) target = total;
-    else target = quantile * total;
-    double cum = 0.0, prevCum = 0.0, prevValue = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double v = values[order[i]];
-        cum += weights[order[i]];
-        if (target <= cum) {
-            if (i == 0) return v;
-            const double denom = cum - prevCum;
-            if (denom <= 0.0) return v;
-            return prevValue + ((target - prevCum) / denom) * (v - prevValue);
-        }
-        prevCum = cum;
-        prevValue = v;
-    }
-    return values[order[n - 1]];
-}
-static double qs_cdf_quantile(const double *grid, const double *post, int64_t n, double prob) {   // pyx:1396-1428
-    if (n <= 0) return NAN;
-    const double target = prob <= 0.0 ? 0.0 : (prob >= 1.0 ? 1.0 : prob);
-    double cum = 0.0, prevCum = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        cum += post[i];
-        if (target <= cum) {
-            if (i == 0) return grid[0];
-            const double denom = cum - prevCum;
-            if (denom <= 0.0) return grid[i];
-            return grid[i - 1] + ((target - prevCum) / denom) * (grid[i] - grid[i - 1]);
-        }
-        prevCum = cum;
-    }
-    return grid[n - 1];
-}
 static inline int64_t qs_sample_index_h(int64_t i, int64_t items, int64_t samples) {   // pyx:1431-1438
     return (int64_t)std::floor((((double)i + 0.5) * (double)items) / (double)samples);
 }
 
-// pyx:1998-2146
-static int qs_posterior(int64_t count, const double *deltas, const double *s2, const double *weights,
-                        const csr_qseed_post_cfg &cf, csr_qseed_post *out) {
-    memset(out, 0, sizeof(*out));
-    double sumW = 0.0, sumW2 = 0.0;
-    for (int64_t i = 0; i < count; ++i) {
-        if (!std::isfinite(deltas[i])) return fail("deltas must be finite");
-        if (!std::isfinite(s2[i]) || s2[i] < 0.0) return fail("samplingVariances must be nonnegative finite");
-        if (!std::isfinite(weights[i]) || weights[i] <= 0.0) return fail("transitionWeights must be positive finite");
-        sumW += weights[i];
-        sumW2 += weights[i] * weights[i];
+// Grid posteriors of a set of transition lists (pyx:1998-2146), all in ONE launch of k_qs_posterior (csr_qseed_post.h):
+// weighted quantiles by a bitonic sort + a walk of the cumulative weights, one thread per grid point for the likelihood.
+struct QpHostJob {
+    const double *d, *s2, *w;       // host
+    int64_t n;
+};
+static const char *const QP_ERR[] = {"", "deltas must be finite", "samplingVariances must be nonnegative finite",
+                                     "transitionWeights must be positive finite",
+                                     "q seed posterior produced a nonfinite score", "q seed posterior normalization failed"};
+static int qs_posterior_device(csr_ctx *c, const std::vector<QpHostJob> &in, const csr_qseed_post_cfg &cf,
+                               csr_qseed_post *outs) {
+    const size_t nj = in.size();
+    if (nj == 0) return 0;
+    const int64_t G = std::max<int64_t>(cf.grid_size, 1);
+    size_t need_ = 0;
+    auto take = [&](size_t b) { const size_t o = need_; need_ += (b + 255) / 256 * 256; return o; };
+    struct Off { size_t d, s2, w, key, ord, lp; int64_t P; };
+    std::vector<Off> off(nj);
+    const size_t oJobs = take(sizeof(QpJob) * nj), oOut = take(sizeof(csr_qseed_post) * nj), oSt = take(sizeof(int) * nj);
+    for (size_t j = 0; j < nj; ++j) {
+        const size_t n = (size_t)std::max<int64_t>(in[j].n, 1);
+        int64_t P = 1;
+        while (P < (int64_t)n) P <<= 1;
+        off[j] = Off{take(8 * n), take(8 * n), take(8 * n), take(8 * (size_t)P), take(4 * (size_t)P), take(8 * 3 * (size_t)G), P};
     }
-    double eff = 0.0;
-    if (sumW2 > 0.0) eff = (sumW * sumW) / sumW2;
-    out->transition_count = count;
-    out->effective_transition_count = eff;
-    if (count < cf.min_transitions || eff < (double)cf.min_transitions) return 0;
-    const double qFloor = cf.q_floor, qCap = cf.q_cap;
-    const double center = qs_weighted_quantile(deltas, weights, count, 0.5);
-    std::vector<double> work((size_t)count);
-    for (int64_t i = 0; i < count; ++i) work[i] = std::fabs(deltas[i] - center);
-    const double robustScale = 1.4826 * qs_weighted_quantile(work.data(), weights, count, 0.5);
-    const double medianS2 = qs_weighted_quantile(s2, weights, count, 0.5);
-    double qPrior = robustScale * robustScale - medianS2;
-    if (qPrior < qFloor) qPrior = qFloor;
-    if (qPrior < cf.q_seed_prior_level) qPrior = cf.q_seed_prior_level;
-    double maxDeltaSq = 0.0;
-    for (int64_t i = 0; i < count; ++i) {
-        double cand = deltas[i] * deltas[i];
-        if (cand > maxDeltaSq) maxDeltaSq = cand;
-        cand -= s2[i];
-        if (cand < 0.0) cand = 0.0;
-        work[i] = cand;
-    }
-    const double q90 = qs_weighted_quantile(work.data(), weights, count, 0.9);
-    const double lower = qFloor;
-    double upper;
-    if (std::isfinite(qCap)) upper = std::fmax(qCap, lower);
-    else {
-        upper = lower * 10.0;
-        const double cands[5] = {qPrior * 1.0e4, q90 * 100.0, medianS2 * 100.0, maxDeltaSq * 10.0, lower * 1.0e6};
-        for (double cnd : cands)
-            if (cnd > upper && cnd > lower) upper = cnd;
-    }
-    const int64_t G = (upper <= lower * (1.0 + 1.0e-10)) ? 1 : cf.grid_size;
-    std::vector<double> grid((size_t)G), logPost((size_t)G), post((size_t)G);
-    if (G == 1) grid[0] = lower;
-    else {
-        const double logLower = std::log(lower), logUpper = std::log(upper);
-        const double step = (logUpper - logLower) / (double)(G - 1);
-        for (int64_t g = 0; g < G; ++g) grid[g] = std::exp(logLower + step * (double)g);
-    }
-    double nu = cf.robust_t_nu;
-    if (!std::isfinite(nu) || nu <= 0.0) nu = cf.default_t_nu;
-    if (nu < 4.0) nu = 4.0;
-    double medianWeight = qs_weighted_quantile(weights, weights, count, 0.5);
-    if (medianWeight < DBL_MIN) medianWeight = DBL_MIN;
-    const double logPriorCenter = std::log(std::fmax(qPrior, lower));
-    const double logPriorSd = std::fmax(cf.prior_log_sd, 1.0e-6);
-    const double logNorm = std::lgamma((nu + 1.0) * 0.5) - std::lgamma(nu * 0.5) -
-                           0.5 * (std::log(nu) + std::log(3.14159265358979323846264338327950288));
-    double maxLogPost = -INFINITY;
-    int64_t modeIndex = 0;
-    for (int64_t g = 0; g < G; ++g) {
-        const double q = grid[g];
-        double logLikeSum = 0.0;
-        for (int64_t i = 0; i < count; ++i) {
-            double var = q + s2[i];
-            if (var < DBL_MIN) var = DBL_MIN;
-            double wn = weights[i] / medianWeight;
-            if (wn < 0.25) wn = 0.25;
-            else if (wn > 4.0) wn = 4.0;
-            logLikeSum += wn * (logNorm - 0.5 * std::log(var) -
-                                0.5 * (nu + 1.0) * std::log1p((deltas[i] * deltas[i]) / (nu * var)));
+    CHECK(c->qpBuf.reserve(need_));
+    char *base = (char *)c->qpBuf.ptr;
+    std::vector<QpJob> jobs(nj);
+    for (size_t j = 0; j < nj; ++j) {
+        const size_t n = (size_t)in[j].n;
+        if (n) {
+            HIPOK(hipMemcpyAsync(base + off[j].d, in[j].d, 8 * n, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemcpyAsync(base + off[j].s2, in[j].s2, 8 * n, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemcpyAsync(base + off[j].w, in[j].w, 8 * n, hipMemcpyHostToDevice, c->stream));
         }
-        const double lq = (std::log(q) - logPriorCenter) / logPriorSd;
-        const double logPrior = -0.5 * lq * lq;
-        const double lp = logLikeSum + logPrior;
-        if (!std::isfinite(lp)) return fail("q seed posterior produced a nonfinite score");
-        logPost[g] = lp;
-        if (lp > maxLogPost) { maxLogPost = lp; modeIndex = g; }
+        QpJob &q = jobs[j];
+        q.n = in[j].n; q.P = off[j].P;
+        q.d = (const double *)(base + off[j].d); q.s2 = (const double *)(base + off[j].s2); q.w = (const double *)(base + off[j].w);
+        q.key = (double *)(base + off[j].key); q.work = nullptr; q.ord = (int *)(base + off[j].ord);
+        q.logPost = (double *)(base + off[j].lp);
+        q.out = (csr_qseed_post *)(base + oOut) + j;
+        q.status = (int *)(base + oSt) + j;
     }
-    double total = 0.0;
-    for (int64_t g = 0; g < G; ++g) { post[g] = std::exp(logPost[g] - maxLogPost); total += post[g]; }
-    if (!std::isfinite(total) || total <= 0.0) return fail("q seed posterior normalization failed");
-    for (int64_t g = 0; g < G; ++g) post[g] = post[g] / total;
-    out->ok = 1;
-    out->median_sampling_variance = medianS2;
-    out->prior_level = qPrior;
-    out->posterior_mode = grid[modeIndex];
-    out->posterior_median = qs_cdf_quantile(grid.data(), post.data(), G, 0.5);
-    out->posterior_q05 = qs_cdf_quantile(grid.data(), post.data(), G, 0.05);
-    out->posterior_q95 = qs_cdf_quantile(grid.data(), post.data(), G, 0.95);
-    out->transition_q90 = q90;
+    HIPOK(hipMemcpyAsync(base + oJobs, jobs.data(), sizeof(QpJob) * nj, hipMemcpyHostToDevice, c->stream));
+    QpCfg k;
+    k.q_floor = cf.q_floor; k.q_cap = cf.q_cap; k.robust_t_nu = cf.robust_t_nu; k.q_seed_prior_level = cf.q_seed_prior_level;
+    k.prior_log_sd = cf.prior_log_sd; k.default_t_nu = cf.default_t_nu; k.min_transitions = cf.min_transitions; k.grid_size = G;
+    {
+        Scope sc_(c, "qseed_posterior");
+        hipLaunchKernelGGL(k_qs_posterior, dim3((unsigned)nj), dim3(1024), 0, c->stream, (const QpJob *)(base + oJobs), k);
+    }
+    LAUNCH_CHECK("k_qs_posterior");
+    std::vector<int> st(nj);
+    HIPOK(hipMemcpyAsync(outs, base + oOut, sizeof(csr_qseed_post) * nj, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(st.data(), base + oSt, sizeof(int) * nj, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    for (size_t j = 0; j < nj; ++j)
+        if (st[j] != 0) return fail("%s", QP_ERR[st[j] < 6 ? st[j] : 0]);
     return 0;
 }
 
@@ -230,7 +136,7 @@ static int qs_same_track(csr_ctx *c, std::vector<QsJob> &jobs, const csr_qseed_s
         workBytes = std::max(workBytes, 24 * (size_t)a.m * sc);
     }
     const size_t oWork = take(workBytes);
-    CHECK(c->qsBuf.reserve(need_));
+    CHECK(c->qsBuf.reserve(need_ + 512 + (sizeof(QsSelJob) + 32) * jobs.size()));
     char *base = (char *)c->qsBuf.ptr;
     struct Scal { int64_t pairs; unsigned long long err; };
     std::vector<Scal> scal(jobs.size());
@@ -262,11 +168,17 @@ static int qs_same_track(csr_ctx *c, std::vector<QsJob> &jobs, const csr_qseed_s
     }
     LAUNCH_CHECK("k_qs_count");
     HIPOK(hipStreamSynchronize(c->stream));
-    std::vector<std::vector<double>> raws(jobs.size());
+    // phase B: the precision sample stays on the device; its two quantiles (pyx:1658-1662: median and cap quantile, linear
+    // interpolation between order statistics) come from exact rank selection (k_qs_select), four ranks per chain
+    std::vector<QsSelJob> sel(jobs.size());
+    std::vector<double> frac(2 * jobs.size(), 0.0);
+    size_t nSel = 0;
     {
         Scope sc_(c, "qseed_sample");
         for (size_t i = 0; i < jobs.size(); ++i) {
             QsJob &jb = jobs[i];
+            memset(&sel[i], 0, sizeof(sel[i]));
+            for (int q = 0; q < 4; ++q) sel[i].rank[q] = -1;
             if (jb.empty) continue;
             if (scal[i].err != ~0ull) return fail("%s", QS_ERR[scal[i].err & 0xFF]);
             QsArgs &a = jb.a;
@@ -277,23 +189,48 @@ static int qs_same_track(csr_ctx *c, std::vector<QsJob> &jobs, const csr_qseed_s
             jb.dg.precision_sample_count = a.sampleCount;
             if (a.sampleCount <= 0) continue;
             hipLaunchKernelGGL(k_qs_sample, dim3((unsigned)((a.sampleCount + 255) / 256)), dim3(256), 0, c->stream, a);
-            raws[i].resize((size_t)a.sampleCount);
-            HIPOK(hipMemcpyAsync(raws[i].data(), a.raw, 8 * (size_t)a.sampleCount, hipMemcpyDeviceToHost, c->stream));
+            sel[i].v = a.raw;
+            sel[i].n = a.sampleCount;
+            const double qs[2] = {0.5, cf.precision_cap_quantile};
+            for (int k = 0; k < 2; ++k) {
+                const int64_t ns = a.sampleCount;
+                const double pos = qs[k] <= 0.0 ? 0.0 : (qs[k] >= 1.0 ? (double)(ns - 1) : qs[k] * (double)(ns - 1));
+                const int64_t lo = (int64_t)std::floor(pos);
+                sel[i].rank[2 * k] = lo;
+                sel[i].rank[2 * k + 1] = std::min<int64_t>(lo + 1, ns - 1);
+                frac[2 * i + k] = pos - (double)lo;
+            }
+            ++nSel;
         }
     }
     LAUNCH_CHECK("k_qs_sample");
-    HIPOK(hipStreamSynchronize(c->stream));
-    // phase C: the cap (pyx:1658-1662), then the per-transition reductions
+    std::vector<double> caps(jobs.size(), NAN);
+    if (nSel > 0) {
+        const size_t oSel = (need_ + 255) / 256 * 256;          // behind everything laid out above (qsBuf was sized with it)
+        char *sb = base + oSel;
+        for (size_t i = 0; i < jobs.size(); ++i) sel[i].out = (double *)(sb + sizeof(QsSelJob) * jobs.size()) + 4 * i;
+        HIPOK(hipMemcpyAsync(sb, sel.data(), sizeof(QsSelJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
+        {
+            Scope sc_(c, "qseed_select");
+            hipLaunchKernelGGL(k_qs_select, dim3((unsigned)jobs.size()), dim3(1024), 0, c->stream, (const QsSelJob *)sb);
+        }
+        LAUNCH_CHECK("k_qs_select");
+        std::vector<double> osel(4 * jobs.size(), 0.0);
+        HIPOK(hipMemcpyAsync(osel.data(), sb + sizeof(QsSelJob) * jobs.size(), 8 * osel.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < jobs.size(); ++i) {
+            if (jobs[i].empty || jobs[i].a.sampleCount <= 0) continue;
+            const double *v = &osel[4 * i];
+            const double med = sel[i].rank[1] == sel[i].rank[0] ? v[0] : v[0] + frac[2 * i] * (v[1] - v[0]);
+            const double qp = sel[i].rank[3] == sel[i].rank[2] ? v[2] : v[2] + frac[2 * i + 1] * (v[3] - v[2]);
+            caps[i] = std::fmin(qp, cf.precision_cap_multiplier * med);
+        }
+    } else {
+        HIPOK(hipStreamSynchronize(c->stream));
+    }
+    // phase C: the per-transition reductions with that cap
     struct Down { std::vector<char> buf; };
     std::vector<Down> down(jobs.size());
-    std::vector<double> caps(jobs.size(), NAN);
-    qs_parallel_for((int)jobs.size(), [&](int i) {
-        if (jobs[i].empty || jobs[i].a.sampleCount <= 0) return;
-        const double med = qs_linear_quantile(raws[i], 0.5);
-        const double qp = qs_linear_quantile(raws[i], cf.precision_cap_quantile);
-        caps[i] = std::fmin(qp, cf.precision_cap_multiplier * med);
-        std::vector<double>().swap(raws[i]);
-    });
     {
         Scope sc_(c, "qseed_transitions");
         for (size_t i = 0; i < jobs.size(); ++i) {
@@ -516,8 +453,13 @@ extern "C" int csr_qseed_pooled(int64_t m, int64_t n, const double *data, const 
 
 extern "C" int csr_qseed_posterior(int64_t count, const double *deltas, const double *sampling_var, const double *weights,
                                    const csr_qseed_post_cfg *cfg, csr_qseed_post *out) {
+    DEFAULT_CTX_GUARD;
     if (!cfg || !out || (count > 0 && (!deltas || !sampling_var || !weights))) return fail("null argument");
-    return qs_posterior(count, deltas, sampling_var, weights, *cfg, out);
+    csr_ctx *c = default_ctx();
+    if (!c) return -1;
+    CHECK(ctx_select(c));
+    std::vector<QpHostJob> in(1, QpHostJob{deltas, sampling_var, weights, count});
+    return qs_posterior_device(c, in, *cfg, out);
 }
 
 // core.py:3621-3780 for every chain of the batch
@@ -554,17 +496,13 @@ extern "C" int csr_batch_qseed(csr_ctx *c, const csr_qseed_cfg *cfg, csr_qseed_o
         if (std::isfinite(qCap)) v = std::min(v, qCap);
         return v;
     };
-    // the grid posteriors of the chains are independent host work (64 x <= 2048 log / log1p each): one thread per few chains
+    // the grid posteriors of all chains in one launch (csr_qseed_post.h)
     std::vector<csr_qseed_post> ests((size_t)nc);
-    std::vector<std::string> errs((size_t)nc);
     {
-        qs_parallel_for(nc, [&](int i) {
-            QsJob &jb = jobs[i];
-            if (qs_posterior((int64_t)jb.deltas.size(), jb.deltas.data(), jb.svar.data(), jb.weights.data(), pc, &ests[i]) != 0)
-                errs[i] = g_err;                        // thread-local message of this worker
-        });
+        std::vector<QpHostJob> in((size_t)nc);
         for (int i = 0; i < nc; ++i)
-            if (!errs[i].empty()) return fail("%s", errs[i].c_str());
+            in[i] = QpHostJob{jobs[i].deltas.data(), jobs[i].svar.data(), jobs[i].weights.data(), (int64_t)jobs[i].deltas.size()};
+        CHECK(qs_posterior_device(c, in, pc, ests.data()));
     }
     for (int i = 0; i < nc; ++i) {
         QsJob &jb = jobs[i];
@@ -577,7 +515,10 @@ extern "C" int csr_batch_qseed(csr_ctx *c, const csr_qseed_cfg *cfg, csr_qseed_o
             std::vector<double> d, s, w;
             CHECK(qs_pooled(c, jb.a, d, s, w));
             csr_qseed_post pooled;
-            CHECK(qs_posterior((int64_t)d.size(), d.data(), s.data(), w.data(), pc, &pooled));
+            {
+                std::vector<QpHostJob> in(1, QpHostJob{d.data(), s.data(), w.data(), (int64_t)d.size()});
+                CHECK(qs_posterior_device(c, in, pc, &pooled));
+            }
             if (pooled.ok) { est = pooled; source = 1; }
         }
         int reason = est.ok ? 0 : 3;

@@ -7,6 +7,7 @@
 #include "csr_writers.h"
 #include "csr_folds.h"
 #include "csr_qseed.h"
+#include "csr_qseed_post.h"
 #include "csr_objective.h"
 
 #include <algorithm>
@@ -195,7 +196,7 @@ struct csr_ctx {
         double *dPen = nullptr;
         long long *dSelRank = nullptr;
     } bg;
-    DevBuf qsBuf;                       // Q0-seed work space
+    DevBuf qsBuf, qpBuf;                // Q0-seed work space (sampling / posterior)
     DevBuf stageBuf;                    // host -> device staging of per-bin vectors (csr_batch_upload_multipliers)
     DevBuf bgBuf, wrBuf, textBuf;       // host-buffer background solver / bedGraph writer work space (this device)
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
@@ -326,7 +327,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
             (void)hipEventDestroy(pr.second);
         }
     for (hipEvent_t ev : c->eventPool) (void)hipEventDestroy(ev);
-    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf, &c->stageBuf})
+    for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf, &c->qpBuf, &c->stageBuf})
         if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) (void)hipHostFree(c->hMail);
     if (c->evFork) (void)hipEventDestroy(c->evFork);

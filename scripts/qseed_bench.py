@@ -28,10 +28,11 @@ kt = {k: (v[0], round(v[1], 3)) for k, v in b.kernel_times().items() if k.starts
 b.profile(False)
 t = time.perf_counter(); Q, diag = oq.estimate_initial_process_noise(oq, matrixData=data, matrixMunc=munc, **kw); cpu = time.perf_counter() - t
 assert np.array_equal(Q, got[0][0]), (Q, got[0][0])
-assert diag["qSeedPosteriorMedianLevel"] == got[0][1]["qSeedPosteriorMedianLevel"]
+rel = abs(diag["qSeedPosteriorMedianLevel"] - got[0][1]["qSeedPosteriorMedianLevel"]) / diag["qSeedPosteriorMedianLevel"]
+assert rel <= 1e-12, rel      # device log / log1p / exp vs glibc (the grid posterior runs on the device since round 2)
 print(json.dumps({"row": "8(f) rank 4 Q0 seed", "m": m, "chains": len(lens), "bins": int(sum(lens)),
                   "gpu_wall_ms_all_chains_best": round(min(ts) * 1e3, 2), "gpu_wall_ms_all_chains_median": round(sorted(ts)[2] * 1e3, 2),
                   "gpu_kernels_ms_total_(launches,ms)_over_5_calls": kt,
                   "cpu_oracle_ms_chr1_only": round(cpu * 1e3, 1), "chr1_bins": n0,
                   "chr1_Q": [float(Q[0, 0]), float(Q[1, 1])], "chr1_source": diag["qSeedSource"],
-                  "identical_Q_and_posterior_median": True}))
+                  "identical_Q": True, "posterior_median_rel_diff_vs_cpu": rel}))
