@@ -116,6 +116,14 @@ struct Prm {
     void *carryOutB;    // pong
     unsigned int *rerunCount;
     unsigned int *rerunCountPass;   // counter of THIS validation pass (deferred validation launches 1-4 passes and checks the last)
+    // Folded validation: a clean stage launches no validation kernel of its own -- the NEXT speculative kernel of the stream
+    // compares, in its prologue, the previous stage's carry-ins with its neighbours' carry-outs (check only, no repair: a
+    // mismatch is counted and the pipeline replayed).  The kernel boundary in between makes the carries visible; the two
+    // stages use different carry sets.  prevKind = CK_* of the previous stage's policy (0: nothing to check).
+    int prevKind;
+    const void *prevCarryIn, *prevCarryOut;
+    unsigned int *prevCount, *prevCountPass;
+    const unsigned char *prevActive;
 };
 
 enum : uint32_t {
@@ -520,7 +528,9 @@ __device__ __forceinline__ bool near_ulps(float a, float b, float scale, int k) 
 #ifndef CSR_U_B
 #define CSR_U_B 4
 #endif
-enum { FAM_OTHER = 0, FAM_FWD_FUSED = 1, FAM_BWD_TREND = 2 };      // what run_chain dispatches its LDS-DMA variants on
+enum { FAM_OTHER = 0, FAM_FWD_FUSED = 1, FAM_BWD_TREND = 2 };
+enum { CK_NONE = 0, CK_FWDP_TREND, CK_FWDX_TREND, CK_FWD_FUSED_TREND, CK_FWDP_LEVEL, CK_FWDX_LEVEL, CK_FWD_FUSED_LEVEL,
+       CK_BWD_TREND, CK_BWD_LEVEL };      // carry types of the folded validation (Prm::prevKind)      // what run_chain dispatches its LDS-DMA variants on
 
 // UF ("unit F"): F = [[1, f], [0, 1]] -- what the reference's constructMatrixF always builds (core.py:2164-2176).  1 * x and
 // 0 * x + y are exact, so the UF instances drop those operations and produce THE SAME BITS with fewer dependent-issue
@@ -530,6 +540,7 @@ template <bool UF>
 struct FwdPTrendT {
     static constexpr bool UNITF = UF;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_FWDP_TREND;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -651,6 +662,7 @@ using FwdPTrend = FwdPTrendT<false>;
 struct FwdPLevel {
     static constexpr bool UNITF = false;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_FWDP_LEVEL;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -721,6 +733,7 @@ template <bool UF>
 struct FwdXTrendT {
     static constexpr bool UNITF = UF;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_FWDX_TREND;
     static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -801,6 +814,7 @@ using FwdXTrend = FwdXTrendT<false>;
 struct FwdXLevel {
     static constexpr bool UNITF = false;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_FWDX_LEVEL;
     static constexpr bool USES_Q = false;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -869,6 +883,7 @@ template <bool UF>
 struct FwdTrendFusedT {
     static constexpr bool UNITF = UF;
     static constexpr int FAMILY = FAM_FWD_FUSED;
+    static constexpr int KIND = CK_FWD_FUSED_TREND;
     using PT = FwdPTrendT<UF>;
     using XT = FwdXTrendT<UF>;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
@@ -970,6 +985,7 @@ struct FwdTrendFusedDma : FwdTrendFusedT<UF> {
 struct FwdLevelFused {
     static constexpr bool UNITF = false;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_FWD_FUSED_LEVEL;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -1072,6 +1088,7 @@ template <bool UF>
 struct BwdTrendT {
     static constexpr bool UNITF = UF;
     static constexpr int FAMILY = FAM_BWD_TREND;
+    static constexpr int KIND = CK_BWD_TREND;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = true;     // main phase can emit the reference layout through LDS tiles (walk_nat)
@@ -1281,6 +1298,7 @@ struct BwdTrendDma : BwdTrendT<UF> {
 struct BwdLevel {
     static constexpr bool UNITF = false;
     static constexpr int FAMILY = FAM_OTHER;
+    static constexpr int KIND = CK_BWD_LEVEL;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
     static constexpr bool NATOUT_FWD = false;
     static constexpr bool NATOUT = false;
@@ -1623,6 +1641,48 @@ __device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::C
     }
 }
 
+// Folded validation of the PREVIOUS stage (Prm::prevKind), run by every lane for its own block in the prologue of a
+// speculative kernel.
+template <class PCH>
+__device__ __forceinline__ bool prev_stage_bad(const Prm &p, int64_t b, const int4 &bi) {
+    using Carry = typename PCH::Carry;
+    const Carry *cin = reinterpret_cast<const Carry *>(p.prevCarryIn);
+    const Carry *cout = reinterpret_cast<const Carry *>(p.prevCarryOut);
+    const bool live = b < p.NB && (p.prevActive == nullptr || p.prevActive[p.blkChain[b]] != 0);
+    const bool edge = PCH::FWD ? (b == (int64_t)bi.z) : (b == (int64_t)bi.w);
+    const bool check = live && !edge;
+    const int64_t nbr = check ? (PCH::FWD ? b - 1 : b + 1) : 0;
+    const Carry prev = cout[nbr];
+    const Carry mine = cin[live ? b : 0];
+    return check & !PCH::same(p, prev, mine);
+}
+__device__ __forceinline__ void check_previous_stage(const Prm &p, int64_t b, const int4 &bi) {
+    if (p.prevKind == CK_NONE) return;          // uniform
+    bool bad = false;
+    switch (p.prevKind) {
+        case CK_FWDP_TREND: bad = prev_stage_bad<FwdPTrendT<false>>(p, b, bi); break;
+        case CK_FWDX_TREND: bad = prev_stage_bad<FwdXTrendT<false>>(p, b, bi); break;
+        case CK_FWD_FUSED_TREND: bad = prev_stage_bad<FwdTrendFusedT<false>>(p, b, bi); break;
+        case CK_FWDP_LEVEL: bad = prev_stage_bad<FwdPLevel>(p, b, bi); break;
+        case CK_FWDX_LEVEL: bad = prev_stage_bad<FwdXLevel>(p, b, bi); break;
+        case CK_FWD_FUSED_LEVEL: bad = prev_stage_bad<FwdLevelFused>(p, b, bi); break;
+        case CK_BWD_TREND: bad = prev_stage_bad<BwdTrendT<false>>(p, b, bi); break;
+        case CK_BWD_LEVEL: bad = prev_stage_bad<BwdLevel>(p, b, bi); break;
+        default: break;
+    }
+    if (bad) {
+        atomicAdd(p.prevCount, 1u);
+        atomicAdd(p.prevCountPass, 1u);
+    }
+}
+// the same check as a kernel of its own (a stage that nothing follows before the next settle point)
+__global__ __launch_bounds__(64) void k_chain_check(Prm p) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    check_previous_stage(p, b, bi);
+}
+
 // Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
 // NAT = true: separate instantiation whose main phase writes the reference layout through LDS tiles (walk_nat*); the
 // plain one stays as lean as before (the tile walkers cost ~50-100 VGPRs and slowed the ECM sweeps by 25 % when both
@@ -1634,6 +1694,7 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
     const bool live = b < p.NB && chain_on(p, b);
     int4 bi = make_int4(0, 0, 0, 0);
     if (b < p.NB) bi = p.blk[b];
+    check_previous_stage(p_, b, bi);
     const int64_t bfirst = bi.z, blast = bi.w;
     typename CH::Carry c = CH::init_cold(p);
     typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
@@ -1774,6 +1835,7 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state cha
     if (b < p.NB) bi = p.blk[b];
     int lastLen = p.B;
     if (!CH::FWD && live) lastLen = p.blk[bi.w].y;
+    check_previous_stage(p, b, bi);
     typename CH::Carry c = CH::init_cold(p);
     typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
     typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
@@ -1809,6 +1871,7 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natfwd(Prm p) {
     int4 bi = make_int4(0, 0, 0, 0);
     if (b < p.NB) bi = p.blk[b];
     const int lastLen = p.B;
+    check_previous_stage(p, b, bi);
     typename DCH::Carry c = DCH::init_cold(p);
     typename DCH::Carry *cin = reinterpret_cast<typename DCH::Carry *>(p.carryIn);
     typename DCH::Carry *cout = reinterpret_cast<typename DCH::Carry *>(p.carryOutA);
@@ -1843,6 +1906,7 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
     if (b < p.NB) bi = p.blk[b];
     int lastLen = p.B;
     if (live) lastLen = p.blk[bi.w].y;
+    check_previous_stage(p, b, bi);
     typename DCH::Carry c = DCH::init_cold(p);
     typename DCH::Carry *cin = reinterpret_cast<typename DCH::Carry *>(p.carryIn);
     typename DCH::Carry *cout = reinterpret_cast<typename DCH::Carry *>(p.carryOutA);

@@ -204,6 +204,14 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     char *ci_, *coa, *cob;
     CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
     p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;
+    {
+        // second (carry-in, carry-out) set: consecutive stages alternate, so that a stage's carries survive until the next
+        // speculative kernel has checked them (folded validation, run_chain)
+        char *b0, *b1;
+        CHECK(dalloc(c, &b0, nb * 32)); CHECK(dalloc(c, &b1, nb * 32));
+        c->carrySet[0][0] = ci_; c->carrySet[0][1] = coa; c->carrySet[1][0] = b0; c->carrySet[1][1] = b1;
+        c->pendChk = csr_ctx::PendingCheck{};
+    }
     c->configured = true;
     c->rs = csr_run_stats{};
     return 0;

@@ -200,6 +200,17 @@ struct csr_ctx {
     DevBuf stageBuf;                    // host -> device staging of per-bin vectors (csr_batch_upload_multipliers)
     DevBuf bgBuf, wrBuf, textBuf;       // host-buffer background solver / bedGraph writer work space (this device)
     hipStream_t side = nullptr;         // NIS/NLL epilogue runs here, concurrently with the smoother chain
+    // Folded validation (Prm::prevKind): a clean optimistic stage leaves its check to the next speculative kernel; the two use
+    // different carry sets.  pendChk = the check that has not been handed to a kernel yet (flushed by read_mail).
+    struct PendingCheck {
+        bool valid = false;
+        int kind = 0, stage = 0;
+        const void *cin = nullptr, *cout = nullptr;
+        const unsigned char *active = nullptr;
+    } pendChk;
+    void *carrySet[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [set][carryIn, carryOutA]
+    int carryToggle = 0;
+    bool foldCheck = true;              // CONSENRICH_AMD_FOLD_CHECK=0: every stage launches its own validation kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // profiling
     bool profiling = false;
@@ -237,6 +248,8 @@ static void free_batch(csr_ctx *c) {
     c->pendExport = 0;
     c->dMail = nullptr;
     c->dChainQ = nullptr;
+    c->pendChk = csr_ctx::PendingCheck{};
+    c->carrySet[0][0] = c->carrySet[0][1] = c->carrySet[1][0] = c->carrySet[1][1] = nullptr;
     c->kapScratch[0] = c->kapScratch[1] = nullptr;
     c->kapIn = c->kapOut = nullptr;
     c->bg = csr_ctx::BgState{};
@@ -292,6 +305,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_D"))) c->natOutD = atoi(e) != 0;
