@@ -2525,8 +2525,16 @@ __global__ __launch_bounds__(256) void k_fill_rows(float *dst, int64_t rows, flo
 }
 
 // natural xs0 -> residuals (pyx:6846-6848): resid[g][j] = float(data[j][g] - xs0[g]); (m, Npad) -> (Npad, m) through LDS
+// (Both residual kernels also carry a pending folded validation, Prm::prevKind: the smoother stage's check when the
+// residuals are the next launch of the stream -- one thread per block, the grid always has more threads than blocks.)
+__device__ __forceinline__ void resid_prologue_check(const Prm &p) {
+    if (p.prevKind == CK_NONE) return;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b < p.NB) check_previous_stage(p, b, p.blk[b]);
+}
 __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
     extern __shared__ float tileR[];                 // [m][65]
+    resid_prologue_check(p);
     const int64_t g0 = (int64_t)blockIdx.x * 64;
     const int t = threadIdx.x;
     const int gl = t & 63, r0 = t >> 6;
@@ -2553,6 +2561,7 @@ template <int K>
 __global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
     extern __shared__ float tileR[];                 // [m][K*64+4]: the row stride keeps float4 rows 16-B aligned
     constexpr int RS = K * 64 + 4;
+    resid_prologue_check(p);
     const int64_t g0 = (int64_t)blockIdx.x * (K * 64);
     const int t = threadIdx.x;
     const int q = t & 15, r0 = t >> 4;               // q: group of 4 bins, r0: sample row within a sweep of 16

@@ -874,20 +874,24 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(nat_array(c, CSR_ARR_XS, &xs));
         CHECK(nat_array(c, CSR_ARR_RESID, &res));
         Scope sc(c, "residuals");
+        Prm pr = c->p;
+        pr.xTolUlps = c->xTolUlps;
+        // grid x 256 threads >= blocks: Npad / (K * 64) workgroups, K <= 4, block length >= 32
+        if ((int64_t)((c->Npad + 255) / 256) * 256 >= c->NB) take_pending_check(c, pr);
         if ((c->m & 3) == 0) {
             const int K = (c->residTile == 1 || c->residTile == 2 || c->residTile == 4) ? c->residTile : 1;
             const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
             const dim3 grid((unsigned)((c->Npad + K * 64 - 1) / (K * 64)));
             if (K == 4 && lds <= 65536)
-                hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, c->p, xs, d, res, c->Npad);
+                hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, pr, xs, d, res, c->Npad);
             else if (K == 2 && lds <= 65536)
-                hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, c->p, xs, d, res, c->Npad);
+                hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, pr, xs, d, res, c->Npad);
             else
                 hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
-                                   c->stream, c->p, xs, d, res, c->Npad);
+                                   c->stream, pr, xs, d, res, c->Npad);
         } else
             hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
-                               c->p, xs, d, res, c->Npad);
+                               pr, xs, d, res, c->Npad);
         LAUNCH_CHECK("k_resid");
     }
     if (lateD) {
