@@ -408,7 +408,8 @@ def test_ecm_with_failed_optimistic_validations_follows_the_reference_sequence(p
         got = [(int(o.iters_done), paths[c], b.download(c, "xs"), b.download(c, "Ps"), b.download(c, "kappa"))
                for c, o in enumerate(outs)]
         rs = b.run_stats()
-    assert rs["pipeline_redos"] >= 1 and (rs["reruns_p"] + rs["reruns_x"] + rs["reruns_b"]) > 0, rs
+    deferred = os.environ.get("CONSENRICH_AMD_DEFER", "1") != "0" and os.environ.get("CONSENRICH_AMD_DEFER_ITER", "1") != "0"
+    assert (rs["reruns_p"] + rs["reruns_x"] + rs["reruns_b"]) > 0 and (rs["pipeline_redos"] >= 1 or not deferred), rs
     for c, (d_, v_) in enumerate(sets):
         n = n_list[c]
         r = oracle.cfixedBackgroundECM(matrixData=d_, matrixPluginMuncInit=v_, matrixF=np.asarray(cases.F_TREND, np.float32),
