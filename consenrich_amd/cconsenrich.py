@@ -4,7 +4,7 @@ Same names, keyword arguments, defaults, return tuples and error behaviour as th
 (/root/reference/src/consenrich/cconsenrich.pyx: cforwardPass :6393, cbackwardPass :6635, cforwardPassLevel :6853,
 cbackwardPassLevel :7052, cfixedBackgroundECMLevel :7153, cfixedBackgroundECM :7660,
 cExpectedTransitionResidualSums :710, cExpectedTransitionResidualSumsLevel :818); the arithmetic runs on an MI355X
-through the C ABI in include/consenrich_amd.h (ctypes, no torch).  ``core.py`` resolves these callables by module
+through the C ABI in include/consenrich_amd.h (ctypes only).  ``core.py`` resolves these callables by module
 attribute at call time (core.py:3286-3290), so ``consenrich.cconsenrich.<name> = consenrich_amd.cconsenrich.<name>``
  routes the reference's own ``runConsenrich`` through the GPU.
 
@@ -90,11 +90,6 @@ def _model(d, matrixF, matrixQ0, stateInit, stateCovarInit, pad, oMin, oMax, pMi
     return mdl
 
 
-def _flat_store(dst, src):
-    """The Cython loops write through raw row-major pointers (pyx:498-508): mirror that on the caller's buffer."""
-    dst.reshape(-1)[: src.size] = src.reshape(-1)
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # forward pass
 # ------------------------------------------------------------------------------------------------------------------
@@ -170,26 +165,20 @@ def _forward(d, matrixData, matrixPluginMuncInit, matrixF, matrixQ0, intervalToB
     flags |= L.USE_APN if useAPN else 0
     flags |= L.RETURN_NLL if returnNLL else 0
     flags |= L.NLL_IN_D if storeNLLInD else 0
-    Dbuf = np.empty(n, dtype=np.float32)
     io = L.FwdIO()
     io.m, io.n = m, n
     io.data, io.munc = L.fp(data), L.fp(munc)
     io.lam, io.kappa, io.qscale = L.fp(lam), L.fp(kap), L.fp(qs)
     io.flags = flags
-    io.D = L.fp(Dbuf)
+    # The Cython loops write through raw row-major pointers (pyx:498-508): the library does the same, straight into the
+    # caller's (C-contiguous, checked above) buffers -- the first n*d, n*d*d and (n-1)*d*d floats; nothing is staged or
+    # copied on the host (at chr1 x 32 the bounce buffers and their first-touch page faults cost more than the GPU pass)
+    io.D = L.fp(vectorD)
     if doStore:
-        xf = np.empty((n, d), np.float32)
-        Pf = np.empty((n, d, d), np.float32)
-        pnb = np.zeros((n, d, d), np.float32)
-        io.xf, io.Pf, io.pnoise = L.fp(xf), L.fp(Pf), L.fp(pnb)
+        pn_dst = pn if pn.size else np.empty((1, d, d), np.float32)      # n == 1: no entry is written
+        io.xf, io.Pf, io.pnoise = L.fp(sf), L.fp(sc), L.fp(pn_dst)
     out = L.FwdOut()
     L.check(L.lib().csr_forward_pass(C.byref(mdl), C.byref(io), C.byref(out)))
-    vectorD[:n] = Dbuf
-    if doStore:
-        _flat_store(sf, xf)
-        _flat_store(sc, Pf)
-        if n > 1:
-            _flat_store(pn, pnb[: n - 1])
     phiHat = float(np.float32(out.sum_d / float(n)))
     if returnNLL:
         return (phiHat, 0, vectorD, float(out.sum_nll))
@@ -259,23 +248,33 @@ def _backward(d, matrixData, matrixF, stateForward, stateCovarForward, pNoiseFor
     if m <= 0:
         raise ValueError("matrixData must have at least one track")
     mdl = _model(d, matrixF, np.eye(2, dtype=np.float32), 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0)
-    xf_c = np.ascontiguousarray(xf[:n, :d])
-    Pf_c = np.ascontiguousarray(Pf[:n, :d, :d])
-    pn_c = np.zeros((n, d, d), np.float32)
-    if n > 1:
-        pn_c[: n - 1] = pn[: n - 1, :d, :d]
-    xs_b = np.empty((n, d), np.float32)
-    Ps_b = np.empty((n, d, d), np.float32)
-    lag_b = np.zeros((max(n - 1, 1), d, d), np.float32)
-    res_b = np.empty((n, m), np.float32)
+    # inputs: the library reads n rows of xf / Pf and n - 1 rows of pNoise; a caller array whose rows are exactly (d) /
+    # (d, d) wide is read in place, anything wider is packed first
+    xf_c = xf if xf.shape[1] == d else np.ascontiguousarray(xf[:n, :d])
+    Pf_c = Pf if Pf.shape[1:] == (d, d) else np.ascontiguousarray(Pf[:n, :d, :d])
+    if pn.shape[1:] == (d, d) and pn.shape[0] >= max(n - 1, 1):
+        pn_c = pn
+    else:
+        pn_c = np.zeros((max(n - 1, 1), d, d), np.float32)
+        if n > 1:
+            pn_c[: n - 1] = pn[: n - 1, :d, :d]
+    # outputs: written in place when the caller's (or the freshly allocated) array has exactly the shape the pass fills;
+    # larger preallocated arrays (`shape[0] >= n`, pyx:6545-6561) go through a bounce buffer and a sliced store
+    rows = min(n - 1, lag.shape[0])  # `if k < lagCovSmoothedArr.shape[0]` pyx:6840
+    xs_b = xs if xs.shape == (n, d) else np.empty((n, d), np.float32)
+    Ps_b = Ps if Ps.shape == (n, d, d) else np.empty((n, d, d), np.float32)
+    lag_b = lag if (lag.shape[1:] == (d, d) and lag.shape[0] >= max(n - 1, 1)) else np.zeros((max(n - 1, 1), d, d), np.float32)
+    res_b = res if res.shape == (n, m) else np.empty((n, m), np.float32)
     L.check(L.lib().csr_backward_pass(C.byref(mdl), m, n, L.fp(data), L.fp(xf_c), L.fp(Pf_c), L.fp(pn_c),
                                       L.fp(xs_b), L.fp(Ps_b), L.fp(lag_b), int(lag_b.shape[0]), L.fp(res_b)))
-    xs[:n, :d] = xs_b
-    Ps[:n, :d, :d] = Ps_b
-    rows = min(n - 1, lag.shape[0])  # `if k < lagCovSmoothedArr.shape[0]` pyx:6840
-    if rows > 0:
+    if xs_b is not xs:
+        xs[:n, :d] = xs_b
+    if Ps_b is not Ps:
+        Ps[:n, :d, :d] = Ps_b
+    if lag_b is not lag and rows > 0:
         lag[:rows, :d, :d] = lag_b[:rows]
-    res[:n, :m] = res_b
+    if res_b is not res:
+        res[:n, :m] = res_b
     return (xs, Ps, lag, res)
 
 

@@ -3,7 +3,7 @@
 //
 // The reference has nothing to mirror here (chromosomes are a sequential loop in one process, consenrich.py:8809).  RCCL is
 // bound at run time (dlopen of librccl.so.1): the library loads, and every single-GPU entry point works, on a machine
-// without RCCL; only the csr_comm_* entry points need it.  No PyTorch anywhere: the caller hands over the 128-byte unique id
+// without RCCL; only the csr_comm_* entry points need it.  The caller hands over the 128-byte unique id
 // (created by rank 0 with csr_comm_unique_id and distributed by the caller's launcher -- bench.py uses a file on the node).
 
 #include <dlfcn.h>

@@ -26,6 +26,45 @@ static csr_ctx *default_ctx() {
     return g_default;
 }
 
+// Freshly allocated NumPy outputs are unmapped pages: a D2H copy into them runs at the first-touch page-fault rate
+// (~10 GB/s on one thread, scripts/ubench/pcie.hip) -- five times slower than the PCIe copy itself, and at chr1 x 32 the
+// residual matrix alone is 159 MB.  A few host threads touch the pages (read a byte, write it back: contents unchanged)
+// WHILE the upload and the kernels run, so the downloads land in mapped memory.  CONSENRICH_AMD_PREFAULT_THREADS=0 disables.
+struct Prefault {
+    std::vector<std::thread> th;
+    int nthreads = 8;
+    Prefault() {
+        if (const char *e = getenv("CONSENRICH_AMD_PREFAULT_THREADS")) nthreads = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && nthreads > hw) nthreads = hw;
+    }
+    void add(void *ptr, size_t bytes) {
+        if (!ptr || nthreads <= 0 || bytes < ((size_t)4 << 20)) return;
+        char *base = static_cast<char *>(ptr);
+        const size_t per = ((bytes + nthreads - 1) / nthreads + 4095) / 4096 * 4096;
+        for (int t = 0; t < nthreads; ++t) {
+            const size_t lo = per * (size_t)t;
+            if (lo >= bytes) break;
+            const size_t hi = std::min(bytes, lo + per);
+            th.emplace_back([base, lo, hi] {
+                for (size_t o = lo; o < hi; o += 4096) {
+                    volatile char *q = base + o;
+                    const char v = *q;
+                    *q = v;
+                }
+                volatile char *last = base + (hi - 1);
+                const char v = *last;
+                *last = v;
+            });
+        }
+    }
+    void join() {
+        for (auto &t : th) t.join();
+        th.clear();
+    }
+    ~Prefault() { join(); }
+};
+
 static int configure_single(csr_ctx *c, const csr_model *mdl, int64_t m, int64_t n) {
     const bool reuse = c->configured && c->chains.size() == 1 && c->chains[0].n == n && c->m == m &&
                        c->mdl.state_dim == mdl->state_dim;
@@ -57,6 +96,14 @@ extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_
     if ((io->flags & CSR_USE_QSCALE) && !io->qscale) return fail("CSR_USE_QSCALE without qscale");
     csr_ctx *c = default_ctx();
     if (!c) return -1;
+    const int dd = mdl->state_dim == 1 ? 1 : 2;
+    Prefault pf;
+    pf.add(io->D, sizeof(float) * (size_t)io->n);
+    if (io->xf && io->Pf && io->pnoise) {
+        pf.add(io->xf, sizeof(float) * (size_t)io->n * dd);
+        pf.add(io->Pf, sizeof(float) * (size_t)io->n * dd * dd);
+        if (io->n > 1) pf.add(io->pnoise, sizeof(float) * (size_t)(io->n - 1) * dd * dd);
+    }
     CHECK(configure_single(c, mdl, io->m, io->n));
     CHECK(csr_batch_upload(c, 0, io->data, io->munc));
     CHECK(csr_batch_upload_multipliers(c, 0, (io->flags & CSR_USE_LAMBDA) ? io->lambda : nullptr,
@@ -65,6 +112,7 @@ extern "C" int csr_forward_pass(const csr_model *mdl, const csr_fwd_io *io, csr_
     CHECK(csr_batch_stats(c));
     CHECK(csr_batch_forward(c, io->flags, &out->sum_d, &out->sum_nll));
     CHECK(csr_batch_export(c, CSR_EXPORT_FORWARD));
+    pf.join();
     CHECK(csr_batch_download(c, 0, CSR_ARR_D, io->D));
     if (io->xf) {
         if (!io->Pf || !io->pnoise) return fail("xf/Pf/pnoise must be given together");
@@ -84,6 +132,12 @@ extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, con
     if (lag_rows < std::max<int64_t>(n - 1, 1)) return fail("lagCovSmoothed too small");
     csr_ctx *c = default_ctx();
     if (!c) return -1;
+    const int dd = mdl->state_dim == 1 ? 1 : 2;
+    Prefault pf;
+    pf.add(resid, sizeof(float) * (size_t)n * (size_t)m);
+    pf.add(xs, sizeof(float) * (size_t)n * dd);
+    pf.add(Ps, sizeof(float) * (size_t)n * dd * dd);
+    if (n > 1) pf.add(lag, sizeof(float) * (size_t)(n - 1) * dd * dd);
     CHECK(configure_single(c, mdl, m, n));
     // only `data` matters for the smoother (residuals); munc is not an input of cbackwardPass
     const ChainInfo &ci = c->chains[0];
@@ -100,6 +154,7 @@ extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, con
     c->fwdFlags = 0;
     CHECK(backward_impl(c, true, nullptr));
     CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));
+    pf.join();
     CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
     CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
     CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));
@@ -119,12 +174,19 @@ extern "C" int csr_fixed_background_ecm(const csr_model *mdl, const csr_ecm_cfg 
     if (cfg->use_kappa && !kappa) return fail("use_kappa without kappa buffer");
     csr_ctx *c = default_ctx();
     if (!c) return -1;
+    const int dd = mdl->state_dim == 1 ? 1 : 2;
+    Prefault pf;
+    pf.add(resid, sizeof(float) * (size_t)n * (size_t)m);
+    pf.add(xs, sizeof(float) * (size_t)n * dd);
+    pf.add(Ps, sizeof(float) * (size_t)n * dd * dd);
+    if (n > 1) pf.add(lag, sizeof(float) * (size_t)(n - 1) * dd * dd);
     CHECK(configure_single(c, mdl, m, n));
     CHECK(csr_batch_upload(c, 0, data, munc));
     CHECK(csr_batch_upload_multipliers(c, 0, cfg->use_lambda ? lambda : nullptr, cfg->use_kappa ? kappa : nullptr, qscale));
     CHECK(csr_batch_stats(c));
     CHECK(csr_batch_ecm(c, cfg, qscale ? CSR_USE_QSCALE : 0u, out, nll_path));
     CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID | CSR_EXPORT_MULT));
+    pf.join();
     CHECK(csr_batch_download(c, 0, CSR_ARR_XS, xs));
     CHECK(csr_batch_download(c, 0, CSR_ARR_PS, Ps));
     CHECK(csr_batch_download(c, 0, CSR_ARR_LAG, lag));

@@ -4,7 +4,7 @@ Chromosomes/contigs are fully independent fits (reference: sequential loop conse
 state inside runConsenrich), so the path shards with NO data-path collective: every rank fits its own chains with its
 own DeviceBatch.  The only communication is the final gather of the per-bin output tracks, done once per job over RCCL /
 xGMI: `RcclComm` binds the library's csr_comm_* entry points (RCCL itself is dlopen'ed by libconsenrich_amd.so) -- the
-tracks are packed on the device straight from the exported arrays and all-gathered, no host bounce, NO PyTorch.  The
+tracks are packed on the device straight from the exported arrays and all-gathered, no host bounce.  The
 rendezvous (rank 0's 128-byte unique id) goes through a file on the node, keyed by the launcher's MASTER_PORT and process id.
 The host-side bookkeeping (ownership, packed layout, re-assembly in genome order) is transport-agnostic (`pack_layout`,
 `unpack_gathered`, `gather_tracks`) and is what the world-size-2 CPU test drives over gloo.
@@ -101,7 +101,7 @@ def gather_tracks(local: Dict[int, np.ndarray], lengths: Sequence[int], row_widt
 
 def _rendezvous_path() -> str:
     """One file per job on the node: the launcher's port + its process id (every rank of a node is a child of the same
-    launcher process: `python -m torch.distributed.run`, mpirun, a shell loop ...); CONSENRICH_AMD_RDZV_FILE overrides."""
+    launcher process: a distributed launcher, mpirun, a shell loop ...); CONSENRICH_AMD_RDZV_FILE overrides."""
     explicit = os.environ.get("CONSENRICH_AMD_RDZV_FILE")
     if explicit:
         return explicit

@@ -12,8 +12,9 @@ if os.environ.get("SHARD"):      # "8:0" = the contigs rank 0 of 8 would own
     from consenrich_amd.sharding import lpt_assign
     w, r = map(int, os.environ["SHARD"].split(":")); lengths = [lengths[i] for i in lpt_assign(lengths, w)[r]]
 b = DeviceBatch(0); b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234); b.stats(); b.synchronize()
-for rep in range(2):
-    b.profile(True); t = time.perf_counter()
+prof = os.environ.get("PROFILE", "1") == "1"      # PROFILE=0: wall time without the per-kernel event pairs
+for rep in range(3):
+    b.profile(prof); t = time.perf_counter()
     outs, paths = b.ecm(max_iters=iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
     b.synchronize(); dt = time.perf_counter() - t
     kt = b.kernel_times(); b.profile(False)

@@ -205,23 +205,22 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
                      C.sizeof(L.RunStats)]
 
 
-def test_qseed_posterior_host_tail_matches_reference_golden_vectors():
-    """csr_qseed_posterior is host arithmetic inside the product library (no device call): the grid posterior of the Q0
-    seed (pyx:1905-2146) against the golden vectors of the compiled reference, here on the CPU."""
-    import os
-
+def test_qseed_posterior_fails_loudly_without_a_gpu():
+    """The grid posterior of the Q0 seed (pyx:1905-2146) runs on the device since round 2 (csr_qseed_post.h; its golden
+    vectors are checked under -m gpu, tests/test_gpu_qseed.py): without a GPU the call must raise, not compute on the host."""
     import numpy as np
+    import pytest
 
     import qseed_cases as qc
+    from conftest import gpu_available
+    from consenrich_amd import _lib as L
     from consenrich_amd import qseed
 
-    golden = os.path.join(os.path.dirname(__file__), "golden")
-    for case in qc.native_cases():
-        if case["kind"] != "post":
-            continue
-        with np.load(os.path.join(golden, case["name"] + ".npz")) as z:
-            gold = {k: z[k] for k in z.files}
-        qc.same(qc.run_native(qseed, case), gold, rtol=1e-12)
+    if gpu_available():
+        pytest.skip("a GPU is visible: the device path is covered by tests/test_gpu_qseed.py")
+    case = next(c for c in qc.native_cases() if c["kind"] == "post")
+    with pytest.raises(L.ConsenrichAMDError, match="no CPU fallback"):
+        qc.run_native(qseed, case)
 
 
 def test_qseed_mirror_argument_validation_without_a_gpu():
@@ -256,5 +255,5 @@ def test_qseed_mirror_argument_validation_without_a_gpu():
                         ((one, one, one, 1e-5, 1.0, 8.0, "s", 1e-5, 8, math.log(4.0), 8.0, 0), "gridSize must be positive")):
         with pytest.raises(ValueError, match=msg):
             amd.cQSeedPosteriorFromTransitions(*kwargs)
-    with pytest.raises(ValueError, match="samplingVariances must be nonnegative finite"):     # data-dependent, host tail
-        amd.cQSeedPosteriorFromTransitions(one, -one, one, 1e-5, 1.0, 8.0, "s", *tail)
+    # (the data-dependent checks -- "samplingVariances must be nonnegative finite", ... -- are made by the device kernels:
+    # tests/test_gpu_qseed.py)
