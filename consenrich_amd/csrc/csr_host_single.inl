@@ -41,8 +41,9 @@ struct Prefault {
     void add(void *ptr, size_t bytes) {
         if (!ptr || nthreads <= 0 || bytes < ((size_t)4 << 20)) return;
         char *base = static_cast<char *>(ptr);
-        const size_t per = ((bytes + nthreads - 1) / nthreads + 4095) / 4096 * 4096;
-        for (int t = 0; t < nthreads; ++t) {
+        const int nt = (int)std::min<size_t>((size_t)nthreads, bytes / ((size_t)8 << 20) + 1);      // >= 8 MB per thread
+        const size_t per = ((bytes + nt - 1) / nt + 4095) / 4096 * 4096;
+        for (int t = 0; t < nt; ++t) {
             const size_t lo = per * (size_t)t;
             if (lo >= bytes) break;
             const size_t hi = std::min(bytes, lo + per);
