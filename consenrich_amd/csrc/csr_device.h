@@ -120,6 +120,10 @@ struct Prm {
     // compares, in its prologue, the previous stage's carry-ins with its neighbours' carry-outs (check only, no repair: a
     // mismatch is counted and the pipeline replayed).  The kernel boundary in between makes the carries visible; the two
     // stages use different carry sets.  prevKind = CK_* of the previous stage's policy (0: nothing to check).
+    // superblock view of the bit-exact state chain (k_sb_state_*): widened {gs, zbar, P00pred, P10pred} records in the view's
+    // blocking, and the index of a padding block behind the last group that lanes without a block of their own walk
+    const double4 *sbRec;
+    int64_t sbPad;
     int prevKind;
     const void *prevCarryIn, *prevCarryOut;
     unsigned int *prevCount, *prevCountPass;
@@ -2041,6 +2045,178 @@ __global__ __launch_bounds__(64) void k_state_seq_trend(Prm p, const int64_t *ch
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bit-exact state chain on SUPERBLOCKS (levelTrend).  Two float32-rounded state trajectories that start apart agree to
+// an ulp after ~10^2 bins but need ~10^4 to coincide bit for bit (the trend's ulps are far finer than the level's, so a
+// trend difference is only ever corrected when the level happens to round differently: scripts/ubench/merge_time.c), so
+// bitwise validation never passes on the batch's own 32..256-bin blocks.  This chain therefore works on a second
+// blocking of the batch: pd.B = thousands of bins per lane, window p.warm of the same order.  The machinery is that of
+// k_chain_spec / k_chain_fix (carry-in recorded, carry-out ping-pong, passes to the fixed point = the sequential
+// recursion); the walker is specialised the way k_state_seq_trend is, because a launch has only tens of wavefronts and
+// each is bound by instruction issue: records arrive widened (double4 {gs, zbar, P00pred, P10pred}), EVERY lane of a
+// wavefront walks every step (no predicates: lanes without work walk a padding block, sbPad, or recompute what they
+// already hold), loads run a register buffer ahead.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool UF>
+__device__ __forceinline__ void sb_step(const Prm &p, double &x0, double &x1, const double4 &r, float2 &out) {
+    // x0, x1: the float32 carries held as doubles (exactly)
+    if constexpr (UF) {
+        const double xp0 = r32(fma(p.F01, x1, x0));
+        const double dl = r.x * (r.y - xp0);
+        out.x = (float)fma(r.z, dl, xp0);
+        out.y = (float)fma(r.w, dl, x1);
+    } else {
+        FwdXTrend::Carry c{(float)x0, (float)x1};
+        FwdXTrend::In in;
+        in.gs = r.x; in.zbar = r.y;
+        in.cp = make_float2((float)r.z, (float)r.w);       // exact round trip of float32 values
+        FwdXTrend::step<false>(p, c, in, 0, 0, 0, 0);
+        out = make_float2(c.x0, c.x1);
+    }
+    x0 = (double)out.x;
+    x1 = (double)out.y;
+}
+// Steps [sLo, sHi) (multiples of 2 * SB_U) of the block whose slot base is `base`, all 64 lanes.  Two register buffers of
+// SB_U records; hipcc drains the memory counter (loads AND stores, one counter on gfx9) at the loop's back-edge, so the
+// body ends with SB_U steps that issue nothing: the outputs of the second half are held in registers and stored at the
+// top of the next iteration, and everything still in flight at the back-edge was issued >= SB_U steps (~0.7 us) earlier.
+// (With the stores where the results are produced the drain waited for the acknowledgement of a store issued a few
+// instructions earlier, once per 2 * SB_U steps: 73 instead of ~50 ns per step.)
+#define SB_U 16
+template <bool UF, bool STORE>
+__device__ __forceinline__ void sb_walk(const Prm &p, double &x0, double &x1, int64_t base, int sLo, int sHi) {
+    const double4 *r = p.sbRec + base + (int64_t)sLo * 64;
+    float2 *o = p.tXf + base + (int64_t)sLo * 64;
+    const int cnt = sHi - sLo;
+    double4 A[SB_U], Bq[SB_U];
+    float2 held[SB_U];
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+        A[u] = r[(int64_t)u * 64];
+        held[u] = make_float2(0.f, 0.f);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < cnt; i0 += 2 * SB_U) {
+        if constexpr (STORE) {
+            if (i0 > 0) {
+#pragma unroll
+                for (int u = 0; u < SB_U; ++u) o[(int64_t)(i0 - SB_U + u) * 64] = held[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) Bq[u] = r[(int64_t)(i0 + SB_U + u) * 64];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) {
+            float2 v;
+            sb_step<UF>(p, x0, x1, A[u], v);
+            if constexpr (STORE) o[(int64_t)(i0 + u) * 64] = v;
+        }
+        if (i0 + 2 * SB_U < cnt) {
+#pragma unroll
+            for (int u = 0; u < SB_U; ++u) A[u] = r[(int64_t)(i0 + 2 * SB_U + u) * 64];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) sb_step<UF>(p, x0, x1, Bq[u], held[u]);
+    }
+    if constexpr (STORE) {
+        if (cnt > 0) {
+#pragma unroll
+            for (int u = 0; u < SB_U; ++u) o[(int64_t)(cnt - SB_U + u) * 64] = held[u];
+        }
+    }
+}
+
+template <bool UF>
+__global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    const int64_t bfirst = bi.z;
+    const int B = p.B;
+    using Carry = FwdXTrend::Carry;
+    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
+    Carry *cout = reinterpret_cast<Carry *>(p.carryOutA);
+    double x0 = (double)(float)p.init, x1 = 0.0;       // FwdXTrend::init_true == init_cold
+    // window: the last p.warm bins before the block (qmax blocks, the farthest one from step lo); a lane whose chain starts
+    // inside the window walks from the chain's first bin, i.e. from the true prior (k_chain_spec's rule)
+    const int qmax = (p.warm + B - 1) / B;
+    const int rem = p.warm - (qmax - 1) * B;
+    const int lo = B - rem;
+    const int avail = live ? (int)(b - bfirst) : 0;
+    for (int q = qmax; q >= 1; --q) {
+        const bool act = live && q <= avail;
+        if (!__any(act)) continue;
+        const int64_t base = tbase(act ? b - q : p.sbPad, B);
+        if (q == qmax && lo > 0 && __any(act && avail == qmax)) {
+            // lanes at their chain's first block need its head too
+            const bool head = act && avail == qmax;
+            double y0 = x0, y1 = x1;
+            sb_walk<UF, false>(p, y0, y1, tbase(head ? b - q : p.sbPad, B), 0, lo);
+            x0 = head ? y0 : x0;
+            x1 = head ? y1 : x1;
+        }
+        double y0 = x0, y1 = x1;
+        sb_walk<UF, false>(p, y0, y1, base, (q == qmax) ? lo : 0, B);
+        x0 = act ? y0 : x0;
+        x1 = act ? y1 : x1;
+    }
+    if (live) cin[b] = Carry{(float)x0, (float)x1};
+    // own block (a chain's last block is walked past its end into zeroed records: those slots are nobody's, and a chain's
+    // last carry-out is never read)
+    sb_walk<UF, true>(p, x0, x1, tbase(live ? b : p.sbPad, B), 0, B);
+    if (live) cout[b] = Carry{(float)x0, (float)x1};
+}
+
+template <bool UF>
+__global__ __launch_bounds__(64) void k_sb_state_fix(Prm p, int which) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < p.NB && chain_on(p, b);
+    using Carry = FwdXTrend::Carry;
+    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
+    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
+    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    const bool check = live && b != (int64_t)bi.z;
+    const Carry prev = ocur[check ? b - 1 : 0];
+    const Carry mine = cin[live ? b : 0];
+    const bool rerun = check & (((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) != 0u);
+    if (rerun) cin[b] = prev;
+    if (live && !rerun) onxt[b] = ocur[b];
+    if (!__any(rerun)) return;
+    // the whole wavefront walks: lanes that need no re-run recompute their block from the carry-in they hold (same bits)
+    double x0 = (double)(rerun ? prev.x0 : mine.x0), x1 = (double)(rerun ? prev.x1 : mine.x1);
+    sb_walk<UF, true>(p, x0, x1, tbase(live ? b : p.sbPad, p.B), 0, p.B);
+    if (rerun) {
+        onxt[b] = Carry{(float)x0, (float)x1};
+        atomicAdd(p.rerunCount, 1u);
+        atomicAdd(p.rerunCountPass, 1u);
+    }
+}
+
+// gain + statistics records of the batch's blocking -> widened records of the superblock view (one thread per destination slot)
+__global__ __launch_bounds__(256) void k_sb_records(Prm pd, const int64_t *srcChainFirst, int srcB, const int64_t *chainOff,
+                                                    const float4 *__restrict__ gain, const double2 *__restrict__ sz,
+                                                    double4 *__restrict__ dst) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / pd.B;
+    const int s = (int)(row % pd.B);
+    const int64_t b = G * 64 + l;
+    if (b >= pd.NB || !chain_on(pd, b)) return;
+    const int4 bi = pd.blk[b];
+    if (s >= bi.y) return;
+    const int ch = pd.blkChain[b];
+    const int64_t rel = (int64_t)bi.x + s - chainOff[ch];
+    const int64_t i = tidx(srcChainFirst[ch] + rel / srcB, (int)(rel % srcB), srcB);
+    const float4 r = gain[i];
+    dst[slot] = make_double4(unpack_d(r.x, r.y), sz[i].y, (double)r.z, (double)r.w);
+}
+
 // diagnostic: a near-empty kernel (used to attribute kernel-boundary costs when profiling)
 __global__ __launch_bounds__(64) void k_probe(Prm p) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -2428,6 +2604,26 @@ __global__ __launch_bounds__(256) void k_import_f32(Prm p, const float *nat, int
     if (s >= bi.y) return;
     const int64_t g = (int64_t)bi.x + s;
     dst[slot * dstStride + dstComp] = nat[g * ncomp + comp];
+}
+
+// Records of a per-bin array from one blocking of the batch to another (same chains, same bin offsets; block lengths
+// srcB -> pd.B).  One thread per DESTINATION slot: coalesced stores, 64 scattered loads per instruction -- this moves
+// ~40 B per bin once per bit-exact forward pass (superblock view of the state chain), not worth an LDS transposition.
+template <class T>
+__global__ __launch_bounds__(256) void k_reblock(Prm pd, const int64_t *srcChainFirst, int srcB, const int64_t *chainOff,
+                                                 const T *__restrict__ src, T *__restrict__ dst) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(slot & 63);
+    const int64_t row = slot >> 6;
+    const int64_t G = row / pd.B;
+    const int s = (int)(row % pd.B);
+    const int64_t b = G * 64 + l;
+    if (b >= pd.NB || !chain_on(pd, b)) return;
+    const int4 bi = pd.blk[b];
+    if (s >= bi.y) return;
+    const int ch = pd.blkChain[b];
+    const int64_t rel = (int64_t)bi.x + s - chainOff[ch];          // bin index inside its chain
+    dst[slot] = src[tidx(srcChainFirst[ch] + rel / srcB, (int)(rel % srcB), srcB)];
 }
 
 // blocked -> blocked copy of a per-bin float array, active chains only (ECM: the kappa of a validated iteration becomes

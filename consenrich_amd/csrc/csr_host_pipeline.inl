@@ -271,6 +271,111 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
 
+// ---- superblock view of the batch (bit-exact state chain) -------------------------------------------------------
+static int ensure_sb_view(csr_ctx *c) {
+    csr_ctx::SbView &v = c->sb;
+    if (v.ready) return 0;
+    const int B = c->sbBins;
+    const int nc = (int)c->chains.size();
+    std::vector<int64_t> first((size_t)nc);
+    int64_t nb = 0;
+    for (int i = 0; i < nc; ++i) {
+        first[(size_t)i] = nb;
+        nb += (c->chains[i].n + B - 1) / B;
+    }
+    std::vector<int4> blk((size_t)nb);
+    std::vector<int> bch((size_t)nb);
+    for (int i = 0; i < nc; ++i) {
+        const ChainInfo &ci = c->chains[i];
+        const int64_t cnt = (ci.n + B - 1) / B;
+        for (int64_t k = 0; k < cnt; ++k) {
+            int4 e;
+            e.x = (int)(ci.off + k * B);
+            e.y = (int)std::min<int64_t>(B, ci.n - k * B);
+            e.z = (int)first[(size_t)i];
+            e.w = (int)(first[(size_t)i] + cnt - 1);
+            blk[(size_t)(first[(size_t)i] + k)] = e;
+            bch[(size_t)(first[(size_t)i] + k)] = i;
+        }
+    }
+    v.B = B; v.NB = nb; v.NG = (nb + 63) / 64; v.TN = v.NG * (int64_t)B * 64;
+    CHECK(dalloc(c, &v.blk, nb)); CHECK(dalloc(c, &v.blkChain, nb)); CHECK(dalloc(c, &v.chainFirst, nc));
+    HIPOK(hipMemcpyAsync(v.blk, blk.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(v.blkChain, bch.data(), sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(v.chainFirst, first.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
+    // (+ one padding group: lanes without a block of their own walk block NG * 64, zero records)
+    const int64_t TP = v.TN + (int64_t)B * 64;
+    CHECK(dalloc(c, &v.rec, TP)); CHECK(dalloc(c, &v.tXf, TP));
+    HIPOK(hipMemsetAsync(v.rec, 0, sizeof(double4) * TP, c->stream));
+    HIPOK(hipMemsetAsync(v.tXf, 0, sizeof(float2) * TP, c->stream));
+    char *q[3];
+    for (char *&x : q) CHECK(dalloc(c, &x, nb * 32));
+    v.carryIn = q[0]; v.carryOutA = q[1]; v.carryOutB = q[2];
+    v.ready = true;
+    return 0;
+}
+
+// Bit-exact state chain of the levelTrend model on the superblock view (k_sb_state_*): widen + re-block the (gain,
+// statistics) records, speculate, validate / repair to the fixed point, re-block the filtered state back.  The fixed point
+// is the sequential recursion whatever the block length.
+template <bool UF>
+static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
+    CHECK(ensure_sb_view(c));
+    CHECK(flush_pending_check(c));
+    csr_ctx::SbView &v = c->sb;
+    Prm q = p;
+    q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
+    q.sbRec = v.rec; q.sbPad = v.NG * 64; q.tXf = v.tXf;
+    q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
+    q.warm = c->sbWarm;
+    unsigned int *const cnt = reinterpret_cast<unsigned int *>(c->dMail);
+    q.rerunCount = cnt + ST_X;
+    q.rerunCountPass = cnt + MAIL_DUMMY;
+    q.prevKind = CK_NONE;
+    const int grid = (int)v.NG;
+    {
+        Scope sc(c, "state_reblock_in");
+        hipLaunchKernelGGL(k_sb_records, dim3((int)((v.TN + 255) / 256)), dim3(256), 0, c->stream, q, c->dChainFirst, c->B,
+                           c->dChainOff, p.tXin, p.tSZ, v.rec);
+    }
+    LAUNCH_CHECK("k_sb_records");
+    {
+        Scope sc(c, "fwd_state_chain");
+        hipLaunchKernelGGL(k_sb_state_spec<UF>, dim3(grid), dim3(64), 0, c->stream, q);
+    }
+    LAUNCH_CHECK("k_sb_state_spec");
+    // validation / repair passes in bursts (run_chain's rule: a burst that re-ran nothing is the fixed point; a pass that
+    // finds nothing to do costs microseconds)
+    int which = 0, burst = 1;
+    bool done = false;
+    for (int64_t it = 0; it <= v.NB + 1 && !done; ++it) {
+        {
+            Scope sc(c, "fwd_state_fix");
+            for (int rep = 0; rep < burst; ++rep) {
+                hipLaunchKernelGGL(k_sb_state_fix<UF>, dim3(grid), dim3(64), 0, c->stream, q, which);
+                which ^= 1;
+                c->rs.fix_launches++;
+            }
+        }
+        LAUNCH_CHECK("k_sb_state_fix");
+        CHECK(read_mail(c, MAIL_HDR));
+        const unsigned int fresh = take_fresh(c, ST_X);
+        if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_fix (superblocks) iter %lld reruns %u\n", (long long)it, fresh);
+        if (fresh == 0) done = true;
+        c->rs.reruns_x += fresh;
+        burst = it == 0 ? 2 : std::min(32, burst * 2);
+    }
+    if (!done) return fail("fwd_state_chain (superblocks): fix-up did not reach a fixed point");
+    {
+        Scope sc(c, "state_reblock_out");
+        hipLaunchKernelGGL(k_reblock<float2>, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, v.chainFirst, v.B, c->dChainOff,
+                           v.tXf, p.tXf);
+    }
+    LAUNCH_CHECK("k_reblock");
+    return 0;
+}
+
 // Join the side stream.  The per-chain sums (22 workgroups of 1024 threads, ~10 us) run on the main stream after the
 // join: left on the side stream behind the epilogue they starve for whole-CU slots while a bandwidth-bound kernel of the
 // main stream keeps the chip full (measured 0.64 ms instead of 0.01).
@@ -366,10 +471,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             c->fwdWindow = nullptr;
         } else if (c->mdl.state_dim == 2) {
             c->lastFwdWindow = nullptr;
+            const bool sbX = c->xTolUlps == 0 && c->sbState && !c->seqState;
             const bool seqX = c->xTolUlps == 0 && c->seqState;
-            // (the sequential state chain below costs tens of milliseconds: its gains are validated first -- one host
-            // round trip -- rather than optimistically)
-            if (seqX) dP = false;
+            // (the bit-exact state chains below cost milliseconds: their gains are validated first -- one host round
+            // trip -- rather than optimistically)
+            if (seqX || sbX) dP = false;
             if (unit_f(c, p)) CHECK(run_chain<FwdPTrendT<true>>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             else CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             if (seqX) {
@@ -383,6 +489,10 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                     hipLaunchKernelGGL(k_state_seq_trend<false>, dim3((unsigned)c->chains.size()), dim3(64), 0, c->stream, p,
                                        c->dChainFirst, c->dChainNb);
                 LAUNCH_CHECK("k_state_seq_trend");
+                dX = false;
+            } else if (sbX) {
+                if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
+                else CHECK(state_chain_superblocks<false>(c, p));
                 dX = false;
             } else
             if (unit_f(c, p)) CHECK(run_chain<FwdXTrendT<true>>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));

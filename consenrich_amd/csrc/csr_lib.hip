@@ -161,7 +161,24 @@ struct csr_ctx {
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
     bool unitFEnabled = true;   // CONSENRICH_AMD_UNITF=0: the general-F instances of the levelTrend chains even for F = [[1, f], [0, 1]]
-    bool seqState = true;       // bit-exact validation, levelTrend: sequential state chain (CONSENRICH_AMD_SEQ_STATE=0: speculative)
+    bool seqState = false;      // bit-exact validation, levelTrend: one wavefront per chain walks the state chain sequentially (CONSENRICH_AMD_SEQ_STATE=1)
+    // bit-exact validation, levelTrend (default): the state chain speculates on SUPERBLOCKS of sbBins bins with an sbWarm-bin
+    // window -- two float32-rounded state trajectories need ~10^4 bins to coincide bit for bit (scripts/ubench/merge_time.c),
+    // so the batch's own 32..256-bin blocks never validate; the gain / statistics records are re-blocked into a second view
+    // of the batch (own block table and carries) for this one chain and the filtered state is re-blocked back
+    bool sbState = true;        // CONSENRICH_AMD_SB_STATE=0: off (speculation on the batch's own blocks, or seqState)
+    int sbBins = 8192, sbWarm = 16384;      // CONSENRICH_AMD_SB_BINS / CONSENRICH_AMD_SB_WARM
+    struct SbView {
+        bool ready = false;
+        int B = 0;
+        int64_t NB = 0, NG = 0, TN = 0;
+        int4 *blk = nullptr;
+        int *blkChain = nullptr;
+        int64_t *chainFirst = nullptr;
+        double4 *rec = nullptr;     // {gs, zbar, P00pred, P10pred} per bin, + one padding group
+        float2 *tXf = nullptr;
+        void *carryIn = nullptr, *carryOutA = nullptr, *carryOutB = nullptr;
+    } sb;
     bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
     bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
     // debugging switches, read once from the environment at creation (never on the launch path)
@@ -254,6 +271,7 @@ static void free_batch(csr_ctx *c) {
     c->kapIn = c->kapOut = nullptr;
     c->bg = csr_ctx::BgState{};
     c->dActive = nullptr;
+    c->sb = csr_ctx::SbView{};
     for (auto &n : c->nat) n = nullptr;
 }
 
@@ -304,6 +322,9 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64);
+    if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;

@@ -216,13 +216,14 @@ def test_unit_f_instances_equal_the_general_ones_bit_for_bit(product, monkeypatc
 
 
 def test_ulp_tolerant_validation_stays_within_parity_budget(product, monkeypatch):
-    """(The bit-exact runs use the SPECULATIVE state chain here, CONSENRICH_AMD_SEQ_STATE=0 -- the production exact mode runs
-    that chain sequentially, one wavefront per chromosome -- so that the re-run counts of the two validation modes can be
+    """(The bit-exact runs speculate the state chain on the batch's OWN blocks here, CONSENRICH_AMD_SB_STATE=0 -- the production
+    exact mode runs that chain on 8192-bin superblocks -- so that the re-run counts of the two validation modes can be
     compared.)
     Default mode: speculative carries are accepted within 2 float32 ulps.  Against the exact sequential run the
     tracks must agree far inside the 1e-5 budget (a few ulps on the level; the trend inherits ulp(level)-sized noise,
     covered by the absolute tolerance), with large |x| (coarse ulps) to make the test bite."""
     monkeypatch.setenv("CONSENRICH_AMD_SEQ_STATE", "0")
+    monkeypatch.setenv("CONSENRICH_AMD_SB_STATE", "0")
     n_list = [60000, 7000]
     seq = _run_batch(32 * 2048, (0, 0, 0), 2, n_list, 8, 300, xtol=0)
     tol = _run_batch(64, (64, 128, 64), 2, n_list, 8, 300, xtol=2)
