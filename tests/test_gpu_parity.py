@@ -239,6 +239,27 @@ def test_ulp_tolerant_validation_stays_within_parity_budget(product, monkeypatch
                                    else 1e-6 * scale, err_msg=str(key))
 
 
+def test_exact_state_chain_on_superblocks_equals_the_sequential_kernel(product, monkeypatch):
+    """Bit-exact mode runs the levelTrend state chain on superblocks of a re-blocked view (k_sb_state_*; 8192 bins, 16384-bin
+    window by default).  With 256-bin superblocks and a 448-bin window nearly every block fails its bitwise validation
+    and the repairs cascade through the chains (partial last blocks, chains shorter than a block, a padding lane group):
+    the fixed point must still be the sequential recursion -- k_state_seq_trend, one wavefront per chain, bit for bit."""
+    n_list = [60000, 7000, 300, 1, 16640]
+    monkeypatch.setenv("CONSENRICH_AMD_SEQ_STATE", "1")
+    seq = _run_batch(0, (-1, -1, -1), 2, n_list, 8, 300, xtol=0)
+    monkeypatch.setenv("CONSENRICH_AMD_SEQ_STATE", "0")
+    for bins, warm in (("256", "448"), ("8192", "16384"), ("64", "0")):
+        monkeypatch.setenv("CONSENRICH_AMD_SB_BINS", bins)
+        monkeypatch.setenv("CONSENRICH_AMD_SB_WARM", warm)
+        sb = _run_batch(0, (-1, -1, -1), 2, n_list, 8, 300, xtol=0)
+        for key, val in seq.items():
+            if key != "stats" and not isinstance(key, str):
+                assert np.array_equal(val, sb[key]), (bins, key)
+        assert np.array_equal(sb["sn"], seq["sn"]) and np.array_equal(sb["sd"], seq["sd"])
+        if bins != "8192":
+            assert sb["stats"]["reruns_x"] > 0, sb["stats"]
+
+
 def _full_chain(mod, d, n, m, seed=4242):
     data, munc = cases.synth(n, m, seed)
     _lam, kap, _qs = cases.multipliers(n, seed)
