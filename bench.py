@@ -303,6 +303,10 @@ def main() -> int:
         extras["exact_mode"] = {"x_tol_ulps": 0, "ms_per_step": 1000.0 * ee / ex_steps, "value": total_bins * ex_steps / ee,
                                 "unit": "genomic bins/s", "steps": ex_steps, "block_len": rx["block_len"],
                                 "warm_bins": [rx["warm_p"], rx["warm_x"], rx["warm_b"]],
+                                "state_chain": {"superblock_bins": int(os.environ.get("CONSENRICH_AMD_SB_BINS", "8192")),
+                                                "window_bins": int(os.environ.get("CONSENRICH_AMD_SB_WARM", "16384")),
+                                                "note": "bitwise speculation of the state chain on a re-blocked view; "
+                                                        "reruns[1] counts superblocks re-run over 1 + steps steps"},
                                 "reruns": [rx["reruns_p"], rx["reruns_x"], rx["reruns_b"]],
                                 "fix_launches": rx["fix_launches"]}
         ex.close()
