@@ -364,7 +364,7 @@ static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
         if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_fix (superblocks) iter %lld reruns %u\n", (long long)it, fresh);
         if (fresh == 0) done = true;
         c->rs.reruns_x += fresh;
-        burst = it == 0 ? 2 : std::min(32, burst * 2);
+        burst = c->dbgLog ? 1 : (it == 0 ? 2 : std::min(32, burst * 2));      // (debug log: one pass per read-back)
     }
     if (!done) return fail("fwd_state_chain (superblocks): fix-up did not reach a fixed point");
     {
