@@ -1,11 +1,11 @@
-"""Run a few bench steps (for profiling under rocprofv3)."""
+"""Run a few bench steps (for profiling under rocprofv3).  XTOL=0: the bit-exact validation mode."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 from consenrich_amd import _lib as L
 from consenrich_amd.batch import DeviceBatch, ModelParams
 from consenrich_amd.sharding import hg38_chain_lengths
 m = int(os.environ.get("M", "32"))
-b = DeviceBatch(0)
+b = DeviceBatch(0, x_tol_ulps=int(os.environ.get("XTOL", "2")))
 lengths = hg38_chain_lengths(int(os.environ.get("BINBP", "200")))
 if os.environ.get("SHARD"):
     from consenrich_amd.sharding import lpt_assign

@@ -23,5 +23,10 @@ cp "$(find $O/sq -name '*counter_collection.csv' | head -1)" $O/${R}_pmc_sq.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_e -o f -- python3 scripts/ecm_once.py > $O/fetch_e.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_e -o w -- python3 scripts/ecm_once.py > $O/write_e.log 2>&1
 python3 scripts/pmc_traffic.py "$(find $O/fetch_e -name '*counter_collection.csv' | head -1)" "$(find $O/write_e -name '*counter_collection.csv' | head -1)" $O/${R}_pmc_traffic_ecm.json > $O/${R}_pmc_traffic_ecm.txt
-rm -rf $O/kt $O/fetch $O/write $O/sq $O/fetch_e $O/write_e
+# the bit-exact mode (superblock state chain): kernel trace of the same steps with XTOL=0
+export XTOL=0
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktx -o kt -- python3 scripts/one_step.py > $O/ktx.log 2>&1
+cp "$(find $O/ktx -name '*kernel_stats.csv' | head -1)" $O/${R}_kernel_stats_exact_mode.csv
+unset XTOL
+rm -rf $O/kt $O/ktx $O/fetch $O/write $O/sq $O/fetch_e $O/write_e
 ls -la $O
