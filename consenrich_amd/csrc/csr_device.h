@@ -26,6 +26,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace csr {
@@ -120,6 +121,16 @@ struct Prm {
     // compares, in its prologue, the previous stage's carry-ins with its neighbours' carry-outs (check only, no repair: a
     // mismatch is counted and the pipeline replayed).  The kernel boundary in between makes the carries visible; the two
     // stages use different carry sets.  prevKind = CK_* of the previous stage's policy (0: nothing to check).
+    // Warm-started speculation (ECM sweeps of small batches): consecutive sweeps differ only by the kappa of one E-step, so
+    // the carry the PREVIOUS sweep held at the first bin of a block's window is a far better start than the cold prior, and
+    // the window can be a fraction of the cold one.  ckptIn[b]: carry of the previous sweep's walk of block b at the point
+    // where a window of p.warm bins for a later (forward) / earlier (smoother) block begins; ckptOut / ckptSaveWarm: where,
+    // and for which window length, this sweep records its own.  Validation is unchanged (carry-in against the neighbour's
+    // carry-out), so a poor start costs a re-run, never a wrong result.  Null pointers = cold start / nothing recorded.
+    const void *ckptIn;
+    void *ckptOut;
+    int ckptSaveWarm;
+    unsigned int *localFixCount;    // blocks repaired inside the speculative kernel (wave_local_repair): statistics only
     // superblock view of the bit-exact state chain (k_sb_state_*): widened {gs, zbar, P00pred, P10pred} records in the view's
     // blocking, and the index of a padding block behind the last group that lanes without a block of their own walk
     const double4 *sbRec;
@@ -1687,11 +1698,65 @@ __global__ __launch_bounds__(64) void k_chain_check(Prm p) {
     check_previous_stage(p, b, bi);
 }
 
+// Wave-local validation and repair (warm-started sweeps only).  63 of a wavefront's 64 blocks have their neighbour in the
+// same wavefront: its carry-out is one lane away, so the comparison that the validation pass makes (carry-in against the
+// neighbour's carry-out) and the repair (re-run from that carry-out) can happen before the kernel ends, round by round
+// until no lane changes.  A warm-started window is short because nearly every block's start is good; the few blocks whose
+// multipliers moved a lot since the previous sweep fail, and repaired here they cost one more block walk of one wavefront
+// instead of a replay of the iteration.  The block at a wavefront's edge is still checked by the next kernel's prologue
+// (check_previous_stage) against the neighbouring wavefront's final carry-out.
+template <class CH>
+__device__ __forceinline__ typename CH::Carry wave_neighbour_carry(const typename CH::Carry &c) {
+    constexpr int NWORDS = (int)(sizeof(typename CH::Carry) / 4);
+    static_assert(sizeof(typename CH::Carry) % 4 == 0, "carries are whole words");
+    int w[NWORDS];
+    __builtin_memcpy(w, &c, sizeof(c));
+#pragma unroll
+    for (int k = 0; k < NWORDS; ++k) w[k] = CH::FWD ? __shfl_up(w[k], 1) : __shfl_down(w[k], 1);
+    typename CH::Carry r;
+    __builtin_memcpy(&r, w, sizeof(r));
+    return r;
+}
+template <class CH>
+__device__ __forceinline__ void carry_select(typename CH::Carry &dst, const typename CH::Carry &src, bool take) {
+    // word-wise (a divergent struct phi was mis-compiled once: see k_chain_fix)
+    constexpr int NWORDS = (int)(sizeof(typename CH::Carry) / 4);
+    int a[NWORDS], b[NWORDS];
+    __builtin_memcpy(a, &dst, sizeof(dst));
+    __builtin_memcpy(b, &src, sizeof(src));
+#pragma unroll
+    for (int k = 0; k < NWORDS; ++k) a[k] = take ? b[k] : a[k];
+    __builtin_memcpy(&dst, a, sizeof(dst));
+}
+template <class CH, class WCH>
+__device__ __forceinline__ void wave_local_repair(const Prm &p, typename CH::Carry &cinLane, typename CH::Carry &cOut,
+                                                  int64_t b, const int4 &bi, bool live) {
+    const int lane = threadIdx.x & 63;
+    const int64_t bfirst = bi.z, blast = bi.w;
+    const bool hasNb = live && (CH::FWD ? (lane > 0 && b > bfirst) : (lane < 63 && b < blast));
+    for (int round = 0; round < 64; ++round) {
+        const typename CH::Carry nb = wave_neighbour_carry<CH>(cOut);
+        const bool bad = hasNb & !CH::same(p, nb, cinLane);
+        if (!__any(bad)) break;
+        typename CH::Carry c2 = nb;
+        walk_block<WCH, true>(p, c2, b, bi.y, bad, bfirst, 0, p.B);
+        carry_select<CH>(cinLane, nb, bad);
+        carry_select<CH>(cOut, c2, bad);
+        if (bad) atomicAdd(p.localFixCount, 1u);
+    }
+}
+template <class CH, class = void>
+struct PlainOf { using type = CH; };
+template <class CH>
+struct PlainOf<CH, std::void_t<typename CH::Plain>> { using type = typename CH::Plain; };
+
 // Speculative pass: one lane per block, 64 consecutive blocks per wavefront.
 // NAT = true: separate instantiation whose main phase writes the reference layout through LDS tiles (walk_nat*); the
 // plain one stays as lean as before (the tile walkers cost ~50-100 VGPRs and slowed the ECM sweeps by 25 % when both
 // paths lived in one kernel).
-template <class CH, bool NAT = false, bool PCQ = false>
+// WS = true: the warm-started instance (Prm::ckptIn / ckptOut, wave_local_repair) -- a separate one, because the extra
+// code cost the plain ECM sweep kernels 8 % when it lived in them (register allocation of the hot loop).
+template <class CH, bool NAT = false, bool PCQ = false, bool WS = false>
 __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const Prm p = lane_model_if<PCQ>(p_, b);
@@ -1707,10 +1772,16 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
     const int B = p.B;
     const int qmax = (p.warm + B - 1) / B;
     const int rem = p.warm - (qmax - 1) * B;           // bins taken from the farthest block, in (0, B]
+    // recording point of this block's own checkpoint (for a window of ckptSaveWarm bins of the NEXT sweep):
+    // FWD: the window begins at step svSplit of this block; BWD: steps [0, svSplit) of this block are inside the window
+    const int svq = (WS && p.ckptSaveWarm > 0) ? (p.ckptSaveWarm + B - 1) / B : 0;
+    const int svSplit = CH::FWD ? svq * B - p.ckptSaveWarm : p.ckptSaveWarm - (svq - 1) * B;
     if constexpr (CH::FWD) {
         const int avail = live ? (int)(b - bfirst) : 0;        // preceding blocks of this chain (all full)
         const int qstart = avail < qmax ? avail : qmax;
         if (live && qstart == avail) c = CH::init_true(p);
+        else if (WS && live && p.ckptIn != nullptr && qmax > 0)      // window strictly inside the chain: start from the previous sweep's carry there
+            c = reinterpret_cast<const typename CH::Carry *>(p.ckptIn)[b - qmax];
         for (int q = qmax; q >= 1; --q) {
             const bool act = live && q <= qstart;
             if (!__any(act)) continue;
@@ -1722,19 +1793,30 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
             }
             walk_block<CH, false>(p, c, b - q, B, act, bfirst, lo, B);
         }
-        if (live) cin[b] = c;
+        typename CH::Carry cinLane = c;
+        if constexpr (!WS) { if (live) cin[b] = c; }
         if constexpr (NAT && CH::NATOUT_FWD) {
             extern __shared__ __attribute__((aligned(16))) unsigned char natTileMemF[];
             walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
+        } else if (WS && svq > 0 && p.ckptOut != nullptr) {
+            if (svSplit > 0) walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, svSplit);
+            if (live && b != blast) reinterpret_cast<typename CH::Carry *>(p.ckptOut)[b] = c;
+            walk_block<CH, true>(p, c, b, bi.y, live, bfirst, svSplit, B);
+            if constexpr (WS) {
+                if (p.ckptIn != nullptr) wave_local_repair<CH, CH>(p, cinLane, c, b, bi, live);
+            }
         } else {
             walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         }
+        if constexpr (WS) { if (live) cin[b] = cinLane; }
         if (live) cout[b] = c;
     } else {
         const int avail = live ? (int)(blast - b) : 0;         // following blocks of this chain
         const int qstart = avail < qmax ? avail : qmax;
         int lastLen = B;
         if (live) lastLen = p.blk[blast].y;
+        if (WS && live && p.ckptIn != nullptr && qmax > 0 && avail > qmax)      // window strictly inside the chain
+            c = reinterpret_cast<const typename CH::Carry *>(p.ckptIn)[b + qmax];
         for (int q = qmax; q >= 1; --q) {
             const bool act = live && q <= qstart;
             if (!__any(act)) continue;
@@ -1747,14 +1829,23 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
             }
             walk_block<CH, false>(p, c, bq, len, act, bfirst, 0, hi);
         }
-        if (live) cin[b] = c;
+        typename CH::Carry cinLane = c;
+        if constexpr (!WS) { if (live) cin[b] = c; }
         if constexpr (NAT && CH::NATOUT) {
             // dynamic LDS (sizeof(NatTiles) bytes) of this instantiation only
             extern __shared__ __attribute__((aligned(16))) unsigned char natTileMem[];
             walk_nat<CH>(p, c, b, bi.y, live, b == blast, bi.x, *reinterpret_cast<NatTiles *>(natTileMem));
+        } else if (WS && svq > 0 && p.ckptOut != nullptr) {
+            if (svSplit < B) walk_block<CH, true>(p, c, b, bi.y, live, bfirst, svSplit, B);
+            if (live && b != blast) reinterpret_cast<typename CH::Carry *>(p.ckptOut)[b] = c;
+            if (svSplit > 0) walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, svSplit);
+            if constexpr (WS) {
+                if (p.ckptIn != nullptr) wave_local_repair<CH, CH>(p, cinLane, c, b, bi, live);
+            }
         } else {
             walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, B);
         }
+        if constexpr (WS) { if (live) cin[b] = cinLane; }
         if (live) cout[b] = c;
     }
 }
@@ -1830,7 +1921,7 @@ __device__ __forceinline__ void dma_phase(const Prm &p, typename CH::Carry &c, u
     }
 }
 
-template <class CH>
+template <class CH, bool WS = false>      // WS: warm-started instance (see k_chain_spec)
 __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state chains only: they never read Q
     extern __shared__ unsigned ringMem[];
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1844,6 +1935,12 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state cha
     typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
     typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
     const int W = p.warm, T = W + p.B;
+    if (WS && p.ckptIn != nullptr && W > 0 && live) {
+        // warm-started window (see Prm::ckptIn): strictly inside the chain, begin from the previous sweep's carry there
+        const int qw = (W + p.B - 1) / p.B;
+        const int64_t avail = CH::FWD ? b - (int64_t)bi.z : (int64_t)bi.w - b;
+        if (avail > qw) c = reinterpret_cast<const typename CH::Carry *>(p.ckptIn)[CH::FWD ? b - qw : b + qw];
+    }
     LaneCursor<CH::FWD> cons, iss;
     cons.init(p, W, b, live, bi, lastLen);
     iss.init(p, W, b, live, bi, lastLen);
@@ -1854,9 +1951,22 @@ __global__ __launch_bounds__(64) void k_chain_spec_dma(Prm p) {     // state cha
     }
     int t = 0;
     dma_phase<CH, false>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W, T);
-    if (live) cin[b] = c;
+    typename CH::Carry cinLane = c;
+    if constexpr (!WS) { if (live) cin[b] = c; }
+    if (WS && p.ckptSaveWarm > 0 && p.ckptOut != nullptr) {
+        // main-phase steps before this block's own checkpoint: FWD the bins ahead of the next sweep's window, BWD the bins
+        // behind it (the same count in both directions)
+        const int sq = (p.ckptSaveWarm + p.B - 1) / p.B;
+        const int done = sq * p.B - p.ckptSaveWarm;
+        dma_phase<CH, true>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, W + done, T);
+        if (live && b != (int64_t)bi.w) reinterpret_cast<typename CH::Carry *>(p.ckptOut)[b] = c;    // (a chain's last block is nobody's window start)
+    }
     dma_phase<CH, true>(p, c, ringMem, b, live, bi, lastLen, cons, iss, t, T, T);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (WS) {
+        if (p.ckptIn != nullptr) wave_local_repair<CH, typename PlainOf<CH>::type>(p, cinLane, c, b, bi, live);
+        if (live) cin[b] = cinLane;
+    }
     if (live) cout[b] = c;
 }
 

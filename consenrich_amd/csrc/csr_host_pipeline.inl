@@ -99,6 +99,7 @@ static void grow_warm(csr_ctx *c, int &warmRef, unsigned int fresh) {
 }
 static int &stage_warm(csr_ctx *c, int stage) {
     if (stage == ST_P && c->fwdWindow) return *c->fwdWindow;        // fused forward chain with its own window
+    if (stage == ST_B && c->bwdWindow) return *c->bwdWindow;        // warm-started smoother sweep
     return stage == ST_P ? c->warmP : (stage == ST_X ? c->warmX : c->warmB);
 }
 static int64_t &stage_reruns(csr_ctx *c, int stage) {
@@ -158,6 +159,16 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                         hipLaunchKernelGGL((k_chain_spec_dmawarm_natfwd<FwdTrendFusedDma<2, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 7 * 64, tl), c->stream, p);
                     launched = true;
+                } else if (c->useDmaFused && !p.natOut && !pcq && p.ckptOut != nullptr) {
+                    // warm-started ECM sweep (kappa only is the reference's default loop)
+                    const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
+                    if (mm == F_KAPPA)
+                        hipLaunchKernelGGL((k_chain_spec_dma<FwdTrendFusedDma<1, CH::UNITF>, true>), dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 5 * 64, c->stream, p);
+                    else
+                        hipLaunchKernelGGL((k_chain_spec_dma<FwdTrendFusedDma<2, CH::UNITF>, true>), dim3(grid), dim3(64),
+                                           sizeof(unsigned) * DMA_R * 7 * 64, c->stream, p);
+                    launched = true;
                 } else if (c->useDmaFused && !p.natOut && !pcq) {
                     const uint32_t mm = p.flags & (F_LAMBDA | F_KAPPA | F_QSCALE);
                     if (mm == 0)
@@ -194,6 +205,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             }
             if (!launched) {
                 if (pcq) hipLaunchKernelGGL((k_chain_spec<CH, false, true>), dim3(grid), dim3(64), 0, c->stream, p);
+                else if (p.ckptOut != nullptr) hipLaunchKernelGGL((k_chain_spec<CH, false, false, true>), dim3(grid), dim3(64), 0, c->stream, p);
                 else hipLaunchKernelGGL((k_chain_spec<CH, false, false>), dim3(grid), dim3(64), 0, c->stream, p);
             }
         }
@@ -269,6 +281,40 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         if (c->dbgForceIters == 0) burst = it == 0 ? 2 : std::min(32, burst * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
+}
+
+// ---- warm-started speculation of the ECM sweeps (Prm::ckptIn) -----------------------------------------------------
+// Fills the checkpoint fields of `p` for the chain about to be launched in direction fwd / !fwd and returns the window
+// variable to use (nullptr: the cold one).  Call ws_launched() after the launch.
+static int ws_prepare(csr_ctx *c, Prm &p, bool fwd, int **window) {
+    *window = nullptr;
+    p.ckptIn = nullptr; p.ckptOut = nullptr; p.ckptSaveWarm = 0;
+    if (!c->wsActive || !c->wsEnabled || c->xTolUlps == 0 || p.chainQ != nullptr) return 0;
+    // Only the latency-bound batches gain: those the block-length rule gives 32-bin blocks (< 2 M bins: a 1/8-genome shard,
+    // 0.64 -> 0.53 ms per ECM iteration).  Larger ones are bandwidth-bound, walk mostly their own block (64 .. 256 bins) and
+    // have thousands of wavefront edges -- an edge block that fails costs a replay of the iteration: measured 0.88 -> 1.05 ms
+    // on a quarter genome, 2.31 -> 2.46 ms on the genome.
+    if (c->B > c->wsMaxBlock) return 0;
+    int &warm = fwd ? c->wsWarmF : c->wsWarmB;
+    if (warm >= (fwd ? c->warmFM : c->warmB)) return 0;       // widened up to the cold window: nothing left to gain
+    void **ck = fwd ? c->ckF : c->ckB;
+    for (int k = 0; k < 2; ++k)
+        if (!ck[k]) { char *q; CHECK(dalloc(c, &q, c->NB * 32)); ck[k] = q; }
+    const int saved = fwd ? c->wsSavedF : c->wsSavedB;
+    const int sweep = fwd ? c->wsSweepF : c->wsSweepB;
+    p.ckptOut = ck[(sweep + 1) & 1];
+    p.ckptSaveWarm = warm;
+    p.localFixCount = reinterpret_cast<unsigned int *>(c->dMail) + MAIL_LOCAL;
+    if (!c->wsCold && saved == warm && saved > 0) {
+        p.ckptIn = ck[sweep & 1];
+        *window = &warm;
+    }
+    return 0;
+}
+static void ws_launched(csr_ctx *c, const Prm &p, bool fwd) {
+    if (p.ckptOut == nullptr) return;
+    if (fwd) { c->wsSavedF = p.ckptSaveWarm; c->wsSweepF += 1; }
+    else { c->wsSavedB = p.ckptSaveWarm; c->wsSweepB += 1; }
 }
 
 // ---- superblock view of the batch (bit-exact state chain) -------------------------------------------------------
@@ -458,6 +504,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             c->fwdWindow = mult ? &c->warmFM : &c->warmP;
             dX = false;
             p.predCompact = c->mdl.state_dim == 2 ? 1 : 0;
+            if (!natOut && mult && c->mdl.state_dim == 2) {        // ECM sweep: window from the previous sweep's carries
+                int *w = nullptr;
+                CHECK(ws_prepare(c, p, true, &w));
+                if (w) c->fwdWindow = w;
+            }
             if (natOut && c->natOutEnabled && c->natOutFwd && c->mdl.state_dim == 2) {     // xf / Pf also in the reference layout
                 CHECK(nat_array(c, CSR_ARR_XF, &p.natXs));
                 CHECK(nat_array(c, CSR_ARR_PF, &p.natPs));
@@ -467,6 +518,8 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<FwdTrendFusedT<true>>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else CHECK(run_chain<FwdLevelFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
+            ws_launched(c, p, true);
+            p.ckptIn = nullptr; p.ckptOut = nullptr; p.ckptSaveWarm = 0;
             c->lastFwdWindow = c->fwdWindow;
             c->fwdWindow = nullptr;
         } else if (c->mdl.state_dim == 2) {
@@ -557,6 +610,12 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
     const bool dB = defer && c->deferEnabled && c->optimistic[ST_B];
+    if (!natOut && c->mdl.state_dim == 2 && estep != 0) {       // ECM sweep: window from the previous sweep's carries
+        int *w = nullptr;
+        CHECK(ws_prepare(c, p, false, &w));
+        c->bwdWindow = w;
+    }
+    struct BwdWindowReset { csr_ctx *c; ~BwdWindowReset() { c->bwdWindow = nullptr; } } bwdWindowReset{c};
     if (p.qFromKappa && !natOut) {
         if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<BwdTrendQ2T<true>>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
         else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrendQ2>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
@@ -566,6 +625,8 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     } else if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<BwdTrendT<true>>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     else if (c->mdl.state_dim == 2) CHECK(run_chain<BwdTrend>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
     else CHECK(run_chain<BwdLevel>(c, p, "bwd_chain", "bwd_fix", ST_B, dB));
+    ws_launched(c, p, false);
+    c->lastBwdWindow = c->bwdWindow;
     if (dB) {
         c->pendBwd = true;
         c->pendActiveB = active;
@@ -594,8 +655,19 @@ static int check_stages(csr_ctx *c) {
             continue;
         }
         stage_reruns(c, stg) += fresh;
+        int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow
+                    : (stg == ST_B && c->lastBwdWindow) ? *c->lastBwdWindow : stage_warm(c, stg);
+        if (&wstage == &c->wsWarmF || &wstage == &c->wsWarmB) {
+            // a warm-started window (ECM sweeps) was too short at a wavefront's edge: widen IT (up to the cold window, where
+            // warm starting switches itself off) and leave the stage's own policy alone
+            const int npw = c->launchedPasses[stg];
+            const bool stoodWs = npw > 1 && pass[npw - 1] == 0;
+            if (c->dbgLog) fprintf(stderr, "[csr] settle: warm-started stage %d re-ran %u blocks, window %d -> %d\n", stg, fresh, wstage, wstage * 2);
+            wstage = (wstage * 2 + 15) / 16 * 16;
+            if (!stoodWs && firstFail < 0) firstFail = stg;
+            continue;
+        }
         c->cleanRuns[stg] = 0;
-        int &wstage = (stg == ST_P && c->lastFwdWindow) ? *c->lastFwdWindow : stage_warm(c, stg);
         grow_warm(c, wstage, pass[0]);
         const bool stands = np >= 1 && pass[np - 1] == 0;      // the last validation pass re-ran nothing: a fixed point
         if (c->dbgLog)
@@ -755,8 +827,9 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
         bool fwdFresh = false;   // forward results already match the current multipliers
         struct SweepStateReset {     // also on the error paths
             csr_ctx *c;
-            ~SweepStateReset() { c->sweepSkipQ = false; c->kapIn = c->kapOut = nullptr; }
+            ~SweepStateReset() { c->sweepSkipQ = false; c->kapIn = c->kapOut = nullptr; c->wsActive = c->wsCold = false; }
         } sweepStateReset{c};
+        c->wsSavedF = c->wsSavedB = 0;      // the first sweep of a call starts cold (the data / background may have changed)
         // kappa only (the reference CLI's default, constants.py:270-271): the smoother chain holds the moments of bins k
         // and k+1 and the lag covariance when it finishes bin k, so it evaluates the E-step itself; only the last inner
         // sweep's moments can become the result of this iteration, the others are not even stored.
@@ -772,6 +845,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
         // Returns the buffer holding the iteration's final kappa (nullptr: no sweep ran, the resident one is unchanged).
         float *iterKappa = nullptr;
         auto launch_iteration = [&](bool defer, bool skipFirstForward) -> int {
+            c->wsActive = true;
             float *cur = nullptr;                   // nullptr = the resident kappa (the one this iteration starts from)
             for (int64_t inner = 0; inner < cfg->inner_iters; ++inner) {
                 c->kapIn = cur;
@@ -786,6 +860,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
             c->kapIn = cur;
             CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, defer));      // pyx:8300 (stores everything: it is the
             c->kapIn = nullptr;                                               // forward pass that stays resident)
+            c->wsActive = false;
             iterKappa = cur;
             return 0;
         };
@@ -803,7 +878,10 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
                 c->pendExport = 0;
                 if (hadPending && check_stages(c) >= 0) {
                     c->rs.pipeline_redos += 1;
-                    CHECK(launch_iteration(false, false));
+                    c->wsCold = true;               // the replay starts every window cold (and records fresh checkpoints)
+                    const int rcReplay = launch_iteration(false, false);
+                    c->wsCold = false;
+                    CHECK(rcReplay);
                     CHECK(read_mail(c, c->mailBytes));
                     c->pendFwd = c->pendBwd = false;
                     for (int stg = ST_P; stg <= ST_B; ++stg) (void)take_fresh(c, stg);

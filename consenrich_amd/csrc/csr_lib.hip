@@ -60,7 +60,7 @@ extern "C" int csr_device_count(void) {
 // context
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t MAIL_HDR = 80;     // 20 x u32 counters
-constexpr int MAIL_PASS0 = 4, MAIL_DUMMY = 16, MAX_DEFER_PASSES = 4;
+constexpr int MAIL_PASS0 = 4, MAIL_DUMMY = 16, MAIL_LOCAL = 17, MAX_DEFER_PASSES = 4;    // MAIL_LOCAL: blocks repaired inside speculative kernels
 
 struct ChainInfo {
     int64_t n;      // bins
@@ -103,6 +103,20 @@ struct csr_ctx {
     bool pinP = false, pinX = false, pinB = false, pinFM = false;
     int warmFM = 96;            // fused forward chain with per-bin multipliers (see forward_impl)
     int *fwdWindow = nullptr;   // window variable of the forward stage being launched (see stage_warm)
+    int *bwdWindow = nullptr;   // ... of the smoother stage (warm-started ECM sweeps)
+    int *lastBwdWindow = nullptr;
+    // Warm-started speculation inside the ECM loop (Prm::ckptIn): a sweep's chains start their windows from the carries the
+    // previous sweep recorded (double-buffered per direction), with windows of wsWarmF / wsWarmB bins instead of the cold
+    // ones.  A failed validation at a wavefront's edge widens them; a window that changed since the checkpoints were
+    // recorded makes the next sweep start cold once.
+    bool wsEnabled = true;      // CONSENRICH_AMD_WARMSTART=0: off
+    bool wsActive = false;      // set by the ECM loop around its sweeps
+    bool wsCold = false;        // replay of a failed iteration: record checkpoints, do not start from them
+    int wsWarmF = 32, wsWarmB = 32;         // CONSENRICH_AMD_WS_WARM_F / _B
+    int wsMaxBlock = 32;                    // CONSENRICH_AMD_WS_MAX_BLOCK: largest block length (= batch size class) that warm-starts
+    int wsSavedF = 0, wsSavedB = 0;         // window length the resident checkpoints were recorded for (0: none)
+    int wsSweepF = 0, wsSweepB = 0;         // parity of the double buffers
+    void *ckF[2] = {nullptr, nullptr}, *ckB[2] = {nullptr, nullptr};
     int *lastFwdWindow = nullptr;   // ... of the last forward stage launched (a failed settle widens that one)
     bool Bfixed = false;
     bool adaptWarm = true;
@@ -272,6 +286,9 @@ static void free_batch(csr_ctx *c) {
     c->bg = csr_ctx::BgState{};
     c->dActive = nullptr;
     c->sb = csr_ctx::SbView{};
+    c->ckF[0] = c->ckF[1] = c->ckB[0] = c->ckB[1] = nullptr;
+    c->wsSavedF = c->wsSavedB = 0;
+    c->wsActive = c->wsCold = false;
     for (auto &n : c->nat) n = nullptr;
 }
 
@@ -323,6 +340,10 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_WARMSTART"))) c->wsEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_WS_MAX_BLOCK"))) c->wsMaxBlock = atoi(e);
+    if ((e = getenv("CONSENRICH_AMD_WS_WARM_F"))) c->wsWarmF = std::max(16, (atoi(e) + 15) / 16 * 16);
+    if ((e = getenv("CONSENRICH_AMD_WS_WARM_B"))) c->wsWarmB = std::max(16, (atoi(e) + 15) / 16 * 16);
     if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
@@ -489,6 +510,9 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
     out->warm_x = c->warmX;
     out->warm_b = c->warmB;
     out->x_tol_ulps = c->xTolUlps;
+    out->local_repairs = c->hMail ? (int64_t)reinterpret_cast<const unsigned int *>(c->hMail)[MAIL_LOCAL] : 0;
+    out->ws_warm_f = c->wsWarmF;
+    out->ws_warm_b = c->wsWarmB;
     return 0;
 }
 

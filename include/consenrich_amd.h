@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSR_ABI_VERSION 1
+#define CSR_ABI_VERSION 2
 
 /* ---- model / flags ------------------------------------------------------------------------------------- */
 
@@ -469,6 +469,9 @@ typedef struct csr_run_stats {
     int32_t block_len, warm_p, warm_x, warm_b;
     int32_t x_tol_ulps;
     int32_t pipeline_redos;     /* optimistic (deferred) validations that failed and re-ran their pipeline synchronously */
+    int64_t local_repairs;      /* blocks a warm-started ECM sweep validated against their neighbour INSIDE the speculative
+                                   kernel, found wanting and re-ran there (as of the last read-back) */
+    int32_t ws_warm_f, ws_warm_b;   /* windows (bins) of the warm-started ECM sweeps, forward / smoother */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

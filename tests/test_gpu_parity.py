@@ -453,6 +453,59 @@ def test_ecm_with_failed_optimistic_validations_follows_the_reference_sequence(p
             close_mostly(got[c][4], r[7], frac=2e-2, cap=5e-2, msg="kappa")
 
 
+def test_warm_started_ecm_sweeps_repair_inside_the_kernel_and_follow_the_reference(product, oracle, monkeypatch):
+    """ECM sweeps of small batches start their speculative windows from the carries the previous sweep recorded
+    (Prm::ckptIn) and validate / repair 63 of 64 blocks inside the speculative kernel (wave_local_repair).  With 16-bin
+    warm-started windows against 96 / 80-bin cold ones many blocks fail and are repaired in place, a few at wavefront edges
+    fail the global check (replay, windows widen): iteration count, NLL path and moments must be the reference's, and
+    equal -- to the tolerant mode's own 2-ulp class -- to the run with warm starting switched off."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [40000, 9000, 700], 6
+    sets = [cases.synth(n, m, 5100 + i, outlier_frac=0.03) for i, n in enumerate(n_list)]
+
+    def run():
+        with DeviceBatch(0, x_tol_ulps=2) as b:
+            b.configure(ModelParams(state_dim=2), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            b.stats()
+            outs, paths = b.ecm(max_iters=6, inner_iters=5, rtol=1e-7, use_lambda=False, use_kappa=True)
+            b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT)
+            got = [(int(o.iters_done), paths[c], b.download(c, "xs"), b.download(c, "Ps"), b.download(c, "kappa"))
+                   for c, o in enumerate(outs)]
+            return got, b.run_stats()
+
+    monkeypatch.setenv("CONSENRICH_AMD_WS_WARM_F", "16")
+    monkeypatch.setenv("CONSENRICH_AMD_WS_WARM_B", "16")
+    warm, rs = run()
+    assert rs["block_len"] == 32 and rs["local_repairs"] > 0, rs
+    monkeypatch.setenv("CONSENRICH_AMD_WARMSTART", "0")
+    cold, rs0 = run()
+    assert rs0["local_repairs"] == 0, rs0
+    for c, (d_, v_) in enumerate(sets):
+        n = n_list[c]
+        r = oracle.cfixedBackgroundECM(matrixData=d_, matrixPluginMuncInit=v_, matrixF=np.asarray(cases.F_TREND, np.float32),
+                                       matrixQ0=np.diag([1e-3, 1e-4]).astype(np.float32),
+                                       intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0,
+                                       stateCovarInit=1000.0, ECM_fixedBackgroundIters=6, ECM_fixedBackgroundRtol=1e-7,
+                                       ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=True,
+                                       procPrecisionMultiplierMin=5e-3, procPrecisionMultiplierMax=5e3, t_innerIters=5,
+                                       returnIntermediates=True, returnDiagnostics=True, trackOptimizationPath=True,
+                                       logIterations=False)
+        for tag, got in (("warm", warm), ("cold", cold)):
+            assert got[c][0] == r[0], (c, got[c][0], r[0])
+            np.testing.assert_allclose(got[c][1][: r[0]], r[8]["optimization_path"], rtol=5e-8)
+            scale = np.abs(r[2]).max(axis=1, keepdims=True)
+            excess = np.abs(got[c][2].astype(np.float64) - r[2]) - (RTOL * scale + ATOL)
+            k = np.unravel_index(np.argmax(excess), excess.shape)
+            assert excess.max() <= 0.0, (tag, c, k, float(excess.max()), got[c][2][k[0]], r[2][k[0]])
+            np.testing.assert_allclose(got[c][3], r[3], rtol=RTOL, atol=ATOL)
+            close_mostly(got[c][4], r[7], frac=2e-2, cap=5e-2, msg="kappa")
+        np.testing.assert_allclose(warm[c][1], cold[c][1], rtol=5e-8)
+
+
 def test_exact_mode_on_a_chromosome_sized_chain(product):
     """Bit-exact sequential semantics at chr21 size: default blocks (speculative) == one block per chain."""
     n = 233550
