@@ -1,3 +1,6 @@
+"""Worst error of the smoothed state after a 6-iteration ECM in the tolerant mode (k = 2), in units of the parity tolerance
+(1e-5 * max|row| + 2e-6), against the CPU oracle: cold speculative windows and warm-started ones (F = forward window, B =
+smoother window; 0 = warm starting off).  OUTLIERS = fraction of outlier cells, M = samples.  Build container / GPU box."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (R, os.path.join(R, "tests", "golden")): sys.path.insert(0, p)
@@ -7,8 +10,8 @@ from oracle import oracle
 oracle.lib()
 from consenrich_amd import _lib as L
 from consenrich_amd.batch import DeviceBatch, ModelParams
-n_list, m = [40000, 9000, 700], 6
-sets = [cases.synth(n, m, 5100 + i, outlier_frac=0.03) for i, n in enumerate(n_list)]
+OUT = float(os.environ.get("OUTLIERS", "0.02")); n_list, m = [40000, 9000, 700], int(os.environ.get("M", "8"))
+sets = [cases.synth(n, m, 5100 + i, outlier_frac=OUT) for i, n in enumerate(n_list)]
 refs = []
 for c, (d_, v_) in enumerate(sets):
     n = n_list[c]
@@ -32,7 +35,7 @@ def run(tag):
             worst = max(worst, float((np.abs(xs - r[2]) / (1e-5 * scale + 2e-6)).max()))
         rs = b.run_stats()
         print(tag, "worst xs error / tolerance %.3f" % worst, {k: rs[k] for k in ("local_repairs", "pipeline_redos", "reruns_p", "reruns_b", "ws_warm_f", "ws_warm_b")}, flush=True)
-for f, bw in ((0, 0),):
-    if f == 0: os.environ["CONSENRICH_AMD_WARMSTART"] = "0"
+for f, bw in ((0, 0), (32, 32), (48, 48)):
+    os.environ["CONSENRICH_AMD_WARMSTART"] = "0" if f == 0 else "1"
     os.environ["CONSENRICH_AMD_WS_WARM_F"] = str(f); os.environ["CONSENRICH_AMD_WS_WARM_B"] = str(bw)
     run("F=%d B=%d" % (f, bw))

@@ -455,15 +455,15 @@ def test_ecm_with_failed_optimistic_validations_follows_the_reference_sequence(p
 
 def test_warm_started_ecm_sweeps_repair_inside_the_kernel_and_follow_the_reference(product, oracle, monkeypatch):
     """ECM sweeps of small batches start their speculative windows from the carries the previous sweep recorded
-    (Prm::ckptIn) and validate / repair 63 of 64 blocks inside the speculative kernel (wave_local_repair).  With 16-bin
-    warm-started windows against 96 / 80-bin cold ones many blocks fail and are repaired in place, a few at wavefront edges
-    fail the global check (replay, windows widen): iteration count, NLL path and moments must be the reference's, and
-    equal -- to the tolerant mode's own 2-ulp class -- to the run with warm starting switched off."""
+    (Prm::ckptIn) and validate / repair 63 of 64 blocks inside the speculative kernel (wave_local_repair).  With 32-bin
+    warm-started windows against 96 / 80-bin cold ones hundreds of blocks (the ones whose kappa moved most) fail and are
+    repaired in place, a few at wavefront edges fail the global check (replay, windows widen): iteration count, NLL path and
+    moments must be the reference's, for this run and for the one with warm starting switched off."""
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
 
-    n_list, m = [40000, 9000, 700], 6
-    sets = [cases.synth(n, m, 5100 + i, outlier_frac=0.03) for i, n in enumerate(n_list)]
+    n_list, m = [40000, 9000, 700], 32
+    sets = [cases.synth(n, m, 5100 + i, outlier_frac=0.02) for i, n in enumerate(n_list)]
 
     def run():
         with DeviceBatch(0, x_tol_ulps=2) as b:
@@ -477,8 +477,6 @@ def test_warm_started_ecm_sweeps_repair_inside_the_kernel_and_follow_the_referen
                    for c, o in enumerate(outs)]
             return got, b.run_stats()
 
-    monkeypatch.setenv("CONSENRICH_AMD_WS_WARM_F", "16")
-    monkeypatch.setenv("CONSENRICH_AMD_WS_WARM_B", "16")
     warm, rs = run()
     assert rs["block_len"] == 32 and rs["local_repairs"] > 0, rs
     monkeypatch.setenv("CONSENRICH_AMD_WARMSTART", "0")
