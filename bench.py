@@ -290,6 +290,10 @@ def main() -> int:
         extras["ecm"] = {"ms_per_iter": 1000.0 * e / ecm_iters, "iters": ecm_iters, "inner_sweeps": inner,
                          "bin_sweeps_per_s": total_bins * ecm_iters * inner / e,
                          "pipeline_redos": rs_ecm["pipeline_redos"] - rs["pipeline_redos"],
+                         "warm_started_sweeps": {"active": rs_ecm["block_len"] <= 32, "windows_bins": [rs_ecm["ws_warm_f"], rs_ecm["ws_warm_b"]],
+                                                 "blocks_repaired_in_kernel": rs_ecm["local_repairs"],
+                                                 "note": "batches with 32-bin blocks (< 2 M bins per rank: 8-GPU shards) start a "
+                                                         "sweep's windows from the previous sweep's carries"},
                          "note": "per ECM iteration over all chains: 5 x (forward + smoother + kappa E-step) + 1 NLL "
                                  "forward; bin_sweeps = forward+backward+E-step sweeps"}
         # (2) the same step in the bit-exact validation mode (k = 0: results == the sequential recursion; the mode the

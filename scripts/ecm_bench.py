@@ -23,7 +23,8 @@ print(f"GPU ECM: {iters} iters x ({inner} fwd+bwd+E + 1 NLL fwd) over {sum(lengt
       f"-> {dt*1e3/iters:.2f} ms/iter, {sum(lengths)*iters*inner/dt/1e9:.2f} G bin-sweeps/s (fwd+bwd+E-step)")
 print({k: (v[0], round(v[1], 2)) for k, v in kt.items()})
 rs = b.run_stats()
-print("run stats:", {k: rs[k] for k in ("reruns_p", "reruns_x", "reruns_b", "pipeline_redos", "warm_p", "block_len")})
+print("run stats:", {k: rs[k] for k in ("reruns_p", "reruns_x", "reruns_b", "pipeline_redos", "warm_p", "block_len", "local_repairs",
+                                     "ws_warm_f", "ws_warm_b")})
 if os.environ.get("CPU", "1") == "1":
     import cases
     from oracle import oracle as orc
