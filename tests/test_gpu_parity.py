@@ -601,6 +601,67 @@ def test_reference_api_contract(product):
     assert e[0] == 0.0 and e[1] == 0 and e[3] == 0.0
 
 
+@pytest.mark.parametrize("d", [2, 1])
+def test_output_arrays_are_written_in_place(product, oracle, d):
+    """The callables fill the CALLER's arrays (pyx:6545-6561: preallocated outputs, `shape[0] >= n`): arrays of exactly the
+    shape of the pass are written by the library itself (no bounce buffer; n large enough for the host-side page pre-fault to
+    run), larger ones through a sliced store that leaves the rows past n alone; the returned objects are the caller's; a
+    pNoise input of n or of n - 1 rows is the same input."""
+    n, m = 300000, 4
+    data, munc = cases.synth(n, m, 77)
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32) if d == 2 else np.asarray([[1e-3]], np.float32)
+    bm = np.zeros(n, np.int32)
+
+    def fwd(mod, xf, Pf, pn, D):
+        kw = dict(matrixData=data, matrixPluginMuncInit=munc, matrixQ0=Q0, intervalToBlockMap=bm, blockCount=1, stateInit=0.0,
+                  stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn, vectorD=D, returnNLL=True,
+                  ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=False)
+        return mod.cforwardPass(matrixF=F, **kw) if d == 2 else mod.cforwardPassLevel(**kw)
+
+    def bwd(mod, xf, Pf, pn, **out):
+        if d == 2:
+            return mod.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn, **out)
+        return mod.cbackwardPassLevel(matrixData=data, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn, **out)
+
+    def blank(rows, *tail, fill=np.nan):
+        return np.full((rows,) + tail, fill, np.float32)
+
+    ref_f = (blank(n, d), blank(n, d, d), blank(n, d, d, fill=0.0), blank(n))
+    fwd(oracle, *ref_f)
+    ref_b = bwd(oracle, ref_f[0], ref_f[1], ref_f[2])
+    # forward: exact shapes (pNoise with n rows: the last one is never written) and oversized ones
+    xf, Pf, pn, D = blank(n, d), blank(n, d, d), blank(n, d, d, fill=5.0), blank(n)
+    r = fwd(product, xf, Pf, pn, D)
+    assert r[2] is D
+    for got, want in ((xf, ref_f[0]), (Pf, ref_f[1]), (pn[: n - 1], ref_f[2][: n - 1]), (D, ref_f[3])):
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.all(pn[n - 1] == 5.0)
+    xf2, Pf2, pn2, D2 = blank(n + 3, d, fill=7.0), blank(n + 3, d, d, fill=7.0), blank(n - 1, d, d), blank(n + 3, fill=7.0)
+    fwd(product, xf2, Pf2, pn2, D2)
+    assert np.array_equal(xf2[:n], xf) and np.array_equal(Pf2[:n], Pf) and np.array_equal(pn2, pn[: n - 1]) and np.array_equal(D2[:n], D)
+    assert np.all(xf2[n:] == 7.0) and np.all(Pf2[n:] == 7.0) and np.all(D2[n:] == 7.0)
+    # smoother: fresh outputs, exact-shape preallocated outputs (same objects back), oversized ones
+    b0 = bwd(product, xf, Pf, pn)
+    for k, (got, want) in enumerate(zip(b0, ref_b)):
+        rows = n - 1 if k == 2 else n           # lagCovSmoothed has n - 1 meaningful rows
+        np.testing.assert_allclose(got[:rows], want[:rows], rtol=RTOL, atol=ATOL)
+    pre = dict(stateSmoothed=blank(n, d), stateCovarSmoothed=blank(n, d, d), lagCovSmoothed=blank(n - 1, d, d),
+               postFitResiduals=blank(n, m))
+    b1 = bwd(product, xf, Pf, pn2, **pre)                      # (pNoise given with n - 1 rows)
+    assert b1[0] is pre["stateSmoothed"] and b1[1] is pre["stateCovarSmoothed"] and b1[2] is pre["lagCovSmoothed"] \
+        and b1[3] is pre["postFitResiduals"]
+    for a, b_ in zip(b0, b1):
+        assert np.array_equal(a[: b_.shape[0]], b_[: a.shape[0]])
+    big = dict(stateSmoothed=blank(n + 2, d, fill=3.0), stateCovarSmoothed=blank(n + 2, d, d, fill=3.0),
+               lagCovSmoothed=blank(n + 2, d, d, fill=3.0), postFitResiduals=blank(n + 2, m, fill=3.0))
+    b2 = bwd(product, xf, Pf, pn, **big)
+    assert b2[3] is big["postFitResiduals"]
+    assert np.array_equal(b2[0][:n], b1[0]) and np.array_equal(b2[1][:n], b1[1]) and np.array_equal(b2[3][:n], b1[3])
+    assert np.array_equal(b2[2][: n - 1], b1[2][: n - 1])
+    assert np.all(b2[0][n:] == 3.0) and np.all(b2[1][n:] == 3.0) and np.all(b2[3][n:] == 3.0) and np.all(b2[2][n - 1:] == 3.0)
+
+
 def test_ecm_is_silent_unless_logging(product, capfd):
     n, m = 64, 2
     data, munc = cases.synth(n, m, 9)
