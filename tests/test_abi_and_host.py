@@ -257,3 +257,20 @@ def test_qseed_mirror_argument_validation_without_a_gpu():
             amd.cQSeedPosteriorFromTransitions(*kwargs)
     # (the data-dependent checks -- "samplingVariances must be nonnegative finite", ... -- are made by the device kernels:
     # tests/test_gpu_qseed.py)
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """No silent CPU path behind the benchmark either: without a device bench.py ends with the library's error."""
+    import subprocess
+    import sys
+
+    from conftest import gpu_available
+
+    if gpu_available():
+        pytest.skip("a GPU is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-extras"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "no CPU fallback" in r.stderr or "no HIP device" in r.stderr, r.stderr[-1500:]
+

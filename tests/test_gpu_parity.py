@@ -1720,3 +1720,28 @@ def test_lds_dma_paths_agree_with_the_plain_kernels(product, block_len, flags_na
             assert np.all(np.abs(a.astype(np.float64) - b_) <= 2 * RTOL * lvl + ATOL), (c, k)
         else:
             np.testing.assert_allclose(a, b_, rtol=2 * RTOL, atol=ATOL, err_msg=f"{k} chain {c}")
+
+
+def test_bench_line_contract(product):
+    """bench.py prints ONE JSON line with the driver's contract fields plus the roofline object (2 steps, no extras)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extras"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(14375018 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0.0 < rf["frac"] < 1.0
+
