@@ -2167,24 +2167,35 @@ __global__ __launch_bounds__(64) void k_state_seq_trend(Prm p, const int64_t *ch
 // wavefront walks every step (no predicates: lanes without work walk a padding block, sbPad, or recompute what they
 // already hold), loads run a register buffer ahead.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool UF>
-__device__ __forceinline__ void sb_step(const Prm &p, double &x0, double &x1, const double4 &r, float2 &out) {
-    // x0, x1: the float32 carries held as doubles (exactly)
-    if constexpr (UF) {
-        const double xp0 = r32(fma(p.F01, x1, x0));
+// F1: F01 == 1 as well (deltaF = 1, the reference's default, constants.py:146): the predicted level r32(x0 + x1) of two
+// float32 values IS their float32 sum -- double rounding through the 53-bit sum is innocuous for an addition when
+// 53 >= 2 * 24 + 2 (Figueroa) -- so it is ONE v_add_f32 instead of fma + two conversions.  The conversions are what the
+// dependent path of a step mostly consists of (scripts/ubench/step_lat.hip: a v_cvt pair costs as much as three fp64
+// operations), and the carries therefore stay float32 between steps: the same bits with 6 instead of 8 dependent instructions.
+template <bool UF, bool F1>
+__device__ __forceinline__ void sb_step(const Prm &p, float &x0, float &x1, const double4 &r, float2 &out) {
+    if constexpr (UF && F1) {
+        const float xpf = x0 + x1;
+        const double xp0 = (double)xpf, x1d = (double)x1;
         const double dl = r.x * (r.y - xp0);
         out.x = (float)fma(r.z, dl, xp0);
-        out.y = (float)fma(r.w, dl, x1);
+        out.y = (float)fma(r.w, dl, x1d);
+    } else if constexpr (UF) {
+        const double x1d = (double)x1;
+        const double xp0 = r32(fma(p.F01, x1d, (double)x0));
+        const double dl = r.x * (r.y - xp0);
+        out.x = (float)fma(r.z, dl, xp0);
+        out.y = (float)fma(r.w, dl, x1d);
     } else {
-        FwdXTrend::Carry c{(float)x0, (float)x1};
+        FwdXTrend::Carry c{x0, x1};
         FwdXTrend::In in;
         in.gs = r.x; in.zbar = r.y;
         in.cp = make_float2((float)r.z, (float)r.w);       // exact round trip of float32 values
         FwdXTrend::step<false>(p, c, in, 0, 0, 0, 0);
         out = make_float2(c.x0, c.x1);
     }
-    x0 = (double)out.x;
-    x1 = (double)out.y;
+    x0 = out.x;
+    x1 = out.y;
 }
 // Steps [sLo, sHi) (multiples of 2 * SB_U) of the block whose slot base is `base`, all 64 lanes.  Two register buffers of
 // SB_U records; hipcc drains the memory counter (loads AND stores, one counter on gfx9) at the loop's back-edge, so the
@@ -2193,8 +2204,8 @@ __device__ __forceinline__ void sb_step(const Prm &p, double &x0, double &x1, co
 // (With the stores where the results are produced the drain waited for the acknowledgement of a store issued a few
 // instructions earlier, once per 2 * SB_U steps: 73 instead of ~50 ns per step.)
 #define SB_U 16
-template <bool UF, bool STORE>
-__device__ __forceinline__ void sb_walk(const Prm &p, double &x0, double &x1, int64_t base, int sLo, int sHi) {
+template <bool UF, bool F1, bool STORE>
+__device__ __forceinline__ void sb_walk(const Prm &p, float &x0, float &x1, int64_t base, int sLo, int sHi) {
     const double4 *r = p.sbRec + base + (int64_t)sLo * 64;
     float2 *o = p.tXf + base + (int64_t)sLo * 64;
     const int cnt = sHi - sLo;
@@ -2219,7 +2230,7 @@ __device__ __forceinline__ void sb_walk(const Prm &p, double &x0, double &x1, in
 #pragma unroll
         for (int u = 0; u < SB_U; ++u) {
             float2 v;
-            sb_step<UF>(p, x0, x1, A[u], v);
+            sb_step<UF, F1>(p, x0, x1, A[u], v);
             if constexpr (STORE) o[(int64_t)(i0 + u) * 64] = v;
         }
         if (i0 + 2 * SB_U < cnt) {
@@ -2228,7 +2239,7 @@ __device__ __forceinline__ void sb_walk(const Prm &p, double &x0, double &x1, in
         }
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < SB_U; ++u) sb_step<UF>(p, x0, x1, Bq[u], held[u]);
+        for (int u = 0; u < SB_U; ++u) sb_step<UF, F1>(p, x0, x1, Bq[u], held[u]);
     }
     if constexpr (STORE) {
         if (cnt > 0) {
@@ -2238,7 +2249,7 @@ __device__ __forceinline__ void sb_walk(const Prm &p, double &x0, double &x1, in
     }
 }
 
-template <bool UF>
+template <bool UF, bool F1>
 __global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
@@ -2249,7 +2260,7 @@ __global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
     using Carry = FwdXTrend::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
     Carry *cout = reinterpret_cast<Carry *>(p.carryOutA);
-    double x0 = (double)(float)p.init, x1 = 0.0;       // FwdXTrend::init_true == init_cold
+    float x0 = (float)p.init, x1 = 0.0f;       // FwdXTrend::init_true == init_cold
     // window: the last p.warm bins before the block (qmax blocks, the farthest one from step lo); a lane whose chain starts
     // inside the window walks from the chain's first bin, i.e. from the true prior (k_chain_spec's rule)
     const int qmax = (p.warm + B - 1) / B;
@@ -2263,24 +2274,24 @@ __global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
         if (q == qmax && lo > 0 && __any(act && avail == qmax)) {
             // lanes at their chain's first block need its head too
             const bool head = act && avail == qmax;
-            double y0 = x0, y1 = x1;
-            sb_walk<UF, false>(p, y0, y1, tbase(head ? b - q : p.sbPad, B), 0, lo);
+            float y0 = x0, y1 = x1;
+            sb_walk<UF, F1, false>(p, y0, y1, tbase(head ? b - q : p.sbPad, B), 0, lo);
             x0 = head ? y0 : x0;
             x1 = head ? y1 : x1;
         }
-        double y0 = x0, y1 = x1;
-        sb_walk<UF, false>(p, y0, y1, base, (q == qmax) ? lo : 0, B);
+        float y0 = x0, y1 = x1;
+        sb_walk<UF, F1, false>(p, y0, y1, base, (q == qmax) ? lo : 0, B);
         x0 = act ? y0 : x0;
         x1 = act ? y1 : x1;
     }
-    if (live) cin[b] = Carry{(float)x0, (float)x1};
+    if (live) cin[b] = Carry{x0, x1};
     // own block (a chain's last block is walked past its end into zeroed records: those slots are nobody's, and a chain's
     // last carry-out is never read)
-    sb_walk<UF, true>(p, x0, x1, tbase(live ? b : p.sbPad, B), 0, B);
-    if (live) cout[b] = Carry{(float)x0, (float)x1};
+    sb_walk<UF, F1, true>(p, x0, x1, tbase(live ? b : p.sbPad, B), 0, B);
+    if (live) cout[b] = Carry{x0, x1};
 }
 
-template <bool UF>
+template <bool UF, bool F1>
 __global__ __launch_bounds__(64) void k_sb_state_fix(Prm p, int which) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b < p.NB && chain_on(p, b);
@@ -2298,10 +2309,10 @@ __global__ __launch_bounds__(64) void k_sb_state_fix(Prm p, int which) {
     if (live && !rerun) onxt[b] = ocur[b];
     if (!__any(rerun)) return;
     // the whole wavefront walks: lanes that need no re-run recompute their block from the carry-in they hold (same bits)
-    double x0 = (double)(rerun ? prev.x0 : mine.x0), x1 = (double)(rerun ? prev.x1 : mine.x1);
-    sb_walk<UF, true>(p, x0, x1, tbase(live ? b : p.sbPad, p.B), 0, p.B);
+    float x0 = rerun ? prev.x0 : mine.x0, x1 = rerun ? prev.x1 : mine.x1;
+    sb_walk<UF, F1, true>(p, x0, x1, tbase(live ? b : p.sbPad, p.B), 0, p.B);
     if (rerun) {
-        onxt[b] = Carry{(float)x0, (float)x1};
+        onxt[b] = Carry{x0, x1};
         atomicAdd(p.rerunCount, 1u);
         atomicAdd(p.rerunCountPass, 1u);
     }

@@ -380,6 +380,7 @@ static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
     q.rerunCountPass = cnt + MAIL_DUMMY;
     q.prevKind = CK_NONE;
     const int grid = (int)v.NG;
+    const bool f1 = UF && p.F01 == 1.0 && c->unitF1Enabled;     // deltaF = 1: the predicted level is one float32 add (sb_step)
     {
         Scope sc(c, "state_reblock_in");
         hipLaunchKernelGGL(k_sb_records, dim3((int)((v.TN + 255) / 256)), dim3(256), 0, c->stream, q, c->dChainFirst, c->B,
@@ -388,7 +389,8 @@ static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
     LAUNCH_CHECK("k_sb_records");
     {
         Scope sc(c, "fwd_state_chain");
-        hipLaunchKernelGGL(k_sb_state_spec<UF>, dim3(grid), dim3(64), 0, c->stream, q);
+        if (f1) hipLaunchKernelGGL((k_sb_state_spec<UF, UF>), dim3(grid), dim3(64), 0, c->stream, q);
+        else hipLaunchKernelGGL((k_sb_state_spec<UF, false>), dim3(grid), dim3(64), 0, c->stream, q);
     }
     LAUNCH_CHECK("k_sb_state_spec");
     // validation / repair passes in bursts (run_chain's rule: a burst that re-ran nothing is the fixed point; a pass that
@@ -399,7 +401,8 @@ static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
         {
             Scope sc(c, "fwd_state_fix");
             for (int rep = 0; rep < burst; ++rep) {
-                hipLaunchKernelGGL(k_sb_state_fix<UF>, dim3(grid), dim3(64), 0, c->stream, q, which);
+                if (f1) hipLaunchKernelGGL((k_sb_state_fix<UF, UF>), dim3(grid), dim3(64), 0, c->stream, q, which);
+                else hipLaunchKernelGGL((k_sb_state_fix<UF, false>), dim3(grid), dim3(64), 0, c->stream, q, which);
                 which ^= 1;
                 c->rs.fix_launches++;
             }

@@ -123,7 +123,9 @@ struct csr_ctx {
     bool useDmaWarm = true;    // ... and, with reference-layout outputs, for its warm-up phase
     bool useDmaFused = true;   // fused forward chain without reference-layout outputs: LDS-DMA ring
     bool useDma = true;        // LDS-DMA speculative kernels for the chains that provide them
-    int xTolUlps = 2;
+    int xTolUlps = 0;           // carry validation: 0 = bit-exact sequential semantics (DEFAULT of every context since round 3: the
+                                // only mode that holds the parity gate through the ECM loop on ill-conditioned data, tests/test_hard_data.py);
+                                // k > 0 = k-ulp acceptance, the opt-in throughput mode (csr_set_validation / CONSENRICH_AMD_XTOL_ULPS)
     bool statsWide = true;  // statistics kernel with 16-byte loads (four bins per thread)
     int statsWideUnroll = 4;    // ... sample rows it loads together (2, 4, 8)
     int statsUnroll = 8;    // sample rows loaded together by the statistics kernel (8, 16, 32)
@@ -174,6 +176,7 @@ struct csr_ctx {
     bool deferEnabled = true;
     bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    bool unitF1Enabled = true;  // CONSENRICH_AMD_UNITF1=0: the superblock walker's fma + conversion form of the predicted level even for F01 == 1
     bool unitFEnabled = true;   // CONSENRICH_AMD_UNITF=0: the general-F instances of the levelTrend chains even for F = [[1, f], [0, 1]]
     bool seqState = false;      // bit-exact validation, levelTrend: one wavefront per chain walks the state chain sequentially (CONSENRICH_AMD_SEQ_STATE=1)
     // bit-exact validation, levelTrend (default): the state chain speculates on SUPERBLOCKS of sbBins bins with an sbWarm-bin
@@ -347,6 +350,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_UNITF1"))) c->unitF1Enabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
