@@ -2249,6 +2249,73 @@ __device__ __forceinline__ void sb_walk(const Prm &p, float &x0, float &x1, int6
     }
 }
 
+// The same walk for the lane's OWN block with wave-uniform addressing: all 64 blocks of a wavefront belong to one wave-group
+// G, so the row of step s starts at the uniform address (G * B + s) * 64 and a lane adds its own index.  The records and the
+// outputs go through BUFFER instructions (resource descriptor of the group's region in SGPRs, the lane's byte offset in one
+// VGPR computed once, the row offset in an SGPR advanced by the scalar unit): the per-step 64-bit vector address arithmetic
+// of sb_walk -- 3-4 of its ~18 instructions per step, on a wavefront that is bound by instruction issue -- disappears.
+// Lanes without a block of their own (past the batch's last block, inactive chains) walk their natural slots of the group:
+// zeroed records, outputs nobody reads.
+typedef unsigned int csr_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int csr_u2 __attribute__((ext_vector_type(2)));
+#define CSR_RSRC_FLAGS 0x00020000     /* raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950) */
+__device__ __forceinline__ double4 sb_rec_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const csr_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    const csr_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0);
+    return make_double4(words2double(a.x, a.y), words2double(a.z, a.w), words2double(b.x, b.y), words2double(b.z, b.w));
+}
+__device__ __forceinline__ void sb_out_store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, float2 v) {
+    csr_u2 w;
+    w.x = __float_as_uint(v.x);
+    w.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, ws, voff, soff, 0);
+}
+template <bool UF, bool F1, bool STORE>
+__device__ __forceinline__ void sb_walk_u(const Prm &p, float &x0, float &x1, unsigned G, unsigned lane, int B) {
+    // the group's region: B rows of 64 records (32 B each: <= 16 MB for 8192-bin superblocks) / 64 outputs (8 B each)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double4 *>(p.sbRec) + (size_t)G * (size_t)B * 64u, 0, B * 64 * 32, CSR_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.tXf + (size_t)G * (size_t)B * 64u, 0, B * 64 * 8,
+                                                                        CSR_RSRC_FLAGS);
+    const int vr = (int)lane * 32, vo = (int)lane * 8;
+    double4 A[SB_U], Bq[SB_U];
+    float2 held[SB_U];
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+        A[u] = sb_rec_load(rs, vr, u * 2048);
+        held[u] = make_float2(0.f, 0.f);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < B; i0 += 2 * SB_U) {
+        if constexpr (STORE) {
+            if (i0 > 0) {
+#pragma unroll
+                for (int u = 0; u < SB_U; ++u) sb_out_store(ws, vo, (i0 - SB_U + u) * 512, held[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) Bq[u] = sb_rec_load(rs, vr, (i0 + SB_U + u) * 2048);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) {
+            float2 v;
+            sb_step<UF, F1>(p, x0, x1, A[u], v);
+            if constexpr (STORE) sb_out_store(ws, vo, (i0 + u) * 512, v);
+        }
+        if (i0 + 2 * SB_U < B) {
+#pragma unroll
+            for (int u = 0; u < SB_U; ++u) A[u] = sb_rec_load(rs, vr, (i0 + 2 * SB_U + u) * 2048);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) sb_step<UF, F1>(p, x0, x1, Bq[u], held[u]);
+    }
+    if constexpr (STORE) {
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) sb_out_store(ws, vo, (B - SB_U + u) * 512, held[u]);
+    }
+}
+
 template <bool UF, bool F1>
 __global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -2287,7 +2354,7 @@ __global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
     if (live) cin[b] = Carry{x0, x1};
     // own block (a chain's last block is walked past its end into zeroed records: those slots are nobody's, and a chain's
     // last carry-out is never read)
-    sb_walk<UF, F1, true>(p, x0, x1, tbase(live ? b : p.sbPad, B), 0, B);
+    sb_walk_u<UF, F1, true>(p, x0, x1, blockIdx.x, threadIdx.x, B);
     if (live) cout[b] = Carry{x0, x1};
 }
 
@@ -2310,11 +2377,150 @@ __global__ __launch_bounds__(64) void k_sb_state_fix(Prm p, int which) {
     if (!__any(rerun)) return;
     // the whole wavefront walks: lanes that need no re-run recompute their block from the carry-in they hold (same bits)
     float x0 = rerun ? prev.x0 : mine.x0, x1 = rerun ? prev.x1 : mine.x1;
-    sb_walk<UF, F1, true>(p, x0, x1, tbase(live ? b : p.sbPad, p.B), 0, p.B);
+    sb_walk_u<UF, F1, true>(p, x0, x1, blockIdx.x, threadIdx.x, p.B);
     if (rerun) {
         onxt[b] = Carry{x0, x1};
         atomicAdd(p.rerunCount, 1u);
         atomicAdd(p.rerunCountPass, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SYSTOLIC walker of the bit-exact state chain (round 3; replaces the lane-per-superblock walker above by default).
+// One wavefront per superblock; its 64 lanes are 64 CONSECUTIVE BINS of the chain, so the records are read and the filtered
+// state is written in the natural (reference) layout, fully coalesced, once per 64 steps -- the lane-per-superblock walker
+// read one 2-KB record row per step and was bound by what a single wavefront can stream with 16 rows of look-ahead
+// (scripts/ubench/stream_lat.hip: 30-40 GB/s per wavefront, 60 ns per step whatever its instruction count).
+// The recursion itself runs as a shift register: in every step ALL lanes evaluate  x <- step(x of the lane below, own record);
+// lane j holds the true filtered state of its bin after step j and recomputes the same bits afterwards (its input, lane j-1,
+// no longer changes), lanes above j hold values that are overwritten when their turn comes.  The move between neighbouring
+// lanes is a DPP wave shift (v_mov_b32_dpp wave_shr:1) whose destination keeps the CARRY in lane 0; there is no LDS, no
+// v_readlane and no memory instruction on the step path: 2 DPP moves + 9 arithmetic instructions, ~20 ns per bin.
+// MODE 2: F = [[1, 1], [0, 1]] (predicted level = one float32 add, see sb_step); 1: F = [[1, f], [0, 1]]; 0: any F.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_shr1_keep0(float keepLane0, float src) {
+    // lanes 1..63 <- src of the lane below; lane 0 keeps keepLane0 (bound_ctrl = 0: an out-of-range source leaves the destination)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keepLane0), __builtin_bit_cast(int, src),
+                                                                 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+// Four superblocks per workgroup: the four wavefronts of a workgroup go to the four SIMDs of a CU, so a launch of <= 1024
+// superblocks runs ONE wavefront per SIMD (single-wavefront workgroups were placed two and three to a SIMD while others
+// stayed empty: 47-70 instead of 25 ns per step).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sb_sys(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
+                                                float2 *__restrict__ natXf, int which, int fix) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.NB || !chain_on(p, b)) return;                 // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int4 bi = p.blk[b];
+    using Carry = FwdXTrend::Carry;
+    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
+    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
+    Carry *onxt = fix ? reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB) : reinterpret_cast<Carry *>(p.carryOutA);
+    float c0 = (float)p.init, c1 = 0.0f;                      // FwdXTrend::init_true == init_cold
+    if (fix) {
+        if (b == (int64_t)bi.z) {                             // a chain's first superblock starts from the true prior: never re-run
+            if (lane == 0) onxt[b] = ocur[b];
+            return;
+        }
+        const Carry prev = ocur[b - 1], mine = cin[b];
+        const bool differ = ((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) != 0u;
+        if (!differ) {
+            if (lane == 0) onxt[b] = ocur[b];
+            return;
+        }
+        c0 = prev.x0; c1 = prev.x1;
+    }
+    if (lane == 0) cin[b] = Carry{c0, c1};
+    const int n = bi.y;
+    const int64_t g0 = (int64_t)bi.x + lane;
+    const int nb = (n + 63) >> 6;
+    // records of batches t and t + 1 are resident, t + 2 in flight (3 x 8 registers)
+    float4 ga = natGain[g0], sa = natSZ[g0];
+    float4 gb = ga, sb_ = sa;
+    if (nb > 1) { gb = natGain[g0 + 64]; sb_ = natSZ[g0 + 64]; }
+    float x0v = 0.0f, x1v = 0.0f;
+#pragma unroll 1
+    for (int t = 0; t < nb; ++t) {
+        float4 gc = gb, sc = sb_;
+        if (t + 2 < nb) { gc = natGain[g0 + (int64_t)(t + 2) * 64]; sc = natSZ[g0 + (int64_t)(t + 2) * 64]; }
+        const double gs = unpack_d(ga.x, ga.y), zbar = unpack_d(sa.z, sa.w);
+        const double p00 = (double)ga.z, p10 = (double)ga.w;
+        float s0 = c0, s1 = c1;                                // shifted vectors: lane 0 = the carry into this batch
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                s0 = dpp_shr1_keep0(s0, x0v);
+                s1 = dpp_shr1_keep0(s1, x1v);
+                if constexpr (MODE == 2) {
+                    const float xpf = s0 + s1;
+                    const double xp0 = (double)xpf, x1d = (double)s1;
+                    const double dl = gs * (zbar - xp0);
+                    x0v = (float)fma(p00, dl, xp0);
+                    x1v = (float)fma(p10, dl, x1d);
+                } else if constexpr (MODE == 1) {
+                    const double x1d = (double)s1;
+                    const double xp0 = r32(fma(p.F01, x1d, (double)s0));
+                    const double dl = gs * (zbar - xp0);
+                    x0v = (float)fma(p00, dl, xp0);
+                    x1v = (float)fma(p10, dl, x1d);
+                } else {
+                    FwdXTrend::Carry c{s0, s1};
+                    FwdXTrend::In in;
+                    in.gs = gs; in.zbar = zbar;
+                    in.cp = make_float2(ga.z, ga.w);
+                    FwdXTrend::step<false>(p, c, in, 0, 0, 0, 0);
+                    x0v = c.x0; x1v = c.x1;
+                }
+            }
+        }
+        const int left = n - (t << 6);                         // bins of this batch (64 except at a chain's end)
+        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(x0v, x1v);
+        const int last = left >= 64 ? 63 : left - 1;
+        c0 = rl32(x0v, last);
+        c1 = rl32(x1v, last);
+        ga = gb; sa = sb_; gb = gc; sb_ = sc;
+    }
+    if (lane == 0) {
+        onxt[b] = Carry{c0, c1};
+        if (fix) {
+            atomicAdd(p.rerunCount, 1u);
+            atomicAdd(p.rerunCountPass, 1u);
+        }
+    }
+}
+
+// natural float2 track -> the batch's blocked layout through LDS tiles (32 steps x 64 blocks per workgroup): coalesced on
+// both sides (the per-slot gather of k_import_f32 reads one 128-byte line per 8 bytes it needs)
+__global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__restrict__ nat, float2 *__restrict__ dst) {
+    __shared__ float2 tile[32][65];
+    const int tilesPerGroup = p.B >> 5;
+    const int64_t G = blockIdx.x / tilesPerGroup;
+    const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
+    const int t = threadIdx.x;
+    const int r = t >> 5, si = t & 31;
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int l = pass * 8 + r;
+        const int64_t b = G * 64 + l;
+        float2 v = make_float2(0.f, 0.f);
+        if (b < p.NB && chain_on(p, b)) {
+            const int4 bi = p.blk[b];
+            if (s0 + si < bi.y) v = nat[(int64_t)bi.x + s0 + si];
+        }
+        tile[si][l] = v;
+    }
+    __syncthreads();
+    const int lane = t & 63, r0 = t >> 6;
+    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64;
+    const int64_t bw = G * 64 + lane;
+    int len = 0;                                               // slots of inactive chains / past a block's end stay untouched
+    if (bw < p.NB && chain_on(p, bw)) len = p.blk[bw].y;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + r0;
+        if (s0 + row < len) dst[rowBase + (int64_t)row * 64 + lane] = tile[row][lane];
     }
 }
 

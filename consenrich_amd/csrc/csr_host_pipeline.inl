@@ -321,8 +321,20 @@ static void ws_launched(csr_ctx *c, const Prm &p, bool fwd) {
 static int ensure_sb_view(csr_ctx *c) {
     csr_ctx::SbView &v = c->sb;
     if (v.ready) return 0;
-    const int B = c->sbBins;
+    int B = c->sbBins;
     const int nc = (int)c->chains.size();
+    if (c->sbSystolic && !c->sbBinsPinned) {
+        // one wavefront per superblock, one wavefront per SIMD: the shortest superblock (a multiple of 8192 bins) that leaves
+        // no more superblocks than the device has SIMDs
+        hipDeviceProp_t prop;
+        int simds = 1024;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+        for (;; B += 8192) {
+            int64_t cnt = 0;
+            for (int i = 0; i < nc; ++i) cnt += (c->chains[i].n + B - 1) / B;
+            if (cnt <= simds || B >= (1 << 20)) break;
+        }
+    }
     std::vector<int64_t> first((size_t)nc);
     int64_t nb = 0;
     for (int i = 0; i < nc; ++i) {
@@ -351,14 +363,88 @@ static int ensure_sb_view(csr_ctx *c) {
     HIPOK(hipMemcpyAsync(v.chainFirst, first.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
     // (+ one padding group: lanes without a block of their own walk block NG * 64, zero records)
-    const int64_t TP = v.TN + (int64_t)B * 64;
-    CHECK(dalloc(c, &v.rec, TP)); CHECK(dalloc(c, &v.tXf, TP));
-    HIPOK(hipMemsetAsync(v.rec, 0, sizeof(double4) * TP, c->stream));
-    HIPOK(hipMemsetAsync(v.tXf, 0, sizeof(float2) * TP, c->stream));
+    if (!c->sbSystolic) {
+        const int64_t TP = v.TN + (int64_t)B * 64;
+        CHECK(dalloc(c, &v.rec, TP)); CHECK(dalloc(c, &v.tXf, TP));
+        HIPOK(hipMemsetAsync(v.rec, 0, sizeof(double4) * TP, c->stream));
+        HIPOK(hipMemsetAsync(v.tXf, 0, sizeof(float2) * TP, c->stream));
+    }
     char *q[3];
     for (char *&x : q) CHECK(dalloc(c, &x, nb * 32));
     v.carryIn = q[0]; v.carryOutA = q[1]; v.carryOutB = q[2];
     v.ready = true;
+    return 0;
+}
+
+// Bit-exact state chain, systolic form (k_sb_sys): the gain / statistics records go to the natural layout (one tiled
+// conversion launch), one wavefront per superblock walks 64 bins per batch as a shift register and writes the filtered state
+// straight into the reference-layout xf array; superblocks start from the cold prior and the validation / repair passes run
+// to the fixed point (= the sequential recursion, whatever the superblock length); one tiled launch brings the filtered state
+// back into the batch's blocked layout for the epilogue and the smoother.
+static int state_chain_systolic(csr_ctx *c, const Prm &p) {
+    CHECK(ensure_sb_view(c));
+    CHECK(flush_pending_check(c));
+    csr_ctx::SbView &v = c->sb;
+    if (!c->sbNatGain) { CHECK(dalloc(c, &c->sbNatGain, c->Npad)); CHECK(dalloc(c, &c->sbNatSZ, c->Npad)); }
+    float *natXf;
+    CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    {
+        Scope sc(c, "state_records_natural");
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        L.count = 2;
+        L.d[0].src = reinterpret_cast<const float *>(p.tXin); L.d[0].dst = reinterpret_cast<float *>(c->sbNatGain); L.d[0].E = 4; L.d[0].n = 4;
+        L.d[1].src = reinterpret_cast<const float *>(p.tSZ); L.d[1].dst = reinterpret_cast<float *>(c->sbNatSZ); L.d[1].E = 4; L.d[1].n = 4;
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p, L);
+    }
+    LAUNCH_CHECK("k_export_tiled (state records)");
+    Prm q = p;
+    q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
+    q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
+    unsigned int *const cnt = reinterpret_cast<unsigned int *>(c->dMail);
+    q.rerunCount = cnt + ST_X;
+    q.rerunCountPass = cnt + MAIL_DUMMY;
+    q.prevKind = CK_NONE;
+    const int mode = unit_f(c, p) ? ((p.F01 == 1.0 && c->unitF1Enabled) ? 2 : 1) : 0;
+    const int grid = (int)((v.NB + 3) / 4);
+    auto launch = [&](int which, int fix) {
+        float2 *xf = reinterpret_cast<float2 *>(natXf);
+        if (mode == 2) hipLaunchKernelGGL(k_sb_sys<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
+        else if (mode == 1) hipLaunchKernelGGL(k_sb_sys<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
+        else hipLaunchKernelGGL(k_sb_sys<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
+    };
+    {
+        Scope sc(c, "fwd_state_chain");
+        launch(0, 0);
+    }
+    LAUNCH_CHECK("k_sb_sys");
+    int which = 0, burst = 2;
+    bool done = false;
+    for (int64_t it = 0; it <= v.NB + 1 && !done; ++it) {
+        {
+            Scope sc(c, "fwd_state_fix");
+            for (int rep = 0; rep < burst; ++rep) {
+                launch(which, 1);
+                which ^= 1;
+                c->rs.fix_launches++;
+            }
+        }
+        LAUNCH_CHECK("k_sb_sys (repair)");
+        CHECK(read_mail(c, MAIL_HDR));
+        const unsigned int fresh = take_fresh(c, ST_X);
+        if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_fix (systolic superblocks) iter %lld reruns %u\n", (long long)it, fresh);
+        if (fresh == 0) done = true;
+        c->rs.reruns_x += fresh;
+        burst = c->dbgLog ? 1 : std::min(32, burst * 2);
+    }
+    if (!done) return fail("fwd_state_chain (systolic superblocks): fix-up did not reach a fixed point");
+    {
+        Scope sc(c, "state_reblock_out");
+        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
+                           reinterpret_cast<const float2 *>(natXf), p.tXf);
+    }
+    LAUNCH_CHECK("k_import_tiled_f2");
+    c->xfNat = true;
     return 0;
 }
 
@@ -483,6 +569,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     c->fwdQCompact = p.qFromKappa != 0;
     defer = defer && c->deferEnabled;
     c->fwdNat = false;
+    c->xfNat = false;
     c->dNat = false;
     c->pendFwdNat = natOut;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
@@ -547,7 +634,8 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 LAUNCH_CHECK("k_state_seq_trend");
                 dX = false;
             } else if (sbX) {
-                if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
+                if (c->sbSystolic) CHECK(state_chain_systolic(c, p));
+                else if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
                 else CHECK(state_chain_superblocks<false>(c, p));
                 dX = false;
             } else
@@ -1032,7 +1120,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         if (!c->haveFwd) return fail("no forward results to export");
         if (!lateD && !c->dNat) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));   // dNat: the epilogue wrote it already
         if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
-            CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));
+            if (!c->xfNat) CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));    // xfNat: the systolic state chain wrote it
             CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
         }
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
