@@ -33,9 +33,14 @@ core.py:3861-6142) for a whole batch of chromosomes on one GPU.
      postFitResiduals (n,m), NIS (n,), intervalToBlockMap[, background][, precision diagnostics]); the level model's
      arrays are zero-padded to the levelTrend shapes (core.py:4178-4192, 6004-6006).
 
-Steps 2f-2g restate pure-Python code of `consenrich.core`, which cannot be imported in the build image: they are checked
-against the CPU twin (oracle/driver.py) and a NumPy restatement of the formulas, not against reference outputs ("parity
-unpinned" for that glue).  Everything the passes COMPUTE with natives is the reference's arithmetic.
+Steps 2d-2g restate pure-Python code of `consenrich.core`, which cannot be imported in the build image.  They are pinned by
+the known answers the reference's own tests hold for them (tests/test_a12_pins.py): the weighted-RMS shift gate
+(test_core.py:4533-4610), the planned pass count / minimum of three passes and the final fixed-background phase
+(:4614-4693), the background warm start on a constant matrix (:4471-4491), the warm-start summary (:4494-4530); the
+penalised objective (2f) has no reference-held literal and is checked against the CPU twin (oracle/driver.py) and a NumPy
+restatement.  Everything the passes COMPUTE with natives is the reference's arithmetic.  The per-pass record is kept under
+the reference's diagnostics keys (`ChainFit.loop_diagnostics`, `ChainFit.post_process_noise_fit()`; core.py:5262-5340,
+3355-3417).
 """
 from __future__ import annotations
 
@@ -76,10 +81,42 @@ class FitConfig:
     background_warm_start: bool = False          # step 1 (run_consenrich_batch sets it when no initial background is given)
 
 
+def background_shift_gate(shift_rms: float, proposal_rms: float, reference_rms: float, rtol: float) -> dict:
+    """core.py:5228-5243, 5262-5270 from the three weighted RMS values (the device computes them from the resident weight track,
+    `csr_batch_background_update`): scale max(proposal RMS, reference RMS, 1), threshold rtol * scale, stable iff the shift is
+    within it -- under the reference's diagnostics keys."""
+    tol = float(float(rtol) * float(max(float(proposal_rms), float(reference_rms), 1.0)))
+    return {"background_shift": float(shift_rms), "background_shift_threshold": tol,
+            "background_shift_stable": bool(float(shift_rms) <= tol)}
+
+
+def weighted_rms(weights, proposal, reference) -> Tuple[float, float, float]:
+    """(shift, proposal, reference) weighted RMS of core.py:5199-5227 for host arrays (what the device returns per chain)."""
+    w = np.asarray(weights, np.float64)
+    sw = float(np.sum(w, dtype=np.float64))
+    if sw <= 0.0:
+        raise ValueError("shift RMS requires positive weights")
+    g1, g0 = np.asarray(proposal, np.float64), np.asarray(reference, np.float64)
+    d = g1 - g0
+    return (float(np.sqrt(float(np.dot(w, d * d)) / sw)), float(np.sqrt(float(np.dot(w, g1 * g1)) / sw)),
+            float(np.sqrt(float(np.dot(w, g0 * g0)) / sw)))
+
+
+def planned_outer_passes(cfg: "FitConfig") -> int:
+    """core.py:4704-4713: max(ECM_minOuterIters, max(1, ECM_outerIters)) passes are planned when the background is fitted."""
+    if not cfg.fit_background:
+        return 1
+    return max(int(cfg.min_outer), max(1, int(cfg.outer_passes)))
+
+
 @dataclass
 class ChainFit:
     passes: int = 0
     converged: bool = False
+    outer_stop_reason: str = "max_outer_passes"               # core.py:4747, 5040, 5371-5383
+    loop_diagnostics: List[dict] = field(default_factory=list)     # one dict per ECM phase, the reference's keys (core.py:5262-5340)
+    warm_start: dict = field(default_factory=dict)            # core.py:4689-4695
+    planned_passes: int = 0
     ecm_iters: List[int] = field(default_factory=list)
     nll: List[float] = field(default_factory=list)
     shift: List[float] = field(default_factory=list)
@@ -93,6 +130,31 @@ class ChainFit:
     final_ecm_converged: Optional[bool] = None
     final_nll: Optional[float] = None                         # sumNLL of the final forward pass (core.py:5583)
     final_forward_nis: Optional[float] = None                 # mean NIS of the final forward pass (core.py:5824)
+
+    def post_process_noise_fit(self, cfg: "FitConfig") -> dict:
+        """The reference's `diagnostics["post_process_noise_fit"]` summary of this chain (`_fitDiagnosticsMetadata`,
+        core.py:3355-3417), the keys its own tests read (test_core.py:4528-4530, 4604-4609, 4665-4672)."""
+        loop = [r for r in self.loop_diagnostics if not r.get("final_fixed_background_ecm")]
+        last = loop[-1] if loop else {}
+        conv = [bool(r["converged"]) for r in self.loop_diagnostics if r.get("converged") is not None]
+        return {
+            "requested_outer_passes": max(1, int(cfg.outer_passes)) if cfg.fit_background else 1,
+            "min_outer_passes": int(cfg.min_outer) if cfg.fit_background else 1,
+            "planned_outer_passes": int(self.planned_passes),
+            "actual_outer_passes": int(self.passes),
+            "outer_converged": bool(self.converged),
+            "outer_stop_reason": str(self.outer_stop_reason),
+            "background_shift": last.get("background_shift", 0.0),
+            "background_shift_threshold": last.get("background_shift_threshold"),
+            "outer_objective_per_cell": last.get("outer_objective_per_cell"),
+            "outer_objective_stable": bool(last.get("outer_objective_stable", False)),
+            "outer_stable_iters": int(last.get("outer_stable_iters", 0)),
+            "outer_patience_target": int(cfg.patience),
+            "inner_ecm_converged": bool(self.loop_diagnostics[-1].get("converged")) if self.loop_diagnostics else False,
+            "warm_start": dict(self.warm_start),
+            "all_ecm_converged": (bool(conv) and all(conv)) if conv else None,
+            "fixed_background_ecm": [dict(r) for r in self.loop_diagnostics],
+        }
 
 
 def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False) -> List[ChainFit]:
@@ -126,7 +188,17 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
     prev_obj = [float("nan")] * nc
     fwd_flags = L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
     have_stats = False
-    for p in range(cfg.outer_passes):
+    planned = planned_outer_passes(cfg)
+    last_inner = [False] * nc
+    last_obj_stable = [False] * nc
+    for c in range(nc):
+        fits[c].planned_passes = planned
+        fits[c].warm_start = {"background": bool(keep_background),                       # core.py:4689-4695
+                              "background_prepass": bool(cfg.fit_background and cfg.background_warm_start and not keep_background),
+                              "background_prepass_source": "banded_weighted_data" if (cfg.fit_background and cfg.background_warm_start
+                                                                                     and not keep_background) else "",
+                              "observation_precision": False, "process_precision": False}
+    for p in range(planned):
         if not have_stats:
             batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
@@ -137,6 +209,13 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
                 fits[c].nll.append(float(outs[c].final_nll))
                 fits[c].passes = p + 1
         if not cfg.fit_background:
+            for c in range(nc):                         # core.py:4994-5062: one phase, no background model
+                fits[c].converged = True
+                fits[c].outer_stop_reason = "fit_background_false"
+                fits[c].loop_diagnostics.append({"outer_pass": 1, "iters_done": int(outs[c].iters_done),
+                                                 "final_nll": float(outs[c].final_nll),
+                                                 "converged": bool(outs[c].converged) or bool(outs[c].skipped == 1),
+                                                 "background_shift": 0.0, "background_shift_threshold": 0.0})
             break
         info = batch.background_update(cfg.penalties[0], cfg.penalties[1], zero_center=cfg.zero_center,
                                        use_nonnegative=cfg.use_nonnegative,
@@ -155,7 +234,7 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
             if not active[c]:
                 continue
             o = info[c]
-            scale = max(o["proposal_rms"], o["reference_rms"], 1.0)
+            gate = background_shift_gate(o["shift_rms"], o["proposal_rms"], o["reference_rms"], cfg.shift_rtol)
             fits[c].shift.append(float(o["shift_rms"]))
             fits[c].irls_passes.append(int(o["passes"]))
             t = terms[c]
@@ -168,13 +247,46 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
             fits[c].objective.append(dict(t, forward_nll=float(fnll[c]), penalized_objective=obj,
                                           penalized_objective_per_cell=cur, stable=obj_stable))
             inner_ok = bool(outs[c].converged) or bool(outs[c].skipped == 1)
-            ok = o["shift_rms"] <= cfg.shift_rtol * scale and obj_stable and inner_ok
+            ok = gate["background_shift_stable"] and obj_stable and inner_ok
             stable[c] = stable[c] + 1 if ok else 0
+            last_inner[c], last_obj_stable[c] = inner_ok, obj_stable
+            tol_obj = cfg.outer_nll_rtol * max(abs(cur), abs(fits[c].objective[-2]["penalized_objective_per_cell"]), 1.0) \
+                if len(fits[c].objective) >= 2 else float("nan")
+            fits[c].loop_diagnostics.append({
+                "outer_pass": p + 1, "iters_done": int(outs[c].iters_done), "max_iters": int(cfg.ecm_iters),
+                "final_nll": float(outs[c].final_nll), "converged": inner_ok,
+                "nll_increase_count": int(outs[c].nll_increase_count), "diagnostics_source": "cfixedBackgroundECM",
+                **gate,
+                "outer_ecm_fit_nll": float(outs[c].final_nll), "outer_forward_nll": float(fnll[c]),
+                "outer_objective": obj, "outer_objective_per_cell": cur,
+                "outer_objective_change_per_cell": abs(cur - fits[c].objective[-2]["penalized_objective_per_cell"])
+                if len(fits[c].objective) >= 2 else float("nan"),
+                "outer_objective_threshold_per_cell": tol_obj, "outer_objective_stable": obj_stable,
+                "outer_effective_observation_count": int(t["effective_observation_count"]),
+                "outer_robust_observation_penalty": t["robust_observation_penalty"],
+                "outer_robust_process_penalty": t["robust_process_penalty"],
+                "outer_background_smoothness_penalty": t["first_difference_penalty"] + t["second_difference_penalty"],
+                "outer_background_first_difference_penalty": t["first_difference_penalty"],
+                "outer_background_second_difference_penalty": t["second_difference_penalty"],
+                "outer_background_negative_penalty": t["negative_penalty"],
+                "outer_inner_ecm_converged": inner_ok, "outer_stable_iters": int(stable[c]),
+                "outer_patience_target": int(cfg.patience)})
             if p + 1 >= cfg.min_outer and stable[c] >= cfg.patience:
                 fits[c].converged = True
+                fits[c].outer_stop_reason = "background_objective_inner_stable"        # core.py:5371-5375
                 active[c] = False
         if not any(active):
             break
+    if cfg.fit_background:
+        for c in range(nc):                                # core.py:5377-5383
+            if fits[c].converged:
+                continue
+            if not last_inner[c]:
+                fits[c].outer_stop_reason = "max_outer_passes_inner_ecm_unconverged"
+            elif not last_obj_stable[c]:
+                fits[c].outer_stop_reason = "max_outer_passes_objective"
+            elif stable[c] < cfg.patience:
+                fits[c].outer_stop_reason = "max_outer_passes_patience"
     return fits
 
 
@@ -243,6 +355,11 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
             fits[c].final_ecm_iters = int(outs[c].iters_done)
             fits[c].final_ecm_nll = float(outs[c].final_nll)
             fits[c].final_ecm_converged = bool(outs[c].converged) or bool(outs[c].skipped == 1)
+            fits[c].loop_diagnostics.append({"outer_pass": fits[c].passes + 1, "iters_done": int(outs[c].iters_done),     # core.py:5448-5455
+                                             "max_iters": int(cfg.ecm_iters), "final_nll": float(outs[c].final_nll),
+                                             "converged": fits[c].final_ecm_converged,
+                                             "nll_increase_count": int(outs[c].nll_increase_count),
+                                             "diagnostics_source": "cfixedBackgroundECM", "final_fixed_background_ecm": True})
     # final store-all forward / backward on data - background with the final multipliers (core.py:5560-5600).  The
     # statistics of the final background are resident (the ECM phase above or, without a background fit, the loop's)
     sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags)

@@ -71,6 +71,31 @@ def penalized_objective(forward_nll, munc, background, lam, kap, cfg):
             "effective_observation_count": count}
 
 
+def background_shift_gate(weights, proposal, reference, rtol):
+    """core.py:5199-5243: weighted RMS shift of the background proposal against the current background, its scale
+    max(proposal RMS, reference RMS, 1) and the stability test -- with the reference's diagnostics keys (core.py:5262-5270).
+    Pinned by the reference's own known answer (tests/test_core.py:4533-4610)."""
+    w = np.asarray(weights, np.float64)
+    sw = float(np.sum(w, dtype=np.float64))
+    if sw <= 0.0:
+        raise ValueError("shift RMS requires positive weights")
+    g1, g0 = np.asarray(proposal, np.float64), np.asarray(reference, np.float64)
+    delta = g1 - g0
+    shift = float(np.sqrt(float(np.dot(w, delta * delta)) / sw))
+    prop = float(np.sqrt(float(np.dot(w, g1 * g1)) / sw))
+    ref = float(np.sqrt(float(np.dot(w, g0 * g0)) / sw))
+    tol = float(float(rtol) * float(max(prop, ref, 1.0)))
+    return {"background_shift": shift, "background_shift_threshold": tol, "background_shift_stable": bool(shift <= tol),
+            "proposal_rms": prop, "reference_rms": ref}
+
+
+def planned_outer_passes(cfg):
+    """core.py:4704-4713: max(ECM_minOuterIters, max(1, ECM_outerIters)) when the background is fitted, else 1."""
+    if not cfg["fit_background"]:
+        return 1
+    return max(int(cfg["min_outer"]), max(1, int(cfg["outer_passes"])))
+
+
 def fit_chain(data, munc, cfg, initial_background=None):
     data = np.ascontiguousarray(data, np.float32)
     munc = np.ascontiguousarray(munc, np.float32)
@@ -78,7 +103,8 @@ def fit_chain(data, munc, cfg, initial_background=None):
     d = cfg["state_dim"]
     bg = np.zeros(n, np.float32) if initial_background is None else np.ascontiguousarray(initial_background, np.float32).copy()
     lam = kap = None
-    hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "objective": [], "converged": False}
+    hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "objective": [], "converged": False, "loop": [],
+            "stop_reason": "max_outer_passes"}
     prev_obj = float("nan")
     fwd = orc.cforwardPass if d == 2 else orc.cforwardPassLevel
     lam_first, lam2 = cfg["penalties"]
@@ -96,23 +122,24 @@ def fit_chain(data, munc, cfg, initial_background=None):
     if d == 2:
         kw["matrixF"] = np.asarray(cfg["F"], np.float32)
     out = None
-    for p in range(cfg["outer_passes"]):
+    inner_ok = obj_stable = False
+    for p in range(planned_outer_passes(cfg)):
         adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)
         out = ecm(matrixData=adj, matrixPluginMuncInit=munc, lambdaExpInit=lam, processPrecExpInit=kap, **kw)
         iters, nll, xs, Ps, lag, res, lam, kap, diag = out
         hist["ecm_iters"].append(int(iters))
         hist["nll"].append(float(nll))
         if not cfg["fit_background"]:
+            hist["converged"] = True                       # core.py:5038-5040
+            hist["stop_reason"] = "fit_background_false"
             break
         w, r, _, _ = bgo.weight_rhs_tracks(data, munc, xs[:, 0], np.float32(cfg["pad"]),
                                            lam if cfg["use_lambda"] else None, cfg["lambda_bounds"])
         nxt, info = bgo.solve_background(w, r, 0, zero_center=cfg["zero_center"], use_nonnegative=cfg["use_nonnegative"],
                                          multiplier=cfg["neg_multiplier"], initial=bg,
                                          penalties_override=(lam_first, lam2), return_info=True)
-        sw = float(w.sum())
-        g1, g0 = nxt.astype(np.float64), bg.astype(np.float64)
-        shift = float(np.sqrt(np.dot(w, (g1 - g0) ** 2) / sw))
-        scale = max(float(np.sqrt(np.dot(w, g1 * g1) / sw)), float(np.sqrt(np.dot(w, g0 * g0) / sw)), 1.0)
+        gate = background_shift_gate(w, nxt, bg, cfg["shift_rtol"])
+        shift = gate["background_shift"]
         hist["shift"].append(shift)
         hist["irls_passes"].append(int(info["passes"]))
         bg = nxt
@@ -133,13 +160,29 @@ def fit_chain(data, munc, cfg, initial_background=None):
                           and abs(cur - prev_obj) <= cfg["outer_nll_rtol"] * max(abs(cur), abs(prev_obj), 1.0))
         prev_obj = cur
         hist["objective"].append(obj)
-        if shift <= cfg["shift_rtol"] * scale and obj_stable and bool(diag["converged"]):
+        inner_ok = bool(diag["converged"])
+        if gate["background_shift_stable"] and obj_stable and inner_ok:
             stable += 1
         else:
             stable = 0
+        hist["loop"].append({"outer_pass": p + 1, "iters_done": int(iters), "final_nll": float(nll),
+                             "converged": inner_ok, "background_shift": gate["background_shift"],
+                             "background_shift_threshold": gate["background_shift_threshold"],
+                             "background_shift_stable": gate["background_shift_stable"],
+                             "outer_objective_per_cell": cur, "outer_objective_stable": obj_stable,
+                             "outer_inner_ecm_converged": inner_ok, "outer_stable_iters": int(stable),
+                             "outer_patience_target": int(cfg["patience"])})
         if p + 1 >= cfg["min_outer"] and stable >= cfg["patience"]:
             hist["converged"] = True
+            hist["stop_reason"] = "background_objective_inner_stable"          # core.py:5371-5375
             break
+    if cfg["fit_background"] and not hist["converged"]:                          # core.py:5377-5383
+        if not inner_ok:
+            hist["stop_reason"] = "max_outer_passes_inner_ecm_unconverged"
+        elif not obj_stable:
+            hist["stop_reason"] = "max_outer_passes_objective"
+        elif stable < cfg["patience"]:
+            hist["stop_reason"] = "max_outer_passes_patience"
     iters, nll, xs, Ps, lag, res, lam, kap, diag = out
     hist.update(passes=len(hist["ecm_iters"]), background=bg, xs=xs, Ps=Ps, resid=res, lam=lam, kap=kap)
     return hist
@@ -204,6 +247,13 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None):
         xs2, Ps2 = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32)
         xs2[:, 0], Ps2[:, 0, 0] = xs[:, 0], Ps[:, 0, 0]
         xs, Ps = xs2, Ps2
+    hist["warm_start"] = {"background": initial_background is not None,                       # core.py:4689-4695
+                          "background_prepass": bool(initial_background is None and cfg["fit_background"])}
+    hist["ecm_calls"] = len(hist["ecm_iters"]) + (1 if cfg["fit_background"] else 0)
+    if cfg["fit_background"]:
+        hist["loop"].append({"outer_pass": hist["passes"] + 1, "iters_done": final["final_ecm_iters"],
+                             "final_nll": final["final_ecm_nll"], "converged": final["final_ecm_converged"],
+                             "final_fixed_background_ecm": True})                             # core.py:5448-5455
     hist.update(final, warm_start_passes=warm_passes, final_nll=float(nll), final_forward_nis=float(phi),
                 out_xs=np.asarray(xs, np.float32), out_Ps=np.asarray(Ps, np.float32), out_resid=np.asarray(res, np.float32),
                 out_NIS=np.asarray(D, np.float32), out_block_map=bm, out_background=bg, out_lam=lam, out_kap=kap,
