@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the Consenrich estimator hot path on MI355X (driver contract: one JSON line on rank 0).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W         (N > 1: this process starts its N rank processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W         (the launcher provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT)
 
 Workload (BASELINE.json metric "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples"):
 22 synthetic chains with the hg38 autosome bin counts at 200 bp (14 375 018 bins), m = 32 samples, levelTrend model,
@@ -13,27 +13,32 @@ resident in HBM:  per-bin sufficient statistics of (data, munc)  ->  forward fil
 With N > 1 the chains are LPT-sharded over the ranks (strong scaling: the genome is fixed); there is no data-path
 collective -- the one RCCL call is the final track gather, done once after the timed region and reported separately.
 
-No PyTorch: the launcher (`python -m torch.distributed.run`) only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in
-the environment; the barrier and the max-over-ranks of the timed region are RCCL all-reduces on the library's stream
-(consenrich_amd.sharding.RcclComm -> csr_comm_* in libconsenrich_amd.so, librccl dlopen'ed there), the rendezvous of the
-128-byte RCCL id is a file on the node.
+`value` is measured in the library's DEFAULT validation mode (bit-exact sequential semantics, x_tol_ulps = 0: every output of
+the forward pass equals the reference's bit for bit -- the only mode that holds the 1e-5 gate through the ECM loop on
+ill-conditioned data, tests/test_hard_data.py).  The opt-in 2-ulp throughput mode (a single pass stays within a few float32
+ulps of the reference, gated on hard data by the same test file) is reported beside it as `throughput_mode`.
+
+No PyTorch: a launcher only provides the rank environment; the barrier and the max-over-ranks of the timed region are RCCL
+all-reduces on the library's stream (consenrich_amd.sharding.RcclComm -> csr_comm_* in libconsenrich_amd.so, librccl
+dlopen'ed there); the 128-byte RCCL id travels through the job's directory on the node (consenrich_amd.launch).  If the RCCL
+communicator cannot be created the measurement is still taken (file barrier, `config.comm` = "file") and printed, and the
+process exits NON-ZERO: a job whose one collective never came up has failed.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
-import shutil
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")     # PMC pass of THIS workload (scripts/pmc_traffic.py)
+TRAFFIC_FILES = {0: os.path.join("profiles", "r03_pmc_traffic_exact.json"),      # PMC passes of THIS workload (scripts/pmc_traffic.py)
+                 2: os.path.join("profiles", "r03_pmc_traffic.json")}
+EXIT_RCCL_FAILED = 3
 
 
 def b_alg(m: int) -> int:
@@ -49,55 +54,18 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
         "fwd_chain": 16.0 + 16.0 + 16.0 + 8.0,  # lambda/kappa/qscale/blockMap in, Pf + pNoise + xf out (fused chain)
         "fwd_cov_chain": 16.0 + 16.0 + 16.0,    # lambda/kappa/qscale/blockMap in, Pf + pNoise out
         "fwd_state_chain": 8.0,                 # xf out
+        "fwd_state": 8.0,                       # bit-exact state chain: speculative pass + repair passes as one unit, xf out
         "fwd_dstat": 4.0,                       # D out
         "bwd_chain": 8.0 + 16.0 + 16.0,         # xs + Ps + lagCov out
         "export_natural": 0.0,                  # layout conversion: pure overhead
     }.get(name, 0.0)
 
 
-class FileComm:
-    """Control-plane fallback over files on the node (barrier and max only): used to agree on whether RCCL is usable on
-    every rank, and in its place if it is not -- so that a broken RCCL installation costs the gather, not the measurement."""
-
-    def __init__(self, rank: int, world: int):
-        self.rank, self.world, self.k = rank, world, 0
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-        self.dir = os.path.join(base, f"consenrich_amd_fc_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-        os.makedirs(self.dir, exist_ok=True)
-
-    def allreduce_max(self, value: float, timeout_s: float = 600.0) -> float:
-        self.k += 1
-        mine = os.path.join(self.dir, f"{self.k}_{self.rank}")
-        with open(mine + ".tmp", "w") as fh:
-            fh.write(repr(float(value)))
-        os.replace(mine + ".tmp", mine)
-        vals, deadline = [], time.monotonic() + timeout_s
-        for r in range(self.world):
-            path = os.path.join(self.dir, f"{self.k}_{r}")
-            while True:
-                try:
-                    with open(path) as fh:
-                        vals.append(float(fh.read()))
-                    break
-                except (FileNotFoundError, ValueError):
-                    if time.monotonic() > deadline:
-                        raise TimeoutError(f"rank {self.rank}: rank {r} never reached barrier {self.k}")
-                    time.sleep(0.0005)
-        return max(vals)
-
-    def barrier(self):
-        self.allreduce_max(0.0)
-
-    def close(self):
-        self.barrier()
-        if self.rank == 0:
-            time.sleep(0.2)
-            shutil.rmtree(self.dir, ignore_errors=True)
-
-
 def cpu_baseline(m: int, max_seconds: float = 15.0):
     """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload: a chr1-sized chain.
     (scripts/cpu_port_vs_reference.py, build container only: the port runs within 3 % of the compiled reference.)"""
+    import numpy as np
+
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import cases
     from consenrich_amd.sharding import hg38_chain_lengths
@@ -137,7 +105,7 @@ def cpu_baseline(m: int, max_seconds: float = 15.0):
     }
 
 
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -147,52 +115,80 @@ def main() -> int:
     ap.add_argument("--q0", default="1e-3,1e-4", help="diagonal of the base process noise Q0 (long-memory regime: 1e-5,1e-6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the exact-mode and ECM measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the throughput-mode, ECM and calibration-fold measurements")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (no RCCL: file barrier)")
-    args = ap.parse_args()
+    ap.add_argument("--fake-ranks", action="store_true",
+                    help="CPU rehearsal of the launcher and control plane: no GPU, no measurement; rank 0 prints a stub line")
+    return ap.parse_args(argv)
+
+
+def fake_rank(args) -> int:
+    """What `--fake-ranks` runs in every rank: the job's control plane without a GPU (tests/test_launch.py)."""
+    from consenrich_amd.launch import JobFiles
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    files = JobFiles(rank, world)
+    seen = files.allreduce_sum(1.0, timeout_s=60.0)
+    slowest = files.allreduce_max(float(rank), timeout_s=60.0)
+    fail = os.environ.get("CONSENRICH_AMD_FAKE_FAIL_RANK")
+    files.close(remove=False)
+    if rank == 0:
+        print(json.dumps({"fake": True, "n_gpus": world, "n_ranks_seen": int(round(seen)), "max_rank": int(slowest)}))
+    return 5 if fail is not None and int(fail) == rank else 0
+
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly: become the launcher of N rank processes (nothing in this process has touched the GPU)
+        from consenrich_amd.launch import spawn_ranks
+
+        return spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus)
+    if args.fake_ranks:
+        return fake_rank(args)
+
+    import numpy as np
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one process per GPU)", file=sys.stderr)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
         return 2
 
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.launch import JobFiles
     from consenrich_amd.sharding import RcclComm, hg38_chain_lengths, lpt_assign
 
+    L.require_gpu()          # no GPU, no number: there is no CPU fallback to time
     m = args.samples
     q00, q11 = (float(v) for v in args.q0.split(","))
     lengths = hg38_chain_lengths(args.bin_bp)
     total_bins = int(sum(lengths))
     mine = lpt_assign(lengths, world)[rank]
     my_lens = [lengths[i] for i in mine]
+    my_bins = int(sum(my_lens))
 
     model = ModelParams(state_dim=2, Q0=((q00, 0.0), (0.0, q11)))
-    batch = DeviceBatch(local_rank)
-    comm, comm_kind, comm_note, fc, rccl_hung = None, "none", None, None, False
+    batch = DeviceBatch(local_rank)                          # the library's default validation mode (bit-exact)
+    comm, comm_kind, comm_note, files, rccl_failed, rccl_hung = None, "none", None, None, False, False
+    n_ranks_seen = 1
     if world > 1:
-        fc = FileComm(rank, world)
-        probe_ok = 0.0
+        files = JobFiles(rank, world)
         if args.same_device:
-            probe_ok, comm_note = 1.0, "same-device rehearsal: RCCL refuses two ranks on one GPU"
+            comm, comm_kind = files, "file"
+            comm_note = "same-device rehearsal: RCCL refuses two ranks on one GPU"
         else:
-            import ctypes
-
-            if L.lib().csr_comm_unique_id(ctypes.create_string_buffer(128)) != 0:      # RCCL loads and sees this device?
-                probe_ok, comm_note = 1.0, f"rank {rank}: {L.last_error()}"
-        rccl_hung = False
-        if fc.allreduce_max(probe_ok) == 0.0:
-            # communicator creation is a collective: run it under a watchdog so that a bootstrap that never completes on this
-            # node costs the gather, not the measurement (the ranks then agree, through the files, to use the file barrier)
+            # communicator creation is a collective: under a watchdog, so that a bootstrap that never completes still leaves a
+            # measurement (taken over the file barrier) and a diagnosis -- and a non-zero exit status
             import threading
 
             box = {}
 
             def make():
                 try:
-                    box["comm"] = RcclComm(batch, world, rank)
+                    box["comm"] = RcclComm(batch, world, rank, files=files)
                 except Exception as exc:        # noqa: BLE001
                     box["err"] = repr(exc)
 
@@ -200,16 +196,16 @@ def main() -> int:
             th.start()
             th.join(timeout=float(os.environ.get("CONSENRICH_AMD_RCCL_TIMEOUT", "240")))
             mine_ok = "comm" in box
-            if fc.allreduce_max(0.0 if mine_ok else 1.0) == 0.0:
+            if files.allreduce_max(0.0 if mine_ok else 1.0) == 0.0:
                 comm, comm_kind = box["comm"], "rccl"
+                n_ranks_seen = comm.ranks_seen()
             else:
-                comm, comm_kind = fc, "file"
+                comm, comm_kind, rccl_failed = files, "file", True
                 rccl_hung = th.is_alive()
-                comm_note = f"rank {rank}: RCCL communicator not created ({box.get('err', 'timeout')})" if not mine_ok \
-                    else "RCCL communicator not created on another rank"
-        else:
-            comm, comm_kind = fc, "file"
-            comm_note = comm_note or "RCCL unusable on another rank"
+                comm_note = (f"rank {rank}: RCCL communicator not created ({box.get('err', 'timeout inside ncclCommInitRank')})"
+                             if not mine_ok else "RCCL communicator not created on another rank")
+        if comm_kind == "file":
+            n_ranks_seen = int(round(files.allreduce_sum(1.0)))
     batch.configure(model, m, my_lens)
     batch.synthesize(seed=1234 + rank)
     flags = L.RETURN_NLL
@@ -235,46 +231,69 @@ def main() -> int:
         fence(b)
         return max_over_ranks(time.perf_counter() - t0)
 
-    # statistics + forward (store, NLL) + backward + every track in the reference layout + residuals + per-chain phiHat /
-    # NLL read-back (the step's one host synchronisation), as one C-ABI call
-    elapsed = timed(batch, lambda: batch.step(flags, what), args.warmup, args.steps)
-    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
-    value = total_bins * args.steps / elapsed
+    def profile_kernels(b, steps):
+        """per-kernel durations: HIP events on the library's stream, separate (untimed) pass of the same steps"""
+        b.profile(True)
+        for _ in range(steps):
+            b.step(flags, what)
+        times = b.kernel_times()
+        b.profile(False)
+        return {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1), "ms_per_step": v[1] / max(steps, 1)} for k, v in times.items()}
 
-    # per-kernel durations: HIP events on the library's stream, separate (untimed) pass of the same steps
-    batch.profile(True)
-    for _ in range(args.steps):
-        batch.step(flags, what)
-    times = batch.kernel_times()
-    batch.profile(False)
-    rs = batch.run_stats()
-    my_bins = int(sum(my_lens))
-    per_kernel = {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1), "ms_per_step": v[1] / max(args.steps, 1)}
-                  for k, v in times.items()}
-    # dominant kernel = the longest one ON THE CRITICAL PATH: the NIS/NLL epilogue runs on the side stream underneath the
-    # smoother / residual kernels (its event-measured duration is stretched by that overlap), so it never is
-    critical = {k: v for k, v in per_kernel.items() if k != "fwd_dstat"} or per_kernel
-    dom = max(critical, key=lambda k: critical[k]["ms_per_step"]) if critical else None
-    roofline = None
-    if dom is not None:
+    def roofline_of(per_kernel, xtol):
+        # dominant kernel = the longest one ON THE CRITICAL PATH: the NIS/NLL epilogue runs on the side stream underneath the
+        # smoother / residual kernels (its event-measured duration is stretched by that overlap), so it never is.  The
+        # bit-exact state chain (speculative pass + repair passes: `fwd_state_chain` + `fwd_state_fix`) is ONE unit of work
+        # spread over many launches of one kernel: it is priced as such (bytes of the unit / time of the unit per step).
+        crit = {k: dict(v) for k, v in per_kernel.items() if k != "fwd_dstat"}
+        if "fwd_state_fix" in crit and "fwd_state_chain" in crit:
+            a, f = crit.pop("fwd_state_chain"), crit.pop("fwd_state_fix")
+            crit["fwd_state"] = {"launches": a["launches"] + f["launches"], "ms_per_step": a["ms_per_step"] + f["ms_per_step"],
+                                 "avg_ms": a["ms_per_step"] + f["ms_per_step"]}       # one unit per step
+        if not crit:
+            return None
+        dom = max(crit, key=lambda k: crit[k]["ms_per_step"])
         alg_bytes = kernel_alg_bytes(dom, m, 2) * my_bins
-        avg_s = per_kernel[dom]["avg_ms"] * 1e-3
+        avg_s = crit[dom]["avg_ms"] * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, TRAFFIC_FILE)
-        # the committed PMC pass was taken on the default workload at N = 1; it does not describe other shapes / shards
-        if os.path.exists(pmc_path) and world == 1 and m == 32 and args.bin_bp == 200 and args.q0 == "1e-3,1e-4":
+        pmc_path = os.path.join(ROOT, TRAFFIC_FILES.get(xtol, ""))
+        # a committed PMC pass describes the default workload at N = 1 only
+        if os.path.isfile(pmc_path) and world == 1 and m == 32 and args.bin_bp == 200 and args.q0 == "1e-3,1e-4":
             try:
                 with open(pmc_path) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_source = f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes of this " \
+                traffic_source = f"{TRAFFIC_FILES[xtol]} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes of this " \
                                  "command; not measured in this run)"
-            except Exception:
+            except Exception:       # noqa: BLE001
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                    "alg_bytes_per_bin": kernel_alg_bytes(dom, m, 2), "bins_per_launch": my_bins,
-                    "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+        out = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+               "alg_bytes_per_bin": kernel_alg_bytes(dom, m, 2), "bins_per_launch": my_bins,
+               "avg_launch_ms": crit[dom]["avg_ms"], "launches_per_step": crit[dom]["launches"] / max(args.steps, 1)}
+        if dom == "fwd_state":
+            out["limit"] = ("dependent fp64 latency, not bandwidth: the exact float32-rounded state recursion is sequential per "
+                            "chain; one wavefront per superblock walks it as a 64-lane shift register (~25-31 ns per bin), and "
+                            "the repair passes follow the longest stretch in which the true trajectory meets no speculative one "
+                            "(DESIGN.md section 3)")
+        return out
+
+    # ---- the headline: the library's default mode --------------------------------------------------------------------
+    elapsed = timed(batch, lambda: batch.step(flags, what), args.warmup, args.steps)
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    value = total_bins * args.steps / elapsed
+    per_kernel = profile_kernels(batch, args.steps)
+    rs = batch.run_stats()
+    roofline = roofline_of(per_kernel, rs["x_tol_ulps"])
+    # the dominant bandwidth-bound kernel beside it (what an HBM roofline is meaningful for)
+    stream = {k: v for k, v in per_kernel.items() if k in ("stats", "residuals")}
+    roofline_streaming = None
+    if stream:
+        sk = max(stream, key=lambda k: stream[k]["ms_per_step"])
+        ach = kernel_alg_bytes(sk, m, 2) * my_bins / (stream[sk]["avg_ms"] * 1e-3) / 1e9
+        roofline_streaming = {"bound": "hbm", "kernel": sk, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": kernel_alg_bytes(sk, m, 2),
+                              "avg_launch_ms": stream[sk]["avg_ms"]}
 
     extras = {}
     if not args.no_extras:
@@ -282,52 +301,52 @@ def main() -> int:
         ecm_iters, inner = 3, 5
         batch.stats()
 
-        def ecm_once():
-            batch.ecm(max_iters=ecm_iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
+        def ecm_once(b=batch):
+            b.ecm(max_iters=ecm_iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
 
         e = timed(batch, ecm_once, 1, 2) / 2.0
-        rs_ecm = batch.run_stats()
-        extras["ecm"] = {"ms_per_iter": 1000.0 * e / ecm_iters, "iters": ecm_iters, "inner_sweeps": inner,
-                         "bin_sweeps_per_s": total_bins * ecm_iters * inner / e,
-                         "pipeline_redos": rs_ecm["pipeline_redos"] - rs["pipeline_redos"],
-                         "warm_started_sweeps": {"active": rs_ecm["block_len"] <= 32, "windows_bins": [rs_ecm["ws_warm_f"], rs_ecm["ws_warm_b"]],
-                                                 "blocks_repaired_in_kernel": rs_ecm["local_repairs"],
-                                                 "note": "batches with 32-bin blocks (< 2 M bins per rank: 8-GPU shards) start a "
-                                                         "sweep's windows from the previous sweep's carries"},
+        extras["ecm"] = {"x_tol_ulps": rs["x_tol_ulps"], "ms_per_iter": 1000.0 * e / ecm_iters, "iters": ecm_iters,
+                         "inner_sweeps": inner, "bin_sweeps_per_s": total_bins * ecm_iters * inner / e,
                          "note": "per ECM iteration over all chains: 5 x (forward + smoother + kappa E-step) + 1 NLL "
-                                 "forward; bin_sweeps = forward+backward+E-step sweeps"}
-        # (2) the same step in the bit-exact validation mode (k = 0: results == the sequential recursion; the mode the
-        # reference-shaped drop-in callables default to)
-        ex = DeviceBatch(local_rank, x_tol_ulps=0)
-        ex.configure(model, m, my_lens)
-        ex.synthesize(seed=1234 + rank)
-        ex_steps = max(1, min(args.steps, 3))
-        ee = timed(ex, lambda: ex.step(flags, what), 1, ex_steps)
-        rx = ex.run_stats()
-        extras["exact_mode"] = {"x_tol_ulps": 0, "ms_per_step": 1000.0 * ee / ex_steps, "value": total_bins * ex_steps / ee,
-                                "unit": "genomic bins/s", "steps": ex_steps, "block_len": rx["block_len"],
-                                "warm_bins": [rx["warm_p"], rx["warm_x"], rx["warm_b"]],
-                                "state_chain": {"superblock_bins": int(os.environ.get("CONSENRICH_AMD_SB_BINS", "8192")),
-                                                "window_bins": int(os.environ.get("CONSENRICH_AMD_SB_WARM", "16384")),
-                                                "note": "bitwise speculation of the state chain on a re-blocked view; "
-                                                        "reruns[1] counts superblocks re-run over 1 + steps steps"},
-                                "reruns": [rx["reruns_p"], rx["reruns_x"], rx["reruns_b"]],
-                                "fix_launches": rx["fix_launches"]}
-        ex.close()
-        # (3) the same step with the delete-block calibration folds of every chromosome as extra chains of the batch
+                                 "forward; bin_sweeps = forward+backward+E-step sweeps; default (bit-exact) mode"}
+        # (2) the same step with the delete-block calibration folds of every chromosome as extra chains of the batch
         # (uncertainty.py:1370-1419: folds = 2 independent refits per chromosome, constants.py:437; DeviceBatch.make_fold):
-        # what fills an under-occupied shard -- the latency-bound chain kernels take about as long for 3x the chains
+        # independent chains fill the GPU the latency-bound exact state chain leaves idle
         folds = 2
         fb = DeviceBatch(local_rank)
         fb.configure(model, m, [n for n in my_lens for _ in range(folds + 1)])
         fb.synthesize(seed=4321 + rank)
-        ef = timed(fb, lambda: fb.step(flags, what), 1, max(1, min(args.steps, 5)))
-        fsteps = max(1, min(args.steps, 5))
-        extras["with_calibration_folds"] = {"folds": folds, "ms_per_step": 1000.0 * ef / fsteps,
+        fsteps = max(1, min(args.steps, 3))
+        ef = timed(fb, lambda: fb.step(flags, what), 1, fsteps)
+        extras["with_calibration_folds"] = {"x_tol_ulps": rs["x_tol_ulps"], "folds": folds, "ms_per_step": 1000.0 * ef / fsteps,
                                             "value": total_bins * (folds + 1) * fsteps / ef, "unit": "genomic bins/s",
                                             "note": "every chromosome three times in the batch (fit + 2 fold refits, "
                                                     "synthetic data of the same shape); bins of all refits counted"}
         fb.close()
+        # (3) the opt-in throughput mode (2-ulp carry acceptance): same step, same outputs within a few float32 ulps
+        tb = DeviceBatch(local_rank, x_tol_ulps=2)
+        tb.configure(model, m, my_lens)
+        tb.synthesize(seed=1234 + rank)
+        et = timed(tb, lambda: tb.step(flags, what), args.warmup, args.steps)
+        tk = profile_kernels(tb, args.steps)
+        trs = tb.run_stats()
+        tvalue = total_bins * args.steps / et
+        tb.stats()
+        ete = timed(tb, lambda: ecm_once(tb), 1, 2) / 2.0
+        extras["throughput_mode"] = {
+            "x_tol_ulps": 2, "ms_per_step": 1000.0 * et / max(args.steps, 1), "value": tvalue, "unit": "genomic bins/s",
+            "roofline": roofline_of(tk, 2),
+            "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": tvalue * b_alg(m) / 1e9, "peak": HBM_PEAK_GBS * world,
+                              "unit": "GB/s", "frac": tvalue * b_alg(m) / 1e9 / (HBM_PEAK_GBS * world)},
+            "ecm_ms_per_iter": 1000.0 * ete / ecm_iters,
+            "block_len": trs["block_len"], "warm_bins": [trs["warm_p"], trs["warm_x"], trs["warm_b"]],
+            "reruns": [trs["reruns_p"], trs["reruns_x"], trs["reruns_b"]], "pipeline_redos": trs["pipeline_redos"],
+            "kernels_rank0": tk,
+            "contract": "opt-in (DeviceBatch(x_tol_ulps=2)): a speculative carry is accepted within 2 float32 ulps; a single "
+                        "pass stays within a few ulps of the reference on every bin, also on hard data "
+                        "(tests/test_hard_data.py); iterated through the ECM loop on ill-conditioned data it inherits the "
+                        "reference's own sensitivity to ulp-level perturbations, which is why it is not the default"}
+        tb.close()
 
     gather_ms, gather_note = None, comm_note
     if comm_kind == "rccl" and not args.no_gather:
@@ -343,8 +362,10 @@ def main() -> int:
             if rank == 0 and not all(g is not None and g.shape == (lengths[i], 2) and np.all(np.isfinite(g))
                                      for i, g in enumerate(gathered)):
                 gather_note = "gathered tracks have unexpected shapes / values"
+                rccl_failed = True
         except Exception as exc:        # noqa: BLE001
             gather_note = f"gather failed: {exc!r}"
+            rccl_failed = True
 
     if rank == 0:
         out = {
@@ -358,9 +379,13 @@ def main() -> int:
                             "levelTrend",
                 "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"], "q0_diag": [q00, q11],
                 "warm_bins": [rs["warm_p"], rs["warm_x"], rs["warm_b"]], "x_tol_ulps": rs["x_tol_ulps"],
-                "comm": comm_kind,
+                "validation": "bit-exact sequential semantics (library default)" if rs["x_tol_ulps"] == 0
+                              else f"{rs['x_tol_ulps']}-ulp carry acceptance",
+                "comm": comm_kind, "n_ranks_seen": n_ranks_seen,
             },
+            "build": L.build_id(),
             "roofline": roofline,
+            "roofline_streaming": roofline_streaming,
             "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": value * b_alg(m) / 1e9,
                               "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                               "frac": value * b_alg(m) / 1e9 / (HBM_PEAK_GBS * world)},
@@ -376,17 +401,23 @@ def main() -> int:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m)
         print(json.dumps(out))
+        sys.stdout.flush()
+    status = EXIT_RCCL_FAILED if rccl_failed else 0
+    if rccl_hung:
+        # a thread of this process is still inside ncclCommInitRank: a normal interpreter exit would wait for it.  The line is
+        # out; leave with the failure status.
+        if files is not None:
+            try:
+                files.close()
+            except Exception:       # noqa: BLE001
+                pass
+        os._exit(status)
     if comm is not None:
         comm.barrier()
-        if comm is not fc:
-            comm.close()
-    if fc is not None:
-        fc.close()
-    if rccl_hung:               # a thread is still stuck inside ncclCommInitRank: do not wait for it at interpreter exit
-        sys.stdout.flush()
-        os._exit(0)
-    batch.close()
-    return 0
+    batch.close()                   # closes the RCCL communicator attached to it, then the context
+    if files is not None:
+        files.close()
+    return status
 
 
 if __name__ == "__main__":

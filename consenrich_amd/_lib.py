@@ -153,6 +153,7 @@ class RunStats(C.Structure):
 SYMBOLS = {
     "csr_last_error": (C.c_char_p, []),
     "csr_abi_version": (C.c_int, []),
+    "csr_build_id": (C.c_char_p, []),
     "csr_device_count": (C.c_int, []),
     "csr_create": (C.c_void_p, [C.c_int]),
     "csr_destroy": (None, [C.c_void_p]),
@@ -222,6 +223,7 @@ SYMBOLS = {
     "csr_comm_world": (C.c_int, [C.c_void_p]),
     "csr_comm_rank": (C.c_int, [C.c_void_p]),
     "csr_comm_allreduce_max": (C.c_int, [C.c_void_p, DP]),
+    "csr_comm_allreduce_sum": (C.c_int, [C.c_void_p, DP]),
     "csr_comm_barrier": (C.c_int, [C.c_void_p]),
     "csr_batch_gather_tracks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, FP]),
     "csr_expected_transition_residual_sums": (C.c_int, [C.c_int32, C.c_int64, DP, DP, DP, DP, DP, DP, I64P]),
@@ -250,6 +252,11 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def build_id() -> str:
+    """What the loaded library was built from: "abi N src <hash16> <flags>" (csr_build_id)."""
+    return lib().csr_build_id().decode("ascii", "replace")
 
 
 def last_error() -> str:

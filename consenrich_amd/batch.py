@@ -63,12 +63,22 @@ class DeviceBatch:
         self.chain_lens = []
         self.m = 0
         self.d = 2
+        self._comms = []
+
+    def _attach_comm(self, comm):
+        self._comms.append(comm)
+
+    def _detach_comm(self, comm):
+        if comm in self._comms:
+            self._comms.remove(comm)
 
     def set_validation(self, x_tol_ulps: int):
         L.check(self._lib.csr_set_validation(self._ctx, int(x_tol_ulps)))
 
     def close(self):
         if self._ctx:
+            for comm in list(getattr(self, "_comms", [])):      # a communicator holds the context's device and stream
+                comm.close()
             self._lib.csr_destroy(self._ctx)
             self._ctx = None
 

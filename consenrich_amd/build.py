@@ -1,7 +1,13 @@
-"""Build libconsenrich_amd.so for gfx950 with hipcc (cross-compiles without a GPU; ~10 s)."""
+"""Build libconsenrich_amd.so for gfx950 with hipcc (cross-compiles without a GPU; ~60 s).
+
+The library records what it was built from (`csr_build_id`: a hash of every source file and the compiler flags).  `build()`
+rebuilds exactly when that record differs from the sources in the tree -- file times do not enter (a prebuilt library that
+travelled to another machine with the tree is kept if, and only if, it IS a build of these sources)."""
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -17,6 +23,7 @@ OUT = os.path.join(OUT_DIR, "libconsenrich_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
          "-Wall", "-Wno-unused-function",
          "-Wno-bitwise-instead-of-logical"]     # branch-free '&' of predicates in the chain policies is deliberate
+FLAG_TAG = "gfx950,O3,fp-contract=off"
 
 
 def hipcc() -> str:
@@ -26,21 +33,49 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm): consenrich_amd has no CPU fallback and cannot be built without it")
 
 
-def up_to_date() -> bool:
+def source_hash() -> str:
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id() -> str:
+    """csr_build_id() of the library on disk, read from the file itself ('' if there is none or it predates the record)."""
     if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+        return ""
+    with open(OUT, "rb") as fh:
+        m = re.search(rb"CSR_BUILD_ID:(abi \d+ src [0-9a-f]{16} [ -~]*)\0", fh.read())
+    return m.group(1).decode("ascii") if m else ""
+
+
+def up_to_date() -> bool:
+    return f" src {source_hash()} " in built_id() + " "
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    want = source_hash()
     if not force and up_to_date():
+        if verbose:
+            print(f"consenrich_amd: found a build of these sources ({built_id()})", file=sys.stderr)
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, "-o", OUT, SRC]
+    tmp = OUT + f".{os.getpid()}.tmp"
+    cmd = [hipcc(), *FLAGS, f'-DCSR_SOURCE_HASH="{want}"', f'-DCSR_BUILD_FLAGS="{FLAG_TAG}"', "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    if verbose:
+        print(f"consenrich_amd: compiled {OUT} (src {want})", file=sys.stderr)
     return OUT
 
 

@@ -120,17 +120,20 @@ extern "C" int csr_comm_rank(csr_comm *k) { return k ? k->rank : -1; }
 
 // max over ranks of *value (in place); also the barrier of the timed region: an all-reduce of one double on the library's
 // stream followed by a stream synchronisation completes only when every rank has entered it with its queue drained.
-extern "C" int csr_comm_allreduce_max(csr_comm *k, double *value) {
+static int comm_allreduce(csr_comm *k, double *value, ncclRedOp_t op) {
     if (!k || !value) return fail("null argument");
     csr_ctx *c = k->ctx;
     CHECK(ctx_select(c));
     if (c->configured) CHECK(settle(c));
     HIPOK(hipMemcpyAsync(k->dScalar, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLOK(g_rccl.AllReduce(k->dScalar, k->dScalar + 1, 1, ncclDouble, ncclMax, k->comm, c->stream));
+    NCCLOK(g_rccl.AllReduce(k->dScalar, k->dScalar + 1, 1, ncclDouble, op, k->comm, c->stream));
     HIPOK(hipMemcpyAsync(value, k->dScalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
+extern "C" int csr_comm_allreduce_max(csr_comm *k, double *value) { return comm_allreduce(k, value, ncclMax); }
+// sum over ranks of *value (in place): an all-reduce of 1.0 tells a caller how many ranks the communicator really spans
+extern "C" int csr_comm_allreduce_sum(csr_comm *k, double *value) { return comm_allreduce(k, value, ncclSum); }
 extern "C" int csr_comm_barrier(csr_comm *k) {
     double v = 0.0;
     return csr_comm_allreduce_max(k, &v);
@@ -162,6 +165,10 @@ extern "C" int csr_batch_gather_tracks(csr_ctx *c, csr_comm *k, int64_t cap_bins
     if (!k || k->ctx != c) return fail("communicator does not belong to this context");
     CHECK(settle(c));
     if (!c->nat[CSR_ARR_XS] || !c->nat[CSR_ARR_PS]) return fail("smoothed tracks were not exported (CSR_EXPORT_SMOOTH)");
+    // the natural arrays must hold the RESIDENT fit: a later ecm / forward_backward / background_apply without an export
+    // would otherwise be gathered as stale tracks
+    if (!c->haveBwd || c->natSmoothGen != c->fitGen)
+        return fail("the exported smoothed tracks are not those of the resident fit: export (CSR_EXPORT_SMOOTH) after the last pass");
     const int nc = (int)c->chains.size();
     int64_t mine = 0;
     std::vector<int64_t> pos(nc);

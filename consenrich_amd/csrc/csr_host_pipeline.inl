@@ -697,6 +697,8 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
     }
     c->smoothNat = natOut;
     c->pendNatOut = natOut;
+    c->fitGen += 1;
+    if (natOut) c->natSmoothGen = c->fitGen;        // this smoother writes xs / Ps in the reference layout itself
     // constant process noise (no kappa / qScale / adaptive noise): the smoother need not read pNoise at all
     p.qFromMult = (c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA))) ? 1 : 0;
     (void)wantLag;      // the lag-one covariance is produced by the smoother's own main phase
@@ -1155,6 +1157,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
         CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
     }
+    if (what & CSR_EXPORT_SMOOTH) c->natSmoothGen = c->fitGen;
     if (what & CSR_EXPORT_MULT) {
         CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
         CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));

@@ -50,6 +50,17 @@ static int fail(const char *fmt, ...) {
 
 extern "C" const char *csr_last_error(void) { return g_err; }
 extern "C" int csr_abi_version(void) { return CSR_ABI_VERSION; }
+#ifndef CSR_SOURCE_HASH
+#define CSR_SOURCE_HASH "unknown"
+#endif
+#ifndef CSR_BUILD_FLAGS
+#define CSR_BUILD_FLAGS ""
+#endif
+#define CSR_STR2(x) #x
+#define CSR_STR(x) CSR_STR2(x)
+// (the marker in front lets consenrich_amd/build.py find the record in the file without loading the library)
+static const char g_buildId[] = "CSR_BUILD_ID:abi " CSR_STR(CSR_ABI_VERSION) " src " CSR_SOURCE_HASH " " CSR_BUILD_FLAGS;
+extern "C" const char *csr_build_id(void) { return g_buildId + 13; }
 extern "C" int csr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -139,6 +150,7 @@ struct csr_ctx {
     int64_t Npad = 0, NB = 0, NG = 0, TN = 0;
     bool statsValid = false;
     bool haveFwd = false, haveBwd = false;
+    uint64_t fitGen = 0, natSmoothGen = ~0ull;     // generation of the resident smoothed fit / of the natural xs + Ps arrays (csr_batch_gather_tracks)
     bool smoothNat = false;     // the last smoother pass wrote xs / Ps / lag straight into the natural arrays (the
                                 // block-transposed copies are stale; nothing but the ECM E-steps reads those)
     bool pendNatOut = false;

@@ -5,7 +5,8 @@ state inside runConsenrich), so the path shards with NO data-path collective: ev
 own DeviceBatch.  The only communication is the final gather of the per-bin output tracks, done once per job over RCCL /
 xGMI: `RcclComm` binds the library's csr_comm_* entry points (RCCL itself is dlopen'ed by libconsenrich_amd.so) -- the
 tracks are packed on the device straight from the exported arrays and all-gathered, no host bounce.  The
-rendezvous (rank 0's 128-byte unique id) goes through a file on the node, keyed by the launcher's MASTER_PORT and process id.
+rendezvous (rank 0's 128-byte unique id) goes through the job's directory on the node (`consenrich_amd.launch.JobFiles`:
+token-stamped files, explicit directory / token from the launcher or derived per launch attempt).
 The host-side bookkeeping (ownership, packed layout, re-assembly in genome order) is transport-agnostic (`pack_layout`,
 `unpack_gathered`, `gather_tracks`) and is what the world-size-2 CPU test drives over gloo.
 """
@@ -13,7 +14,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -99,69 +99,55 @@ def gather_tracks(local: Dict[int, np.ndarray], lengths: Sequence[int], row_widt
     return unpack_gathered(recv, lengths, world, row_width)
 
 
-def _rendezvous_path() -> str:
-    """One file per job on the node: the launcher's port + its process id (every rank of a node is a child of the same
-    launcher process: a distributed launcher, mpirun, a shell loop ...); CONSENRICH_AMD_RDZV_FILE overrides."""
-    explicit = os.environ.get("CONSENRICH_AMD_RDZV_FILE")
-    if explicit:
-        return explicit
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    return os.path.join(base, f"consenrich_amd_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-
-
-def exchange_unique_id(rank: int, make_id, path: str, timeout_s: float = 300.0) -> bytes:
-    """Rank 0 creates the 128-byte id and publishes it atomically at `path`; every other rank polls for it."""
+def exchange_unique_id(rank: int, make_id, files, timeout_s: float = 300.0) -> bytes:
+    """Rank 0 creates the 128-byte id and publishes it in the job's directory (`launch.JobFiles`: atomic, token-stamped);
+    every other rank polls for a VALID file -- one of this user, carrying this job's token, 128 bytes long.  A leftover of an
+    earlier job in a re-used directory is ignored, not read."""
     if rank == 0:
         raw = make_id()
         if len(raw) != 128:
             raise ValueError("the unique id must have 128 bytes")
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as fh:
-            fh.write(raw)
-        os.replace(tmp, path)           # atomic: a reader sees all 128 bytes or no file
+        files.publish("rccl_id", raw)
         return raw
-    deadline = time.monotonic() + timeout_s
-    while True:
-        try:
-            with open(path, "rb") as fh:
-                raw = fh.read()
-            if len(raw) == 128:
-                return raw
-        except FileNotFoundError:
-            pass
-        if time.monotonic() > deadline:
-            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
-        time.sleep(0.01)
+    return files.fetch("rccl_id", timeout_s, expect_len=128)
 
 
 class RcclComm:
     """One RCCL communicator per rank, on the device of a DeviceBatch's context.  Single node (xGMI)."""
 
-    def __init__(self, batch, world: Optional[int] = None, rank: Optional[int] = None, timeout_s: float = 300.0):
+    def __init__(self, batch, world: Optional[int] = None, rank: Optional[int] = None, timeout_s: float = 300.0, files=None):
         from . import _lib as L
+        from .launch import JobFiles
 
         self._L = L
         self._lib = L.lib()
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self._batch = batch
-        self._path = _rendezvous_path() if self.world > 1 else None
+        self._comm = None
+
         def make_id() -> bytes:
             uid = C.create_string_buffer(128)
             L.check(self._lib.csr_comm_unique_id(uid))
             return uid.raw
 
-        raw = make_id() if self.world == 1 else exchange_unique_id(self.rank, make_id, self._path, timeout_s)
+        if self.world == 1:
+            raw = make_id()
+        else:
+            files = files if files is not None else JobFiles(self.rank, self.world)
+            raw = exchange_unique_id(self.rank, make_id, files, timeout_s)
         uid = C.create_string_buffer(raw, 128)
         self._comm = self._lib.csr_comm_create(batch._ctx, uid, self.world, self.rank)
         if not self._comm:
             raise L.ConsenrichAMDError(L.last_error())
-        self.barrier()                              # every rank has read the id: rank 0 may remove the file
-        if self.rank == 0 and self._path:
-            try:
-                os.unlink(self._path)
-            except OSError:
-                pass
+        batch._attach_comm(self)                    # the batch closes its communicators before its context goes away
+        self.barrier()
+
+    def ranks_seen(self) -> int:
+        """Sum over ranks of 1.0 through RCCL: the number of ranks the communicator really spans."""
+        v = C.c_double(1.0)
+        self._L.check(self._lib.csr_comm_allreduce_sum(self._comm, C.byref(v)))
+        return int(round(v.value))
 
     def barrier(self):
         self._L.check(self._lib.csr_comm_barrier(self._comm))
@@ -189,6 +175,7 @@ class RcclComm:
         if getattr(self, "_comm", None):
             self._lib.csr_comm_destroy(self._comm)
             self._comm = None
+            self._batch._detach_comm(self)
 
     def __enter__(self):
         return self

@@ -130,6 +130,9 @@ csr_ctx *csr_create(int device_ordinal);    /* NULL on failure */
 void csr_destroy(csr_ctx *ctx);
 const char *csr_last_error(void);
 int csr_abi_version(void);
+/* "abi <n> src <sha256 of the library's sources, 16 hex digits> <compiler flags>": lets a caller (bench.py, __graft_entry__)
+ * record WHICH build ran -- a prebuilt library that travelled with the tree is distinguishable from a rebuild of newer sources. */
+const char *csr_build_id(void);
 
 /* Speculative-block tuning: block_len (multiple of 32; 0 = keep / choose from the batch size) and warm-up lengths in
  * BINS (rounded up to a multiple of 16; negative = keep) for the forward covariance chain, the forward state chain and
@@ -455,11 +458,14 @@ int csr_comm_rank(csr_comm *comm);
 /* *value := max over ranks (ncclAllReduce on the library's stream + stream synchronisation: also a barrier that completes
  * only when every rank's queue is drained). */
 int csr_comm_allreduce_max(csr_comm *comm, double *value);
+/* *value := sum over ranks: an all-reduce of 1.0 tells the caller how many ranks the communicator really spans. */
+int csr_comm_allreduce_sum(csr_comm *comm, double *value);
 int csr_comm_barrier(csr_comm *comm);
 /* (smoothed level xs[:,0], its variance Ps[:,0,0]) of every bin of the rank's chains, packed chain after chain on the device
  * straight from the exported arrays (CSR_EXPORT_SMOOTH; no host bounce), then ncclAllGather: every rank ends with
  * world x cap_bins (level, variance) pairs; rank r's chains start at pair r * cap_bins.  cap_bins = max over ranks of the
- * rank's total bins (same value on every rank).  host_out: world * cap_bins * 2 floats, or NULL. */
+ * rank's total bins (same value on every rank).  host_out: world * cap_bins * 2 floats, or NULL.  Fails when the exported
+ * arrays are not those of the resident fit (a pass ran since the last CSR_EXPORT_SMOOTH). */
 int csr_batch_gather_tracks(csr_ctx *ctx, csr_comm *comm, int64_t cap_bins, float *host_out);
 
 typedef struct csr_run_stats {

@@ -1744,4 +1744,29 @@ def test_bench_line_contract(product):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0.0 < rf["frac"] < 1.0
+    # the headline is measured in the library's default mode, which is the bit-exact one; the line says which build ran
+    assert d["config"]["x_tol_ulps"] == 0 and d["config"]["n_ranks_seen"] == 1
+    assert d["build"].startswith("abi ") and " src " in d["build"]
+    rs = d["roofline_streaming"]
+    assert rs["kernel"] in ("stats", "residuals") and 0.2 < rs["frac"] < 1.0
+
+
+def test_bench_started_plainly_with_two_ranks_on_one_gpu(product):
+    """`python bench.py --gpus 2` started plainly (no launcher): the parent spawns its two rank processes, which shard the
+    genome and meet through the job's directory; --same-device puts both on GPU 0 (RCCL refuses two ranks on one device, so the
+    barrier is the file one).  One line from rank 0, n_ranks_seen = 2, exit status 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--steps", "2", "--warmup",
+                        "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["n_ranks_seen"] == 2 and d["config"]["comm"] == "file"
+    assert d["value"] == pytest.approx(14375018 / (d["ms_per_step"] * 1e-3), rel=1e-6)
 

@@ -66,25 +66,32 @@ def test_two_rank_gather_reassembles_genome_order():
 
 def _rdzv_worker(rank, path, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from consenrich_amd.launch import JobFiles
     from consenrich_amd.sharding import exchange_unique_id
 
-    q.put((rank, exchange_unique_id(rank, lambda: bytes(range(128)) if rank == 0 else b"", path, timeout_s=60.0)))
+    files = JobFiles(rank, 3, directory=path, token="job-under-test")
+    q.put((rank, exchange_unique_id(rank, lambda: bytes(range(128)) if rank == 0 else b"", files, timeout_s=60.0)))
 
 
 @pytest.mark.timeout(120)
-def test_unique_id_rendezvous_through_a_file(tmp_path):
-    """The torch-free rendezvous of the RCCL communicator: rank 0 publishes its 128-byte id atomically, the others poll
-    (here 3 processes; the late starter is rank 0)."""
+def test_unique_id_rendezvous_through_the_job_directory(tmp_path):
+    """The torch-free rendezvous of the RCCL communicator: rank 0 publishes its 128-byte id atomically in the job's directory,
+    the others poll (here 3 processes; the late starter is rank 0).  The directory already holds a STALE id of an earlier job
+    (another token): the early ranks must not take it."""
     import multiprocessing as mp
     import time
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    path = str(tmp_path / "rdzv")
+    path = str(tmp_path / "job")
+    os.makedirs(path, mode=0o700)
+    with open(os.path.join(path, "rccl_id"), "wb") as fh:           # leftover of a job that died before it cleaned up
+        fh.write(b"some-earlier-job\n" + bytes(128))
     procs = [ctx.Process(target=_rdzv_worker, args=(r, path, q)) for r in (1, 2)]
     for p in procs:
         p.start()
-    time.sleep(0.3)
+    time.sleep(0.5)
+    assert q.empty()                                                # nobody accepted the stale file
     p0 = ctx.Process(target=_rdzv_worker, args=(0, path, q))
     p0.start()
     got = dict(q.get(timeout=90) for _ in range(3))
