@@ -35,7 +35,10 @@ __all__ = [
 # ------------------------------------------------------------------------------------------------------------------
 # argument coercion with the typed-buffer semantics of the Cython signatures (mode="c" float32 / int32 ndarrays)
 # ------------------------------------------------------------------------------------------------------------------
-def _typed(arr, name, dtype, ndim):
+def _typed(arr, name, dtype, ndim, out=False):
+    """The reference's typed-buffer argument checks (`np.ndarray[dtype, ndim, mode="c"]`, pyx:6394-6398).  out=True: the array
+    is written in place (the library copies device results straight into it), so a read-only buffer is refused here like
+    Cython's writable buffer acquisition does."""
     if not isinstance(arr, np.ndarray):
         raise TypeError(f"Argument '{name}' has incorrect type (expected numpy.ndarray, got {type(arr).__name__})")
     if arr.dtype != dtype:
@@ -44,6 +47,8 @@ def _typed(arr, name, dtype, ndim):
         raise ValueError(f"Buffer has wrong number of dimensions (expected {ndim}, got {arr.ndim})")
     if not arr.flags.c_contiguous:
         raise ValueError("ndarray is not C-contiguous")
+    if out and not arr.flags.writeable:
+        raise ValueError("buffer source array is read-only")
     return arr
 
 
@@ -112,7 +117,7 @@ def _forward(d, matrixData, matrixPluginMuncInit, matrixF, matrixQ0, intervalToB
     qs = _coerce_qscale(processQScale, n) if useQS else None
 
     if n <= 0 or m <= 0:  # pyx:6494-6501
-        D = np.empty(n, dtype=np.float32) if vectorD is None else _typed(vectorD, "vectorD", np.float32, 1)
+        D = np.empty(n, dtype=np.float32) if vectorD is None else _typed(vectorD, "vectorD", np.float32, 1, out=True)
         return (np.float32(0.0), 0, D, 0.0) if returnNLL else (np.float32(0.0), 0, D)
     if blockCount <= 0:
         raise ValueError("blockCount must be positive")
@@ -139,13 +144,13 @@ def _forward(d, matrixData, matrixPluginMuncInit, matrixF, matrixQ0, intervalToB
     if vectorD is None:
         vectorD = np.empty(n, dtype=np.float32)
     else:
-        vectorD = _typed(vectorD, "vectorD", np.float32, 1)
+        vectorD = _typed(vectorD, "vectorD", np.float32, 1, out=True)
         if vectorD.shape[0] < n:
             raise ValueError("vectorD length must match intervalCount")
     if doStore:
-        sf = _typed(stateForward, "stateForward", np.float32, 2)
-        sc = _typed(stateCovarForward, "stateCovarForward", np.float32, 3)
-        pn = _typed(pNoiseForward, "pNoiseForward", np.float32, 3)
+        sf = _typed(stateForward, "stateForward", np.float32, 2, out=True)
+        sc = _typed(stateCovarForward, "stateCovarForward", np.float32, 3, out=True)
+        pn = _typed(pNoiseForward, "pNoiseForward", np.float32, 3, out=True)
         if sf.shape[0] < n or sf.shape[1] < d:
             raise ValueError(f"stateForward shape must match intervalCount by {d}")
         if sc.shape[0] < n or sc.shape[1] < d or sc.shape[2] < d:
@@ -236,13 +241,13 @@ def _backward(d, matrixData, matrixF, stateForward, stateCovarForward, pNoiseFor
     Pf = _typed(stateCovarForward, "stateCovarForward", np.float32, 3)
     pn = _typed(pNoiseForward, "pNoiseForward", np.float32, 3)
     m, n = data.shape
-    xs = np.empty((n, d), np.float32) if stateSmoothed is None else _typed(stateSmoothed, "stateSmoothed", np.float32, 2)
+    xs = np.empty((n, d), np.float32) if stateSmoothed is None else _typed(stateSmoothed, "stateSmoothed", np.float32, 2, out=True)
     Ps = (np.empty((n, d, d), np.float32) if stateCovarSmoothed is None
-          else _typed(stateCovarSmoothed, "stateCovarSmoothed", np.float32, 3))
+          else _typed(stateCovarSmoothed, "stateCovarSmoothed", np.float32, 3, out=True))
     lag = (np.empty((max(n - 1, 1), d, d), np.float32) if lagCovSmoothed is None
-           else _typed(lagCovSmoothed, "lagCovSmoothed", np.float32, 3))
+           else _typed(lagCovSmoothed, "lagCovSmoothed", np.float32, 3, out=True))
     res = (np.empty((n, m), np.float32) if postFitResiduals is None
-           else _typed(postFitResiduals, "postFitResiduals", np.float32, 2))
+           else _typed(postFitResiduals, "postFitResiduals", np.float32, 2, out=True))
     if n <= 0:
         return (xs, Ps, lag, res)
     if m <= 0:

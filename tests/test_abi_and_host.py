@@ -123,6 +123,18 @@ def test_reference_error_contract_is_enforced_before_any_launch(L):
         cc.cforwardPass(**{**kw, "matrixData": np.zeros((2, 12), np.float64)})
     with pytest.raises(ValueError, match="not C-contiguous"):
         cc.cforwardPass(**{**kw, "matrixData": np.zeros((12, 2), np.float32).T})
+    # caller-provided outputs are written in place by the device-to-host copy: a read-only buffer is refused up front (the
+    # Cython original fails in its writable buffer acquisition; a copy into a read-only mapping would be a segfault)
+    ro = np.empty(12, np.float32)
+    ro.setflags(write=False)
+    with pytest.raises(ValueError, match="read-only"):
+        cc.cforwardPass(**kw, vectorD=ro)
+    ro2 = np.empty((12, 2), np.float32)
+    ro2.setflags(write=False)
+    with pytest.raises(ValueError, match="read-only"):
+        cc.cbackwardPass(matrixData=kw["matrixData"], matrixF=kw["matrixF"], stateForward=np.zeros((12, 2), np.float32),
+                         stateCovarForward=np.zeros((12, 2, 2), np.float32), pNoiseForward=np.zeros((12, 2, 2), np.float32),
+                         stateSmoothed=ro2)
     lv = {k: v for k, v in kw.items() if k != "matrixF"}
     with pytest.raises(ValueError, match=r"matrixQ0\[0, 0\] must be positive"):
         cc.cforwardPassLevel(**{**lv, "matrixQ0": np.zeros((1, 1), np.float32)})

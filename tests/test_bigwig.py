@@ -169,3 +169,142 @@ def test_bigwig_of_resident_tracks_round_trips_to_the_bedgraph_text(tmp_path):
                 want = [(int(a), int(b_), float(np.float32(float(v)))) for _c, a, b_, v in rows]
                 assert r.intervals(nm) == want, (fname, nm)
             assert r.header()["nBasesCovered"] == sum(s for _n, s in sizes)
+
+
+def test_toy_file_is_byte_identical_to_the_hand_made_fixture(tmp_path):
+    """tests/golden/bigwig_toy_uncompressed.bin was written out by hand from the bbi format tables with literal numbers
+    (tests/golden/make_bigwig_toy_fixture.py imports nothing of the product): the writer's uncompressed file of the
+    reference's toy track must be those 8555 bytes."""
+    from consenrich_amd import bigwig as bw
+
+    bg, cs = _toy(tmp_path)
+    out = tmp_path / "toy.bw"
+    bw.convert_bedgraph_to_bigwig(str(bg), str(cs), str(out), compress=False)
+    want = open(os.path.join(os.path.dirname(__file__), "golden", "bigwig_toy_uncompressed.bin"), "rb").read()
+    got = out.read_bytes()
+    assert len(got) == len(want) == 8555
+    diff = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+    assert not diff, diff[:8]
+
+
+def test_fields_sit_at_the_offsets_the_format_fixes(tmp_path):
+    """A two-chromosome fixed-step track with several sections and zoom levels, uncompressed, taken apart with struct at the byte
+    offsets of the bbi tables (no reader class): header magic / version / offsets, zoom headers, chromosome-tree key and value
+    sizes, section count, EVERY section header, R-tree block size and itemsPerSlot, the trailing magic."""
+    import struct
+
+    from consenrich_amd import bigwig as bw
+
+    step = 50
+    sizes = [("chrX", step * 12000 - 11), ("chrY", step * 1030)]
+    lines, truth = [], []
+    for name, size in sizes:
+        n = -(-size // step)
+        for k in range(n):
+            lines.append(f"{name}\t{k * step}\t{min((k + 1) * step, size)}\t{(k % 97) * 0.25:.4f}")
+        truth.append(n)
+    bg, cs, out = tmp_path / "t.bedGraph", tmp_path / "t.sizes", tmp_path / "t.bw"
+    bg.write_text("\n".join(lines) + "\n", encoding="ascii")
+    cs.write_text("".join(f"{c}\t{s}\n" for c, s in sizes), encoding="ascii")
+    bw.convert_bedgraph_to_bigwig(str(bg), str(cs), str(out), compress=False, chunk_lines=700)
+    b = out.read_bytes()
+    magic, version, nzoom, ct_off, data_off, index_off, fc, dfc, sql, summ_off, ubuf, ext = struct.unpack_from("<IHHQQQHHQQIQ", b, 0)
+    assert (magic, version, fc, dfc, sql, ubuf, ext) == (0x888FFC26, 4, 0, 0, 0, 0, 0)
+    assert nzoom >= 1 and summ_off == 64 + 24 * nzoom and ct_off == summ_off + 40
+    reductions = [struct.unpack_from("<IIQQ", b, 64 + 24 * i) for i in range(nzoom)]
+    assert [r[0] for r in reductions] == bw.zoom_plan(step, max(truth))[:nzoom] and all(r[1] == 0 for r in reductions)
+    assert struct.unpack_from("<Q", b, summ_off)[0] == sum(s for _c, s in sizes)            # every base covered once
+    tmagic, tblock, tkey, tval, titems, _ = struct.unpack_from("<IIIIQQ", b, ct_off)
+    assert (tmagic, tblock, tkey, tval, titems) == (0x78CA8C91, 2, 4, 8, 2)
+    assert data_off == ct_off + 32 + 4 + 2 * (4 + 8)
+    nsec = struct.unpack_from("<Q", b, data_off)[0]
+    assert nsec == sum(-(-n // bw.ITEMS_PER_SECTION) for n in truth)
+    pos, seen = data_off + 8, []
+    for cid, n in enumerate(truth):
+        for j in range(-(-n // bw.ITEMS_PER_SECTION)):
+            cnt = min(bw.ITEMS_PER_SECTION, n - j * bw.ITEMS_PER_SECTION)
+            c, cs_, ce, istep, ispan, typ, res, count = struct.unpack_from("<IIIIIBBH", b, pos)
+            first = j * bw.ITEMS_PER_SECTION
+            assert (c, cs_, istep, ispan, typ, res, count) == (cid, first * step, 0, 0, 1, 0, cnt)
+            assert ce == min((first + cnt) * step, sizes[cid][1])
+            s0, e0, v0 = struct.unpack_from("<IIf", b, pos + 24)
+            assert (s0, e0) == (first * step, min((first + 1) * step, sizes[cid][1])) and v0 == np.float32((first % 97) * 0.25)
+            seen.append((pos, 24 + 12 * cnt))
+            pos += 24 + 12 * cnt
+    assert pos == index_off
+    rmagic, rblock, ritems, sc, sb, ec, eb, endoff, per_slot, rres = struct.unpack_from("<IIQIIIIQII", b, index_off)
+    assert (rmagic, rblock, ritems, sc, sb, ec, eb, per_slot, rres) == (0x2468ACE0, 256, nsec, 0, 0, 1, sizes[1][1], 1, 0)
+    leaf, _r, count = struct.unpack_from("<BBH", b, index_off + 48)
+    assert (leaf, count) == (1, nsec)
+    for k, (off, ln) in enumerate(seen):
+        assert struct.unpack_from("<IIIIQQ", b, index_off + 52 + 32 * k)[4:] == (off, ln)
+    assert struct.unpack_from("<I", b, len(b) - 4)[0] == 0x888FFC26
+
+
+def test_first_offending_row_decides_also_across_chunk_boundaries(tmp_path):
+    """The reference's contract (io.py:693-752): rows are judged in order, the first offending row raises, its first failing
+    check words the message.  Vectorised chunks of 3 lines here, so that predecessors sit in another chunk."""
+    from consenrich_amd import bigwig as bw
+
+    cs = tmp_path / "c.sizes"
+    cs.write_text("chr1\t1000\nchr2\t1000\n", encoding="ascii")
+    good = ["chr1\t0\t10\t1", "chr1\t10\t20\t1", "# comment", "chr1\t20\t30\t1", "chr1\t30\t40\t1"]
+    cases = [
+        (good + ["chr1\t35\t50\t1"], r"Overlapping bedGraph interval at row 6"),
+        (good + ["chr1\t5\t8\t1"], r"not sorted at row 6"),
+        (good + ["chr2\t0\t5\t1", "chr1\t50\t60\t1"], r"not sorted at row 7"),
+        (good + ["chr1\t40\t50\t1\textra", "chr1\t0\t5\t1"], r"Malformed bedGraph row 6 .*expected 4 columns"),
+        (good + ["chr1\t40\tx\t1"], r"Invalid bedGraph coordinates on row 6"),
+        (good + ["chr1\t40\t50\tvalue"], r"Invalid bedGraph value on row 6"),
+        (good + ["chr1\t-4\t-9\tinf"], r"Non-finite bedGraph value on row 6"),             # value is checked before coordinates' signs
+        (good + ["chr1\t-4\t-9\t1"], r"Negative start coordinate on bedGraph row 6"),
+        (good + ["chr1\t40\t1001\t1", "chrZ\t0\t1\t1"], r"End coordinate 1001 on bedGraph row 6 exceeds chr1 size of 1000"),
+        (good + ["chr1\t10\t5\t1"], r"End coordinate must be greater than start on bedGraph row 6"),    # malformed before unsorted
+        (["chr1\t0\t10\t1", "chr1\t0\t10\t1"], r"Overlapping bedGraph interval at row 2"),
+    ]
+    for rows, msg in cases:
+        p = tmp_path / "x.bedGraph"
+        p.write_text("\n".join(rows) + "\n", encoding="ascii")
+        for chunk in (3, 200000):
+            with pytest.raises(ValueError, match=msg):
+                bw.convert_bedgraph_to_bigwig(str(p), str(cs), str(tmp_path / "x.bw"), chunk_lines=chunk)
+    assert [f for f in os.listdir(tmp_path) if f.endswith(".bw")] == []
+
+
+def test_chrom_sizes_reader_contract(tmp_path):
+    from consenrich_amd import bigwig as bw
+
+    p = tmp_path / "s.sizes"
+    p.write_text("# header\nchr1\t100\textra\n\nchr2 200\n", encoding="ascii")
+    assert bw.read_chrom_sizes(str(p)) == [("chr1", 100), ("chr2", 200)]
+    for text, msg in (("chr1\n", "Malformed chromosome sizes row 1"), ("chr1\t10\nchr2\tten\n", "Invalid chromosome size on row 2"),
+                      ("chr1\t0\n", "Chromosome chr1 has non-positive size on row 1"),
+                      ("chr1\t5\nchr1\t6\n", "Duplicate chromosome chr1"), ("# nothing\n\n", "No chromosome sizes found"),
+                      ("chr1\t5\nchr1\t6\nchrB\n", "Duplicate chromosome chr1"), ("chrB\nchr1\t5\nchr1\t6\n", "Malformed chromosome sizes row 1")):
+        p.write_text(text, encoding="ascii")
+        with pytest.raises(ValueError, match=msg):
+            bw.read_chrom_sizes(str(p))
+
+
+def test_file_path_writes_zoom_levels_and_a_multi_level_chromosome_tree(tmp_path):
+    """pyBigWig's addHeader defaults to 10 zoom levels; the file path now writes the reduction levels of `zoom_plan` for a
+    fixed-step track.  1 000 scaffolds (> 256: a two-level chromosome B+ tree) read back through the independent reader."""
+    from consenrich_amd import bigwig as bw
+    from oracle.bigwig_reader import BigWig
+
+    step = 200
+    sizes = [(f"scaffold_{k}", step * (7000 if k == 0 else 3) - (k % 5)) for k in range(1000)]
+    lines = []
+    for name, size in sizes:
+        for k in range(-(-size // step)):
+            lines.append(f"{name}\t{k * step}\t{min((k + 1) * step, size)}\t{((k * 7) % 13) * 0.5:.4f}")
+    bg, cs, out = tmp_path / "t.bedGraph", tmp_path / "t.sizes", tmp_path / "t.bw"
+    bg.write_text("\n".join(lines) + "\n", encoding="ascii")
+    cs.write_text("".join(f"{c}\t{s}\n" for c, s in sizes), encoding="ascii")
+    bw.convert_bedgraph_to_bigwig(str(bg), str(cs), str(out), chunk_lines=1500)
+    r = BigWig(str(out))
+    assert r.chroms == {c: (i, s) for i, (c, s) in enumerate(sizes)}
+    assert [z[0] for z in r.zooms] == bw.zoom_plan(step, 7000) and len(r.zooms) >= 1
+    assert len(r.intervals("scaffold_0")) == 7000 and r.intervals("scaffold_999") == [(0, 200, 0.0), (200, 400, 3.5), (400, 596, 0.5)]
+    red, _count, recs = r.zoom_records(0, "scaffold_0")
+    assert red == 10 * step and recs[0][:3] == (0, 10 * step, 10 * step)
