@@ -55,6 +55,7 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
         "fwd_cov_chain": 16.0 + 16.0 + 16.0,    # lambda/kappa/qscale/blockMap in, Pf + pNoise out
         "fwd_state_chain": 8.0,                 # xf out
         "fwd_state": 8.0,                       # bit-exact state chain: speculative pass + repair passes as one unit, xf out
+        "fwd_state_seq": 8.0,                   # ... its sequential fallback (CONSENRICH_AMD_SEQ_STATE=1)
         "fwd_dstat": 4.0,                       # D out
         "bwd_chain": 8.0 + 16.0 + 16.0,         # xs + Ps + lagCov out
         "export_natural": 0.0,                  # layout conversion: pure overhead
