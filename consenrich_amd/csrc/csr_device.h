@@ -135,6 +135,7 @@ struct Prm {
     // blocking, and the index of a padding block behind the last group that lanes without a block of their own walk
     const double4 *sbRec;
     int64_t sbPad;
+    unsigned long long *sbDbg;      // CONSENRICH_AMD_SB_DEBUG: counters of the delta-form repair passes (blocks, batches, rounds, fallback batches, merged exits), else null
     int prevKind;
     const void *prevCarryIn, *prevCarryOut;
     unsigned int *prevCount, *prevCountPass;
@@ -2409,7 +2410,7 @@ __device__ __forceinline__ float dpp_shr1_keep0(float keepLane0, float src) {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_sys(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
                                                 float2 *__restrict__ natXf, int which, int fix) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= p.NB || !chain_on(p, b)) return;                 // wave-uniform
     const int lane = threadIdx.x & 63;
     const int4 bi = p.blk[b];
@@ -2487,6 +2488,184 @@ __global__ __launch_bounds__(256) void k_sb_sys(Prm p, const float4 *__restrict_
         if (fix) {
             atomicAdd(p.rerunCount, 1u);
             atomicAdd(p.rerunCountPass, 1u);
+        }
+    }
+}
+
+// One state step of a lane from a given predecessor state with the lane's own record (the systolic walker's step body)
+template <int MODE>
+__device__ __forceinline__ void sys_step(const Prm &p, float s0, float s1, double gs, double zbar, double p00, double p10,
+                                         float gz, float gw, float &o0, float &o1) {
+    if constexpr (MODE == 2) {
+        const float xpf = s0 + s1;
+        const double xp0 = (double)xpf, x1d = (double)s1;
+        const double dl = gs * (zbar - xp0);
+        o0 = (float)fma(p00, dl, xp0);
+        o1 = (float)fma(p10, dl, x1d);
+    } else if constexpr (MODE == 1) {
+        const double x1d = (double)s1;
+        const double xp0 = r32(fma(p.F01, x1d, (double)s0));
+        const double dl = gs * (zbar - xp0);
+        o0 = (float)fma(p00, dl, xp0);
+        o1 = (float)fma(p10, dl, x1d);
+    } else {
+        FwdXTrend::Carry c{s0, s1};
+        FwdXTrend::In in;
+        in.gs = gs; in.zbar = zbar;
+        in.cp = make_float2(gz, gw);
+        FwdXTrend::step<false>(p, c, in, 0, 0, 0, 0);
+        o0 = c.x0; o1 = c.x1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// REPAIR passes of the bit-exact state chain in DELTA form (round 3).  A superblock that is re-run holds its previous
+// trajectory S (the filtered state an earlier pass wrote, a valid trajectory of the SAME records from a slightly different
+// carry) and is given the true carry T.  While the levels agree, T - S stays EXACTLY constant between the bins where a level
+// rounds the other way, so instead of walking the 64 bins of a batch one after the other every lane
+// k tests in parallel the hypothesis  T_{k-1} = S_{k-1} + delta  =>  step(S_{k-1} + delta, record_k) == S_k + delta .
+// All lanes up to the first failing one f-1 are then PROVEN (induction from the true state at the batch's first unresolved
+// bin, whose lane uses that true state itself as its predecessor), and lane f's own result is the true T_f as well -- its
+// predecessor was proven -- although it differs from the hypothesis: it becomes the new base, delta is re-derived there and
+// the next round starts behind it.  A round costs one parallel step + ballot + four v_readlane and resolves the bins up to
+// and including the next change of delta (~12 % of the bins change it: ~9 rounds per 64 bins instead of 64 dependent steps).
+// The floats S + delta are hypotheses only (an inexact sum just fails the test); what is stored is always a step() result
+// of a proven predecessor, so the pass is exact by construction.  Where delta changes at every bin (the first ~100 bins
+// behind a carry that was far off) a batch falls back to the systolic walk after SB_DELTA_ROUNDS rounds.  When T meets S bit
+// for bit the rest of the superblock is already right: the wavefront stops and keeps the old carry-out.
+// ---------------------------------------------------------------------------------------------------------------
+#define SB_DELTA_ROUNDS 20
+#ifndef SB_DELTA_DEPTH
+#define SB_DELTA_DEPTH 8
+#endif
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
+                                                  float2 *__restrict__ natXf, int which) {
+    // (readfirstlane: the wavefront's index is uniform, and telling the compiler so keeps the superblock's table entry, the
+    // carries and the whole round control -- pos, f, delta -- in scalar registers)
+    const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int lane = threadIdx.x & 63;
+    const int4 bi = p.blk[b];
+    using Carry = FwdXTrend::Carry;
+    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
+    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
+    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
+    if (b == (int64_t)bi.z) {                                 // a chain's first superblock started from the true prior
+        if (lane == 0) onxt[b] = ocur[b];
+        return;
+    }
+    const Carry prev = ocur[b - 1], mine = cin[b], oldOut = ocur[b];
+    if ((((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) == 0u)) {
+        if (lane == 0) onxt[b] = oldOut;
+        return;
+    }
+    if (lane == 0) cin[b] = prev;
+    if (p.sbDbg != nullptr && lane == 0) atomicAdd(p.sbDbg, 1ull);
+    const long long dbgT0 = p.sbDbg != nullptr ? wall_clock64() : 0;
+    unsigned dbgFb = 0, dbgRounds = 0, dbgBatches = 0;
+    float t0 = prev.x0, t1 = prev.x1;                          // TRUE state at the bin before the next unresolved one
+    float sc0 = mine.x0, sc1 = mine.x1;                        // the old trajectory's state at the bin before the batch
+    const int n = bi.y;
+    const int64_t g0 = (int64_t)bi.x + lane;
+    const int nb = (n + 63) >> 6;
+    // A batch in delta form takes a few hundred cycles -- far less than a trip to HBM -- so the records and the old trajectory
+    // of SB_DELTA_DEPTH batches ahead are kept in flight in a ring of registers (statically indexed: the batch loop is unrolled
+    // over the ring's slots).
+    constexpr int DEPTH = SB_DELTA_DEPTH;
+    float4 rg[DEPTH], rs[DEPTH];
+    float2 ro[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+        const int tt = u < nb ? u : nb - 1;
+        rg[u] = natGain[g0 + (int64_t)tt * 64];
+        rs[u] = natSZ[g0 + (int64_t)tt * 64];
+        ro[u] = natXf[g0 + (int64_t)tt * 64];
+    }
+    bool merged = false;
+    auto batch = [&](int t, const float4 &ga, const float4 &sa, const float2 &so) {
+        const double gs = unpack_d(ga.x, ga.y), zbar = unpack_d(sa.z, sa.w);
+        const double p00 = (double)ga.z, p10 = (double)ga.w;
+        const int left = min(64, n - (t << 6));
+        const unsigned long long leftMask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        // old trajectory at the previous bin: lane 0 <- sc (the bin before the batch)
+        const float sp0 = dpp_shr1_keep0(sc0, so.x), sp1 = dpp_shr1_keep0(sc1, so.y);
+        const float tb0 = t0, tb1 = t1;                        // true carry into the batch (for the fallback)
+        float to0 = so.x, to1 = so.y;
+        float d0 = t0 - sc0, d1 = t1 - sc1;
+        int pos = 0, rounds = 0;
+        bool fallback = false;
+#pragma unroll 1
+        while (pos < left) {
+            if (++rounds > SB_DELTA_ROUNDS) { fallback = true; break; }
+            const bool base = lane == pos;
+            const float q0 = base ? t0 : sp0 + d0, q1 = base ? t1 : sp1 + d1;
+            float n0, n1;
+            sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, ga.z, ga.w, n0, n1);
+            const float c0 = so.x + d0, c1 = so.y + d1;
+            // lane masks straight from the comparisons (no boolean is materialised)
+            const unsigned long long okm = __builtin_amdgcn_uicmp(f2u(n0), f2u(c0), 32 /* ICMP_EQ */) &
+                                           __builtin_amdgcn_uicmp(f2u(n1), f2u(c1), 32);
+            const unsigned long long fail = ~okm & (~0ull << pos) & leftMask;
+            const int f = fail ? (int)__ffsll((long long)fail) - 1 : left;
+            const int hi = f < left ? f : left - 1;            // bins pos .. hi are settled by this round: their step() results stand
+            if (lane >= pos && lane <= hi) { to0 = n0; to1 = n1; }
+            t0 = rl32(n0, hi);
+            t1 = rl32(n1, hi);
+            d0 = t0 - rl32(so.x, hi);
+            d1 = t1 - rl32(so.y, hi);
+            pos = hi + 1;
+        }
+        if (fallback) {
+            // delta changes at (nearly) every bin here: walk the batch as a shift register from its true carry
+            float s0 = tb0, s1 = tb1, x0v = 0.0f, x1v = 0.0f;
+#pragma unroll 1
+            for (int q = 0; q < 64; ++q) {
+                s0 = dpp_shr1_keep0(s0, x0v);
+                s1 = dpp_shr1_keep0(s1, x1v);
+                sys_step<MODE>(p, s0, s1, gs, zbar, p00, p10, ga.z, ga.w, x0v, x1v);
+            }
+            to0 = x0v; to1 = x1v;
+            t0 = rl32(x0v, left - 1);
+            t1 = rl32(x1v, left - 1);
+        }
+        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(to0, to1);
+        sc0 = rl32(so.x, left - 1);
+        sc1 = rl32(so.y, left - 1);
+        // the true trajectory has met the old one bit for bit: everything behind this bin is already right
+        merged = ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
+        dbgFb += fallback ? 1u : 0u; dbgRounds += (unsigned)rounds; dbgBatches += 1u;
+    };
+#pragma unroll 1
+    for (int tg = 0; tg < nb && !merged; tg += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int t = tg + u;
+            if (t < nb && !merged) {
+                batch(t, rg[u], rs[u], ro[u]);
+                const int tn = t + DEPTH;
+                if (tn < nb) {
+                    rg[u] = natGain[g0 + (int64_t)tn * 64];
+                    rs[u] = natSZ[g0 + (int64_t)tn * 64];
+                    ro[u] = natXf[g0 + (int64_t)tn * 64];
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        onxt[b] = merged ? oldOut : Carry{t0, t1};
+        atomicAdd(p.rerunCount, 1u);
+        atomicAdd(p.rerunCountPass, 1u);
+        if (p.sbDbg != nullptr) {
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - dbgT0);
+            // slowest superblock of the launch sequence: ticks (10 ns), packed with its batches / rounds / fallbacks
+            const unsigned long long packed = (dt << 40) | ((unsigned long long)(dbgBatches & 0xfff) << 28) | ((unsigned long long)(dbgRounds & 0xffff) << 12) | (dbgFb & 0xfff);
+            atomicMax(p.sbDbg + 5, packed);
+            atomicAdd(p.sbDbg + 6, dt);
+            atomicAdd(p.sbDbg + 1, (unsigned long long)dbgBatches);
+            atomicAdd(p.sbDbg + 2, (unsigned long long)dbgRounds);
+            atomicAdd(p.sbDbg + 3, (unsigned long long)dbgFb);
+            if (merged) atomicAdd(p.sbDbg + 4, 1ull);
         }
     }
 }

@@ -407,8 +407,20 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
     q.prevKind = CK_NONE;
     const int mode = unit_f(c, p) ? ((p.F01 == 1.0 && c->unitF1Enabled) ? 2 : 1) : 0;
     const int grid = (int)((v.NB + 3) / 4);
+    q.sbDbg = nullptr;
+    if (getenv("CONSENRICH_AMD_SB_DEBUG")) {
+        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 8));
+        HIPOK(hipMemsetAsync(c->sbDbg, 0, 64, c->stream));
+        q.sbDbg = c->sbDbg;
+    }
     auto launch = [&](int which, int fix) {
         float2 *xf = reinterpret_cast<float2 *>(natXf);
+        if (fix && c->sbDelta) {        // repair passes in delta form (k_sb_delta)
+            if (mode == 2) hipLaunchKernelGGL(k_sb_delta<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
+            else if (mode == 1) hipLaunchKernelGGL(k_sb_delta<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
+            else hipLaunchKernelGGL(k_sb_delta<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
+            return;
+        }
         if (mode == 2) hipLaunchKernelGGL(k_sb_sys<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
         else if (mode == 1) hipLaunchKernelGGL(k_sb_sys<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
         else hipLaunchKernelGGL(k_sb_sys<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
@@ -438,6 +450,15 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
         burst = c->dbgLog ? 1 : std::min(32, burst * 2);
     }
     if (!done) return fail("fwd_state_chain (systolic superblocks): fix-up did not reach a fixed point");
+    if (q.sbDbg) {
+        unsigned long long h[8];
+        HIPOK(hipMemcpyAsync(h, c->sbDbg, 64, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[csr] delta repairs: superblocks re-run %llu, batches %llu, rounds %llu (%.2f per batch), fallback batches %llu, merged exits %llu; superblock %d bins, %lld superblocks\n",
+                h[0], h[1], h[2], h[1] ? (double)h[2] / (double)h[1] : 0.0, h[3], h[4], v.B, (long long)v.NB);
+        fprintf(stderr, "[csr]   slowest superblock: %.1f us, %llu batches, %llu rounds, %llu fallback batches; mean %.1f us per re-run superblock\n",
+                (double)(h[5] >> 40) * 0.01, (h[5] >> 28) & 0xfff, (h[5] >> 12) & 0xffff, h[5] & 0xfff, h[0] ? (double)h[6] * 0.01 / (double)h[0] : 0.0);
+    }
     {
         Scope sc(c, "state_reblock_out");
         hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,

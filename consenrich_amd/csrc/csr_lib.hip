@@ -198,6 +198,8 @@ struct csr_ctx {
     bool sbState = true;        // CONSENRICH_AMD_SB_STATE=0: off (speculation on the batch's own blocks, or seqState)
     int sbBins = 8192, sbWarm = 16384;      // CONSENRICH_AMD_SB_BINS / CONSENRICH_AMD_SB_WARM
     bool sbBinsPinned = false;  // CONSENRICH_AMD_SB_BINS given: no automatic choice of the superblock length
+    unsigned long long *sbDbg = nullptr;
+    bool sbDelta = true;        // CONSENRICH_AMD_SB_DELTA=0: repair passes as plain systolic walks (k_sb_sys) instead of the delta form (k_sb_delta)
     bool sbSystolic = true;     // CONSENRICH_AMD_SB_SYSTOLIC=0: the round-2 lane-per-superblock walker (re-blocked records, window sbWarm)
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
     bool xfNat = false;         // the resident forward pass left xf in the reference layout already (systolic walker)
@@ -306,6 +308,7 @@ static void free_batch(csr_ctx *c) {
     c->dActive = nullptr;
     c->sb = csr_ctx::SbView{};
     c->sbNatGain = c->sbNatSZ = nullptr;
+    c->sbDbg = nullptr;
     c->xfNat = false;
     c->ckF[0] = c->ckF[1] = c->ckB[0] = c->ckB[1] = nullptr;
     c->wsSavedF = c->wsSavedB = 0;
@@ -368,6 +371,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) { c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64); c->sbBinsPinned = true; }
     if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_SB_SYSTOLIC"))) c->sbSystolic = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF1"))) c->unitF1Enabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;

@@ -333,3 +333,85 @@ int emul_events(int64_t m, int64_t n, const float *data, const float *munc, doub
     free(xfS); free(xfT); free(Pf); free(pn);
     return 0;
 }
+
+/* Superblock repair passes of the bit-exact state chain on the host: pass 0 = every superblock from the cold prior, pass p =
+ * every superblock whose carry-in differs from its neighbour's carry-out re-run from it.  For the re-run blocks of each pass:
+ * events = bins where (new - old trajectory) changes, batches (64 bins) by number of events.  out[pass*6 + ..] = {blocks re-run,
+ * bins, events, batches, batches with > 20 events, bins until new == old (sum over merged blocks)} */
+int emul_sb_passes(int64_t m, int64_t n, const float *data, const float *munc, double F01, double Q00, double Q11, double pad,
+                   int B, int maxpass, double *out) {
+    prob P = {m, n, data, munc, F01, Q00, Q11, pad, 5e-3, 5e3, 8.0, 0.0, 1000.0};
+    const int64_t NB = (n + B - 1) / B;
+    /* exact gains: one sequential pass of the fused recursion gives P and the state; the state chain alone is re-walked below
+       with the SAME covariance trajectory (the covariance chain is validated separately on the device) */
+    float *xfT = malloc(sizeof(float) * n * 2), *Pf = malloc(sizeof(float) * n * 4), *pn = calloc(n * 4, sizeof(float));
+    rulecfg R = {-1, 0, 0.0};
+    estats st; memset(&st, 0, sizeof st);
+    forward_blocked(&P, NULL, (int)n, 0, &R, xfT, Pf, pn, &st);
+    /* per-bin gain record from the sequential covariance: re-derive gs, p00pred, p10pred, zbar by re-running the P recursion */
+    double *gs = malloc(sizeof(double) * n), *zb = malloc(sizeof(double) * n);
+    float *pp0 = malloc(sizeof(float) * n), *pp1 = malloc(sizeof(float) * n);
+    {
+        double p00 = 1000.0, p01 = 0.0, p11 = 1000.0;
+        for (int64_t k = 0; k < n; ++k) {
+            const double t00 = p00 + F01 * p01, t01 = p01 + F01 * p11;
+            const double a00 = R32(t00 + t01 * F01 + Q00), a01 = R32(t01), a10 = R32(p01 + p11 * F01), a11 = R32(p11 + Q11);
+            double s0 = 0, s1z = 0;
+            for (int64_t j = 0; j < m; ++j) {
+                double r = (double)munc[j * n + k] + pad; if (r < 1e-12) r = 1e-12;
+                s0 += 1.0 / r; s1z += (double)data[j * n + k] / r;
+            }
+            const double is = 1.0 + a00 * s0, g = s0 / is, gH = s0 / (is * is);
+            gs[k] = g; zb[k] = s1z / s0; pp0[k] = (float)a00; pp1[k] = (float)a10;
+            const double i00 = 1.0 - a00 * g, i10 = -(a10 * g);
+            p00 = R32(i00 * i00 * a00 + gH * a00 * a00);
+            p01 = R32(i00 * (i10 * a00 + a01) + gH * a00 * a10);
+            p11 = R32((i10 * i10 * a00 + 2.0 * i10 * a10 + a11) + gH * a10 * a10);
+        }
+    }
+    float *cur = malloc(sizeof(float) * n * 2), *nw = malloc(sizeof(float) * n * 2);
+    float *cin = malloc(sizeof(float) * NB * 2), *cout = malloc(sizeof(float) * NB * 2), *cout2 = malloc(sizeof(float) * NB * 2);
+#define STATE_STEP(x0, x1, k) do { const float xpf = (x0) + (float)F01 * (x1); const double xp0 = xpf, x1d = (x1); \
+        const double dl = gs[k] * (zb[k] - xp0); (x0) = (float)(xp0 + (double)pp0[k] * dl); (x1) = (float)(x1d + (double)pp1[k] * dl); } while (0)
+    for (int64_t b = 0; b < NB; ++b) {
+        float x0 = 0.f, x1 = 0.f;
+        cin[2 * b] = x0; cin[2 * b + 1] = x1;
+        const int64_t s = b * B, e = s + B < n ? s + B : n;
+        for (int64_t k = s; k < e; ++k) { STATE_STEP(x0, x1, k); cur[2 * k] = x0; cur[2 * k + 1] = x1; }
+        cout[2 * b] = x0; cout[2 * b + 1] = x1;
+    }
+    int pass = 0;
+    for (pass = 1; pass <= maxpass; ++pass) {
+        double *o = out + (pass - 1) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = 0;
+        memcpy(cout2, cout, sizeof(float) * NB * 2);
+        for (int64_t b = 1; b < NB; ++b) {
+            if (cout[2 * (b - 1)] == cin[2 * b] && cout[2 * (b - 1) + 1] == cin[2 * b + 1]) continue;
+            float x0 = cout[2 * (b - 1)], x1 = cout[2 * (b - 1) + 1];
+            cin[2 * b] = x0; cin[2 * b + 1] = x1;
+            const int64_t s = b * B, e = s + B < n ? s + B : n;
+            float pd0 = x0 - cur[2 * s - 2], pd1 = x1 - cur[2 * s - 1];
+            int evb = 0; int64_t mergedAt = -1;
+            o[0] += 1;
+            for (int64_t k = s; k < e; ++k) {
+                STATE_STEP(x0, x1, k);
+                const float d0 = x0 - cur[2 * k], d1 = x1 - cur[2 * k + 1];
+                if (d0 != pd0 || d1 != pd1) { o[2] += 1; evb += 1; }
+                pd0 = d0; pd1 = d1;
+                nw[2 * k] = x0; nw[2 * k + 1] = x1;
+                if (mergedAt < 0 && d0 == 0.f && d1 == 0.f) mergedAt = k - s;
+                if (((k - s) & 63) == 63 || k == e - 1) { o[3] += 1; if (evb > 20) o[4] += 1; evb = 0; }
+                o[1] += 1;
+            }
+            if (mergedAt >= 0) o[5] += (double)mergedAt; else o[5] += (double)(e - s);
+            for (int64_t k = s; k < e; ++k) { cur[2 * k] = nw[2 * k]; cur[2 * k + 1] = nw[2 * k + 1]; }
+            cout2[2 * b] = x0; cout2[2 * b + 1] = x1;
+        }
+        memcpy(cout, cout2, sizeof(float) * NB * 2);
+        if (o[0] == 0) break;
+    }
+    int bad = 0;
+    for (int64_t k = 0; k < n * 2; ++k) if (cur[k] != xfT[k]) { bad = 1; break; }
+    free(xfT); free(Pf); free(pn); free(gs); free(zb); free(pp0); free(pp1); free(cur); free(nw); free(cin); free(cout); free(cout2);
+    return bad ? -pass : pass;
+}
