@@ -2538,9 +2538,13 @@ __device__ __forceinline__ void sys_step(const Prm &p, float s0, float s1, doubl
 #ifndef SB_DELTA_DEPTH
 #define SB_DELTA_DEPTH 8
 #endif
+// spec = 1: the FIRST pass, against the trajectory of the 2-ulp state chain that the natural xf array holds (a few ulps from the
+// truth everywhere, self-consistent inside each of its own blocks): every superblock takes that trajectory's state at the bin
+// before it as its carry guess (delta = 0 to begin with) -- a round then proves whole stretches of the guess right and re-bases at
+// the guess's own block boundaries -- instead of walking all its bins from a cold prior.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
-                                                  float2 *__restrict__ natXf, int which) {
+                                                  float2 *__restrict__ natXf, int which, int spec) {
     // (readfirstlane: the wavefront's index is uniform, and telling the compiler so keeps the superblock's table entry, the
     // carries and the whole round control -- pos, f, delta -- in scalar registers)
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2550,15 +2554,26 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
     using Carry = FwdXTrend::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
     const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
-    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
-    if (b == (int64_t)bi.z) {                                 // a chain's first superblock started from the true prior
-        if (lane == 0) onxt[b] = ocur[b];
-        return;
-    }
-    const Carry prev = ocur[b - 1], mine = cin[b], oldOut = ocur[b];
-    if ((((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) == 0u)) {
-        if (lane == 0) onxt[b] = oldOut;
-        return;
+    Carry *onxt = spec ? reinterpret_cast<Carry *>(p.carryOutA) : reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
+    Carry prev, mine, oldOut;
+    if (spec) {
+        // carry guess = the resident (2-ulp) trajectory at the bin before the superblock; a chain's first superblock starts
+        // from the true prior, which is also where that trajectory started
+        const bool first = b == (int64_t)bi.z;
+        const float2 g = first ? make_float2((float)p.init, 0.0f) : natXf[(int64_t)bi.x - 1];
+        prev = Carry{g.x, g.y};
+        mine = prev;
+        oldOut = prev;                                          // (never used: spec never exits early)
+    } else {
+        if (b == (int64_t)bi.z) {                             // a chain's first superblock started from the true prior
+            if (lane == 0) onxt[b] = ocur[b];
+            return;
+        }
+        prev = ocur[b - 1]; mine = cin[b]; oldOut = ocur[b];
+        if ((((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) == 0u)) {
+            if (lane == 0) onxt[b] = oldOut;
+            return;
+        }
     }
     if (lane == 0) cin[b] = prev;
     if (p.sbDbg != nullptr && lane == 0) atomicAdd(p.sbDbg, 1ull);
@@ -2633,7 +2648,7 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
         sc0 = rl32(so.x, left - 1);
         sc1 = rl32(so.y, left - 1);
         // the true trajectory has met the old one bit for bit: everything behind this bin is already right
-        merged = ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
+        merged = !spec && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
         dbgFb += fallback ? 1u : 0u; dbgRounds += (unsigned)rounds; dbgBatches += 1u;
     };
 #pragma unroll 1
@@ -2654,8 +2669,10 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
     }
     if (lane == 0) {
         onxt[b] = merged ? oldOut : Carry{t0, t1};
-        atomicAdd(p.rerunCount, 1u);
-        atomicAdd(p.rerunCountPass, 1u);
+        if (!spec) {
+            atomicAdd(p.rerunCount, 1u);
+            atomicAdd(p.rerunCountPass, 1u);
+        }
         if (p.sbDbg != nullptr) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - dbgT0);
             // slowest superblock of the launch sequence: ticks (10 ns), packed with its batches / rounds / fallbacks

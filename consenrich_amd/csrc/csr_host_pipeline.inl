@@ -388,11 +388,28 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
     if (!c->sbNatGain) { CHECK(dalloc(c, &c->sbNatGain, c->Npad)); CHECK(dalloc(c, &c->sbNatSZ, c->Npad)); }
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    // First-pass guess: the state chain in its 2-ulp form on the batch's own blocks (one bandwidth-bound launch, validated with
+    // the k = 2 rule), converted to the natural layout together with the records.  The delta-form first pass then proves and
+    // corrects that trajectory instead of walking every superblock from a cold prior.
+    const bool seeded = c->sbDelta && c->sbSeed;
+    if (seeded) {
+        const int keep = c->xTolUlps;
+        c->xTolUlps = 2;
+        int rc;
+        if (unit_f(c, p)) rc = run_chain<FwdXTrendT<true>>(c, p, "fwd_state_seed", "fwd_state_seed_fix", ST_X, false);
+        else rc = run_chain<FwdXTrend>(c, p, "fwd_state_seed", "fwd_state_seed_fix", ST_X, false);
+        c->xTolUlps = keep;
+        CHECK(rc);
+    }
     {
         Scope sc(c, "state_records_natural");
         ExpList L;
         memset(&L, 0, sizeof(L));
         L.count = 2;
+        if (seeded) {
+            L.count = 3;
+            L.d[2].src = reinterpret_cast<const float *>(p.tXf); L.d[2].dst = natXf; L.d[2].E = 2; L.d[2].n = 2;
+        }
         L.d[0].src = reinterpret_cast<const float *>(p.tXin); L.d[0].dst = reinterpret_cast<float *>(c->sbNatGain); L.d[0].E = 4; L.d[0].n = 4;
         L.d[1].src = reinterpret_cast<const float *>(p.tSZ); L.d[1].dst = reinterpret_cast<float *>(c->sbNatSZ); L.d[1].E = 4; L.d[1].n = 4;
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p, L);
@@ -415,10 +432,11 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
     }
     auto launch = [&](int which, int fix) {
         float2 *xf = reinterpret_cast<float2 *>(natXf);
-        if (fix && c->sbDelta) {        // repair passes in delta form (k_sb_delta)
-            if (mode == 2) hipLaunchKernelGGL(k_sb_delta<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
-            else if (mode == 1) hipLaunchKernelGGL(k_sb_delta<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
-            else hipLaunchKernelGGL(k_sb_delta<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which);
+        if ((fix || seeded) && c->sbDelta) {        // delta form (k_sb_delta): repair passes, and the first pass when a 2-ulp trajectory is resident
+            const int spec = fix ? 0 : 1;
+            if (mode == 2) hipLaunchKernelGGL(k_sb_delta<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
+            else if (mode == 1) hipLaunchKernelGGL(k_sb_delta<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
+            else hipLaunchKernelGGL(k_sb_delta<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             return;
         }
         if (mode == 2) hipLaunchKernelGGL(k_sb_sys<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);

@@ -199,6 +199,7 @@ struct csr_ctx {
     int sbBins = 8192, sbWarm = 16384;      // CONSENRICH_AMD_SB_BINS / CONSENRICH_AMD_SB_WARM
     bool sbBinsPinned = false;  // CONSENRICH_AMD_SB_BINS given: no automatic choice of the superblock length
     unsigned long long *sbDbg = nullptr;
+    bool sbSeed = false;        // CONSENRICH_AMD_SB_SEED=1: the first pass of the exact state chain corrects the 2-ulp trajectory in delta form instead of walking every superblock from the cold prior (measured slower while a round costs ~170 ns: 1.07 + 0.36 vs 0.94 ms; bit-identical, tests/fuzz run with it once)
     bool sbDelta = true;        // CONSENRICH_AMD_SB_DELTA=0: repair passes as plain systolic walks (k_sb_sys) instead of the delta form (k_sb_delta)
     bool sbSystolic = true;     // CONSENRICH_AMD_SB_SYSTOLIC=0: the round-2 lane-per-superblock walker (re-blocked records, window sbWarm)
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
@@ -372,6 +373,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_SB_SYSTOLIC"))) c->sbSystolic = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_SEED"))) c->sbSeed = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF1"))) c->unitF1Enabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;
