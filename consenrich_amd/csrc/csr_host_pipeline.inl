@@ -324,11 +324,13 @@ static int ensure_sb_view(csr_ctx *c) {
     int B = c->sbBins;
     const int nc = (int)c->chains.size();
     if (c->sbSystolic && !c->sbBinsPinned) {
-        // one wavefront per superblock, one wavefront per SIMD: the shortest superblock (a multiple of 8192 bins) that leaves
-        // no more superblocks than the device has SIMDs
+        // one wavefront per superblock, at most one wavefront per SIMD: the shortest superblock (a multiple of 8192 bins) that
+        // leaves no more superblocks than 5/8 of the device's SIMDs (measured at genome scale: 16 384 bins 7.2 ms, 24 576 / 32 768
+        // bins 7.0 ms, 8 192 bins 8.3 ms per step -- fewer, longer repair passes win slightly while a pass costs the slowest
+        // superblock's walk)
         hipDeviceProp_t prop;
         int simds = 1024;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount * 5 / 8;
         for (;; B += 8192) {
             int64_t cnt = 0;
             for (int i = 0; i < nc; ++i) cnt += (c->chains[i].n + B - 1) / B;

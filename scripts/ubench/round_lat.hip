@@ -1,0 +1,94 @@
+// micro-benchmark (gfx950): cycles per ROUND of the delta-form repair pass (k_sb_delta, csr_device.h) in isolation, and of
+// variants of its bookkeeping, with everything in registers.  A round = hypothesis q = S_prev + delta (the base lane takes the
+// true state), one state step, comparison with S + delta, first failing lane, re-base there.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define N 4096
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+__device__ __forceinline__ void step(float s0, float s1, double gs, double zbar, double p00, double p10, float &o0, float &o1) {
+    const float xpf = s0 + s1;
+    const double xp0 = (double)xpf, x1d = (double)s1;
+    const double dl = gs * (zbar - xp0);
+    o0 = (float)fma(p00, dl, xp0);
+    o1 = (float)fma(p10, dl, x1d);
+}
+template <int V>
+__global__ void k(float *out, long long *cyc, float a, int stride) {
+    const int lane = threadIdx.x;
+    const double gs = 0.26 + lane * 1e-4, zbar = 3.1, p00 = 0.8, p10 = 0.05;
+    float so0 = a + lane * 1e-3f, so1 = 1e-4f * lane, sp0 = so0 - 1e-3f, sp1 = so1 - 1e-4f;
+    float t0 = a, t1 = 0.f, d0 = 0.f, d1 = 0.f, to0 = 0.f, to1 = 0.f;
+    int pos = 0;
+    long long c0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < N; ++it) {
+        if (V == 0) {           // the shipped round
+            const bool base = lane == pos;
+            const float q0 = base ? t0 : sp0 + d0, q1 = base ? t1 : sp1 + d1;
+            float n0, n1;
+            step(q0, q1, gs, zbar, p00, p10, n0, n1);
+            const float c0_ = so0 + d0, c1_ = so1 + d1;
+            unsigned long long okm = __builtin_amdgcn_uicmp(__float_as_uint(n0), __float_as_uint(c0_), 32) &
+                                     __builtin_amdgcn_uicmp(__float_as_uint(n1), __float_as_uint(c1_), 32);
+            okm |= ~(1ull << ((pos + stride) & 63));                    // synthetic: exactly one failing lane, `stride` ahead
+            const unsigned long long fail = ~okm & (~0ull << pos);
+            const int f = fail ? (int)__ffsll((long long)fail) - 1 : 64;
+            const int hi = f < 64 ? f : 63;
+            if (lane >= pos && lane <= hi) { to0 = n0; to1 = n1; }
+            t0 = rl(n0, hi); t1 = rl(n1, hi);
+            d0 = t0 - rl(so0, hi); d1 = t1 - rl(so1, hi);
+            pos = (hi + 1) & 63;
+        } else if (V == 1) {    // only the arithmetic of a round (no cross-lane bookkeeping): q -> step -> hypothesis compare folded into a sum
+            const float q0 = sp0 + d0, q1 = sp1 + d1;
+            float n0, n1;
+            step(q0, q1, gs, zbar, p00, p10, n0, n1);
+            d0 = n0 - so0; d1 = n1 - so1;
+        } else if (V == 2) {    // bookkeeping only: mask -> ff1 -> 4 readlanes -> delta (no step)
+            unsigned long long okm = __builtin_amdgcn_uicmp(__float_as_uint(d0 + sp0), __float_as_uint(so0), 32);
+            okm |= ~(1ull << ((pos + stride) & 63));
+            const unsigned long long fail = ~okm & (~0ull << pos);
+            const int f = fail ? (int)__ffsll((long long)fail) - 1 : 64;
+            const int hi = f < 64 ? f : 63;
+            t0 = rl(sp0, hi); t1 = rl(sp1, hi);
+            d0 = t0 - rl(so0, hi); d1 = t1 - rl(so1, hi);
+            pos = (hi + 1) & 63;
+        } else if (V == 3) {    // the round with the base lane injected by DPP from the settled values (no `lane == pos` select):
+                                // H = settled ? T : S + delta kept per lane, predecessor = wave shift of H
+            const unsigned long long settled = pos ? ((1ull << pos) - 1ull) : 0ull;
+            const bool st = (settled >> lane) & 1ull;
+            const float h0 = st ? to0 : so0 + d0, h1 = st ? to1 : so1 + d1;
+            const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t0), __builtin_bit_cast(int, h0), 0x138, 0xf, 0xf, false));
+            const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t1), __builtin_bit_cast(int, h1), 0x138, 0xf, 0xf, false));
+            float n0, n1;
+            step(q0, q1, gs, zbar, p00, p10, n0, n1);
+            unsigned long long okm = __builtin_amdgcn_uicmp(__float_as_uint(n0), __float_as_uint(h0), 32) &
+                                     __builtin_amdgcn_uicmp(__float_as_uint(n1), __float_as_uint(h1), 32);
+            okm |= ~(1ull << ((pos + stride) & 63));
+            const unsigned long long fail = ~okm & ~settled;
+            const int f = fail ? (int)__ffsll((long long)fail) - 1 : 64;
+            const int hi = f < 64 ? f : 63;
+            if (!st && lane <= hi) { to0 = n0; to1 = n1; }
+            d0 = rl(n0, hi) - rl(so0, hi); d1 = rl(n1, hi) - rl(so1, hi);
+            pos = (hi + 1) & 63;
+        }
+    }
+    long long c1 = __builtin_readcyclecounter();
+    out[threadIdx.x] = t0 + t1 + d0 + d1 + to0 + to1 + pos;
+    if (threadIdx.x == 0) cyc[0] = c1 - c0;
+}
+template <int V> void run(const char *name, int stride) {
+    float *out; long long *cyc;
+    (void)hipMalloc(&out, 4 * 64); (void)hipMalloc(&cyc, 8);
+    for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(k<V>, dim3(1), dim3(64), 0, 0, out, cyc, 3.0f, stride); (void)hipDeviceSynchronize(); }
+    long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-70s %.1f cycles per round\n", name, (double)c / N);
+}
+int main() {
+    run<0>("shipped round", 7);
+    run<1>("arithmetic only (hypothesis + step + new delta, no cross-lane work)", 7);
+    run<2>("bookkeeping only (mask, s_ff1, 4 v_readlane, delta)", 7);
+    run<3>("round with DPP-injected base lane", 7);
+    return 0;
+}
