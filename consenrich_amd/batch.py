@@ -49,7 +49,10 @@ _ARR = {"D": L.ARR_D, "xf": L.ARR_XF, "Pf": L.ARR_PF, "pnoise": L.ARR_PNOISE, "x
 
 
 class DeviceBatch:
-    """One GPU, many chains.  Thin, explicit wrapper: every method is one C-ABI call."""
+    """One GPU, many chains.  Thin, explicit wrapper: every method is one C-ABI call.
+
+    `x_tol_ulps`: carry validation of the forward state chain (csr_set_validation).  None / 0 = the default, bit-exact
+    sequential semantics; 2 = the opt-in throughput mode (a few float32 ulps per pass; not a contract through an ECM loop)."""
 
     def __init__(self, device: int = 0, block_len: int = 0, warm=(-1, -1, -1), x_tol_ulps=None):
         L.require_gpu()

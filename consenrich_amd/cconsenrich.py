@@ -21,8 +21,8 @@ from . import _lib as L
 
 def set_validation(x_tol_ulps: int) -> None:
     """Carry validation of the forward state chain for the calls in this module (see csr_set_validation):
-    0 = bit-exact sequential semantics (the default of this module), k > 0 = accept speculative carries within k
-    float32 ulps (2 is the throughput setting the batch API uses)."""
+    0 = bit-exact sequential semantics (the default, here and in the batch API), k > 0 = accept speculative carries within
+    k float32 ulps (2 is the opt-in throughput setting; its contract is per pass, not through an ECM loop)."""
     L.check(L.lib().csr_set_validation(None, int(x_tol_ulps)))
 
 

@@ -139,13 +139,14 @@ const char *csr_build_id(void);
  * the backward chain.  Results never depend on these beyond the documented validation tolerance. */
 int csr_set_tuning(csr_ctx *ctx, int32_t block_len, int32_t warm_p, int32_t warm_x, int32_t warm_b);
 
-/* Carry validation of the forward STATE chain.  0: a speculative block is accepted only if its carry-in is bit-equal
- * to its predecessor's carry-out (results == the sequential recursion, bit for bit).  k > 0 (default 2): also accepted
- * when |dx0| <= k and |F01||dx1| <= k float32 ulps of max(|level|, 1) -- ~1e-7 relative on the state track, far inside the 1e-5
- * parity budget; needed because exact coalescence of the rounded 2-D recursion can take >10^4 bins.
- * ctx == NULL addresses the default context used by the reference-shaped single-chain entry points, whose default is
- * k = 0 (parity first: results are then reproducible and independent of block length / warm-up); contexts made by
- * csr_create default to k = 2 (throughput).  CONSENRICH_AMD_XTOL_ULPS overrides both. */
+/* Carry validation of the forward STATE chain.  0 (the default of every context, and of the default context the
+ * reference-shaped single-chain entry points use, ctx == NULL): a speculative block is accepted only if its carry-in is
+ * bit-equal to its predecessor's carry-out, so results == the sequential recursion bit for bit, reproducible and independent
+ * of block length / warm-up.  This is the only mode that holds the 1e-5 parity gate through the ECM loop on ill-conditioned
+ * data: there the reference's own arithmetic moves by several times the gate when a few inputs move by one float32 ulp
+ * (tests/test_hard_data.py).  k > 0 opts into the throughput mode: a carry is also accepted when
+ * |dx0| <= k and |F01||dx1| <= k float32 ulps of max(|level|, 1) -- ~1e-7 relative on the state track PER PASS, ~3 x faster;
+ * the contract is per pass, not through an ECM loop.  CONSENRICH_AMD_XTOL_ULPS overrides the default of both. */
 int csr_set_validation(csr_ctx *ctx, int32_t x_tol_ulps);
 
 /* Describe a batch: n_chains independent chains (chromosomes) of chain_len[c] bins, m samples each. (Re)allocates. */
