@@ -2531,10 +2531,11 @@ __device__ __forceinline__ void sys_step(const Prm &p, float s0, float s1, doubl
 // and including the next change of delta (~12 % of the bins change it: ~9 rounds per 64 bins instead of 64 dependent steps).
 // The floats S + delta are hypotheses only (an inexact sum just fails the test); what is stored is always a step() result
 // of a proven predecessor, so the pass is exact by construction.  Where delta changes at every bin (the first ~100 bins
-// behind a carry that was far off) a batch falls back to the systolic walk after SB_DELTA_ROUNDS rounds.  When T meets S bit
+// behind a carry that was far off, and stretches where the levels flip densely) the rest of a batch is walked as a shift
+// register as soon as the rounds so far have settled fewer bins each than a round is worth (the rule travels in the launch
+// argument: at least `advMin` bins per round from round `advFrom` on; a round costs ~6 steps).  When T meets S bit
 // for bit the rest of the superblock is already right: the wavefront stops and keeps the old carry-out.
 // ---------------------------------------------------------------------------------------------------------------
-#define SB_DELTA_ROUNDS 20
 #ifndef SB_DELTA_DEPTH
 #define SB_DELTA_DEPTH 8
 #endif
@@ -2544,12 +2545,14 @@ __device__ __forceinline__ void sys_step(const Prm &p, float s0, float s1, doubl
 // the guess's own block boundaries -- instead of walking all its bins from a cold prior.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
-                                                  float2 *__restrict__ natXf, int which, int spec) {
+                                                  float2 *__restrict__ natXf, int which, int specAndRule) {
     // (readfirstlane: the wavefront's index is uniform, and telling the compiler so keeps the superblock's table entry, the
     // carries and the whole round control -- pos, f, delta -- in scalar registers)
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= p.NB || !chain_on(p, b)) return;
     const int lane = threadIdx.x & 63;
+    const int advMin = (specAndRule >> 8) & 0xff, advFrom = (specAndRule >> 16) & 0xff;     // the fallback rule (see batch())
+    const int spec = specAndRule & 1;
     const int4 bi = p.blk[b];
     using Carry = FwdXTrend::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
@@ -2612,7 +2615,10 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
         bool fallback = false;
 #pragma unroll 1
         while (pos < left) {
-            if (++rounds > SB_DELTA_ROUNDS) { fallback = true; break; }
+            // a round costs about six sequential steps: where the rounds so far have settled fewer than advMin bins each, the
+            // rest of the batch is walked (default: give up after 20 rounds; see csr_ctx::sbAdvMin)
+            if (rounds >= advFrom && pos < advMin * rounds) { fallback = true; break; }
+            ++rounds;
             const bool base = lane == pos;
             const float q0 = base ? t0 : sp0 + d0, q1 = base ? t1 : sp1 + d1;
             float n0, n1;
@@ -2632,10 +2638,12 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
             pos = hi + 1;
         }
         if (fallback) {
-            // delta changes at (nearly) every bin here: walk the batch as a shift register from its true carry
-            float s0 = tb0, s1 = tb1, x0v = 0.0f, x1v = 0.0f;
+            // delta changes at (nearly) every bin here: walk the unsettled bins pos .. left-1 as a shift register.  Lane 0 keeps
+            // the batch's true carry, the settled lanes hold their true states and recompute the same bits from true
+            // predecessors; lane pos + j is right after step j + 1.
+            float s0 = tb0, s1 = tb1, x0v = to0, x1v = to1;
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) {
+            for (int q = pos; q < left; ++q) {
                 s0 = dpp_shr1_keep0(s0, x0v);
                 s1 = dpp_shr1_keep0(s1, x1v);
                 sys_step<MODE>(p, s0, s1, gs, zbar, p00, p10, ga.z, ga.w, x0v, x1v);
@@ -2684,6 +2692,240 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
             atomicAdd(p.sbDbg + 3, (unsigned long long)dbgFb);
             if (merged) atomicAdd(p.sbDbg + 4, 1ull);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The bit-exact state chain WITHOUT a barrier between passes (round 3).  In the pass form above every repair pass costs its
+// slowest superblock (a stretch where the levels flip densely takes three times the mean) while the front that matters --
+// the true trajectory working its way down a chain until it meets what lies ahead -- only waits for its own superblock.  Here
+// one launch does the whole chain: a wavefront owns a superblock for the life of the kernel; it walks it once from the cold
+// prior (the speculative pass), publishes its carry-out, and then re-runs it in delta form (same rounds as k_sb_delta)
+// whenever its PREDECESSOR publishes a carry-out that differs from the carry it last started from.  A run in flight is
+// abandoned for a newer carry at a batch boundary; the stored trajectory is then a sequence of valid pieces and the delta
+// rounds need no more than that (a hypothesis across a seam just fails) -- only the early exit "the new trajectory has met the
+// old one" has to wait until the run is past the last seam (`brk`), because what lies behind the meeting point must be one
+// piece ending in the published carry-out.  "Final" travels down a chain with the carries: a chain's first superblock is
+// final after its walk, a superblock is final when a run that started from a final carry ends.  The result is the same fixed
+// point as the pass form's: the sequential recursion, bit for bit.
+// Progress: superblocks are handed out by a ticket taken when a workgroup STARTS, so the predecessor a wavefront waits for
+// belongs to a workgroup that is already running (or to its own); nothing depends on all workgroups being resident.  Every
+// wait is bounded: a wavefront that polls `spinLimit` times without news raises the bail-out flag and leaves, every waiting
+// wavefront leaves when it sees the flag, and the host then runs the pass form instead.
+// Publication: the carry (two floats in one 64-bit word) is stored first, then {version, final} with release order; a reader
+// that sees a version with acquire order reads a carry at least that new.
+// ---------------------------------------------------------------------------------------------------------------
+struct SbAsync {
+    unsigned long long *carry;      // [NB] published carry-out
+    unsigned long long *vf;         // [NB] (version << 1) | final; 0 = nothing published yet
+    unsigned int *ctl;              // [0] ticket, [1] bail-out flag, [2] delta runs, [3] abandoned runs
+    int advMin, advFrom, spinLimit;
+};
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void sb_publish(const SbAsync &a, int64_t b, int lane, float o0, float o1, unsigned ver, bool fin) {
+    if (lane == 0) {
+        __hip_atomic_store(a.carry + b, ((unsigned long long)f2u(o1) << 32) | f2u(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.vf + b, ((unsigned long long)ver << 1) | (fin ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
+                                                  float2 *__restrict__ natXf, SbAsync a) {
+    __shared__ unsigned int sTicket;
+    if (threadIdx.x == 0) sTicket = atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int64_t b = (int64_t)sTicket * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (b >= p.NB || !chain_on(p, b)) return;
+    const int lane = threadIdx.x & 63;
+    const int4 bi = p.blk[b];
+    const bool first = b == (int64_t)bi.z;
+    const int n = bi.y;
+    const int64_t g0 = (int64_t)bi.x + lane;
+    const int nb = (n + 63) >> 6;
+    // ---- the speculative walk: from the prior (true for a chain's first superblock, cold otherwise)
+    float out0 = (float)p.init, out1 = 0.0f;
+    if (p.sbDbg != nullptr && b == 0 && lane == 0) p.sbDbg[0] = (unsigned long long)wall_clock64();
+    {
+        float4 ga = natGain[g0], sa = natSZ[g0];
+        float4 gb = ga, sb_ = sa;
+        if (nb > 1) { gb = natGain[g0 + 64]; sb_ = natSZ[g0 + 64]; }
+        float x0v = 0.0f, x1v = 0.0f;
+#pragma unroll 1
+        for (int t = 0; t < nb; ++t) {
+            float4 gc = gb, sc = sb_;
+            if (t + 2 < nb) { gc = natGain[g0 + (int64_t)(t + 2) * 64]; sc = natSZ[g0 + (int64_t)(t + 2) * 64]; }
+            const double gs = unpack_d(ga.x, ga.y), zbar = unpack_d(sa.z, sa.w);
+            const double p00 = (double)ga.z, p10 = (double)ga.w;
+            float s0 = out0, s1 = out1;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    s0 = dpp_shr1_keep0(s0, x0v);
+                    s1 = dpp_shr1_keep0(s1, x1v);
+                    sys_step<MODE>(p, s0, s1, gs, zbar, p00, p10, ga.z, ga.w, x0v, x1v);
+                }
+            }
+            const int left = n - (t << 6);
+            if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(x0v, x1v);
+            const int last = left >= 64 ? 63 : left - 1;
+            out0 = rl32(x0v, last);
+            out1 = rl32(x1v, last);
+            ga = gb; sa = sb_; gb = gc; sb_ = sc;
+        }
+    }
+    unsigned ver = 1;
+    sb_publish(a, b, lane, out0, out1, ver, first);
+    if (p.sbDbg != nullptr && lane == 0) atomicMax(p.sbDbg + 1, (unsigned long long)wall_clock64());
+    if (first) return;
+    // ---- repairs
+    float cin0 = (float)p.init, cin1 = 0.0f;        // the carry the latest run started from
+    float trj0 = cin0, trj1 = cin1;                 // the carry the stored batch 0 was computed from (hypotheses only)
+    unsigned seen = 0, runs = 0, aborts = 0;
+    int brk = 0;                                    // first bin of the stored trajectory's last piece
+    constexpr int DEPTH = SB_DELTA_DEPTH;
+    const unsigned long long *pvf = a.vf + (b - 1), *pcarry = a.carry + (b - 1);
+    for (;;) {
+        // wait for news from the predecessor
+        unsigned long long vf;
+        for (unsigned spins = 0;; ++spins) {
+            vf = uni64(__hip_atomic_load(pvf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+            if ((unsigned)(vf >> 1) != seen) break;
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
+            if (spins > (unsigned)a.spinLimit) {
+                if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        seen = (unsigned)(vf >> 1);
+        bool runFinal = (vf & 1ull) != 0ull;
+        unsigned long long cw = uni64(__hip_atomic_load(pcarry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (cw == (((unsigned long long)f2u(cin1) << 32) | f2u(cin0))) {
+            if (runFinal) { sb_publish(a, b, lane, out0, out1, ++ver, true); break; }
+            continue;
+        }
+        // a run (restarted from batch 0 whenever a newer carry arrives while it is in flight)
+        bool completed = false, merged = false;
+        for (;;) {
+            cin0 = __uint_as_float((unsigned)cw); cin1 = __uint_as_float((unsigned)(cw >> 32));
+            ++runs;
+            float t0 = cin0, t1 = cin1;                    // TRUE state at the bin before the next unresolved one
+            float sc0 = trj0, sc1 = trj1;                  // the stored trajectory's state at the bin before the batch
+            float4 rg[DEPTH], rs[DEPTH];
+            float2 ro[DEPTH];
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int tt = u < nb ? u : nb - 1;
+                rg[u] = natGain[g0 + (int64_t)tt * 64];
+                rs[u] = natSZ[g0 + (int64_t)tt * 64];
+                ro[u] = natXf[g0 + (int64_t)tt * 64];
+            }
+            bool newer = false;
+            unsigned long long cwNew = cw;
+#pragma unroll 1
+            for (int tg = 0; tg < nb && !merged && !newer; tg += DEPTH) {
+                // the predecessor's version word: asked for before a group of DEPTH batches, looked at after it (a load that
+                // is looked at sooner makes the wavefront wait for the record loads issued just before it)
+                const unsigned long long pv = __hip_atomic_load(pvf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int done = 0;
+#pragma unroll
+                for (int u = 0; u < DEPTH; ++u) {
+                    const int t = tg + u;
+                    if (t < nb && !merged) {
+                        const float4 ga = rg[u], sa = rs[u];
+                        const float2 so = ro[u];
+                        const double gs = unpack_d(ga.x, ga.y), zbar = unpack_d(sa.z, sa.w);
+                        const double p00 = (double)ga.z, p10 = (double)ga.w;
+                        const int left = min(64, n - (t << 6));
+                        const unsigned long long leftMask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+                        const float sp0 = dpp_shr1_keep0(sc0, so.x), sp1 = dpp_shr1_keep0(sc1, so.y);
+                        const float tb0 = t0, tb1 = t1;
+                        float to0 = so.x, to1 = so.y;
+                        float d0 = t0 - sc0, d1 = t1 - sc1;
+                        int pos = 0, rounds = 0;
+                        bool fallback = false;
+#pragma unroll 1
+                        while (pos < left) {
+                            if (rounds >= a.advFrom && pos < a.advMin * rounds) { fallback = true; break; }
+                            ++rounds;
+                            const bool base = lane == pos;
+                            const float q0 = base ? t0 : sp0 + d0, q1 = base ? t1 : sp1 + d1;
+                            float n0, n1;
+                            sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, ga.z, ga.w, n0, n1);
+                            const float c0 = so.x + d0, c1 = so.y + d1;
+                            const unsigned long long okm = __builtin_amdgcn_uicmp(f2u(n0), f2u(c0), 32 /* ICMP_EQ */) &
+                                                           __builtin_amdgcn_uicmp(f2u(n1), f2u(c1), 32);
+                            const unsigned long long fail = ~okm & (~0ull << pos) & leftMask;
+                            const int f = fail ? (int)__ffsll((long long)fail) - 1 : left;
+                            const int hi = f < left ? f : left - 1;
+                            if (lane >= pos && lane <= hi) { to0 = n0; to1 = n1; }
+                            t0 = rl32(n0, hi);
+                            t1 = rl32(n1, hi);
+                            d0 = t0 - rl32(so.x, hi);
+                            d1 = t1 - rl32(so.y, hi);
+                            pos = hi + 1;
+                        }
+                        if (fallback) {
+                            float s0 = tb0, s1 = tb1, x0v = to0, x1v = to1;
+#pragma unroll 1
+                            for (int q = pos; q < left; ++q) {
+                                s0 = dpp_shr1_keep0(s0, x0v);
+                                s1 = dpp_shr1_keep0(s1, x1v);
+                                sys_step<MODE>(p, s0, s1, gs, zbar, p00, p10, ga.z, ga.w, x0v, x1v);
+                            }
+                            to0 = x0v; to1 = x1v;
+                            t0 = rl32(x0v, left - 1);
+                            t1 = rl32(x1v, left - 1);
+                        }
+                        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(to0, to1);
+                        if (t == 0) { trj0 = cin0; trj1 = cin1; }
+                        sc0 = rl32(so.x, left - 1);
+                        sc1 = rl32(so.y, left - 1);
+                        done = (t << 6) + left;                    // bins of the superblock settled by this run
+                        // met the stored trajectory inside its last piece: what lies behind is right and ends in `out`
+                        merged = done > brk && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
+                        if (done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }
+                        const int tn = t + DEPTH;
+                        if (tn < nb) {
+                            rg[u] = natGain[g0 + (int64_t)tn * 64];
+                            rs[u] = natSZ[g0 + (int64_t)tn * 64];
+                            ro[u] = natXf[g0 + (int64_t)tn * 64];
+                        }
+                    }
+                }
+                // news from the predecessor while these batches ran?
+                const unsigned long long pvu = uni64(pv);
+                if ((unsigned)(pvu >> 1) != seen) {
+                    seen = (unsigned)(pvu >> 1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    cwNew = uni64(__hip_atomic_load(pcarry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (cwNew == cw) runFinal = runFinal || (pvu & 1ull) != 0ull;
+                    else if (!completed && !merged) {                   // abandon: the stored trajectory gets a seam here
+                        newer = true;
+                        runFinal = (pvu & 1ull) != 0ull;
+                        if (done > brk) brk = done;
+                    } else {
+                        seen = seen - 1u;                              // the run is over: let the outer loop see this version
+                    }
+                }
+            }
+            if (!newer) break;
+            ++aborts;
+            cw = cwNew;
+        }
+        (void)completed;
+        sb_publish(a, b, lane, out0, out1, ++ver, runFinal);
+        if (runFinal) break;
+    }
+    if (lane == 0) {
+        atomicAdd(a.ctl + 2, runs);
+        atomicAdd(a.ctl + 3, aborts);
+        if (p.sbDbg != nullptr) atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
     }
 }
 

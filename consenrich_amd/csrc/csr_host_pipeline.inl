@@ -435,7 +435,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
     auto launch = [&](int which, int fix) {
         float2 *xf = reinterpret_cast<float2 *>(natXf);
         if ((fix || seeded) && c->sbDelta) {        // delta form (k_sb_delta): repair passes, and the first pass when a 2-ulp trajectory is resident
-            const int spec = fix ? 0 : 1;
+            const int spec = (fix ? 0 : 1) | (c->sbAdvMin << 8) | (c->sbAdvFrom << 16);
             if (mode == 2) hipLaunchKernelGGL(k_sb_delta<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             else if (mode == 1) hipLaunchKernelGGL(k_sb_delta<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             else hipLaunchKernelGGL(k_sb_delta<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
@@ -445,13 +445,50 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
         else if (mode == 1) hipLaunchKernelGGL(k_sb_sys<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
         else hipLaunchKernelGGL(k_sb_sys<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
     };
-    {
+    bool done = false;
+    if (c->sbAsync && !seeded) {
+        // the whole chain in one launch, no barrier between passes (k_sb_async); a bail-out (a bounded wait ran out) falls
+        // through to the pass form below, which starts over from the cold prior
+        if (!v.pub) { CHECK(dalloc(c, &v.pub, 2 * v.NB + 2)); }
+        SbAsync a;
+        a.carry = v.pub; a.vf = v.pub + v.NB; a.ctl = reinterpret_cast<unsigned int *>(v.pub + 2 * v.NB);
+        a.advMin = c->sbAdvMin; a.advFrom = c->sbAdvFrom; a.spinLimit = c->sbSpinLimit;
+        HIPOK(hipMemsetAsync(v.pub, 0, sizeof(unsigned long long) * (size_t)(2 * v.NB + 2), c->stream));
+        {
+            Scope sc(c, "fwd_state_chain");
+            float2 *xf = reinterpret_cast<float2 *>(natXf);
+            if (mode == 2) hipLaunchKernelGGL(k_sb_async<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            else if (mode == 1) hipLaunchKernelGGL(k_sb_async<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            else hipLaunchKernelGGL(k_sb_async<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+        }
+        LAUNCH_CHECK("k_sb_async");
+        unsigned int ctl[4];
+        HIPOK(hipMemcpyAsync(ctl, a.ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
+        HIPOK(wait_stream(c));
+        c->rs.fix_launches++;
+        if (q.sbDbg) {
+            unsigned long long h[8];
+            HIPOK(hipMemcpy(h, c->sbDbg, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[csr] barrier-free state chain: last speculative walk ends %.1f us after the start, last wavefront leaves at %.1f us; %u delta runs, %u abandoned\n",
+                    (double)(h[1] - h[0]) * 0.01, (double)(h[2] - h[0]) * 0.01, ctl[2], ctl[3]);
+            q.sbDbg = nullptr;
+        }
+        if (ctl[1] == 0) {
+            done = true;
+            c->rs.reruns_x += ctl[2];
+            if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_chain (barrier-free superblocks): %u delta runs, %u abandoned; superblock %d bins, %lld superblocks\n",
+                                   ctl[2], ctl[3], v.B, (long long)v.NB);
+        } else {
+            c->rs.pipeline_redos++;
+            if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_chain (barrier-free superblocks): bailed out, running the pass form\n");
+        }
+    }
+    if (!done) {
         Scope sc(c, "fwd_state_chain");
         launch(0, 0);
     }
     LAUNCH_CHECK("k_sb_sys");
     int which = 0, burst = 2;
-    bool done = false;
     for (int64_t it = 0; it <= v.NB + 1 && !done; ++it) {
         {
             Scope sc(c, "fwd_state_fix");

@@ -197,9 +197,18 @@ struct csr_ctx {
     // of the batch (own block table and carries) for this one chain and the filtered state is re-blocked back
     bool sbState = true;        // CONSENRICH_AMD_SB_STATE=0: off (speculation on the batch's own blocks, or seqState)
     int sbBins = 8192, sbWarm = 16384;      // CONSENRICH_AMD_SB_BINS / CONSENRICH_AMD_SB_WARM
+    // k_sb_delta's fallback rule (CONSENRICH_AMD_SB_ADV = "min,from"): walk the rest of a batch when, from round `from` on, the
+    // rounds have settled fewer than `min` bins each.  Measured flat between "give up after 20 rounds" (4,20) and "walk as soon
+    // as a round is worth less than its six steps" (6,2): 3.75-3.95 ms of repairs either way (profiles/r03_sb_sweeps.txt) -- where
+    // the levels flip densely a round and the steps it replaces cost the same.
+    int sbAdvMin = 4, sbAdvFrom = 20;
     bool sbBinsPinned = false;  // CONSENRICH_AMD_SB_BINS given: no automatic choice of the superblock length
     unsigned long long *sbDbg = nullptr;
     bool sbSeed = false;        // CONSENRICH_AMD_SB_SEED=1: the first pass of the exact state chain corrects the 2-ulp trajectory in delta form instead of walking every superblock from the cold prior (measured slower while a round costs ~170 ns: 1.07 + 0.36 vs 0.94 ms; bit-identical, tests/fuzz run with it once)
+    // CONSENRICH_AMD_SB_ASYNC=0: speculative pass + repair passes as separate launches (k_sb_sys / k_sb_delta) instead of the
+    // barrier-free single launch (k_sb_async); sbSpinLimit bounds every wait inside it (polls of ~2 us; then: bail out to the pass form)
+    bool sbAsync = true;
+    int sbSpinLimit = 1 << 19;
     bool sbDelta = true;        // CONSENRICH_AMD_SB_DELTA=0: repair passes as plain systolic walks (k_sb_sys) instead of the delta form (k_sb_delta)
     bool sbSystolic = true;     // CONSENRICH_AMD_SB_SYSTOLIC=0: the round-2 lane-per-superblock walker (re-blocked records, window sbWarm)
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
@@ -214,6 +223,7 @@ struct csr_ctx {
         double4 *rec = nullptr;     // {gs, zbar, P00pred, P10pred} per bin, + one padding group
         float2 *tXf = nullptr;
         void *carryIn = nullptr, *carryOutA = nullptr, *carryOutB = nullptr;
+        unsigned long long *pub = nullptr;      // k_sb_async: carry[NB], {version, final}[NB], control words
     } sb;
     bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
     bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
@@ -369,10 +379,16 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_WS_MAX_BLOCK"))) c->wsMaxBlock = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_WS_WARM_F"))) c->wsWarmF = std::max(16, (atoi(e) + 15) / 16 * 16);
     if ((e = getenv("CONSENRICH_AMD_WS_WARM_B"))) c->wsWarmB = std::max(16, (atoi(e) + 15) / 16 * 16);
+    if ((e = getenv("CONSENRICH_AMD_SB_ADV"))) {
+        int a = 4, f = 20;
+        if (sscanf(e, "%d,%d", &a, &f) >= 1) { c->sbAdvMin = std::min(255, std::max(0, a)); c->sbAdvFrom = std::min(255, std::max(1, f)); }
+    }
     if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) { c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64); c->sbBinsPinned = true; }
     if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
     if ((e = getenv("CONSENRICH_AMD_SB_SYSTOLIC"))) c->sbSystolic = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_ASYNC"))) c->sbAsync = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
     if ((e = getenv("CONSENRICH_AMD_SB_SEED"))) c->sbSeed = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF1"))) c->unitF1Enabled = atoi(e) != 0;

@@ -5,8 +5,9 @@ Per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE
 on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x (TCC_EA0_RDREQ x 64 B for 128-B
 requests) and must be doubled; WRITE_SIZE is exact for streaming stores.
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps]
-The bit-exact state chain (k_sb_sys: one speculative launch + repair launches per step) is one unit of work spread over many
-launches: its entry "fwd_state" is the SUM over the launches of a step (total / steps), like bench.py prices it.
+The bit-exact state chain (k_sb_async: one launch per step; k_sb_sys + k_sb_delta launches when the barrier-free form is
+switched off) is one unit of work: its entry "fwd_state" is the SUM over its launches of a step (total / steps), like
+bench.py prices it.
 """
 import collections
 import csv
@@ -15,7 +16,7 @@ import sys
 
 SHORT = {"k_stats": "stats", "k_resid": "residuals", "k_export_tiled": "export_natural", "FwdTrendFused": "fwd_chain", "FwdPTrend": "fwd_cov_chain",
          "FwdXTrend": "fwd_state_chain", "BwdTrend": "bwd_chain", "k_fwd_dstat": "fwd_dstat", "k_bwd_lag": "bwd_lagcov", "k_fill_rows": "pnoise_fill",
-         "k_copy_active": "ecm_commit_kappa", "k_sb_sys": "fwd_state", "k_import_tiled": "state_reblock_out"}
+         "k_copy_active": "ecm_commit_kappa", "k_sb_": "fwd_state", "k_import_tiled": "state_reblock_out"}
 PER_STEP = {"fwd_state"}
 
 

@@ -240,24 +240,35 @@ def test_ulp_tolerant_validation_stays_within_parity_budget(product, monkeypatch
 
 
 def test_exact_state_chain_on_superblocks_equals_the_sequential_kernel(product, monkeypatch):
-    """Bit-exact mode runs the levelTrend state chain on superblocks of a re-blocked view (k_sb_state_*; 8192 bins, 16384-bin
-    window by default).  With 256-bin superblocks and a 448-bin window nearly every block fails its bitwise validation
-    and the repairs cascade through the chains (partial last blocks, chains shorter than a block, a padding lane group):
-    the fixed point must still be the sequential recursion -- k_state_seq_trend, one wavefront per chain, bit for bit."""
+    """Bit-exact mode runs the levelTrend state chain on superblocks (k_sb_async: one wavefront per superblock, no barrier between
+    the repair passes; k_sb_sys + k_sb_delta: the pass form).  With 64 / 256-bin superblocks nearly every superblock fails its
+    bitwise validation and the repairs cascade through the chains (partial last blocks, chains shorter than a block, more
+    superblocks than the device holds wavefronts): the fixed point must still be the sequential recursion --
+    k_state_seq_trend, one wavefront per chain, bit for bit."""
     n_list = [60000, 7000, 300, 1, 16640]
     monkeypatch.setenv("CONSENRICH_AMD_SEQ_STATE", "1")
     seq = _run_batch(0, (-1, -1, -1), 2, n_list, 8, 300, xtol=0)
     monkeypatch.setenv("CONSENRICH_AMD_SEQ_STATE", "0")
-    for bins, warm in (("256", "448"), ("8192", "16384"), ("64", "0")):
+    # the barrier-free single launch (default), the pass form, and the single launch with a wait bound so short that it
+    # bails out and the host runs the pass form instead
+    for bins, warm, mode in (("256", "448", "async"), ("8192", "16384", "async"), ("64", "0", "async"), ("256", "448", "passes"),
+                             ("64", "0", "passes"), ("4096", "0", "bail")):
         monkeypatch.setenv("CONSENRICH_AMD_SB_BINS", bins)
         monkeypatch.setenv("CONSENRICH_AMD_SB_WARM", warm)
+        monkeypatch.setenv("CONSENRICH_AMD_SB_ASYNC", "0" if mode == "passes" else "1")
+        if mode == "bail":
+            monkeypatch.setenv("CONSENRICH_AMD_SB_SPIN_LIMIT", "1")
+        else:
+            monkeypatch.delenv("CONSENRICH_AMD_SB_SPIN_LIMIT", raising=False)
         sb = _run_batch(0, (-1, -1, -1), 2, n_list, 8, 300, xtol=0)
         for key, val in seq.items():
             if key != "stats" and not isinstance(key, str):
-                assert np.array_equal(val, sb[key]), (bins, key)
+                assert np.array_equal(val, sb[key]), (bins, mode, key)
         assert np.array_equal(sb["sn"], seq["sn"]) and np.array_equal(sb["sd"], seq["sd"])
         if bins != "8192":
             assert sb["stats"]["reruns_x"] > 0, sb["stats"]
+        if mode == "bail":
+            assert sb["stats"]["pipeline_redos"] > 0, sb["stats"]
 
 
 def _full_chain(mod, d, n, m, seed=4242):
