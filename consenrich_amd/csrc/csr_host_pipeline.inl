@@ -383,7 +383,8 @@ static int ensure_sb_view(csr_ctx *c) {
 // straight into the reference-layout xf array; superblocks start from the cold prior and the validation / repair passes run
 // to the fixed point (= the sequential recursion, whatever the superblock length); one tiled launch brings the filtered state
 // back into the batch's blocked layout for the epilogue and the smoother.
-static int state_chain_systolic(csr_ctx *c, const Prm &p) {
+static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags);
+static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = false, uint32_t flags = 0) {
     CHECK(ensure_sb_view(c));
     CHECK(flush_pending_check(c));
     csr_ctx::SbView &v = c->sb;
@@ -417,6 +418,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p) {
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p, L);
     }
     LAUNCH_CHECK("k_export_tiled (state records)");
+    if (earlyExports) CHECK(early_cov_exports(c, p, flags));
     Prm q = p;
     q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
     q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
@@ -632,9 +634,55 @@ static int forward_epilogue(csr_ctx *c, const Prm &p, bool side) {
     return 0;
 }
 
+// main stream waits for the early covariance exports of the side stream (early_cov_exports)
+static void join_pf(csr_ctx *c) {
+    if (c->pfPending) {
+        (void)hipStreamWaitEvent(c->stream, c->evPf, 0);
+        c->pfPending = false;
+    }
+}
+// Bit-exact mode: the state chain keeps at most 5/8 of the SIMDs busy for milliseconds and is bound by latency, not by
+// bandwidth.  The reference-layout outputs that depend on the covariance chain alone -- Pf, and the process noise when it
+// is one constant matrix -- are written on the side stream underneath it instead of after the smoother.
+static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
+    HIPOK(hipEventRecord(c->evFork2, c->stream));
+    HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
+    const int nm = c->mdl.state_dim * c->mdl.state_dim;
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        float *dst;
+        CHECK(nat_array(c, CSR_ARR_PF, &dst));
+        L.count = 1;
+        L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dst; L.d[0].E = 4; L.d[0].n = nm;
+        Scope sc(c, "export_natural", c->side);
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->side, p, L);
+    }
+    LAUNCH_CHECK("k_export_tiled (early Pf)");
+    c->pfNat = true;
+    if (!(flags & (F_APN | F_QSCALE | F_KAPPA)) && p.chainQ == nullptr) {
+        float *dst;
+        CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));
+        const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
+        Scope sc(c, "export_natural", c->side);
+        if (nm == 4)
+            hipLaunchKernelGGL(k_fill_rows<4>, dim3(grid), dim3(256), 0, c->side, dst, c->Npad, (float)p.Q00, (float)p.Q01,
+                               (float)p.Q10, (float)p.Q11);
+        else
+            hipLaunchKernelGGL(k_fill_rows<1>, dim3(grid), dim3(256), 0, c->side, dst, c->Npad, (float)p.Q00, 0.f, 0.f, 0.f);
+        LAUNCH_CHECK("k_fill_rows (early pNoise)");
+        c->pnNat = true;
+    }
+    HIPOK(hipEventRecord(c->evPf, c->side));
+    c->pfPending = true;
+    return 0;
+}
+
 static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
                         bool side = false, bool natOut = false) {
     if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
+    join_pf(c);         // (an early export nobody asked for afterwards still reads the arrays this pass overwrites)
+    c->pfNat = c->pnNat = false;
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
@@ -712,7 +760,9 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 LAUNCH_CHECK("k_state_seq_trend");
                 dX = false;
             } else if (sbX) {
-                if (c->sbSystolic) CHECK(state_chain_systolic(c, p));
+                // (the early covariance exports fork off behind the state chain's own record conversion)
+                const bool early = natOut && c->earlyPf && active == nullptr && c->natOutEnabled;
+                if (c->sbSystolic) CHECK(state_chain_systolic(c, p, early, flags));
                 else if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
                 else CHECK(state_chain_superblocks<false>(c, p));
                 dX = false;
@@ -862,6 +912,7 @@ static int check_stages(csr_ctx *c) {
 
 static int settle(csr_ctx *c) {
     join_side(c);
+    join_pf(c);
     if (!c->pendFwd && !c->pendBwd) return 0;
     CHECK(read_mail(c, c->mailBytes));
     const bool pf = c->pendFwd, pb = c->pendBwd;
@@ -1198,13 +1249,16 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     if (!lateD && !c->dNat) join_side(c);
     if (what & CSR_EXPORT_FORWARD) {
         if (!c->haveFwd) return fail("no forward results to export");
+        join_pf(c);
         if (!lateD && !c->dNat) CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));   // dNat: the epilogue wrote it already
         if (!c->fwdNat) {       // fwdNat: the forward chain already wrote both in the reference layout
             if (!c->xfNat) CHECK(add_export(c, L, CSR_ARR_XF, (const float *)p.tXf, 2, nv, 0));    // xfNat: the systolic state chain wrote it
-            CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));
+            if (!c->pfNat) CHECK(add_export(c, L, CSR_ARR_PF, (const float *)p.tPf, 4, nm, 0));    // pfNat: written underneath the state chain
         }
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
-        if (constQ && p.chainQ == nullptr) {
+        if (c->pnNat) {
+            // (the constant process noise was filled underneath the state chain as well)
+        } else if (constQ && p.chainQ == nullptr) {
             // one Q0 for every bin of every chain: a streaming fill (rows past a chain's n-1 are padding nobody reads)
             float *dst;
             CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));

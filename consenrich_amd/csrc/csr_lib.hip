@@ -275,6 +275,9 @@ struct csr_ctx {
     int carryToggle = 0;
     bool foldCheck = true;              // CONSENRICH_AMD_FOLD_CHECK=0: every stage launches its own validation kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evFork2 = nullptr, evPf = nullptr;      // early covariance exports on the side stream (bit-exact mode)
+    bool pfPending = false, pfNat = false, pnNat = false;
+    bool earlyPf = true;        // CONSENRICH_AMD_EARLY_PF=0: Pf / constant pNoise exported after the smoother like the other tracks
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -357,7 +360,9 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evFork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evPf, hipEventDisableTiming) != hipSuccess) {
         fail("cannot create the side stream of device %d", device_ordinal);
         delete c;
         return nullptr;
@@ -388,6 +393,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_SYSTOLIC"))) c->sbSystolic = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_ASYNC"))) c->sbAsync = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_EARLY_PF"))) c->earlyPf = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
     if ((e = getenv("CONSENRICH_AMD_SB_SEED"))) c->sbSeed = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
@@ -433,6 +439,8 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (c->hMail) (void)hipHostFree(c->hMail);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->evFork2) (void)hipEventDestroy(c->evFork2);
+    if (c->evPf) (void)hipEventDestroy(c->evPf);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
