@@ -481,7 +481,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_chain (barrier-free superblocks): %u delta runs, %u abandoned; superblock %d bins, %lld superblocks\n",
                                    ctl[2], ctl[3], v.B, (long long)v.NB);
         } else {
-            c->rs.pipeline_redos++;
+            c->rs.sb_bailouts++;
             if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_chain (barrier-free superblocks): bailed out, running the pass form\n");
         }
     }
@@ -645,14 +645,19 @@ static void join_pf(csr_ctx *c) {
 // bandwidth.  The reference-layout outputs that depend on the covariance chain alone -- Pf, and the process noise when it
 // is one constant matrix -- are written on the side stream underneath it instead of after the smoother.
 static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
+    const int nm = c->mdl.state_dim * c->mdl.state_dim;
+    const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA)) && p.chainQ == nullptr;
+    // (a reference-layout array is allocated -- and zeroed ON THE MAIN STREAM -- at its first use: before the fork, so that the
+    // side stream's writes are ordered behind the zeroing)
+    float *dstPf, *dstPn = nullptr;
+    CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
+    if (constQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
     HIPOK(hipEventRecord(c->evFork2, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
-    const int nm = c->mdl.state_dim * c->mdl.state_dim;
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        float *dst;
-        CHECK(nat_array(c, CSR_ARR_PF, &dst));
+        float *dst = dstPf;
         L.count = 1;
         L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dst; L.d[0].E = 4; L.d[0].n = nm;
         Scope sc(c, "export_natural", c->side);
@@ -660,9 +665,8 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
     }
     LAUNCH_CHECK("k_export_tiled (early Pf)");
     c->pfNat = true;
-    if (!(flags & (F_APN | F_QSCALE | F_KAPPA)) && p.chainQ == nullptr) {
-        float *dst;
-        CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));
+    if (constQ) {
+        float *dst = dstPn;
         const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
         Scope sc(c, "export_natural", c->side);
         if (nm == 4)

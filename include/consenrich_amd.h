@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSR_ABI_VERSION 2
+#define CSR_ABI_VERSION 3
 
 /* ---- model / flags ------------------------------------------------------------------------------------- */
 
@@ -479,6 +479,8 @@ typedef struct csr_run_stats {
     int64_t local_repairs;      /* blocks a warm-started ECM sweep validated against their neighbour INSIDE the speculative
                                    kernel, found wanting and re-ran there (as of the last read-back) */
     int32_t ws_warm_f, ws_warm_b;   /* windows (bins) of the warm-started ECM sweeps, forward / smoother */
+    int64_t sb_bailouts;        /* bit-exact state chain: single launches (k_sb_async) that gave up on a bounded wait; the pass
+                                   form then ran instead (same results) */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

@@ -267,8 +267,10 @@ def test_exact_state_chain_on_superblocks_equals_the_sequential_kernel(product, 
         assert np.array_equal(sb["sn"], seq["sn"]) and np.array_equal(sb["sd"], seq["sd"])
         if bins != "8192":
             assert sb["stats"]["reruns_x"] > 0, sb["stats"]
-        if mode == "bail":
-            assert sb["stats"]["pipeline_redos"] > 0, sb["stats"]
+        single_launch = (os.environ.get("CONSENRICH_AMD_SB_STATE", "1") != "0" and os.environ.get("CONSENRICH_AMD_SB_SEED", "0") == "0"
+                         and os.environ.get("CONSENRICH_AMD_SB_SYSTOLIC", "1") != "0")      # (the suite's mode-switch variants)
+        if mode == "bail" and single_launch:
+            assert sb["stats"]["sb_bailouts"] > 0, sb["stats"]
 
 
 def _full_chain(mod, d, n, m, seed=4242):
