@@ -3144,16 +3144,22 @@ __global__ __launch_bounds__(1024) void k_chain_sums(Prm p, const int64_t *chain
     const int c = blockIdx.x;
     const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
     const bool on = p.chainActive == nullptr || p.chainActive[c];
+    // (sixteen independent loads per array and thread in flight: a chain's few 10^4 partial sums are one or two trips to
+    // memory, not five dependent ones -- the kernel is pure latency)
     double aD[4] = {0.0, 0.0, 0.0, 0.0}, aN[4] = {0.0, 0.0, 0.0, 0.0};
     if (on) {
-        for (int64_t i = threadIdx.x; i < nb; i += 4096) {
+        for (int64_t i = threadIdx.x; i < nb; i += 16384) {
+            double vD[16], vN[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int64_t j = i + (int64_t)u * 1024;
-                if (j < nb) {
-                    aD[u] += p.blkSumD[b0 + j];
-                    aN[u] += p.blkSumNLL[b0 + j];
-                }
+                vD[u] = j < nb ? p.blkSumD[b0 + j] : 0.0;
+                vN[u] = j < nb ? p.blkSumNLL[b0 + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                aD[u & 3] += vD[u];
+                aN[u & 3] += vN[u];
             }
         }
     }
