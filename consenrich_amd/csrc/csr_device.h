@@ -3140,7 +3140,7 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
 // per-chain sums in block order (one workgroup per chain; fixed partition and fixed-shape tree: deterministic).
 // Four independent accumulators per thread keep the loads of a long chain (10^4 blocks) in flight together.
 __global__ __launch_bounds__(1024) void k_chain_sums(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
-    __shared__ double sd[1024], sn[1024];
+    __shared__ double sd[16], sn[16];
     const int c = blockIdx.x;
     const int64_t b0 = chainFirstBlock[c], nb = chainNumBlocks[c];
     const bool on = p.chainActive == nullptr || p.chainActive[c];
@@ -3163,19 +3163,27 @@ __global__ __launch_bounds__(1024) void k_chain_sums(Prm p, const int64_t *chain
             }
         }
     }
-    sd[threadIdx.x] = (aD[0] + aD[1]) + (aD[2] + aD[3]);
-    sn[threadIdx.x] = (aN[0] + aN[1]) + (aN[2] + aN[3]);
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            sd[threadIdx.x] += sd[threadIdx.x + w];
-            sn[threadIdx.x] += sn[threadIdx.x + w];
-        }
-        __syncthreads();
+    // fixed-order reduction: inside a wavefront by shuffles, the sixteen wavefront sums through LDS (one barrier)
+    double d = (aD[0] + aD[1]) + (aD[2] + aD[3]), n = (aN[0] + aN[1]) + (aN[2] + aN[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        d += __shfl_down(d, off);
+        n += __shfl_down(n, off);
     }
+    if ((threadIdx.x & 63) == 0) {
+        sd[threadIdx.x >> 6] = d;
+        sn[threadIdx.x >> 6] = n;
+    }
+    __syncthreads();
     if (threadIdx.x == 0 && on) {
-        p.chainSumD[c] = sd[0];
-        p.chainSumNLL[c] = sn[0];
+        double td = 0.0, tn = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            td += sd[w];
+            tn += sn[w];
+        }
+        p.chainSumD[c] = td;
+        p.chainSumNLL[c] = tn;
     }
 }
 
