@@ -2719,8 +2719,15 @@ struct SbAsync {
     unsigned long long *carry;      // [NB] published carry-out
     unsigned long long *vf;         // [NB] (version << 1) | final; 0 = nothing published yet
     unsigned int *ctl;              // [0] ticket, [1] bail-out flag, [2] delta runs, [3] abandoned runs
+    unsigned int *hostDone;         // [chains], host-visible, or nullptr: set to 1 when a chain's last superblock is final
     int advMin, advFrom, spinLimit;
 };
+// a chain is final (its whole filtered state stands in the reference layout): tell the host, which may start that chain's
+// smoother / residuals on another stream while other chains are still being repaired
+__device__ __forceinline__ void sb_chain_done(const Prm &p, const SbAsync &a, int64_t b, const int4 &bi, int lane) {
+    if (a.hostDone != nullptr && lane == 0 && b == (int64_t)bi.w)
+        __hip_atomic_store(a.hostDone + p.blkChain[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -2781,7 +2788,10 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     unsigned ver = 1;
     sb_publish(a, b, lane, out0, out1, ver, first);
     if (p.sbDbg != nullptr && lane == 0) atomicMax(p.sbDbg + 1, (unsigned long long)wall_clock64());
-    if (first) return;
+    if (first) {
+        sb_chain_done(p, a, b, bi, lane);
+        return;
+    }
     // ---- repairs
     float cin0 = (float)p.init, cin1 = 0.0f;        // the carry the latest run started from
     float trj0 = cin0, trj1 = cin1;                 // the carry the stored batch 0 was computed from (hypotheses only)
@@ -2922,10 +2932,14 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         sb_publish(a, b, lane, out0, out1, ++ver, runFinal);
         if (runFinal) break;
     }
+    sb_chain_done(p, a, b, bi, lane);       // (every path that reaches this point has published "final")
     if (lane == 0) {
         atomicAdd(a.ctl + 2, runs);
         atomicAdd(a.ctl + 3, aborts);
-        if (p.sbDbg != nullptr) atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
+        if (p.sbDbg != nullptr) {
+            atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
+            if (b == (int64_t)bi.w) p.sbDbg[8 + p.blkChain[b]] = (unsigned long long)wall_clock64();     // the chain is final
+        }
     }
 }
 

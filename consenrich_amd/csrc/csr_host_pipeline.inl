@@ -384,18 +384,24 @@ static int ensure_sb_view(csr_ctx *c) {
 // to the fixed point (= the sequential recursion, whatever the superblock length); one tiled launch brings the filtered state
 // back into the batch's blocked layout for the epilogue and the smoother.
 static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags);
-static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = false, uint32_t flags = 0) {
+// phase 0: the whole chain.  phase 1 (a step that pipelines its tail per chain, step_pipelined): stop right after the launch of
+// the barrier-free kernel, with per-chain "done" words the host can watch -- c->sbp.active says that this happened (otherwise
+// the whole chain ran, as in phase 0).  phase 2: wait for that launch (or run the pass form if it bailed out); the filtered
+// state is NOT brought back into the blocked layout (the caller does that per group of chains).
+static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = false, uint32_t flags = 0, int phase = 0) {
+    const bool resume = phase == 2;
     CHECK(ensure_sb_view(c));
-    CHECK(flush_pending_check(c));
+    if (!resume) CHECK(flush_pending_check(c));
     csr_ctx::SbView &v = c->sb;
     if (!c->sbNatGain) { CHECK(dalloc(c, &c->sbNatGain, c->Npad)); CHECK(dalloc(c, &c->sbNatSZ, c->Npad)); }
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    c->sbp.active = false;
     // First-pass guess: the state chain in its 2-ulp form on the batch's own blocks (one bandwidth-bound launch, validated with
     // the k = 2 rule), converted to the natural layout together with the records.  The delta-form first pass then proves and
     // corrects that trajectory instead of walking every superblock from a cold prior.
     const bool seeded = c->sbDelta && c->sbSeed;
-    if (seeded) {
+    if (seeded && !resume) {
         const int keep = c->xTolUlps;
         c->xTolUlps = 2;
         int rc;
@@ -404,7 +410,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         c->xTolUlps = keep;
         CHECK(rc);
     }
-    {
+    if (!resume) {
         Scope sc(c, "state_records_natural");
         ExpList L;
         memset(&L, 0, sizeof(L));
@@ -418,7 +424,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p, L);
     }
     LAUNCH_CHECK("k_export_tiled (state records)");
-    if (earlyExports) CHECK(early_cov_exports(c, p, flags));
+    if (earlyExports && !resume) CHECK(early_cov_exports(c, p, flags));
     Prm q = p;
     q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
     q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
@@ -430,8 +436,8 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     const int grid = (int)((v.NB + 3) / 4);
     q.sbDbg = nullptr;
     if (getenv("CONSENRICH_AMD_SB_DEBUG")) {
-        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 8));
-        HIPOK(hipMemsetAsync(c->sbDbg, 0, 64, c->stream));
+        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 8 + (int64_t)c->chains.size()));
+        if (!resume) HIPOK(hipMemsetAsync(c->sbDbg, 0, 8 * (8 + c->chains.size()), c->stream));
         q.sbDbg = c->sbDbg;
     }
     auto launch = [&](int which, int fix) {
@@ -455,8 +461,18 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         SbAsync a;
         a.carry = v.pub; a.vf = v.pub + v.NB; a.ctl = reinterpret_cast<unsigned int *>(v.pub + 2 * v.NB);
         a.advMin = c->sbAdvMin; a.advFrom = c->sbAdvFrom; a.spinLimit = c->sbSpinLimit;
-        HIPOK(hipMemsetAsync(v.pub, 0, sizeof(unsigned long long) * (size_t)(2 * v.NB + 2), c->stream));
-        {
+        a.hostDone = nullptr;
+        if (phase == 1) {
+            // (nothing of this context is in flight that writes these words: the previous launch was waited for)
+            if (!c->hDone) {
+                HIPOK(hipHostMalloc((void **)&c->hDone, sizeof(unsigned int) * c->chains.size()));
+                HIPOK(hipHostGetDevicePointer((void **)&c->dDone, c->hDone, 0));
+            }
+            for (size_t i = 0; i < c->chains.size(); ++i) c->hDone[i] = 0u;
+            a.hostDone = c->dDone;
+        }
+        if (!resume) {
+            HIPOK(hipMemsetAsync(v.pub, 0, sizeof(unsigned long long) * (size_t)(2 * v.NB + 2), c->stream));
             Scope sc(c, "fwd_state_chain");
             float2 *xf = reinterpret_cast<float2 *>(natXf);
             if (mode == 2) hipLaunchKernelGGL(k_sb_async<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
@@ -464,6 +480,13 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             else hipLaunchKernelGGL(k_sb_async<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
         }
         LAUNCH_CHECK("k_sb_async");
+        if (phase == 1) {
+            c->sbp.active = true;
+            c->sbp.p = p;
+            c->sbp.early = earlyExports;
+            c->sbp.flags = flags;
+            return 0;
+        }
         unsigned int ctl[4];
         HIPOK(hipMemcpyAsync(ctl, a.ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
         HIPOK(wait_stream(c));
@@ -473,6 +496,11 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             HIPOK(hipMemcpy(h, c->sbDbg, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "[csr] barrier-free state chain: last speculative walk ends %.1f us after the start, last wavefront leaves at %.1f us; %u delta runs, %u abandoned\n",
                     (double)(h[1] - h[0]) * 0.01, (double)(h[2] - h[0]) * 0.01, ctl[2], ctl[3]);
+            std::vector<unsigned long long> fin(c->chains.size());
+            HIPOK(hipMemcpy(fin.data(), c->sbDbg + 8, 8 * fin.size(), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[csr]   chains final at (us, bins):");
+            for (size_t i = 0; i < fin.size(); ++i) fprintf(stderr, " %.0f:%lld", (double)(fin[i] - h[0]) * 0.01, (long long)c->chains[i].n);
+            fprintf(stderr, "\n");
             q.sbDbg = nullptr;
         }
         if (ctl[1] == 0) {
@@ -483,6 +511,8 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         } else {
             c->rs.sb_bailouts++;
             if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_chain (barrier-free superblocks): bailed out, running the pass form\n");
+            // (a pipelined step may have tails of finished chains in flight that read the track the pass form rewrites)
+            if (resume && c->tail) HIPOK(hipStreamSynchronize(c->tail));
         }
     }
     if (!done) {
@@ -518,7 +548,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         fprintf(stderr, "[csr]   slowest superblock: %.1f us, %llu batches, %llu rounds, %llu fallback batches; mean %.1f us per re-run superblock\n",
                 (double)(h[5] >> 40) * 0.01, (h[5] >> 28) & 0xfff, (h[5] >> 12) & 0xffff, h[5] & 0xfff, h[0] ? (double)h[6] * 0.01 / (double)h[0] : 0.0);
     }
-    {
+    if (!resume) {
         Scope sc(c, "state_reblock_out");
         hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
                            reinterpret_cast<const float2 *>(natXf), p.tXf);
@@ -682,9 +712,12 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
     return 0;
 }
 
+// split: the caller pipelines everything behind the bit-exact state chain per group of chains (step_pipelined); if that chain
+// went out as one barrier-free launch the pass returns right behind it (c->sbp.active) without the NIS / NLL epilogue.
 static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
-                        bool side = false, bool natOut = false) {
+                        bool side = false, bool natOut = false, bool split = false) {
     if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
+    c->sbp.active = false;
     join_pf(c);         // (an early export nobody asked for afterwards still reads the arrays this pass overwrites)
     c->pfNat = c->pnNat = false;
     Prm p = c->p;
@@ -710,6 +743,20 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
         LAUNCH_CHECK("k_fwd_apn");
     } else {
         bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
+        if (wantD && natOut && c->natOutEnabled && c->natOutD) {        // D straight into the reference layout
+            const size_t tileBytes = sizeof(float) * 64 * (size_t)(c->B + 1);
+            bool ok = true;
+            if (tileBytes > 48 * 1024 && !c->dstatLdsRaised) {      // 256-bin blocks: 65.8 KB of dynamic LDS
+                ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_dstat<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileBytes) == hipSuccess;
+                (void)hipGetLastError();
+                c->dstatLdsRaised = ok;
+            }
+            if (ok) {
+                CHECK(nat_array(c, CSR_ARR_D, &p.natD));
+                c->dNat = true;
+            }
+        }
         // Fused chain (tolerant mode).  Its state recursion warms up on SPECULATIVE gains (the split state chain reads the
         // validated ones), so with per-bin multipliers (the ECM loop: kappa per bin) a few blocks need about covariance-window +
         // state-window bins.  Round 1 ran every block with a 160-bin window for them (a failed validation cost a whole
@@ -766,7 +813,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             } else if (sbX) {
                 // (the early covariance exports fork off behind the state chain's own record conversion)
                 const bool early = natOut && c->earlyPf && active == nullptr && c->natOutEnabled;
-                if (c->sbSystolic) CHECK(state_chain_systolic(c, p, early, flags));
+                if (c->sbSystolic) CHECK(state_chain_systolic(c, p, early, flags, split ? 1 : 0));
                 else if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
                 else CHECK(state_chain_superblocks<false>(c, p));
                 dX = false;
@@ -777,21 +824,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         }
-        if (wantD && natOut && c->natOutEnabled && c->natOutD) {        // D straight into the reference layout
-            const size_t tileBytes = sizeof(float) * 64 * (size_t)(c->B + 1);
-            bool ok = true;
-            if (tileBytes > 48 * 1024 && !c->dstatLdsRaised) {      // 256-bin blocks: 65.8 KB of dynamic LDS
-                ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_dstat<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileBytes) == hipSuccess;
-                (void)hipGetLastError();
-                c->dstatLdsRaised = ok;
-            }
-            if (ok) {
-                CHECK(nat_array(c, CSR_ARR_D, &p.natD));
-                c->dNat = true;
-            }
-        }
-        if (wantD) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
+        if (wantD && !c->sbp.active) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
         if (dP || dX) {
             c->pendFwd = true;
             c->pendFlags = flags;
@@ -1237,6 +1270,40 @@ static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, i
     return 0;
 }
 
+// residuals of the bins [off, off + nb) of the batch's natural layout (whole chains: off and nb are multiples of 64)
+static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck) {
+    const int d = c->mdl.state_dim;
+    float *xs, *res;
+    CHECK(nat_array(c, CSR_ARR_XS, &xs));
+    CHECK(nat_array(c, CSR_ARR_RESID, &res));
+    Scope sc(c, "residuals");
+    Prm pr = c->p;
+    pr.xTolUlps = c->xTolUlps;
+    pr.prevKind = CK_NONE;
+    // grid x 256 threads >= blocks: Npad / (K * 64) workgroups, K <= 4, block length >= 32
+    if (foldCheck && off == 0 && (int64_t)((nb + 255) / 256) * 256 >= c->NB) take_pending_check(c, pr);
+    pr.data += off;
+    if (pr.bg) pr.bg += off;
+    xs += off * d;
+    res += off * c->m;
+    if ((c->m & 3) == 0) {
+        const int K = (c->residTile == 1 || c->residTile == 2 || c->residTile == 4) ? c->residTile : 1;
+        const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
+        const dim3 grid((unsigned)((nb + K * 64 - 1) / (K * 64)));
+        if (K == 4 && lds <= 65536)
+            hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, pr, xs, d, res, nb);
+        else if (K == 2 && lds <= 65536)
+            hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, pr, xs, d, res, nb);
+        else
+            hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((nb + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
+                               c->stream, pr, xs, d, res, nb);
+    } else
+        hipLaunchKernelGGL(k_resid, dim3((int)((nb + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
+                           pr, xs, d, res, nb);
+    LAUNCH_CHECK("k_resid");
+    return 0;
+}
+
 static int export_impl(csr_ctx *c, uint32_t what) {
     const int d = c->mdl.state_dim;
     const Prm &p = c->p;
@@ -1300,31 +1367,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export(c, L, CSR_ARR_QSCALE, p.tQs, 1, 1, 0));
     }
     CHECK(flush_export(c, L));
-    if (what & CSR_EXPORT_RESID) {
-        float *xs, *res;
-        CHECK(nat_array(c, CSR_ARR_XS, &xs));
-        CHECK(nat_array(c, CSR_ARR_RESID, &res));
-        Scope sc(c, "residuals");
-        Prm pr = c->p;
-        pr.xTolUlps = c->xTolUlps;
-        // grid x 256 threads >= blocks: Npad / (K * 64) workgroups, K <= 4, block length >= 32
-        if ((int64_t)((c->Npad + 255) / 256) * 256 >= c->NB) take_pending_check(c, pr);
-        if ((c->m & 3) == 0) {
-            const int K = (c->residTile == 1 || c->residTile == 2 || c->residTile == 4) ? c->residTile : 1;
-            const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
-            const dim3 grid((unsigned)((c->Npad + K * 64 - 1) / (K * 64)));
-            if (K == 4 && lds <= 65536)
-                hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, pr, xs, d, res, c->Npad);
-            else if (K == 2 && lds <= 65536)
-                hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, pr, xs, d, res, c->Npad);
-            else
-                hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
-                                   c->stream, pr, xs, d, res, c->Npad);
-        } else
-            hipLaunchKernelGGL(k_resid, dim3((int)((c->Npad + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
-                               pr, xs, d, res, c->Npad);
-        LAUNCH_CHECK("k_resid");
-    }
+    if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true));
     if (lateD) {
         join_side(c);
         CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
@@ -1337,10 +1380,161 @@ static int export_impl(csr_ctx *c, uint32_t what) {
 // Same launches as csr_batch_stats / csr_batch_forward_backward / csr_batch_export / csr_batch_sums in sequence -- a
 // convenience for callers; the four separate calls cost the same (0.411 vs 0.412 ms on a 1/8-genome shard: the host runs
 // ahead of the device, only the final read-back is a round trip).
+// Everything of a step behind the filtered state -- blocked copy of xf, NIS / NLL epilogue, smoother, residuals -- for the
+// chains of `dmask` (device bytes, nullptr = all), on c->stream.  `runs`: the maximal runs of those chains as bin ranges of the
+// natural layout.
+static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, const std::vector<std::pair<int64_t, int64_t>> &runs,
+                     uint32_t what) {
+    Prm pt = pf;
+    pt.chainActive = dmask;
+    pt.prevKind = CK_NONE;
+    float *natXf;
+    CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    {
+        Scope sc(c, "state_reblock_out");
+        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pt,
+                           reinterpret_cast<const float2 *>(natXf), pt.tXf);
+    }
+    LAUNCH_CHECK("k_import_tiled_f2");
+    // the NIS / NLL epilogue beside the (latency-bound) smoother chain, on the side stream
+    HIPOK(hipEventRecord(c->evFork, c->stream));
+    HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+    {
+        Scope sc(c, "fwd_dstat", c->side);
+        if (pt.natD) hipLaunchKernelGGL(k_fwd_dstat<true>, dim3((int)c->NG), dim3(256), sizeof(float) * 64 * (c->B + 1), c->side, pt);
+        else hipLaunchKernelGGL(k_fwd_dstat<false>, dim3((int)c->NG), dim3(256), 0, c->side, pt);
+    }
+    LAUNCH_CHECK("k_fwd_dstat");
+    HIPOK(hipEventRecord(c->evJoin, c->side));
+    CHECK(backward_impl(c, true, dmask, true, true));
+    CHECK(flush_pending_check(c));              // (the residual launches below cover a part of the batch each: no folded check)
+    if (what & CSR_EXPORT_RESID)
+        for (const auto &r : runs) CHECK(launch_resid(c, r.first, r.second, false));
+    HIPOK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+    return 0;
+}
+
+// A step of the bit-exact mode whose tail is PIPELINED PER CHAIN behind the barrier-free state chain.  That launch lasts as
+// long as the slowest chain needs (3.7 ms at genome scale) while most chains are final a millisecond earlier, and it leaves the
+// memory system idle.  The kernel sets a host-visible word per chain when the chain is final; the host watches those words and,
+// whenever the newly finished chains make up an eighth of the batch, launches their tail (blocked copy of xf, NIS / NLL
+// epilogue, smoother, residuals; every kernel under a chain mask) on a second stream; the remainder follows when the state
+// chain has ended.  Same kernels, same results; a chain's tail simply starts when ITS filtered state stands.
+static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handled) {
+    *handled = false;
+    const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA | F_LAMBDA)) && c->p.chainQ == nullptr;
+    if (!(c->tailSplit && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState && c->sbSystolic && c->sbAsync &&
+          !(c->sbDelta && c->sbSeed) && c->natOutEnabled && c->natOutD && c->earlyPf && c->deferEnabled && constQ &&
+          !(what & CSR_EXPORT_MULT) && c->chains.size() >= 2 && c->chains.size() <= 4096))
+        return 0;
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, false, true, true));
+    if (!c->sbp.active) {               // the state chain did not go out as one launch: the pass is complete, carry on as usual
+        CHECK(backward_impl(c, true, nullptr, true, true));
+        if (what) CHECK(csr_batch_export(c, what));
+        *handled = true;
+        return 0;
+    }
+    const Prm pf = c->sbp.p;
+    if (!(c->dNat && c->pfNat && c->pnNat)) {
+        // an output of this pass still needs a conversion launch of its own (export_impl): no pipelining, finish in order
+        CHECK(state_chain_systolic(c, pf, false, flags, 2));
+        const std::vector<std::pair<int64_t, int64_t>> none;
+        Prm pt = pf;
+        float *natXf;
+        CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pt,
+                           reinterpret_cast<const float2 *>(natXf), pt.tXf);
+        LAUNCH_CHECK("k_import_tiled_f2");
+        CHECK(forward_epilogue(c, pf, true));
+        CHECK(backward_impl(c, true, nullptr, true, true));
+        if (what) CHECK(csr_batch_export(c, what));
+        *handled = true;
+        return 0;
+    }
+    const int nc = (int)c->chains.size();
+    int64_t total = 0;
+    for (const ChainInfo &ci : c->chains) total += ci.n;
+    if (!c->dMask[0]) for (auto &m : c->dMask) CHECK(dalloc(c, &m, nc));
+    std::vector<unsigned char> tailed((size_t)nc, 0);
+    int phase = 0;
+    bool any = false;
+    hipStream_t mainStream = c->stream;
+    auto launch_group = [&](const std::vector<unsigned char> &grp) -> int {
+        // runs of consecutive chains -> bin ranges (a chain occupies [off, off + its length rounded up to 64))
+        std::vector<std::pair<int64_t, int64_t>> runs;
+        for (int i = 0; i < nc; ++i) {
+            if (!grp[(size_t)i]) continue;
+            const int64_t o = c->chains[(size_t)i].off, l = (c->chains[(size_t)i].n + 63) / 64 * 64;
+            if (!runs.empty() && runs.back().first + runs.back().second == o) runs.back().second += l;
+            else runs.emplace_back(o, l);
+        }
+        unsigned char *dm = c->dMask[phase];
+        c->hMaskStage[phase].assign(grp.begin(), grp.end());
+        HIPOK(hipMemcpyAsync(dm, c->hMaskStage[phase].data(), (size_t)nc, hipMemcpyHostToDevice, c->stream));
+        CHECK(step_tail(c, pf, dm, runs, what));
+        ++phase;
+        any = true;
+        return 0;
+    };
+    // ---- while the state chain runs: tails of the chains that are final, an eighth of the batch at a time, on the tail stream
+    c->stream = c->tail;
+    int rc = 0;
+    for (;;) {
+        const hipError_t qs = hipStreamQuery(mainStream);
+        if (qs != hipErrorNotReady) { if (qs != hipSuccess) rc = fail("state chain: %s", hipGetErrorString(qs)); break; }
+        if (phase >= 6) { std::this_thread::yield(); continue; }
+        std::vector<unsigned char> grp((size_t)nc, 0);
+        int64_t bins = 0;
+        for (int i = 0; i < nc; ++i)
+            if (!tailed[(size_t)i] && __atomic_load_n(&c->hDone[i], __ATOMIC_ACQUIRE) != 0u) { grp[(size_t)i] = 1; bins += c->chains[(size_t)i].n; }
+        if (bins * 100 >= total * (phase == 0 ? c->tailFirstPct : c->tailNextPct)) {
+            rc = launch_group(grp);
+            if (rc) break;
+            for (int i = 0; i < nc; ++i) if (grp[(size_t)i]) tailed[(size_t)i] = 1;
+        }
+    }
+    c->stream = mainStream;
+    if (rc) return rc;
+    // ---- the launch has ended: its verdict (a bail-out runs the pass form and invalidates nothing that was final, but the
+    // pass form rewrites the whole track from the cold prior: the tails already launched are waited for and everything is redone)
+    const int64_t bail0 = c->rs.sb_bailouts;
+    CHECK(state_chain_systolic(c, pf, false, flags, 2));
+    if (c->rs.sb_bailouts != bail0 && any) {
+        HIPOK(hipStreamSynchronize(c->tail));
+        std::fill(tailed.begin(), tailed.end(), (unsigned char)0);
+    }
+    // ---- the remaining chains: on the main stream, behind the state chain and beside whatever the tail stream still has to do
+    // (groups are disjoint sets of chains, hence of blocks: their kernels share no data; every group leaves no folded check behind)
+    std::vector<unsigned char> rest((size_t)nc, 0);
+    bool anyRest = false;
+    for (int i = 0; i < nc; ++i) if (!tailed[(size_t)i]) { rest[(size_t)i] = 1; anyRest = true; }
+    if (anyRest) CHECK(launch_group(rest));
+    HIPOK(hipEventRecord(c->evTailJoin, c->tail));
+    HIPOK(hipStreamWaitEvent(mainStream, c->evTailJoin, 0));
+    {
+        Scope sc(c, "chain_sums");
+        Prm ps = pf;
+        ps.chainActive = nullptr;
+        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, ps, c->dChainFirst, c->dChainNb);
+    }
+    LAUNCH_CHECK("k_chain_sums");
+    c->pendActiveB = nullptr;           // a replay after a failed optimistic validation covers every chain
+    if (c->pendBwd) c->pendExport |= what;
+    if (what & CSR_EXPORT_SMOOTH) c->natSmoothGen = c->fitGen;
+    c->rs.tail_groups += phase;
+    *handled = true;
+    return 0;
+}
+
 extern "C" int csr_batch_step(csr_ctx *c, uint32_t flags, uint32_t what, double *sum_d, double *sum_nll) {
     CHECK(csr_batch_stats(c));
-    CHECK(csr_batch_forward_backward(c, flags, nullptr, nullptr));
-    if (what) CHECK(csr_batch_export(c, what));
+    bool handled = false;
+    CHECK(step_pipelined(c, flags, what, &handled));
+    if (!handled) {
+        CHECK(csr_batch_forward_backward(c, flags, nullptr, nullptr));
+        if (what) CHECK(csr_batch_export(c, what));
+    }
     if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
     return 0;
 }

@@ -276,6 +276,15 @@ struct csr_ctx {
     bool foldCheck = true;              // CONSENRICH_AMD_FOLD_CHECK=0: every stage launches its own validation kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipEvent_t evFork2 = nullptr, evPf = nullptr;      // early covariance exports on the side stream (bit-exact mode)
+    // step_pipelined: tails of the chains whose filtered state stands, on a stream of their own while the state chain runs
+    hipStream_t tail = nullptr;
+    hipEvent_t evTailFork = nullptr, evTailJoin = nullptr;
+    struct SbPending { bool active = false; Prm p{}; bool early = false; uint32_t flags = 0; } sbp;
+    unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
+    unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<unsigned char> hMaskStage[8];
+    int tailFirstPct = 50, tailNextPct = 15;     // CONSENRICH_AMD_TAIL_PCT="first,next": share of the batch's bins a group must reach
+    bool tailSplit = true;      // CONSENRICH_AMD_TAIL_SPLIT=0: a step's tail follows the state chain for all chains at once
     bool pfPending = false, pfNat = false, pnNat = false;
     bool earlyPf = true;        // CONSENRICH_AMD_EARLY_PF=0: Pf / constant pNoise exported after the smoother like the other tracks
     // profiling
@@ -323,6 +332,11 @@ static void free_batch(csr_ctx *c) {
     c->sb = csr_ctx::SbView{};
     c->sbNatGain = c->sbNatSZ = nullptr;
     c->sbDbg = nullptr;
+    if (c->tail) (void)hipStreamSynchronize(c->tail);
+    if (c->hDone) { (void)hipHostFree(c->hDone); c->hDone = nullptr; c->dDone = nullptr; }
+    for (auto &m : c->dMask) m = nullptr;
+    c->sbp.active = false;
+    c->pfPending = false;
     c->xfNat = false;
     c->ckF[0] = c->ckF[1] = c->ckB[0] = c->ckB[1] = nullptr;
     c->wsSavedF = c->wsSavedB = 0;
@@ -362,7 +376,10 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evFork2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evPf, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->evPf, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evTailFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evTailJoin, hipEventDisableTiming) != hipSuccess) {
         fail("cannot create the side stream of device %d", device_ordinal);
         delete c;
         return nullptr;
@@ -394,6 +411,11 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_ASYNC"))) c->sbAsync = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_EARLY_PF"))) c->earlyPf = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_TAIL_SPLIT"))) c->tailSplit = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_TAIL_PCT"))) {
+        int a = 50, b = 15;
+        if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->tailFirstPct = std::min(100, std::max(1, a)); c->tailNextPct = std::min(100, std::max(1, b)); }
+    }
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
     if ((e = getenv("CONSENRICH_AMD_SB_SEED"))) c->sbSeed = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
@@ -441,6 +463,10 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evPf) (void)hipEventDestroy(c->evPf);
+    if (c->evTailFork) (void)hipEventDestroy(c->evTailFork);
+    if (c->evTailJoin) (void)hipEventDestroy(c->evTailJoin);
+    if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
+    if (c->hDone) (void)hipHostFree(c->hDone);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -517,6 +543,7 @@ struct Scope {
 static void prof_collect(csr_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->tail) (void)hipStreamSynchronize(c->tail);
     for (auto &kv : c->prof) {
         for (auto &pr : kv.second.pending) {
             float ms = 0.f;

@@ -481,6 +481,8 @@ typedef struct csr_run_stats {
     int32_t ws_warm_f, ws_warm_b;   /* windows (bins) of the warm-started ECM sweeps, forward / smoother */
     int64_t sb_bailouts;        /* bit-exact state chain: single launches (k_sb_async) that gave up on a bounded wait; the pass
                                    form then ran instead (same results) */
+    int64_t tail_groups;        /* bit-exact steps: groups of chains whose smoother / residuals were launched on their own (the
+                                   first ones while the state chain of the other chains was still running) */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

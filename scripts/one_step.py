@@ -14,5 +14,8 @@ if os.environ.get("SHARD"):
 b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 for _ in range(int(os.environ.get("STEPS", "3"))):
-    b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
+    if os.environ.get("SPLIT_CALLS"):
+        b.stats(); b.forward_backward(L.RETURN_NLL, False); b.export(what); b.sums()
+    else:
+        b.step(L.RETURN_NLL, what)          # what bench.py times
 b.synchronize()
