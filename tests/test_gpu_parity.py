@@ -273,6 +273,54 @@ def test_exact_state_chain_on_superblocks_equals_the_sequential_kernel(product, 
             assert sb["stats"]["sb_bailouts"] > 0, sb["stats"]
 
 
+def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(product, monkeypatch):
+    """csr_batch_step in the bit-exact mode launches the smoother / residuals of the chains whose filtered state stands while
+    the state chain of the others is still running (step_pipelined, csr_host_pipeline.inl): groups of chains under masks, on
+    a second stream.  Same kernels, so every output must equal the step run in order, bit for bit -- with the default
+    thresholds, with thresholds that make (nearly) every finished chain a group of its own, and when the single launch bails
+    out under the groups already in flight (everything is then redone behind the pass form)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list = [420000, 150000, 90000, 260000, 64, 1, 30001]
+    m = 4
+    sets = [cases.synth(n, m, 7300 + c, mask_frac=0.01, outlier_frac=0.01) for c, n in enumerate(n_list)]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+
+    def run(env):
+        for k in ("CONSENRICH_AMD_TAIL_SPLIT", "CONSENRICH_AMD_TAIL_PCT", "CONSENRICH_AMD_SB_SPIN_LIMIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = {}
+        with DeviceBatch(0) as b:
+            b.configure(ModelParams(state_dim=2), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            for rep in range(2):        # the second step re-uses every buffer of the first
+                sd, sn = b.step(L.RETURN_NLL, what)
+            out["sd"], out["sn"] = np.array(sd), np.array(sn)
+            for c in range(len(n_list)):
+                for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
+                    out[(c, name)] = b.download(c, name)
+            out["stats"] = b.run_stats()
+        return out
+
+    ref = run({"CONSENRICH_AMD_TAIL_SPLIT": "0"})
+    assert ref["stats"]["tail_groups"] == 0
+    for env in ({}, {"CONSENRICH_AMD_TAIL_PCT": "1,1"}, {"CONSENRICH_AMD_TAIL_PCT": "1,1", "CONSENRICH_AMD_SB_SPIN_LIMIT": "1"}):
+        got = run(env)
+        if os.environ.get("CONSENRICH_AMD_TAIL_SPLIT", "1") != "0" and os.environ.get("CONSENRICH_AMD_SB_ASYNC", "1") != "0" \
+                and os.environ.get("CONSENRICH_AMD_SB_STATE", "1") != "0" and os.environ.get("CONSENRICH_AMD_SEQ_STATE", "0") == "0" \
+                and os.environ.get("CONSENRICH_AMD_SB_SYSTOLIC", "1") != "0" and os.environ.get("CONSENRICH_AMD_SB_SEED", "0") == "0" \
+                and os.environ.get("CONSENRICH_AMD_EARLY_PF", "1") != "0" and os.environ.get("CONSENRICH_AMD_NATOUT_D", "1") != "0" \
+                and os.environ.get("CONSENRICH_AMD_DEFER", "1") != "0":
+            assert got["stats"]["tail_groups"] >= 2, (env, got["stats"])       # two steps, at least one group each
+        for key, val in ref.items():
+            if key != "stats":
+                assert np.array_equal(val, got[key]), (env, key)
+
+
 def _full_chain(mod, d, n, m, seed=4242):
     data, munc = cases.synth(n, m, seed)
     _lam, kap, _qs = cases.multipliers(n, seed)
