@@ -401,7 +401,10 @@ def main() -> int:
             "kernels_rank0": per_kernel,
             "speculation": {"blocks": rs["blocks"], "reruns_cov": rs["reruns_p"], "reruns_state": rs["reruns_x"],
                             "reruns_bwd": rs["reruns_b"], "fix_launches": rs["fix_launches"],
-                            "pipeline_redos": rs["pipeline_redos"]},
+                            "pipeline_redos": rs["pipeline_redos"],
+                            # bit-exact steps: groups of chains whose tail was launched on its own (step_pipelined), and single
+                            # launches of the state chain that gave up on a bounded wait (the pass form ran instead)
+                            "tail_groups": rs.get("tail_groups", 0), "state_chain_bailouts": rs.get("sb_bailouts", 0)},
             "gather_ms": gather_ms,
         }
         out.update(extras)
