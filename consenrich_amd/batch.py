@@ -203,7 +203,8 @@ class DeviceBatch:
         return list(outs), path.reshape(nc, -1)
 
     def step(self, flags: int = L.RETURN_NLL, what: int = 0, want_sums: bool = True):
-        """stats() + forward_backward(flags) + export(what) + sums() in one C-ABI call (same launches, same cost)."""
+        """stats() + forward_backward(flags) + export(what) + sums() in one C-ABI call: same kernels, same results; in the
+        bit-exact mode the tail of each chain (smoother, residuals) starts as soon as that chain's filtered state stands."""
         if not want_sums:
             L.check(self._lib.csr_batch_step(self._ctx, int(flags), int(what), None, None))
             return None, None

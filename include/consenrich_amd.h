@@ -178,7 +178,10 @@ int csr_batch_backward(csr_ctx *ctx);
  * a single host synchronisation; the NIS/NLL epilogue runs on a side stream concurrently with the smoother chain. */
 int csr_batch_forward_backward(csr_ctx *ctx, uint32_t flags, double *sum_d, double *sum_nll);
 /* One pass of the hot path in one call: csr_batch_stats + csr_batch_forward_backward +
- * csr_batch_export(what) (what = 0: none) + csr_batch_sums (both pointers NULL: none, validation stays pending). */
+ * csr_batch_export(what) (what = 0: none) + csr_batch_sums (both pointers NULL: none, validation stays pending).
+ * Same kernels and results as the separate calls.  Knowing `what` in advance lets the bit-exact mode (constant process
+ * noise, >= 2 chains) start the smoother / residuals of every chain as soon as THAT chain's filtered state stands, while the
+ * state chain of slower chains is still running (csr_run_stats.tail_groups counts the groups). */
 int csr_batch_step(csr_ctx *ctx, uint32_t flags, uint32_t what, double *sum_d, double *sum_nll);
 /* Per-chain sumD / sumNLL of the resident forward pass (n_chains doubles each, either may be NULL).  Lets a caller
  * queue csr_batch_export behind csr_batch_forward_backward(…, NULL, NULL) and synchronise once, here. */
