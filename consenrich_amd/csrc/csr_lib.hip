@@ -278,7 +278,7 @@ struct csr_ctx {
     hipEvent_t evFork2 = nullptr, evPf = nullptr;      // early covariance exports on the side stream (bit-exact mode)
     // step_pipelined: tails of the chains whose filtered state stands, on a stream of their own while the state chain runs
     hipStream_t tail = nullptr;
-    hipEvent_t evTailFork = nullptr, evTailJoin = nullptr;
+    hipEvent_t evTailJoin = nullptr;
     struct SbPending { bool active = false; Prm p{}; bool early = false; uint32_t flags = 0; } sbp;
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -378,7 +378,6 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         hipEventCreateWithFlags(&c->evFork2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPf, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evTailFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTailJoin, hipEventDisableTiming) != hipSuccess) {
         fail("cannot create the side stream of device %d", device_ordinal);
         delete c;
@@ -463,7 +462,6 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evPf) (void)hipEventDestroy(c->evPf);
-    if (c->evTailFork) (void)hipEventDestroy(c->evTailFork);
     if (c->evTailJoin) (void)hipEventDestroy(c->evTailJoin);
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->hDone) (void)hipHostFree(c->hDone);
