@@ -35,6 +35,7 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
     }
     LAUNCH_CHECK("k_stats");
     c->statsValid = true;
+    c->natSZValid = false;
     c->haveFwd = c->haveBwd = false;
     return 0;
 }
@@ -414,14 +415,22 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         Scope sc(c, "state_records_natural");
         ExpList L;
         memset(&L, 0, sizeof(L));
-        L.count = 2;
-        if (seeded) {
-            L.count = 3;
-            L.d[2].src = reinterpret_cast<const float *>(p.tXf); L.d[2].dst = natXf; L.d[2].E = 2; L.d[2].n = 2;
-        }
+        // the gain records of this pass; the statistics records {S0, zbar} only when the statistics changed since they were last
+        // converted (csr_batch_stats): the sweeps of an ECM iteration share them
+        L.count = 1;
         L.d[0].src = reinterpret_cast<const float *>(p.tXin); L.d[0].dst = reinterpret_cast<float *>(c->sbNatGain); L.d[0].E = 4; L.d[0].n = 4;
-        L.d[1].src = reinterpret_cast<const float *>(p.tSZ); L.d[1].dst = reinterpret_cast<float *>(c->sbNatSZ); L.d[1].E = 4; L.d[1].n = 4;
-        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p, L);
+        Prm pe = p;
+        if (!c->natSZValid) {
+            ExpDesc &e = L.d[L.count++];
+            e.src = reinterpret_cast<const float *>(p.tSZ); e.dst = reinterpret_cast<float *>(c->sbNatSZ); e.E = 4; e.n = 4;
+            pe.chainActive = nullptr;       // the statistics of EVERY chain (csr_batch_stats computed them all), whatever this pass masks
+            c->natSZValid = true;
+        }
+        if (seeded) {
+            ExpDesc &e = L.d[L.count++];
+            e.src = reinterpret_cast<const float *>(p.tXf); e.dst = natXf; e.E = 2; e.n = 2;
+        }
+        hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pe, L);
     }
     LAUNCH_CHECK("k_export_tiled (state records)");
     if (earlyExports && !resume) CHECK(early_cov_exports(c, p, flags));

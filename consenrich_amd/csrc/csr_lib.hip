@@ -211,6 +211,7 @@ struct csr_ctx {
     int sbSpinLimit = 1 << 19;
     bool sbDelta = true;        // CONSENRICH_AMD_SB_DELTA=0: repair passes as plain systolic walks (k_sb_sys) instead of the delta form (k_sb_delta)
     bool sbSystolic = true;     // CONSENRICH_AMD_SB_SYSTOLIC=0: the round-2 lane-per-superblock walker (re-blocked records, window sbWarm)
+    bool natSZValid = false;    // sbNatSZ holds the current statistics of every chain
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
     bool xfNat = false;         // the resident forward pass left xf in the reference layout already (systolic walker)
     struct SbView {
@@ -331,6 +332,7 @@ static void free_batch(csr_ctx *c) {
     c->dActive = nullptr;
     c->sb = csr_ctx::SbView{};
     c->sbNatGain = c->sbNatSZ = nullptr;
+    c->natSZValid = false;
     c->sbDbg = nullptr;
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     if (c->hDone) { (void)hipHostFree(c->hDone); c->hDone = nullptr; c->dDone = nullptr; }
