@@ -384,7 +384,7 @@ static int ensure_sb_view(csr_ctx *c) {
 // straight into the reference-layout xf array; superblocks start from the cold prior and the validation / repair passes run
 // to the fixed point (= the sequential recursion, whatever the superblock length); one tiled launch brings the filtered state
 // back into the batch's blocked layout for the epilogue and the smoother.
-static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags);
+static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool withPf);
 // phase 0: the whole chain.  phase 1 (a step that pipelines its tail per chain, step_pipelined): stop right after the launch of
 // the barrier-free kernel, with per-chain "done" words the host can watch -- c->sbp.active says that this happened (otherwise
 // the whole chain ran, as in phase 0).  phase 2: wait for that launch (or run the pass form if it bailed out); the filtered
@@ -433,7 +433,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pe, L);
     }
     LAUNCH_CHECK("k_export_tiled (state records)");
-    if (earlyExports && !resume) CHECK(early_cov_exports(c, p, flags));
+    if (earlyExports && !resume) CHECK(early_cov_exports(c, p, flags, true));
     Prm q = p;
     q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
     q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
@@ -683,17 +683,18 @@ static void join_pf(csr_ctx *c) {
 // Bit-exact mode: the state chain keeps at most 5/8 of the SIMDs busy for milliseconds and is bound by latency, not by
 // bandwidth.  The reference-layout outputs that depend on the covariance chain alone -- Pf, and the process noise when it
 // is one constant matrix -- are written on the side stream underneath it instead of after the smoother.
-static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
+static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool withPf = true) {
     const int nm = c->mdl.state_dim * c->mdl.state_dim;
     const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA)) && p.chainQ == nullptr;
+    if (!withPf && !constQ) return 0;
     // (a reference-layout array is allocated -- and zeroed ON THE MAIN STREAM -- at its first use: before the fork, so that the
     // side stream's writes are ordered behind the zeroing)
-    float *dstPf, *dstPn = nullptr;
-    CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
+    float *dstPf = nullptr, *dstPn = nullptr;
+    if (withPf) CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
     if (constQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
     HIPOK(hipEventRecord(c->evFork2, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
-    {
+    if (withPf) {
         ExpList L;
         memset(&L, 0, sizeof(L));
         float *dst = dstPf;
@@ -703,7 +704,7 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags) {
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->side, p, L);
     }
     LAUNCH_CHECK("k_export_tiled (early Pf)");
-    c->pfNat = true;
+    if (withPf) c->pfNat = true;
     if (constQ) {
         float *dst = dstPn;
         const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
@@ -790,6 +791,9 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 CHECK(nat_array(c, CSR_ARR_PF, &p.natPs));
                 p.natOut = 1;
                 c->fwdNat = true;
+                // the constant process noise depends on nothing: its reference-layout rows are filled on the side stream beside
+                // the (latency-bound) forward chain instead of after the smoother
+                if (c->earlyPf && active == nullptr) CHECK(early_cov_exports(c, p, flags, false));
             }
             if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<FwdTrendFusedT<true>>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
