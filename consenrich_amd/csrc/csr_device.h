@@ -2945,10 +2945,11 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
 
 // natural float2 track -> the batch's blocked layout through LDS tiles (32 steps x 64 blocks per workgroup): coalesced on
 // both sides (the per-slot gather of k_import_f32 reads one 128-byte line per 8 bytes it needs)
-__global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__restrict__ nat, float2 *__restrict__ dst) {
+// (g0: first wavefront-group of 64 blocks the launch covers -- a launch for some chains only starts at their blocks)
+__global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__restrict__ nat, float2 *__restrict__ dst, int64_t g0 = 0) {
     __shared__ float2 tile[32][65];
     const int tilesPerGroup = p.B >> 5;
-    const int64_t G = blockIdx.x / tilesPerGroup;
+    const int64_t G = g0 + blockIdx.x / tilesPerGroup;
     const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
     const int t = threadIdx.x;
     const int r = t >> 5, si = t & 31;

@@ -1396,17 +1396,18 @@ static int export_impl(csr_ctx *c, uint32_t what) {
 // Everything of a step behind the filtered state -- blocked copy of xf, NIS / NLL epilogue, smoother, residuals -- for the
 // chains of `dmask` (device bytes, nullptr = all), on c->stream.  `runs`: the maximal runs of those chains as bin ranges of the
 // natural layout.
-static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, const std::vector<std::pair<int64_t, int64_t>> &runs,
-                     uint32_t what) {
+struct ChainRun { int64_t off, len, b0, b1; };     // bins [off, off + len) of the natural layout = blocks [b0, b1) of the batch
+static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, const std::vector<ChainRun> &runs, uint32_t what) {
     Prm pt = pf;
     pt.chainActive = dmask;
     pt.prevKind = CK_NONE;
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
-    {
+    for (const ChainRun &r : runs) {        // (only the wavefront-groups that hold blocks of these chains; the mask trims the edges)
+        const int64_t g0 = r.b0 / 64, g1 = (r.b1 + 63) / 64;
         Scope sc(c, "state_reblock_out");
-        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pt,
-                           reinterpret_cast<const float2 *>(natXf), pt.tXf);
+        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, c->stream, pt,
+                           reinterpret_cast<const float2 *>(natXf), pt.tXf, g0);
     }
     LAUNCH_CHECK("k_import_tiled_f2");
     // the NIS / NLL epilogue beside the (latency-bound) smoother chain, on the side stream
@@ -1422,7 +1423,7 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     CHECK(backward_impl(c, true, dmask, true, true));
     CHECK(flush_pending_check(c));              // (the residual launches below cover a part of the batch each: no folded check)
     if (what & CSR_EXPORT_RESID)
-        for (const auto &r : runs) CHECK(launch_resid(c, r.first, r.second, false));
+        for (const ChainRun &r : runs) CHECK(launch_resid(c, r.off, r.len, false));
     HIPOK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
     return 0;
 }
@@ -1452,7 +1453,6 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
     if (!(c->dNat && c->pfNat && c->pnNat)) {
         // an output of this pass still needs a conversion launch of its own (export_impl): no pipelining, finish in order
         CHECK(state_chain_systolic(c, pf, false, flags, 2));
-        const std::vector<std::pair<int64_t, int64_t>> none;
         Prm pt = pf;
         float *natXf;
         CHECK(nat_array(c, CSR_ARR_XF, &natXf));
@@ -1475,12 +1475,15 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
     hipStream_t mainStream = c->stream;
     auto launch_group = [&](const std::vector<unsigned char> &grp) -> int {
         // runs of consecutive chains -> bin ranges (a chain occupies [off, off + its length rounded up to 64))
-        std::vector<std::pair<int64_t, int64_t>> runs;
+        std::vector<ChainRun> runs;
         for (int i = 0; i < nc; ++i) {
             if (!grp[(size_t)i]) continue;
-            const int64_t o = c->chains[(size_t)i].off, l = (c->chains[(size_t)i].n + 63) / 64 * 64;
-            if (!runs.empty() && runs.back().first + runs.back().second == o) runs.back().second += l;
-            else runs.emplace_back(o, l);
+            const ChainInfo &ci = c->chains[(size_t)i];
+            const int64_t l = (ci.n + 63) / 64 * 64;
+            if (!runs.empty() && runs.back().off + runs.back().len == ci.off && runs.back().b1 == ci.b0) {
+                runs.back().len += l;
+                runs.back().b1 = ci.b0 + ci.nb;
+            } else runs.push_back(ChainRun{ci.off, l, ci.b0, ci.b0 + ci.nb});
         }
         unsigned char *dm = c->dMask[phase];
         c->hMaskStage[phase].assign(grp.begin(), grp.end());
