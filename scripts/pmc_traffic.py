@@ -38,12 +38,14 @@ def collect(path, counter):
         if s:
             acc[s].append(float(r["Counter_Value"]))
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    return {k: (sum(v) / steps if k in PER_STEP else sum(v) / len(v)) for k, v in acc.items()}
+    per_launch = {k: (sum(v) / steps if k in PER_STEP else sum(v) / len(v)) for k, v in acc.items()}
+    per_step = {k: sum(v) / steps for k, v in acc.items()}       # a pipelined step launches its tail kernels once per group of chains
+    return per_launch, per_step
 
 
 def main():
-    fetch = collect(sys.argv[1], "FETCH_SIZE")
-    write = collect(sys.argv[2], "WRITE_SIZE")
+    fetch, fetch_step = collect(sys.argv[1], "FETCH_SIZE")
+    write, write_step = collect(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f_kb, w_kb = fetch.get(k, 0.0), write.get(k, 0.0)
@@ -52,11 +54,13 @@ def main():
             "fetch_bytes_corrected": 2.0 * f_kb * 1024.0,      # gfx950: x2 (guide, HBM section)
             "write_bytes": w_kb * 1024.0,
             "hbm_bytes_per_launch": 2.0 * f_kb * 1024.0 + w_kb * 1024.0,
+            "hbm_bytes_per_step": 2.0 * fetch_step.get(k, 0.0) * 1024.0 + write_step.get(k, 0.0) * 1024.0,
         }
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in out.items():
         print(f"{k:18s} fetch(raw) {v['FETCH_SIZE_kb_raw']/1e6:8.3f} GB-ish  write {v['write_bytes']/1e9:8.3f} GB  "
-              f"hbm(corrected) {v['hbm_bytes_per_launch']/1e9:8.3f} GB")
+              f"hbm(corrected) {v['hbm_bytes_per_launch']/1e9:8.3f} GB per launch, {v['hbm_bytes_per_step']/1e9:8.3f} GB per step")
+    print(f"{'sum per step':18s} {sum(v['hbm_bytes_per_step'] for v in out.values())/1e9:8.3f} GB")
 
 
 if __name__ == "__main__":
