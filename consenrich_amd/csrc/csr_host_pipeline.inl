@@ -492,8 +492,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         if (phase == 1) {
             c->sbp.active = true;
             c->sbp.p = p;
-            c->sbp.early = earlyExports;
-            c->sbp.flags = flags;
             return 0;
         }
         unsigned int ctl[4];

@@ -280,7 +280,7 @@ struct csr_ctx {
     // step_pipelined: tails of the chains whose filtered state stands, on a stream of their own while the state chain runs
     hipStream_t tail = nullptr;
     hipEvent_t evTailJoin = nullptr;
-    struct SbPending { bool active = false; Prm p{}; bool early = false; uint32_t flags = 0; } sbp;
+    struct SbPending { bool active = false; Prm p{}; } sbp;     // a state chain launched and not yet waited for (step_pipelined)
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<unsigned char> hMaskStage[8];
