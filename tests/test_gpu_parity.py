@@ -304,6 +304,12 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
                 for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
                     out[(c, name)] = b.download(c, name)
             out["stats"] = b.run_stats()
+            # a step that exports nothing, the exports asked for afterwards (the residuals were not part of the pipelined tails)
+            b.step(L.RETURN_NLL, 0)
+            b.export(what)
+            for c in range(len(n_list)):
+                for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
+                    assert np.array_equal(out[(c, name)], b.download(c, name)), (env, "exports after the step", c, name)
         return out
 
     ref = run({"CONSENRICH_AMD_TAIL_SPLIT": "0"})
