@@ -55,6 +55,95 @@ typedef struct {
     int running, t, runFinal, brk; float x0, x1, pd0, pd1; double clk; int runs, aborts;
 } wave;
 
+
+/* The same schedule WITH the speculative walks on the clock (a batch of a walk costs WOVH + 64 * STEP cycles), optionally with
+ * the first superblock of every chain split into `split` pieces and with walks that are ABANDONED when the predecessor
+ * publishes a final carry (the part walked so far is then re-run in delta form, the rest is walked from the true state).
+ * Returns the time of the last final publication in microseconds. */
+typedef struct {
+    float cin0, cin1, out0, out1; int ver, final, seen;
+    int walking, wt, running, t, runFinal, brk, sEnd, nb; float x0, x1, pd0, pd1; double clk; int runs, aborts;
+} wave2;
+static double timed(const int64_t *len, int split, int walkAbort, long *runsOut, long *abortsOut, int *okOut) {
+    const double WOVH = 50.0, INF = 1e300, WAKE = 2.0 * GHZ * 1e3;
+    int64_t nbk = 0;
+    for (int c = 0; c < 22; ++c) { const int64_t first = len[c] < B ? len[c] : B; nbk += (len[c] > B ? (len[c] - B + B - 1) / B : 0) + ((first + B / split - 1) / (B / split)); }
+    int64_t *off = malloc(sizeof(int64_t) * nbk); int *ln = malloc(sizeof(int) * nbk); char *fst = malloc(nbk);
+    { int64_t b = 0, o = 0; const int Bs = B / split;
+      for (int c = 0; c < 22; ++c) {
+          const int64_t first = len[c] < B ? len[c] : B;
+          for (int64_t k = 0; k < first; k += Bs, ++b) { off[b] = o + k; ln[b] = (int)(first - k < Bs ? first - k : Bs); fst[b] = k == 0; }
+          for (int64_t k = first; k < len[c]; k += B, ++b) { off[b] = o + k; ln[b] = (int)(len[c] - k < B ? len[c] - k : B); fst[b] = 0; }
+          o += len[c];
+      }
+      nbk = b; }
+    wave2 *W = calloc(nbk, sizeof(wave2));
+    long live = 0, runsAll = 0, abortsAll = 0;
+    for (int64_t b = 0; b < nbk; ++b) { W[b].walking = 1; W[b].nb = (ln[b] + 63) / 64; W[b].clk = 0.0; ++live; }
+    double total = 0;
+    while (live) {
+        int64_t b = -1; double best = INF;
+        for (int64_t i = 0; i < nbk; ++i) if (W[i].clk < best) { best = W[i].clk; b = i; }
+        if (b < 0) { printf("  deadlock\n"); break; }
+        wave2 *w = &W[b], *p = fst[b] ? NULL : &W[b - 1];
+        if (w->walking) {
+            if (walkAbort && p && p->final && p->ver != w->seen) {      /* the true carry is here: stop walking from the cold prior */
+                w->seen = p->ver; w->walking = 0; w->sEnd = w->wt; w->brk = 1 << 30;
+                w->pd0 = p->out0 - 0.f; w->pd1 = p->out1 - 0.f;
+                w->cin0 = p->out0; w->cin1 = p->out1; w->x0 = p->out0; w->x1 = p->out1; w->t = 0; w->running = 1; w->runFinal = 1; w->runs++; ++runsAll;
+                continue;
+            }
+            const int l = ln[b] - w->wt * 64 < 64 ? ln[b] - w->wt * 64 : 64;
+            const int64_t s = off[b] + (int64_t)w->wt * 64;
+            for (int i = 0; i < l; ++i) { step(&w->x0, &w->x1, s + i); cur[2 * (s + i)] = w->x0; cur[2 * (s + i) + 1] = w->x1; }
+            w->clk += WOVH + 64 * STEP; w->wt++;
+            if (w->wt == w->nb) {
+                w->walking = 0; w->out0 = w->x0; w->out1 = w->x1; w->ver = 1; w->final = fst[b]; w->sEnd = w->nb; w->brk = 0;
+                if (w->final) { --live; if (w->clk > total) total = w->clk; w->clk = INF; }
+                if (b + 1 < nbk && !fst[b + 1] && !W[b + 1].final && W[b + 1].clk == INF) W[b + 1].clk = best + WAKE;
+            }
+            continue;
+        }
+        const int fresh = p->ver != w->seen;
+        if (!w->running || fresh) {
+            if (!fresh) { w->clk = INF; continue; }
+            w->seen = p->ver;
+            const int same = p->out0 == w->cin0 && p->out1 == w->cin1;
+            if (same) {
+                if (w->running) w->runFinal |= p->final;
+                else if (p->final) { w->final = 1; w->ver++; --live; if (w->clk > total) total = w->clk; w->clk = INF; if (b + 1 < nbk && !fst[b + 1] && W[b + 1].clk == INF && !W[b + 1].final) W[b + 1].clk = best + WAKE; continue; }
+                else { w->clk = INF; continue; }
+            } else {
+                if (w->running) { if (w->t > w->sEnd) w->sEnd = w->t; if (w->brk != (1 << 30) && w->t * 64 > w->brk) w->brk = w->t * 64; w->aborts++; ++abortsAll; }
+                w->pd0 = p->out0 - w->cin0; w->pd1 = p->out1 - w->cin1;
+                w->cin0 = p->out0; w->cin1 = p->out1; w->x0 = p->out0; w->x1 = p->out1; w->t = 0; w->running = 1; w->runFinal = p->final; w->runs++; ++runsAll;
+            }
+        }
+        const int l = ln[b] - w->t * 64 < 64 ? ln[b] - w->t * 64 : 64;
+        const int64_t s = off[b] + (int64_t)w->t * 64;
+        const float o0 = cur[2 * (s + l - 1)], o1 = cur[2 * (s + l - 1) + 1];
+        if (w->t < w->sEnd) w->clk += run_batch(s, l, &w->x0, &w->x1, &w->pd0, &w->pd1);
+        else { for (int i = 0; i < l; ++i) { step(&w->x0, &w->x1, s + i); cur[2 * (s + i)] = w->x0; cur[2 * (s + i) + 1] = w->x1; } w->clk += WOVH + 64 * STEP; }
+        w->t++;
+        const int end = w->t >= w->nb;
+        const int merged = w->t <= w->sEnd && w->x0 == o0 && w->x1 == o1 && w->brk != (1 << 30) && w->t * 64 > w->brk;
+        if (end || merged) {
+            if (end) { w->out0 = w->x0; w->out1 = w->x1; w->brk = 0; w->sEnd = w->nb; }
+            w->running = 0;
+            if (p->ver != w->seen && p->out0 == w->cin0 && p->out1 == w->cin1) { w->seen = p->ver; w->runFinal |= p->final; }
+            w->final = w->runFinal; w->ver++;
+            if (w->final) { --live; if (w->clk > total) total = w->clk; }
+            const double now = w->clk;
+            if (w->final || p->ver == w->seen) w->clk = INF;
+            if (b + 1 < nbk && !fst[b + 1] && !W[b + 1].final && W[b + 1].clk == INF) W[b + 1].clk = now + WAKE;
+        }
+    }
+    int bad = 0; for (int64_t k = 0; k < 2 * N; ++k) if (cur[k] != truth[k]) { bad = 1; break; }
+    *runsOut = runsAll; *abortsOut = abortsAll; *okOut = !bad;
+    free(off); free(ln); free(fst); free(W);
+    return total / GHZ / 1e3;
+}
+
 int main(int argc, char **argv) {
     B = argc > 1 ? atoi(argv[1]) : 24576;
     const double scale = argc > 2 ? atof(argv[2]) : 1.0;
@@ -191,6 +280,15 @@ int main(int argc, char **argv) {
         long ab = 0; for (int64_t b = 0; b < NB; ++b) ab += W[b].aborts;
         printf("%s: %.0f us, %ld superblock runs, %ld aborted; result %s\n", mode == 0 ? "synchronous passes" : mode == 1 ? "asynchronous" : "asynchronous + abort",
                total, runsAll, ab, bad ? "WRONG" : "== sequential");
+    }
+    {
+        static const int cfg[][2] = {{1, 0}, {1, 1}, {6, 0}, {6, 1}, {12, 1}};
+        for (unsigned k = 0; k < sizeof cfg / sizeof cfg[0]; ++k) {
+            long r, a; int ok;
+            const double us = timed(len, cfg[k][0], cfg[k][1], &r, &a, &ok);
+            printf("walks on the clock, first superblock of a chain in %2d piece(s), walks %s: %.0f us, %ld runs, %ld abandoned; result %s\n",
+                   cfg[k][0], cfg[k][1] ? "abandoned for a final carry" : "always finished          ", us, r, a, ok ? "== sequential" : "WRONG");
+        }
     }
     return 0;
 }
