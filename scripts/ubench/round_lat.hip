@@ -72,6 +72,29 @@ __global__ void k(float *out, long long *cyc, float a, int stride) {
             if (!st && lane <= hi) { to0 = n0; to1 = n1; }
             d0 = rl(n0, hi) - rl(so0, hi); d1 = rl(n1, hi) - rl(so1, hi);
             pos = (hi + 1) & 63;
+        } else if (V == 4) {    // delta from the per-lane e = n - S (two readlanes instead of four, no select for the base lane: its
+                                // hypothesis S + delta equals the true state whenever S + e == n holds bitwise in the lane delta
+                                // was read from -- checked per lane, the rare miss takes the true state by two more readlanes)
+            float q0 = sp0 + d0, q1 = sp1 + d1;
+            if (pos & 0x100) { if (lane == (pos & 63)) { q0 = t0; q1 = t1; } }     // (uniform; never taken here)
+            float n0, n1;
+            step(q0, q1, gs, zbar, p00, p10, n0, n1);
+            const float c0_ = so0 + d0, c1_ = so1 + d1;
+            const float e0 = n0 - so0, e1 = n1 - so1;
+            unsigned long long okm = __builtin_amdgcn_uicmp(__float_as_uint(n0), __float_as_uint(c0_), 32) &
+                                     __builtin_amdgcn_uicmp(__float_as_uint(n1), __float_as_uint(c1_), 32);
+            const unsigned long long gm = __builtin_amdgcn_uicmp(__float_as_uint(so0 + e0), __float_as_uint(n0), 32) &
+                                          __builtin_amdgcn_uicmp(__float_as_uint(so1 + e1), __float_as_uint(n1), 32);
+            okm |= ~(1ull << ((pos + stride) & 63));
+            const int p6 = pos & 63;
+            const unsigned long long fail = ~okm & (~0ull << p6);
+            const int f = fail ? (int)__ffsll((long long)fail) - 1 : 64;
+            const int hi = f < 64 ? f : 63;
+            if (lane >= p6 && lane <= hi) { to0 = n0; to1 = n1; }
+            d0 = rl(e0, hi); d1 = rl(e1, hi);
+            int np = (hi + 1) & 63;
+            if (!((gm >> hi) & 1ull)) { t0 = rl(n0, hi); t1 = rl(n1, hi); np |= 0x100; }
+            pos = np;
         }
     }
     long long c1 = __builtin_readcyclecounter();
@@ -90,5 +113,6 @@ int main() {
     run<1>("arithmetic only (hypothesis + step + new delta, no cross-lane work)", 7);
     run<2>("bookkeeping only (mask, s_ff1, 4 v_readlane, delta)", 7);
     run<3>("round with DPP-injected base lane", 7);
+    run<4>("round with delta from the per-lane e = n - S (two readlanes)", 7);
     return 0;
 }
