@@ -474,7 +474,9 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         if (phase == 1) {
             // (nothing of this context is in flight that writes these words: the previous launch was waited for)
             if (!c->hDone) {
-                HIPOK(hipHostMalloc((void **)&c->hDone, sizeof(unsigned int) * c->chains.size()));
+                // (coherent = fine-grained: a system-scope store of the running kernel is visible to the polling host at once,
+                // whatever HIP_HOST_COHERENT says)
+                HIPOK(hipHostMalloc((void **)&c->hDone, sizeof(unsigned int) * c->chains.size(), hipHostMallocCoherent | hipHostMallocMapped));
                 HIPOK(hipHostGetDevicePointer((void **)&c->dDone, c->hDone, 0));
             }
             for (size_t i = 0; i < c->chains.size(); ++i) c->hDone[i] = 0u;
