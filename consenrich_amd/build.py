@@ -23,7 +23,9 @@ OUT = os.path.join(OUT_DIR, "libconsenrich_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
          "-Wall", "-Wno-unused-function",
          "-Wno-bitwise-instead-of-logical"]     # branch-free '&' of predicates in the chain policies is deliberate
-FLAG_TAG = "gfx950,O3,fp-contract=off"
+# tuning aid (scripts/ only): extra -D switches for compile-time constants of the kernels; they enter the source hash
+FLAGS += [f for f in os.environ.get("CONSENRICH_AMD_EXTRA_FLAGS", "").split() if f.startswith("-D")]
+FLAG_TAG = "gfx950,O3,fp-contract=off" + "".join("," + f for f in FLAGS if f.startswith("-D"))
 
 
 def hipcc() -> str:

@@ -1,0 +1,540 @@
+"""SURVEY a12 behind the reference's OWN signature: ``runConsenrich(matrixData, matrixMunc, deltaF, minQ, maxQ, *, ...)``
+(core.py:3861-3916: same parameter names, order and defaults; return tuple of core.py:6126-6142) on the DEVICE-RESIDENT fit
+(`driver.run_consenrich_batch` on a one-chromosome batch) instead of the per-call drop-in path.  A maintainer binds it with
+
+    import consenrich.core, consenrich_amd.core_api
+    consenrich.core.runConsenrich = consenrich_amd.core_api.runConsenrich
+
+and the reference's CLI (consenrich.py:9204-9249) and its calibration fold loop (uncertainty.py:1414) reach the resident fit.
+
+Three layers, so that the same call can be replayed on the CPU twin in the tests:
+  * `resolve_call`   -- pure host code: the reference's validation (its ValueError texts) and the mapping of its ~50 arguments
+                        onto `ModelParams` / `FitConfig`; nothing is silently ignored: what this path cannot honour raises;
+  * `runConsenrich`  -- uploads the two matrices once, runs the resident fit, downloads the final pass;
+  * `assemble_result`-- pure host code: tuple variants and the run-diagnostics dict from the final pass's arrays.
+
+Arguments that the reference's own body never reads (processNoiseWarmupECMIters, processNoiseWarmupOuterPasses: signature
+only, core.py:3900-3901) and its logging knobs (logIndentLevel, logRunRole) are accepted and have no effect, like there.
+`intervalSizeBP` is validated like there; the one diagnostic it feeds (relative sign changes per kb, core.py:4980) is reported
+as None.  `projectStateDuringFiltering=True` is refused: the kernels filter unprojected (the reference's default)."""
+from __future__ import annotations
+
+import operator
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _lib as L
+from .batch import DeviceBatch, ModelParams
+from .driver import ChainFit, FitConfig, run_consenrich_batch
+
+# constants.py:134-135, 149-163, 268-275, 387
+STATE_MODEL_LEVEL, STATE_MODEL_LEVEL_TREND = "level", "levelTrend"
+PROCESS_NOISE_CALIBRATION_FIXED_DIAGONAL, PROCESS_NOISE_CALIBRATION_FIXED = "fixedDiagonal", "fixed"
+PROCESS_DEFAULT_NOISE_CALIBRATION = PROCESS_NOISE_CALIBRATION_FIXED_DIAGONAL
+PROCESS_DEFAULT_Q_SEED_PRIOR_LEVEL = 1.0e-5
+PROCESS_DEFAULT_WARMUP_ECM_ITERS, PROCESS_DEFAULT_WARMUP_OUTER_PASSES = 50, 2
+PROCESS_DEFAULT_PRECISION_MULTIPLIER_MIN, PROCESS_DEFAULT_PRECISION_MULTIPLIER_MAX = 5.0e-3, 5.0e3
+FIT_DEFAULT_T_INNER_ITERS = 5
+FIT_DEFAULT_USE_NONNEGATIVE_BACKGROUND = True
+FIT_DEFAULT_BACKGROUND_NEGATIVE_PENALTY_MULTIPLIER = 1.0
+MASKED_OBSERVATION_VARIANCE = np.float32(1.0e30)
+FIXED_PROCESS_Q = 1.0e-4                                    # core.py:4038
+
+_DEVICE = 0
+
+
+def set_device(device: int) -> None:
+    """GPU the next calls run on (one process per GPU: a rank sets its LOCAL_RANK once)."""
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+# ---- the reference's argument checks (core.py:2202-2291, 2703-2780), restated with its messages -------------------------------
+def _finite_positive(name, value):
+    v = float(value)
+    if not np.isfinite(v) or v <= 0.0:
+        raise ValueError(f"`{name}` must be positive and finite")
+    return v
+
+
+def _finite_nonnegative(name, value):
+    v = float(value)
+    if not np.isfinite(v) or v < 0.0:
+        raise ValueError(f"`{name}` must be nonnegative and finite")
+    return v
+
+
+def _bounds(prefix, lo, hi):
+    lo_, hi_ = _finite_positive(f"{prefix}PrecisionMultiplierMin", lo), _finite_positive(f"{prefix}PrecisionMultiplierMax", hi)
+    if hi_ < lo_:
+        raise ValueError(f"`{prefix}PrecisionMultiplierMax` must be >= `{prefix}PrecisionMultiplierMin`")
+    return lo_, hi_
+
+
+def _process_bounds(lo, hi, nu, state_dim):
+    hi_ = _finite_positive("processPrecisionMultiplierMax", hi)
+    lo_raw = float(lo)
+    if not np.isfinite(lo_raw):
+        raise ValueError("`processPrecisionMultiplierMin` must be finite")
+    if lo_raw < 0.0:                                        # "auto": the convexity-preserving bound (core.py:2231-2245)
+        if nu is None:
+            raise ValueError("`fitParams.ECM_robustTNu` must be positive and finite when "
+                             "`processParams.precisionMultiplierMin` is negative.")
+        nu_ = _finite_positive("ECM_robustTNu", nu)
+        lo_ = (nu_ + float(state_dim)) / (2.0 * nu_) + 1.0e-4
+        if hi_ < lo_:
+            raise ValueError("`processPrecisionMultiplierMax` must be >= the auto `processPrecisionMultiplierMin` "
+                             f"convexity-preserving lower bound {float(lo_):.6g}")
+    else:
+        lo_ = _finite_positive("processPrecisionMultiplierMin", lo_raw)
+    if hi_ < lo_:
+        raise ValueError("`processPrecisionMultiplierMax` must be >= `processPrecisionMultiplierMin`")
+    return lo_, hi_
+
+
+def _optional_vector(name, value, n):
+    if value is None:
+        return None
+    arr = np.asarray(value, dtype=np.float32)
+    if arr.shape != (int(n),):
+        raise ValueError(f"`{name}` must have length {int(n)}")
+    if not np.all(np.isfinite(arr)):
+        raise ValueError(f"`{name}` must contain only finite values")
+    return np.ascontiguousarray(arr, dtype=np.float32)
+
+
+def _optional_q(value):
+    if value is None:
+        return None
+    arr = np.asarray(value, dtype=np.float32)
+    if arr.shape != (2, 2):
+        raise ValueError("`initialProcessQ` must have shape (2, 2)")
+    if not np.all(np.isfinite(arr)):
+        raise ValueError("`initialProcessQ` must contain only finite values")
+    if arr[0, 0] <= 0.0 or arr[1, 1] <= 0.0:
+        raise ValueError("`initialProcessQ` diagonal entries must be positive")
+    if not np.allclose(arr, arr.T, rtol=1.0e-5, atol=1.0e-8):
+        raise ValueError("`initialProcessQ` must be symmetric")
+    try:
+        np.linalg.cholesky(arr.astype(np.float64) + 1.0e-8 * np.eye(2))
+    except Exception as exc:
+        raise ValueError("`initialProcessQ` must be positive definite") from exc
+    return np.ascontiguousarray(arr, dtype=np.float32)
+
+
+def construct_matrix_f(deltaF: float) -> np.ndarray:
+    """core.constructMatrixF (core.py:2164-2176)."""
+    F = np.eye(2, dtype=np.float32)
+    F[0, 1] = np.float32(deltaF)
+    return F
+
+
+def construct_matrix_q(min_diag, q00, q01, q10, q11, tol=1.0e-8) -> np.ndarray:
+    """core.constructMatrixQ (core.py:3781-3858): diagonal floor, |Q01| <= 0.99 sqrt(Q00 Q11), Cholesky check."""
+    floor = _finite_positive("minDiagQ", min_diag)
+    diag = lambda v: floor if (v is None or not np.isfinite(float(v))) else max(float(v), floor)     # noqa: E731
+    Q = np.empty((2, 2), np.float32)
+    Q[0, 0], Q[1, 1] = np.float32(diag(q00)), np.float32(diag(q11))
+    Q[0, 1], Q[1, 0] = np.float32(q01), np.float32(q10)
+    if not np.allclose(Q[0, 1], Q[1, 0], rtol=0.0, atol=1e-4):
+        raise ValueError(f"Matrix is not symmetric: Q=\n{Q}")
+    cap = np.float32(0.99) * np.sqrt(Q[0, 0] * Q[1, 1]).astype(np.float32)
+    Q[0, 1] = np.clip(Q[0, 1], -cap, cap)
+    Q[1, 0] = Q[0, 1]
+    try:
+        np.linalg.cholesky(Q.astype(np.float64) + tol * np.eye(2))
+    except Exception as ex:
+        raise ValueError(f"Process noise covariance Q is not positive definite:\n{Q}") from ex
+    return Q
+
+
+def clamp_process_noise_matrix(Q0, state_model, minQ, maxQ) -> np.ndarray:
+    """core._clampProcessNoiseMatrix (core.py:3525-3546): diagonal into [minQ, cap], cap = inf for a negative maxQ."""
+    floor = _finite_positive("minQ", minQ)
+    cap = np.inf if float(maxQ) < 0.0 else max(float(maxQ), floor)
+    q = np.asarray(Q0, np.float64)
+    clamp = lambda v: min(max(float(v), floor), cap)                                                  # noqa: E731
+    if state_model == STATE_MODEL_LEVEL:
+        return np.asarray([[clamp(q[0, 0])]], np.float32)
+    return construct_matrix_q(floor, clamp(q[0, 0]), float(q[0, 1]), float(q[1, 0]), clamp(q[1, 1]))
+
+
+def background_penalties(blockLenIntervals, smoothness=1.0):
+    """core._backgroundPenaltyWeightsFromSpan (core.py:7479-7491)."""
+    span = max(2.0, float(blockLenIntervals))
+    s = float(smoothness)
+    return float(max(1.0, s * span * span / 4.0)), float(max(1.0, s * span ** 4 / 16.0))
+
+
+def track_summary(values) -> dict:
+    """core._metadataTrackSummary (core.py:2390-2409)."""
+    a = np.asarray(values, np.float64).reshape(-1)
+    a = a[np.isfinite(a)]
+    if a.size == 0:
+        return {k: None for k in ("min", "q05", "median", "mean", "q95", "max")}
+    return {"min": float(a.min()), "q05": float(np.quantile(a, 0.05)), "median": float(np.median(a)),
+            "mean": float(a.mean()), "q95": float(np.quantile(a, 0.95)), "max": float(a.max())}
+
+
+@dataclass
+class RunPlan:
+    """One validated `runConsenrich` call: what runs on the device (`model`, `cfg`, the matrices, warm starts) and what shapes
+    the result (`ret`)."""
+    data: np.ndarray
+    munc: np.ndarray
+    state_model: str
+    model: ModelParams
+    cfg: FitConfig
+    block_len_intervals: int
+    q0: Optional[np.ndarray]                    # float32 (d,d) when fixed / given; None = seeded from the data on the device
+    q_policy: str
+    initial_background: Optional[np.ndarray]
+    initial_lambda: Optional[np.ndarray]
+    initial_kappa: Optional[np.ndarray]
+    requested_kappa: bool
+    ret: dict = field(default_factory=dict)
+
+
+def resolve_call(matrixData, matrixMunc, deltaF, minQ, maxQ, *, stateInit, stateCovarInit, boundState, stateLowerBound,
+                 stateUpperBound, blockLenIntervals, intervalSizeBP=None, projectStateDuringFiltering=False, pad=1.0e-4,
+                 ECM_fixedBackgroundIters=50, ECM_fixedBackgroundRtol=1.0e-4, t_innerIters=FIT_DEFAULT_T_INNER_ITERS,
+                 ECM_robustTNu=8.0, ECM_useObsPrecisionReweighting=True, ECM_useProcessPrecisionReweighting=True,
+                 ECM_useAPN=False, ECM_zeroCenterBackground=False, ECM_outerIters=3, ECM_minOuterIters=None,
+                 ECM_backgroundShiftRtol=1.0e-3, ECM_outerNLLRtol=1.0e-4, ECM_backgroundSmoothness=1.0, fitBackground=True,
+                 useNonnegativeBackground=FIT_DEFAULT_USE_NONNEGATIVE_BACKGROUND,
+                 backgroundNegativePenaltyMultiplier=FIT_DEFAULT_BACKGROUND_NEGATIVE_PENALTY_MULTIPLIER, returnScales=True,
+                 returnBackground=False, stateModel=STATE_MODEL_LEVEL_TREND,
+                 processNoiseCalibration=PROCESS_DEFAULT_NOISE_CALIBRATION, qSeedPriorLevel=PROCESS_DEFAULT_Q_SEED_PRIOR_LEVEL,
+                 processNoiseWarmupECMIters=PROCESS_DEFAULT_WARMUP_ECM_ITERS,
+                 processNoiseWarmupOuterPasses=PROCESS_DEFAULT_WARMUP_OUTER_PASSES, observationPrecisionMultiplierMin=0.25,
+                 observationPrecisionMultiplierMax=4.0, processPrecisionMultiplierMin=PROCESS_DEFAULT_PRECISION_MULTIPLIER_MIN,
+                 processPrecisionMultiplierMax=PROCESS_DEFAULT_PRECISION_MULTIPLIER_MAX, observationMask=None,
+                 initialBackground=None, initialObservationPrecision=None, initialProcessPrecision=None, initialProcessQ=None,
+                 trackOptimizationPath=False, returnPrecisionDiagnostics=False, returnDiagnostics=False, logIndentLevel=0,
+                 logRunRole=None) -> RunPlan:
+    """core.py:3952-4115 (argument handling) and :5658-5690 (F, base Q0), without touching a GPU."""
+    data = np.ascontiguousarray(matrixData, dtype=np.float32)                       # core.py:2737-2756
+    munc = np.ascontiguousarray(matrixMunc, dtype=np.float32)
+    if data.ndim == 1:
+        data = data[None, :]
+    elif data.ndim != 2:
+        raise ValueError(f"matrixData must be 1D or 2D (got ndim={data.ndim})")
+    if munc.ndim == 1:
+        munc = munc[None, :]
+    elif munc.ndim != 2:
+        raise ValueError(f"matrixMunc must be 1D or 2D (got ndim={munc.ndim})")
+    if data.shape != munc.shape:
+        raise ValueError("matrixData and matrixMunc must have identical shapes")
+    if observationMask is not None:                                                 # core.py:2759-2780
+        mask = np.asarray(observationMask, dtype=bool)
+        if mask.ndim == 1:
+            mask = np.broadcast_to(mask[None, :], munc.shape)
+        if mask.shape != munc.shape:
+            raise ValueError("observationMask must match matrixData shape")
+        munc = munc.copy(order="C")
+        munc[~mask] = MASKED_OBSERVATION_VARIANCE
+    pad = _finite_nonnegative("pad", pad)
+    m, n = data.shape
+    if n < 2:
+        raise ValueError("need at least 2 intervals for smoothing")
+    if intervalSizeBP is not None and int(intervalSizeBP) <= 0:
+        raise ValueError("intervalSizeBP must be positive when provided")
+    if bool(projectStateDuringFiltering):
+        raise ValueError("projectStateDuringFiltering=True is not supported by consenrich_amd.core_api.runConsenrich "
+                         "(the device kernels filter unprojected, the reference's default)")
+    requested_kappa = bool(ECM_useProcessPrecisionReweighting)
+    use_apn = bool(ECM_useAPN)
+    use_kappa = requested_kappa and not use_apn                                     # core.py:3974-3976
+    if stateModel is None:
+        state_model = STATE_MODEL_LEVEL_TREND
+    else:
+        state_model = str(stateModel).strip()
+        if state_model not in (STATE_MODEL_LEVEL, STATE_MODEL_LEVEL_TREND):
+            raise ValueError(f"stateModel must be one of ('level', 'levelTrend') (got {stateModel!r})")
+    d = 1 if state_model == STATE_MODEL_LEVEL else 2
+    lam_bounds = _bounds("observation", observationPrecisionMultiplierMin, observationPrecisionMultiplierMax)
+    kap_bounds = _process_bounds(processPrecisionMultiplierMin, processPrecisionMultiplierMax, ECM_robustTNu, d)
+    bg0 = _optional_vector("initialBackground", initialBackground, n)
+    lam0 = _optional_vector("initialObservationPrecision", initialObservationPrecision, n)
+    if lam0 is not None:
+        lam0 = np.ascontiguousarray(np.clip(lam0, *lam_bounds), np.float32)
+    kap0 = _optional_vector("initialProcessPrecision", initialProcessPrecision, n)
+    if kap0 is not None:
+        kap0 = np.ascontiguousarray(np.clip(kap0, *kap_bounds), np.float32)
+    q_given = _optional_q(initialProcessQ)
+    minQ = _finite_positive("minQ", minQ)
+    maxQ = float(maxQ)
+    if np.isnan(maxQ):
+        raise ValueError("`maxQ` must not be NaN")
+    max_q_apn = np.inf if maxQ < 0.0 else max(maxQ, minQ)
+    mode = str(processNoiseCalibration).strip()
+    if mode not in (PROCESS_NOISE_CALIBRATION_FIXED_DIAGONAL, PROCESS_NOISE_CALIBRATION_FIXED):
+        raise ValueError(f"processNoiseCalibration must be one of ('fixedDiagonal', 'fixed') (got {processNoiseCalibration!r})")
+    fixed_q = q_given is None and mode == PROCESS_NOISE_CALIBRATION_FIXED
+    if fixed_q and minQ > FIXED_PROCESS_Q:
+        raise ValueError("`minQ` must not exceed the fixed process Q")
+    if fixed_q and np.isfinite(max_q_apn) and max_q_apn < FIXED_PROCESS_Q:
+        raise ValueError("`maxQ` must be negative or at least the fixed process Q")
+    if isinstance(t_innerIters, (bool, np.bool_)):
+        raise ValueError("t_innerIters must be a positive integer")
+    try:
+        t_inner = operator.index(t_innerIters)
+    except TypeError as ex:
+        raise ValueError("t_innerIters must be a positive integer") from ex
+    if t_inner <= 0:
+        raise ValueError("t_innerIters must be a positive integer")
+    outer = max(1, int(ECM_outerIters))
+    min_outer = 3 if ECM_minOuterIters is None else max(1, int(ECM_minOuterIters))
+    neg_mult = None if backgroundNegativePenaltyMultiplier is None else float(backgroundNegativePenaltyMultiplier)
+    if neg_mult is not None and not np.isfinite(neg_mult):
+        raise ValueError("`backgroundNegativePenaltyMultiplier` must be finite or None")
+    if int(blockLenIntervals) <= 0:
+        raise ValueError("blockLenIntervals must be positive")
+    if not np.isfinite(float(stateCovarInit)) or not np.isfinite(float(stateInit)):
+        raise ValueError("stateInit and stateCovarInit must be finite")
+
+    # transition matrix and base process noise (core.py:5658-5690)
+    if state_model == STATE_MODEL_LEVEL:
+        delta_fit = 1.0
+    else:
+        delta_fit = float(deltaF)
+        if not np.isfinite(delta_fit) or delta_fit <= 0.0:
+            raise ValueError("deltaF must be a positive finite fixed step size")
+    F = construct_matrix_f(delta_fit)
+    if q_given is not None:
+        q0, policy = clamp_process_noise_matrix(q_given, state_model, minQ, maxQ), PROCESS_NOISE_CALIBRATION_FIXED
+    elif mode == PROCESS_NOISE_CALIBRATION_FIXED:
+        q0 = clamp_process_noise_matrix(construct_matrix_q(minQ, FIXED_PROCESS_Q, 0.0, 0.0, FIXED_PROCESS_Q), state_model, minQ, maxQ)
+        policy = mode
+    else:
+        q0, policy = None, mode                             # estimated from the data on the device (core.py:5666-5676)
+    q_model = np.zeros((2, 2), np.float32)
+    if q0 is not None:
+        q_model[:d, :d] = q0[:d, :d]
+    else:
+        q_model[0, 0] = q_model[1, 1] = np.float32(FIXED_PROCESS_Q)       # placeholder until the seed replaces it per chain
+    model = ModelParams(state_dim=d, F=tuple(map(tuple, F.astype(np.float64))), Q0=tuple(map(tuple, q_model.astype(np.float64))),
+                        state_init=float(stateInit), state_covar_init=float(stateCovarInit), pad=float(pad),
+                        lambda_bounds=lam_bounds, kappa_bounds=kap_bounds,
+                        apn=(float(minQ), float(max_q_apn) if np.isfinite(max_q_apn) else 3.0e38, 5.0, 10.0, 2.0))   # pyx defaults of dStat*
+    cfg = FitConfig(penalties=background_penalties(int(blockLenIntervals), float(ECM_backgroundSmoothness)),
+                    ecm_iters=int(ECM_fixedBackgroundIters), ecm_rtol=float(ECM_fixedBackgroundRtol), inner_iters=int(t_inner),
+                    nu=float(ECM_robustTNu), use_lambda=bool(ECM_useObsPrecisionReweighting), use_kappa=use_kappa,
+                    use_apn=use_apn, fit_background=bool(fitBackground), zero_center=bool(ECM_zeroCenterBackground),
+                    use_nonnegative=bool(useNonnegativeBackground), neg_multiplier=0.0 if neg_mult is None else neg_mult,
+                    outer_passes=outer, min_outer=min_outer, shift_rtol=float(max(ECM_backgroundShiftRtol, 0.0)),
+                    seed_q=q0 is None, min_q=float(minQ), max_q=float(maxQ), delta_f=float(delta_fit),
+                    q_seed_prior_level=float(qSeedPriorLevel), outer_nll_rtol=float(max(ECM_outerNLLRtol, 0.0)), pad=float(pad))
+    ret = {"scales": bool(returnScales), "background": bool(returnBackground),
+           "precision": bool(returnPrecisionDiagnostics), "diagnostics": bool(returnDiagnostics),
+           "bound_state": bool(boundState), "lower": float(stateLowerBound), "upper": float(stateUpperBound),
+           "track_path": bool(trackOptimizationPath), "use_apn": use_apn, "max_q_apn": float(max_q_apn), "min_q": float(minQ)}
+    return RunPlan(data=data, munc=munc, state_model=state_model, model=model, cfg=cfg,
+                   block_len_intervals=int(blockLenIntervals), q0=q0, q_policy=policy, initial_background=bg0,
+                   initial_lambda=lam0 if cfg.use_lambda else None, initial_kappa=kap0 if use_kappa else None,
+                   requested_kappa=requested_kappa, ret=ret)
+
+
+def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
+    """The reference's `runDiagnostics` (core.py:5944-5999) from the arrays of the final pass: the keys its own tests read
+    (test_core.py:4055-4110) and the per-pass record; host arithmetic on downloaded tracks, same formulas."""
+    cfg, d = plan.cfg, plan.model.state_dim
+    n = plan.data.shape[1]
+    q0 = np.asarray(final["matrixQ0"], np.float64)
+    lam = final.get("lambdaExp") if cfg.use_lambda else None
+    kap = final.get("processPrecExp") if cfg.use_kappa else None
+    # final forward gain of every replicate (core.py:7671-7731)
+    p00 = np.maximum(np.asarray(final["stateCovarForward"], np.float64)[:, 0, 0], 0.0)
+    prec = np.ones(n) if lam is None else np.clip(np.asarray(lam, np.float64), *plan.model.lambda_bounds)
+    gain = {k: [] for k in ("mean", "median", "sd", "iqr", "count")}
+    r_trace = np.zeros(n)
+    for row in plan.munc:
+        var = np.maximum(np.asarray(row, np.float64) + float(cfg.pad), 1.0e-12)
+        r_trace += var
+        g = (p00 * prec) / var
+        g = g[np.isfinite(g)]
+        gain["count"].append(int(g.size))
+        if g.size == 0:
+            for k in ("mean", "median", "sd", "iqr"):
+                gain[k].append(float("nan"))
+            continue
+        q25, q75 = np.quantile(g, [0.25, 0.75])
+        gain["mean"].append(float(g.mean())); gain["median"].append(float(np.median(g)))
+        gain["sd"].append(float(np.std(g))); gain["iqr"].append(float(q75 - q25))
+    # effective process noise tracks (core.py:2420-2519): base / kappa, or the stored process noise without kappa
+    base_l = np.full(n, q0[0, 0])
+    base_t = np.full(n, q0[1, 1]) if d == 2 else np.zeros(n)
+    eff_l, eff_t = base_l.copy(), base_t.copy()
+    if kap is not None:
+        k = np.maximum(np.clip(np.asarray(kap, np.float64), *plan.model.kappa_bounds), np.finfo(np.float64).tiny)
+        eff_l, eff_t = base_l / k, base_t / k
+    elif final.get("pNoiseForward") is not None and n > 1:
+        pn = np.asarray(final["pNoiseForward"], np.float64)
+        ok = np.all(np.isfinite(pn[: n - 1].reshape(n - 1, -1)), axis=1)
+        eff_l[1:] = np.where(ok, pn[: n - 1, 0, 0], eff_l[1:])
+        if d == 2:
+            eff_t[1:] = np.where(ok, pn[: n - 1, 1, 1], eff_t[1:])
+    lvl, trd, trace = track_summary(eff_l), track_summary(eff_t), track_summary(eff_l + eff_t)
+    use_apn = bool(plan.ret["use_apn"])
+    policy = "adaptive_process_noise" if use_apn else ("student_t_kappa" if cfg.use_kappa else "base")
+    disabled = bool(plan.requested_kappa and use_apn and not cfg.use_kappa)
+    qd = {"policy": policy, "apn_enabled": use_apn, "process_precision_reweighting_requested": bool(plan.requested_kappa),
+          "process_precision_reweighting_effective": bool(cfg.use_kappa),
+          "process_precision_reweighting_disabled_by_apn": disabled,
+          "baseQLevel": float(q0[0, 0]), "baseQTrend": float(q0[1, 1]) if d == 2 else 0.0,
+          "preKappaQLevel": track_summary(base_l), "preKappaQTrend": track_summary(base_t),
+          "effectiveQLevel": lvl, "effectiveQTrend": trd, "effectiveQTrace": trace, "processQScale": track_summary(np.ones(n))}
+    for name, s in (("Level", lvl), ("Trend", trd), ("Trace", trace)):
+        for stat in ("median", "min", "max"):
+            qd[f"effectiveQ{name}{stat.capitalize()}"] = s[stat]
+    nis = np.asarray(final["NIS"], np.float64)
+    nis = nis[np.isfinite(nis)]
+    post = fit.post_process_noise_fit(cfg)
+    post["relative_sign_change_per_kb"] = None
+    calib = {"processNoisePolicy": plan.q_policy, "resolvedMinQ": float(plan.ret["min_q"]),
+             "resolvedMaxQ": float(plan.ret["max_q_apn"]), "transitionCount": float(max(n - 1, 0)),
+             "preKappaQLevel": float(q0[0, 0]), "preKappaQTrend": float(q0[1, 1]) if d == 2 else 0.0}
+    calib.update({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in (fit.q_seed or {}).items()})
+    return {"state_model": plan.state_model, "final_nll": fit.final_nll,
+            "final_forward_nis": float(nis.mean()) if nis.size else float("nan"),
+            "final_forward_gain_contig_summary": gain, "process_noise_calibration": calib,
+            "post_process_noise_fit": post, "optimization_path_tracked": bool(plan.ret["track_path"]),
+            "process_precision_reweighting_requested": bool(plan.requested_kappa),
+            "process_precision_reweighting_effective": bool(cfg.use_kappa),
+            "process_precision_reweighting_disabled_by_apn": disabled, "adaptive_process_noise_effective": use_apn,
+            "process_q_policy": policy, "process_q_diagnostics": qd, "observation_r_trace": track_summary(r_trace)}
+
+
+def assemble_result(plan: RunPlan, fit: ChainFit, final: dict) -> tuple:
+    """core.py:6001-6142: the return tuple variants.  `final` holds the final pass: stateSmoothed (n,2), stateCovarSmoothed
+    (n,2,2) (level model already zero-padded), postFitResiduals (n,m), NIS (n,), intervalToBlockMap, background,
+    stateCovarForward, pNoiseForward, lambdaExp / processPrecExp (or None), matrixQ0, outputTracks (when requested)."""
+    xs = np.asarray(final["stateSmoothed"], np.float32)
+    if plan.ret["bound_state"]:
+        xs = xs.copy()
+        np.clip(xs[:, 0], np.float32(plan.ret["lower"]), np.float32(plan.ret["upper"]), out=xs[:, 0])
+    out = [xs, np.asarray(final["stateCovarSmoothed"], np.float32), np.asarray(final["postFitResiduals"], np.float32),
+           np.asarray(final["NIS"], np.float32)]
+    if plan.ret["scales"]:
+        out.append(np.asarray(final["intervalToBlockMap"], np.int32))
+    if plan.ret["background"]:
+        out.append(np.asarray(final["background"], np.float32))
+    cfg = plan.cfg
+    use_apn = bool(plan.ret["use_apn"])
+    diag = run_diagnostics(plan, fit, final) if (plan.ret["diagnostics"] or plan.ret["precision"]) else None
+    if plan.ret["precision"]:
+        out.append({
+            "precision_track_diagnostics": True, "state_model": plan.state_model, "ECM_useAPN": use_apn,
+            "process_precision_reweighting_requested": bool(plan.requested_kappa),
+            "process_precision_reweighting_effective": bool(cfg.use_kappa),
+            "process_precision_reweighting_disabled_by_apn": bool(plan.requested_kappa and use_apn and not cfg.use_kappa),
+            "process_q_policy": diag["process_q_policy"], "process_q_diagnostics": diag["process_q_diagnostics"],
+            "observationPrecisionMultiplierMin": float(plan.model.lambda_bounds[0]),
+            "observationPrecisionMultiplierMax": float(plan.model.lambda_bounds[1]),
+            "processPrecisionMultiplierMin": float(plan.model.kappa_bounds[0]),
+            "processPrecisionMultiplierMax": float(plan.model.kappa_bounds[1]),
+            "lambdaExp": None if final.get("lambdaExp") is None else np.asarray(final["lambdaExp"], np.float32),
+            "processPrecExp": None if final.get("processPrecExp") is None else np.asarray(final["processPrecExp"], np.float32),
+            "matrixQ0": np.asarray(final["matrixQ0"], np.float32),
+            "outputTracks": {k: np.asarray(v, np.float32) for k, v in final["outputTracks"].items()}})
+    if plan.ret["diagnostics"]:
+        out.append(diag)
+    return tuple(out)
+
+
+def runConsenrich(
+    matrixData: np.ndarray,
+    matrixMunc: np.ndarray,
+    deltaF: float,
+    minQ: float,
+    maxQ: float,
+    *,
+    stateInit: float,
+    stateCovarInit: float,
+    boundState: bool,
+    stateLowerBound: float,
+    stateUpperBound: float,
+    blockLenIntervals: int,
+    intervalSizeBP: Optional[int] = None,
+    projectStateDuringFiltering: bool = False,
+    pad: float = 1.0e-4,
+    ECM_fixedBackgroundIters: int = 50,
+    ECM_fixedBackgroundRtol: float = 1.0e-4,
+    t_innerIters: int = FIT_DEFAULT_T_INNER_ITERS,
+    ECM_robustTNu: float = 8.0,
+    ECM_useObsPrecisionReweighting: bool = True,
+    ECM_useProcessPrecisionReweighting: bool = True,
+    ECM_useAPN: bool = False,
+    ECM_zeroCenterBackground: bool = False,
+    ECM_outerIters: int = 3,
+    ECM_minOuterIters: Optional[int] = None,
+    ECM_backgroundShiftRtol: float = 1.0e-3,
+    ECM_outerNLLRtol: float = 1.0e-4,
+    ECM_backgroundSmoothness: float = 1.0,
+    fitBackground: bool = True,
+    useNonnegativeBackground: bool = FIT_DEFAULT_USE_NONNEGATIVE_BACKGROUND,
+    backgroundNegativePenaltyMultiplier: Optional[float] = (
+        FIT_DEFAULT_BACKGROUND_NEGATIVE_PENALTY_MULTIPLIER
+    ),
+    returnScales: bool = True,
+    returnBackground: bool = False,
+    stateModel: Optional[str] = STATE_MODEL_LEVEL_TREND,
+    processNoiseCalibration: str = PROCESS_DEFAULT_NOISE_CALIBRATION,
+    qSeedPriorLevel: float = PROCESS_DEFAULT_Q_SEED_PRIOR_LEVEL,
+    processNoiseWarmupECMIters: int = PROCESS_DEFAULT_WARMUP_ECM_ITERS,
+    processNoiseWarmupOuterPasses: int = PROCESS_DEFAULT_WARMUP_OUTER_PASSES,
+    observationPrecisionMultiplierMin: float = 0.25,
+    observationPrecisionMultiplierMax: float = 4.0,
+    processPrecisionMultiplierMin: float = PROCESS_DEFAULT_PRECISION_MULTIPLIER_MIN,
+    processPrecisionMultiplierMax: float = PROCESS_DEFAULT_PRECISION_MULTIPLIER_MAX,
+    observationMask: Optional[np.ndarray] = None,
+    initialBackground: Optional[np.ndarray] = None,
+    initialObservationPrecision: Optional[np.ndarray] = None,
+    initialProcessPrecision: Optional[np.ndarray] = None,
+    initialProcessQ: Optional[np.ndarray] = None,
+    trackOptimizationPath: bool = False,
+    returnPrecisionDiagnostics: bool = False,
+    returnDiagnostics: bool = False,
+    logIndentLevel: int = 0,
+    logRunRole: Optional[str] = None,
+):
+    """`consenrich.core.runConsenrich` (core.py:3861) on the device-resident fit; see the module docstring."""
+    kw = dict(locals())
+    for k in ("matrixData", "matrixMunc", "deltaF", "minQ", "maxQ"):
+        kw.pop(k)
+    plan = resolve_call(matrixData, matrixMunc, deltaF, minQ, maxQ, **kw)
+    fit, final = run_plan(plan, device=_DEVICE)
+    return assemble_result(plan, fit, final)
+
+
+def run_plan(plan: RunPlan, device: int = 0):
+    """The device part: one chromosome as a one-chain batch through `run_consenrich_batch`; returns (ChainFit, final arrays)."""
+    m, n = plan.data.shape
+    cfg = plan.cfg
+    with DeviceBatch(device) as b:
+        b.configure(plan.model, m, [n])
+        b.upload(0, plan.data, plan.munc)
+        if plan.initial_lambda is not None or plan.initial_kappa is not None:       # warm-started multipliers (core.py:4637-4648)
+            b.upload_multipliers(0, plan.initial_lambda, plan.initial_kappa, None)
+        fits, results = run_consenrich_batch(
+            b, cfg, block_len_intervals=plan.block_len_intervals, model_q0=None if plan.q0 is None else _pad_q(plan.q0),
+            initial_background=None if plan.initial_background is None else [plan.initial_background],
+            return_background=True, return_precision_diagnostics=True, download=True)
+        fit, res = fits[0], results[0]
+        final = {"stateSmoothed": res[0], "stateCovarSmoothed": res[1], "postFitResiduals": res[2], "NIS": res[3],
+                 "intervalToBlockMap": res[4], "background": res[5], "outputTracks": res[6]["outputTracks"],
+                 "lambdaExp": res[6]["lambdaExp"], "processPrecExp": res[6]["processPrecExp"],
+                 "matrixQ0": res[6]["matrixQ0"], "stateCovarForward": b.download(0, "Pf"),
+                 "pNoiseForward": b.download(0, "pnoise")}
+    d = plan.model.state_dim
+    final["matrixQ0"] = np.asarray(final["matrixQ0"], np.float32)[:d, :d] if d == 1 else np.asarray(final["matrixQ0"], np.float32)
+    return fit, final
+
+
+def _pad_q(q0):
+    q = np.zeros((2, 2), np.float32)
+    q0 = np.asarray(q0, np.float32)
+    q[: q0.shape[0], : q0.shape[1]] = q0
+    return q

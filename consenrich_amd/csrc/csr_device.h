@@ -2739,9 +2739,25 @@ __device__ __forceinline__ void sb_publish(const SbAsync &a, int64_t b, int lane
         __hip_atomic_store(a.vf + b, ((unsigned long long)ver << 1) | (fin ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// LDS ring of the repair runs: per wavefront two halves of SBG batch slots + one row for the poll word.
+// A slot (words): gain record 64 x 4 | zbar low 64 | zbar high 64 | stored x0 64 | stored x1 64.
+#ifndef SB_GROUP
+#define SB_GROUP 6
+#endif
+constexpr int SBG = SB_GROUP;
+constexpr int SB_SLOT_W = 512;
+constexpr int SB_WAVE_W = 2 * SBG * SB_SLOT_W + 64;
+constexpr size_t SB_ASYNC_LDS = 4 * (size_t)SB_WAVE_W * sizeof(unsigned);
+static_assert(5 * SBG + 1 + SBG <= 63, "the group's DMAs and stores must fit the 6-bit vmcnt");
+__device__ __forceinline__ unsigned lds_rd32_wait(const unsigned *q) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(q)) : "memory");
+    return v;
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
                                                   float2 *__restrict__ natXf, SbAsync a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sbRing[];
     __shared__ unsigned int sTicket;
     if (threadIdx.x == 0) sTicket = atomicAdd(a.ctl, 1u);
     __syncthreads();
@@ -2793,12 +2809,41 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         return;
     }
     // ---- repairs
+    // Round 4: the records and the stored trajectory of a run reach the rounds through a per-wavefront LDS ring filled by
+    // LDS-DMA, a GROUP of SBG batches at a time into one of two halves, behind hand-counted waits.  (Round 3 kept a ring of
+    // registers; hipcc could not count its loads across the conditional refills and waited for ALL of them at every batch --
+    // s_waitcnt vmcnt(1) -- so a batch cost max(rounds, one trip to HBM) ~ 1 us.)  In program order a full group issues
+    // [its successor's 5 x SBG record DMAs + the poll DMA] and then exactly SBG stores (one per batch), so vmcnt(SBG) at the top
+    // of the next group says that group's records and its poll word have landed.  The predecessor's version word travels the
+    // same way (one sc1 DMA per group): nothing the compiler would wait for sits between two groups.
     float cin0 = (float)p.init, cin1 = 0.0f;        // the carry the latest run started from
     float trj0 = cin0, trj1 = cin1;                 // the carry the stored batch 0 was computed from (hypotheses only)
     unsigned seen = 0, runs = 0, aborts = 0;
+    unsigned dbgBatches = 0, dbgRounds = 0, dbgFb = 0;
+    unsigned long long dbgTicks = 0;
     int brk = 0;                                    // first bin of the stored trajectory's last piece
-    constexpr int DEPTH = SB_DELTA_DEPTH;
+    unsigned *const ring = sbRing + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SB_WAVE_W;
+    unsigned *const pollRow = ring + 2 * SBG * SB_SLOT_W;
     const unsigned long long *pvf = a.vf + (b - 1), *pcarry = a.carry + (b - 1);
+    const int ng = (nb + SBG - 1) / SBG;
+    auto issue_group = [&](int g) {
+        unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
+#pragma unroll
+        for (int u = 0; u < SBG; ++u) {
+            const int t = g * SBG + u;
+            const int64_t i = g0 + (int64_t)(t < nb ? t : nb - 1) * 64;     // (a batch beyond the end re-reads the last one: the count of DMAs per group is fixed)
+            unsigned *slot = half + u * SB_SLOT_W;
+            dma16(natGain + i, slot);
+            const float *z = reinterpret_cast<const float *>(natSZ + i) + 2;
+            dma4(z, slot + 256);
+            dma4(z + 1, slot + 320);
+            const float *x = reinterpret_cast<const float *>(natXf + i);
+            dma4(x, slot + 384);
+            dma4(x + 1, slot + 448);
+        }
+        // the predecessor's {version, final} word (low half: versions stay far below 2^31), agent scope
+        __builtin_amdgcn_global_load_lds((gbl_cvptr)pvf, (lds_vptr)pollRow, 4, 0, 16 /* sc1 */);
+    };
     for (;;) {
         // wait for news from the predecessor
         unsigned long long vf;
@@ -2824,106 +2869,115 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         for (;;) {
             cin0 = __uint_as_float((unsigned)cw); cin1 = __uint_as_float((unsigned)(cw >> 32));
             ++runs;
-            float t0 = cin0, t1 = cin1;                    // TRUE state at the bin before the next unresolved one
+            float t0 = cin0, t1 = cin1;                    // TRUE state at the bin before the next batch
             float sc0 = trj0, sc1 = trj1;                  // the stored trajectory's state at the bin before the batch
-            float4 rg[DEPTH], rs[DEPTH];
-            float2 ro[DEPTH];
-#pragma unroll
-            for (int u = 0; u < DEPTH; ++u) {
-                const int tt = u < nb ? u : nb - 1;
-                rg[u] = natGain[g0 + (int64_t)tt * 64];
-                rs[u] = natSZ[g0 + (int64_t)tt * 64];
-                ro[u] = natXf[g0 + (int64_t)tt * 64];
-            }
             bool newer = false;
             unsigned long long cwNew = cw;
+            int done = 0;
+            const long long dbgT0 = p.sbDbg != nullptr ? wall_clock64() : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's earlier stores of the trajectory are out; the ring is free
+            issue_group(0);
 #pragma unroll 1
-            for (int tg = 0; tg < nb && !merged && !newer; tg += DEPTH) {
-                // the predecessor's version word: asked for before a group of DEPTH batches, looked at after it (a load that
-                // is looked at sooner makes the wavefront wait for the record loads issued just before it)
-                const unsigned long long pv = __hip_atomic_load(pvf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int done = 0;
+            for (int g = 0; g < ng && !merged && !newer; ++g) {
+                if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SBG) : "memory");
+                // news from the predecessor (as of the moment this group's records were asked for)?
+                const unsigned pvLo = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_rd32_wait(pollRow + lane));
+                if ((pvLo >> 1) != (seen & 0x7fffffffu)) {
+                    seen = pvLo >> 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    cwNew = uni64(__hip_atomic_load(pcarry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (cwNew == cw) runFinal = runFinal || (pvLo & 1u) != 0u;
+                    else {                                              // abandon: the stored trajectory gets a seam here
+                        newer = true;
+                        runFinal = (pvLo & 1u) != 0u;
+                        if (done > brk) brk = done;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < ng) issue_group(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
 #pragma unroll
-                for (int u = 0; u < DEPTH; ++u) {
-                    const int t = tg + u;
+                for (int u = 0; u < SBG; ++u) {
+                    const int t = g * SBG + u;
                     if (t < nb && !merged) {
-                        const float4 ga = rg[u], sa = rs[u];
-                        const float2 so = ro[u];
-                        const double gs = unpack_d(ga.x, ga.y), zbar = unpack_d(sa.z, sa.w);
-                        const double p00 = (double)ga.z, p10 = (double)ga.w;
+                        const unsigned *slot = half + u * SB_SLOT_W;
+                        const uint4 gr = lds_rd128(slot + lane * 4);
+                        const unsigned zl = lds_rd32(slot + 256 + lane), zh = lds_rd32(slot + 320 + lane);
+                        const unsigned sx0 = lds_rd32(slot + 384 + lane), sx1 = lds_rd32(slot + 448 + lane);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const double gs = words2double(gr.x, gr.y), zbar = words2double(zl, zh);
+                        const float gz = __uint_as_float(gr.z), gw = __uint_as_float(gr.w);
+                        const double p00 = (double)gz, p10 = (double)gw;
+                        const float so0 = __uint_as_float(sx0), so1 = __uint_as_float(sx1);
                         const int left = min(64, n - (t << 6));
                         const unsigned long long leftMask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-                        const float sp0 = dpp_shr1_keep0(sc0, so.x), sp1 = dpp_shr1_keep0(sc1, so.y);
-                        const float tb0 = t0, tb1 = t1;
-                        float to0 = so.x, to1 = so.y;
+                        // h: lane k holds the TRUE state of its bin once settled, the hypothesis S_k + delta otherwise.  Every
+                        // lane's predecessor is a wave shift of h (lane 0: the true carry), so settled lanes recompute their own
+                        // bits and pass; the first failing lane f had a proven predecessor: its step result n_f is true.  The
+                        // second step m = step(shift(n)) is issued while the scalar unit digests the comparison: m_k = n_k up
+                        // to f, and m_{f+1} is true as well (from n_f), so the round settles through f + 1 and re-bases there.
+                        // ONE backward branch per round: the re-base is computed unconditionally (a round without a failing
+                        // lane re-bases at the batch's last bin, where m = n: nothing changes), rare paths sit behind the loop --
+                        // at one wavefront per SIMD every taken branch costs an instruction-buffer refill (~30 cycles; the
+                        // first version of this loop took five per round and 160 ns per round instead of 90).
                         float d0 = t0 - sc0, d1 = t1 - sc1;
-                        int pos = 0, rounds = 0;
-                        bool fallback = false;
+                        float h0 = so0 + d0, h1 = so1 + d1;
+                        int rounds = 0, s;
+                        unsigned long long fail;
+                        bool giveUp;
 #pragma unroll 1
-                        while (pos < left) {
-                            if (rounds >= a.advFrom && pos < a.advMin * rounds) { fallback = true; break; }
-                            ++rounds;
-                            const bool base = lane == pos;
-                            const float q0 = base ? t0 : sp0 + d0, q1 = base ? t1 : sp1 + d1;
+                        do {
+                            const float q0 = dpp_shr1_keep0(t0, h0), q1 = dpp_shr1_keep0(t1, h1);
                             float n0, n1;
-                            sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, ga.z, ga.w, n0, n1);
-                            const float c0 = so.x + d0, c1 = so.y + d1;
-                            const unsigned long long okm = __builtin_amdgcn_uicmp(f2u(n0), f2u(c0), 32 /* ICMP_EQ */) &
-                                                           __builtin_amdgcn_uicmp(f2u(n1), f2u(c1), 32);
-                            const unsigned long long fail = ~okm & (~0ull << pos) & leftMask;
-                            const int f = fail ? (int)__ffsll((long long)fail) - 1 : left;
-                            const int hi = f < left ? f : left - 1;
-                            if (lane >= pos && lane <= hi) { to0 = n0; to1 = n1; }
-                            t0 = rl32(n0, hi);
-                            t1 = rl32(n1, hi);
-                            d0 = t0 - rl32(so.x, hi);
-                            d1 = t1 - rl32(so.y, hi);
-                            pos = hi + 1;
-                        }
-                        if (fallback) {
-                            float s0 = tb0, s1 = tb1, x0v = to0, x1v = to1;
+                            sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, gz, gw, n0, n1);
+                            const unsigned long long ne0 = __builtin_amdgcn_uicmp(f2u(n0), f2u(h0), 33 /* ICMP_NE */);
+                            const unsigned long long ne1 = __builtin_amdgcn_uicmp(f2u(n1), f2u(h1), 33);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const float r0 = dpp_shr1_keep0(t0, n0), r1 = dpp_shr1_keep0(t1, n1);
+                            float m0, m1;
+                            sys_step<MODE>(p, r0, r1, gs, zbar, p00, p10, gz, gw, m0, m1);
+                            const float e0 = m0 - so0, e1 = m1 - so1;
+                            __builtin_amdgcn_sched_barrier(0);
+                            fail = (ne0 | ne1) & leftMask;
+                            // bins 0 .. s are settled: m holds their true states (s = f + 1 behind a failing lane f)
+                            s = fail != 0ull ? min((int)__builtin_ctzll(fail) + 1, left - 1) : left - 1;
+                            d0 = rl32(e0, s); d1 = rl32(e1, s);
+                            const bool le = lane <= s;
+                            h0 = le ? m0 : so0 + d0;
+                            h1 = le ? m1 : so1 + d1;
+                            ++rounds;
+                            giveUp = rounds >= a.advFrom && s + 1 < a.advMin * rounds;
+                        } while (fail != 0ull && !giveUp);
+                        if (fail != 0ull) {
+                            // delta changes at (nearly) every bin here: walk the rest of the batch as a shift register
+                            float x0v = h0, x1v = h1;
 #pragma unroll 1
-                            for (int q = pos; q < left; ++q) {
-                                s0 = dpp_shr1_keep0(s0, x0v);
-                                s1 = dpp_shr1_keep0(s1, x1v);
-                                sys_step<MODE>(p, s0, s1, gs, zbar, p00, p10, ga.z, ga.w, x0v, x1v);
+                            for (int q = s + 1; q < left; ++q) {
+                                const float w0 = dpp_shr1_keep0(t0, x0v), w1 = dpp_shr1_keep0(t1, x1v);
+                                sys_step<MODE>(p, w0, w1, gs, zbar, p00, p10, gz, gw, x0v, x1v);
                             }
-                            to0 = x0v; to1 = x1v;
-                            t0 = rl32(x0v, left - 1);
-                            t1 = rl32(x1v, left - 1);
+                            h0 = x0v; h1 = x1v;
+                            ++dbgFb;
                         }
-                        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(to0, to1);
+                        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
+                        dbgRounds += (unsigned)rounds; ++dbgBatches;
                         if (t == 0) { trj0 = cin0; trj1 = cin1; }
-                        sc0 = rl32(so.x, left - 1);
-                        sc1 = rl32(so.y, left - 1);
+                        t0 = rl32(h0, left - 1);
+                        t1 = rl32(h1, left - 1);
+                        sc0 = rl32(so0, left - 1);
+                        sc1 = rl32(so1, left - 1);
                         done = (t << 6) + left;                    // bins of the superblock settled by this run
                         // met the stored trajectory inside its last piece: what lies behind is right and ends in `out`
                         merged = done > brk && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
                         if (done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }
-                        const int tn = t + DEPTH;
-                        if (tn < nb) {
-                            rg[u] = natGain[g0 + (int64_t)tn * 64];
-                            rs[u] = natSZ[g0 + (int64_t)tn * 64];
-                            ro[u] = natXf[g0 + (int64_t)tn * 64];
-                        }
-                    }
-                }
-                // news from the predecessor while these batches ran?
-                const unsigned long long pvu = uni64(pv);
-                if ((unsigned)(pvu >> 1) != seen) {
-                    seen = (unsigned)(pvu >> 1);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    cwNew = uni64(__hip_atomic_load(pcarry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (cwNew == cw) runFinal = runFinal || (pvu & 1ull) != 0ull;
-                    else if (!completed && !merged) {                   // abandon: the stored trajectory gets a seam here
-                        newer = true;
-                        runFinal = (pvu & 1ull) != 0ull;
-                        if (done > brk) brk = done;
-                    } else {
-                        seen = seen - 1u;                              // the run is over: let the outer loop see this version
                     }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA of this run still lands in the ring
+            if (p.sbDbg != nullptr) dbgTicks += (unsigned long long)(wall_clock64() - dbgT0);
             if (!newer) break;
             ++aborts;
             cw = cwNew;
@@ -2938,6 +2992,11 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         atomicAdd(a.ctl + 3, aborts);
         if (p.sbDbg != nullptr) {
             atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
+            atomicAdd(p.sbDbg + 3, (unsigned long long)dbgBatches);
+            atomicAdd(p.sbDbg + 4, (unsigned long long)dbgRounds);
+            atomicAdd(p.sbDbg + 5, (unsigned long long)dbgFb);
+            atomicAdd(p.sbDbg + 6, dbgTicks);
+            atomicMax(p.sbDbg + 7, (dbgTicks << 24) | (unsigned long long)(dbgBatches & 0xffffff));
             if (b == (int64_t)bi.w) p.sbDbg[8 + p.blkChain[b]] = (unsigned long long)wall_clock64();     // the chain is final
         }
     }

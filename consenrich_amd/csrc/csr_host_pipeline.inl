@@ -486,9 +486,17 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             HIPOK(hipMemsetAsync(v.pub, 0, sizeof(unsigned long long) * (size_t)(2 * v.NB + 2), c->stream));
             Scope sc(c, "fwd_state_chain");
             float2 *xf = reinterpret_cast<float2 *>(natXf);
-            if (mode == 2) hipLaunchKernelGGL(k_sb_async<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
-            else if (mode == 1) hipLaunchKernelGGL(k_sb_async<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
-            else hipLaunchKernelGGL(k_sb_async<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            // (the repair runs' LDS ring: > 64 KB of dynamic LDS has to be asked for once per kernel)
+            static bool ldsOk[3] = {false, false, false};
+            if (!ldsOk[mode]) {
+                const void *fn = mode == 2 ? reinterpret_cast<const void *>(&k_sb_async<2>)
+                                 : mode == 1 ? reinterpret_cast<const void *>(&k_sb_async<1>) : reinterpret_cast<const void *>(&k_sb_async<0>);
+                HIPOK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_ASYNC_LDS));
+                ldsOk[mode] = true;
+            }
+            if (mode == 2) hipLaunchKernelGGL(k_sb_async<2>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            else if (mode == 1) hipLaunchKernelGGL(k_sb_async<1>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            else hipLaunchKernelGGL(k_sb_async<0>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
         }
         LAUNCH_CHECK("k_sb_async");
         if (phase == 1) {
@@ -505,6 +513,9 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             HIPOK(hipMemcpy(h, c->sbDbg, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "[csr] barrier-free state chain: last speculative walk ends %.1f us after the start, last wavefront leaves at %.1f us; %u delta runs, %u abandoned\n",
                     (double)(h[1] - h[0]) * 0.01, (double)(h[2] - h[0]) * 0.01, ctl[2], ctl[3]);
+            fprintf(stderr, "[csr]   delta runs: %llu batches, %.2f rounds per batch, %llu walked to the end; %.0f ns per batch inside the runs; busiest wavefront %.1f us in runs over %llu batches\n",
+                    h[3], h[3] ? (double)h[4] / (double)h[3] : 0.0, h[5], h[3] ? (double)h[6] * 10.0 / (double)h[3] : 0.0,
+                    (double)(h[7] >> 24) * 0.01, h[7] & 0xffffffull);
             std::vector<unsigned long long> fin(c->chains.size());
             HIPOK(hipMemcpy(fin.data(), c->sbDbg + 8, 8 * fin.size(), hipMemcpyDeviceToHost));
             fprintf(stderr, "[csr]   chains final at (us, bins):");

@@ -63,6 +63,7 @@ class FitConfig:
     nu: float = 8.0
     use_lambda: bool = False
     use_kappa: bool = True
+    use_apn: bool = False                        # adaptive process noise (pyx:510-527; the sequential kernel); excludes use_kappa (core.py:3975)
     fit_background: bool = True
     zero_center: bool = False
     use_nonnegative: bool = True
@@ -186,7 +187,8 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
         for c in range(nc):
             fits[c].warm_start_passes = int(info[c]["passes"])
     prev_obj = [float("nan")] * nc
-    fwd_flags = L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
+    fwd_flags = (L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
+                 | (L.USE_APN if cfg.use_apn else 0))
     have_stats = False
     planned = planned_outer_passes(cfg)
     last_inner = [False] * nc
@@ -202,7 +204,7 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
         if not have_stats:
             batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, chain_mask=active)
+                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, chain_mask=active)
         for c in range(nc):
             if active[c]:
                 fits[c].ecm_iters.append(int(outs[c].iters_done))
@@ -310,7 +312,7 @@ def precision_diagnostics(batch: DeviceBatch, cfg: FitConfig, chain: int, q0, st
     return {
         "precision_track_diagnostics": True,
         "state_model": stateModel,
-        "ECM_useAPN": False,
+        "ECM_useAPN": bool(cfg.use_apn),
         "process_precision_reweighting_requested": bool(cfg.use_kappa),
         "process_precision_reweighting_effective": bool(cfg.use_kappa),
         "process_precision_reweighting_disabled_by_apn": False,
@@ -346,11 +348,12 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     fits = fit_batch(batch, cfg, keep_background=initial_background is not None)
 
     mult_flags = (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
+    apn_flag = L.USE_APN if cfg.use_apn else 0
     if cfg.fit_background:
         # final fixed-background ECM phase (core.py:5385-5440): every chain, converged background, warm-started multipliers
         batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa)
+                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn)
         for c in range(nc):
             fits[c].final_ecm_iters = int(outs[c].iters_done)
             fits[c].final_ecm_nll = float(outs[c].final_nll)
@@ -362,7 +365,7 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
                                              "diagnostics_source": "cfixedBackgroundECM", "final_fixed_background_ecm": True})
     # final store-all forward / backward on data - background with the final multipliers (core.py:5560-5600).  The
     # statistics of the final background are resident (the ECM phase above or, without a background fit, the loop's)
-    sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags)
+    sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags | apn_flag)
     batch.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
     if return_precision_diagnostics:
         batch.diagnostics(mult_flags)

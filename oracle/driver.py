@@ -96,13 +96,20 @@ def planned_outer_passes(cfg):
     return max(int(cfg["min_outer"]), max(1, int(cfg["outer_passes"])))
 
 
-def fit_chain(data, munc, cfg, initial_background=None):
+def _apn_kwargs(cfg):
+    """adaptive process noise (core.py:3273-3279: APN_minQ = minQ, APN_maxQ = max(maxQ, minQ) or inf); off unless cfg asks"""
+    if not cfg.get("use_apn"):
+        return {}
+    return {"ECM_useAPN": True, "APN_minQ": float(cfg["apn"][0]), "APN_maxQ": float(cfg["apn"][1])}
+
+
+def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, initial_kappa=None):
     data = np.ascontiguousarray(data, np.float32)
     munc = np.ascontiguousarray(munc, np.float32)
     m, n = data.shape
     d = cfg["state_dim"]
     bg = np.zeros(n, np.float32) if initial_background is None else np.ascontiguousarray(initial_background, np.float32).copy()
-    lam = kap = None
+    lam, kap = initial_lambda, initial_kappa                 # warm-started multipliers (core.py:4637-4648)
     hist = {"ecm_iters": [], "nll": [], "shift": [], "irls_passes": [], "objective": [], "converged": False, "loop": [],
             "stop_reason": "max_outer_passes"}
     prev_obj = float("nan")
@@ -118,7 +125,7 @@ def fit_chain(data, munc, cfg, initial_background=None):
               ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
               obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
               procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
-              logIterations=False)
+              logIterations=False, **_apn_kwargs(cfg))
     if d == 2:
         kw["matrixF"] = np.asarray(cfg["F"], np.float32)
     out = None
@@ -151,7 +158,8 @@ def fit_chain(data, munc, cfg, initial_background=None):
                    pad=cfg["pad"], returnNLL=True, lambdaExp=lam, processPrecExp=kap if cfg["use_kappa"] else None,
                    ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
                    obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
-                   procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1])
+                   procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
+                   **_apn_kwargs(cfg))
         if d == 2:
             fkw["matrixF"] = kw["matrixF"]
         obj = penalized_objective(float(fwd(**fkw)[3]), munc, bg, lam, kap, cfg)
@@ -199,7 +207,7 @@ def background_warm_start(data, munc, cfg):
     return np.ascontiguousarray(out, np.float32), int(info["passes"])
 
 
-def run_consenrich_chain(data, munc, cfg, initial_background=None):
+def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambda=None, initial_kappa=None):
     """The whole `runConsenrich` composition for one chromosome (module docstring of consenrich_amd/driver.py, steps 1-5):
     background warm start -> alternation loop -> FINAL fixed-background ECM phase (core.py:5385-5440) -> FINAL store-all
     forward / backward on data - background with the final multipliers (core.py:5560-5600, 4207-4336) -> the pieces of the
@@ -212,7 +220,7 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None):
     bg0 = initial_background
     if bg0 is None and cfg["fit_background"]:
         bg0, warm_passes = background_warm_start(data, munc, cfg)
-    hist = fit_chain(data, munc, cfg, initial_background=bg0)
+    hist = fit_chain(data, munc, cfg, initial_background=bg0, initial_lambda=initial_lambda, initial_kappa=initial_kappa)
     bg, lam, kap = hist["background"], hist["lam"], hist["kap"]
     bm = (np.arange(n, dtype=np.int32) // cfg["block_len_intervals"]).astype(np.int32)
     Q0 = np.asarray(cfg["Q0"], np.float32)
@@ -220,7 +228,8 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None):
                   stateCovarInit=cfg["state_covar_init"], pad=cfg["pad"],
                   ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
                   obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
-                  procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1])
+                  procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
+                  **_apn_kwargs(cfg))
     if d == 2:
         common["matrixF"] = np.asarray(cfg["F"], np.float32)
     adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)

@@ -1,0 +1,231 @@
+"""SURVEY a12 behind the reference's own signature (`consenrich_amd.core_api.runConsenrich`).
+
+CPU part: the signature IS the reference's (names, order, defaults -- the literal list of core.py:3861-3916 is data here);
+`resolve_call` raises the reference's ValueErrors and maps the arguments; the three literal invocations the reference's own
+contract tests make (test_core.py:3992-4110 outer-pass smoke, :4206-4257 level model, :6051-6090 adaptive process noise)
+replayed on the CPU twin give the reference's tuple shapes, dtypes, keys and finite numbers.
+GPU part: the same three invocations through the product on the device, against the twin."""
+import inspect
+
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+
+# core.py:3861-3916: (name, default) in order; REQ = no default
+REQ = inspect.Parameter.empty
+REFERENCE_SIGNATURE = [
+    ("matrixData", REQ), ("matrixMunc", REQ), ("deltaF", REQ), ("minQ", REQ), ("maxQ", REQ),
+    ("stateInit", REQ), ("stateCovarInit", REQ), ("boundState", REQ), ("stateLowerBound", REQ), ("stateUpperBound", REQ),
+    ("blockLenIntervals", REQ), ("intervalSizeBP", None), ("projectStateDuringFiltering", False), ("pad", 1.0e-4),
+    ("ECM_fixedBackgroundIters", 50), ("ECM_fixedBackgroundRtol", 1.0e-4), ("t_innerIters", 5), ("ECM_robustTNu", 8.0),
+    ("ECM_useObsPrecisionReweighting", True), ("ECM_useProcessPrecisionReweighting", True), ("ECM_useAPN", False),
+    ("ECM_zeroCenterBackground", False), ("ECM_outerIters", 3), ("ECM_minOuterIters", None),
+    ("ECM_backgroundShiftRtol", 1.0e-3), ("ECM_outerNLLRtol", 1.0e-4), ("ECM_backgroundSmoothness", 1.0),
+    ("fitBackground", True), ("useNonnegativeBackground", True), ("backgroundNegativePenaltyMultiplier", 1.0),
+    ("returnScales", True), ("returnBackground", False), ("stateModel", "levelTrend"),
+    ("processNoiseCalibration", "fixedDiagonal"), ("qSeedPriorLevel", 1.0e-5), ("processNoiseWarmupECMIters", 50),
+    ("processNoiseWarmupOuterPasses", 2), ("observationPrecisionMultiplierMin", 0.25),
+    ("observationPrecisionMultiplierMax", 4.0), ("processPrecisionMultiplierMin", 5.0e-3),
+    ("processPrecisionMultiplierMax", 5.0e3), ("observationMask", None), ("initialBackground", None),
+    ("initialObservationPrecision", None), ("initialProcessPrecision", None), ("initialProcessQ", None),
+    ("trackOptimizationPath", False), ("returnPrecisionDiagnostics", False), ("returnDiagnostics", False),
+    ("logIndentLevel", 0), ("logRunRole", None),
+]
+TRACK_KEYS = ("baseQLevel", "baseQTrend", "effectiveQLevel", "effectiveQTrend", "muncTrace", "preKappaQLevel",
+              "preKappaQTrend", "processQScale", "sumGain0", "sumGain1")
+
+
+def _case_outer_pass_smoke():
+    """test_core.py:3992-4053: literal inputs and keyword arguments"""
+    rng = np.random.default_rng(0)
+    n, m = 64, 3
+    grid = np.linspace(0.0, 2.0 * np.pi, n, dtype=np.float32)
+    sig = np.sin(grid).astype(np.float32)
+    bg = np.linspace(-0.25, 0.25, n, dtype=np.float32)
+    data = np.vstack([sig + bg + 0.05 * rng.normal(size=n) - 0.04, sig + bg + 0.05 * rng.normal(size=n),
+                      sig + bg + 0.05 * rng.normal(size=n) + 0.03]).astype(np.float32)
+    munc = np.full((m, n), 0.2, dtype=np.float32)
+    kw = dict(deltaF=0.1, minQ=1.0e-6, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=8, intervalSizeBP=1000, ECM_fixedBackgroundIters=3, ECM_outerIters=2,
+              processNoiseWarmupECMIters=1, trackOptimizationPath=True, returnPrecisionDiagnostics=True,
+              returnDiagnostics=True)
+    return data, munc, kw
+
+
+def _case_level_smoke():
+    """test_core.py:4206-4238"""
+    rng = np.random.default_rng(100)
+    n, m = 42, 3
+    grid = np.linspace(0.0, 2.0 * np.pi, n, dtype=np.float32)
+    sig = (0.4 * np.sin(grid) + 0.15 * np.cos(2.0 * grid)).astype(np.float32)
+    data = np.vstack([sig + 0.04 * rng.normal(size=n) - 0.02, sig + 0.04 * rng.normal(size=n),
+                      sig + 0.04 * rng.normal(size=n) + 0.03]).astype(np.float32)
+    munc = np.full((m, n), 0.10, dtype=np.float32)
+    kw = dict(stateModel="level", deltaF=-10.0, minQ=1.0e-4, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False,
+              stateLowerBound=0.0, stateUpperBound=0.0, blockLenIntervals=7, ECM_fixedBackgroundIters=1, ECM_outerIters=1,
+              ECM_minOuterIters=1, ECM_useProcessPrecisionReweighting=True, ECM_useAPN=False, processNoiseWarmupECMIters=1,
+              returnDiagnostics=True)
+    return data, munc, kw
+
+
+def _case_apn_smoke():
+    """test_core.py:6051-6083"""
+    rng = np.random.default_rng(123)
+    n, m = 48, 3
+    grid = np.linspace(0.0, 2.0 * np.pi, n, dtype=np.float32)
+    sig = np.sin(grid).astype(np.float32)
+    data = np.vstack([sig + 0.08 * rng.normal(size=n) - 0.03, sig + 0.08 * rng.normal(size=n),
+                      sig + 0.08 * rng.normal(size=n) + 0.02]).astype(np.float32)
+    munc = np.full((m, n), 0.15, dtype=np.float32)
+    kw = dict(deltaF=0.1, minQ=1.0e-6, maxQ=0.5, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=8, ECM_fixedBackgroundIters=2, ECM_outerIters=1,
+              ECM_useProcessPrecisionReweighting=True, ECM_useAPN=True, processNoiseCalibration="fixedDiagonal")
+    return data, munc, kw
+
+
+CASES = {"outer_pass_smoke": _case_outer_pass_smoke, "level_smoke": _case_level_smoke, "apn_smoke": _case_apn_smoke}
+
+
+def _twin_call(data, munc, kw):
+    from consenrich_amd import core_api
+    import twin_core
+
+    k = dict(kw)
+    plan = core_api.resolve_call(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
+    fit, final = twin_core.twin_run(plan)
+    return plan, core_api.assemble_result(plan, fit, final)
+
+
+def _check_contract(name, out, data):
+    """what the reference's own tests assert about the tuple (test_core.py:4055-4110, 4240-4257, 6085-6090)"""
+    m, n = data.shape
+    xs, Ps, resid, nis = out[:4]
+    assert xs.shape == (n, 2) and Ps.shape == (n, 2, 2) and resid.shape == (n, m) and nis.shape == (n,)
+    assert all(np.asarray(a).dtype == np.float32 for a in (xs, Ps, resid, nis))
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(Ps)) and np.all(np.isfinite(nis))
+    if name == "outer_pass_smoke":
+        assert len(out) == 7
+        prec, diag = out[-2], out[-1]
+        assert prec["precision_track_diagnostics"] is True
+        tracks = prec["outputTracks"]
+        assert tuple(sorted(tracks)) == TRACK_KEYS
+        assert all(np.asarray(t).shape == (n,) for t in tracks.values())
+        assert diag["final_forward_nis"] == pytest.approx(float(np.mean(nis)), rel=1e-6)
+        qd = diag["process_q_diagnostics"]
+        assert qd["effectiveQTraceMin"] <= qd["effectiveQTraceMedian"] <= qd["effectiveQTraceMax"]
+        want = m * (0.2 + 0.0001)
+        for k in ("min", "median", "max"):
+            assert diag["observation_r_trace"][k] == pytest.approx(want)
+        lam = np.asarray(prec["lambdaExp"], np.float64)
+        kap = np.asarray(prec["processPrecExp"], np.float64)
+        assert lam.shape == (n,) and kap.shape == (n,)
+        np.testing.assert_allclose(tracks["muncTrace"], want / lam, rtol=2.0e-6, atol=2.0e-6)
+        gs = diag["final_forward_gain_contig_summary"]
+        assert all(len(gs[k]) == m for k in ("mean", "median", "sd", "iqr", "count")) and all(v >= 0.0 for v in gs["sd"])
+        post = diag["post_process_noise_fit"]
+        assert post["planned_outer_passes"] == 3 and post["requested_outer_passes"] == 2       # max(min 3, requested 2)
+    elif name == "level_smoke":
+        assert len(out) == 6                                     # 4 + block map + run diagnostics
+        np.testing.assert_array_equal(xs[:, 1], np.zeros(n, np.float32))
+        np.testing.assert_array_equal(Ps[:, 0, 1], np.zeros(n, np.float32))
+        np.testing.assert_array_equal(Ps[:, 1, 1], np.zeros(n, np.float32))
+        assert out[-1]["state_model"] == "level"
+    else:
+        assert len(out) == 5                                     # returnScales only
+
+
+def test_signature_is_the_references():
+    from consenrich_amd import core_api
+
+    for fn in (core_api.runConsenrich, core_api.resolve_call):
+        ps = list(inspect.signature(fn).parameters.values())
+        assert [(p.name, p.default) for p in ps] == REFERENCE_SIGNATURE
+        assert all(p.kind == p.POSITIONAL_OR_KEYWORD for p in ps[:5]) and all(p.kind == p.KEYWORD_ONLY for p in ps[5:])
+
+
+def test_argument_mapping_and_the_references_errors():
+    from consenrich_amd import core_api
+
+    data, munc, kw = _case_outer_pass_smoke()
+    k = dict(kw)
+    plan = core_api.resolve_call(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
+    assert plan.cfg.penalties == (16.0, 256.0)                     # L = 8: max(1, L^2/4), max(1, L^4/16) (core.py:7479-7491)
+    assert plan.cfg.seed_q and plan.q0 is None                     # fixedDiagonal: Q0 from the data
+    assert plan.cfg.use_lambda and plan.cfg.use_kappa and not plan.cfg.use_apn
+    assert plan.cfg.outer_passes == 2 and plan.cfg.min_outer == 3 and plan.cfg.ecm_iters == 3
+    assert np.asarray(plan.model.F, np.float32)[0, 1] == np.float32(0.1)
+    base = dict(deltaF=1.0, minQ=1e-6, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+                stateUpperBound=0.0, blockLenIntervals=8)
+
+    def call(**over):
+        a = {**base, **over}
+        return core_api.resolve_call(a.pop("matrixData", data), a.pop("matrixMunc", munc), a.pop("deltaF"), a.pop("minQ"),
+                                     a.pop("maxQ"), **a)
+
+    fixed = call(processNoiseCalibration="fixed")
+    np.testing.assert_array_equal(fixed.q0, np.diag([1e-4, 1e-4]).astype(np.float32))
+    auto = call(processPrecisionMultiplierMin=-1.0)               # auto = (nu + d) / (2 nu) + 1e-4 (core.py:2231-2245)
+    assert auto.model.kappa_bounds[0] == pytest.approx((8.0 + 2.0) / 16.0 + 1.0e-4)
+    masked = call(observationMask=np.arange(data.shape[1]) % 5 != 0)
+    assert np.all(masked.munc[:, ::5] == np.float32(1.0e30)) and np.all(masked.munc[:, 1:5] == np.float32(0.2))
+    for over, text in ((dict(matrixData=data[:, :1], matrixMunc=munc[:, :1]), "need at least 2 intervals"),
+                       (dict(matrixMunc=munc[:2]), "identical shapes"),
+                       (dict(minQ=0.0), "`minQ` must be positive and finite"),
+                       (dict(maxQ=float("nan")), "`maxQ` must not be NaN"),
+                       (dict(pad=-1.0), "`pad` must be nonnegative and finite"),
+                       (dict(deltaF=-1.0), "deltaF must be a positive finite fixed step size"),
+                       (dict(t_innerIters=0), "t_innerIters must be a positive integer"),
+                       (dict(t_innerIters=True), "t_innerIters must be a positive integer"),
+                       (dict(intervalSizeBP=0), "intervalSizeBP must be positive when provided"),
+                       (dict(observationPrecisionMultiplierMin=5.0), "`observationPrecisionMultiplierMax` must be >="),
+                       (dict(processNoiseCalibration="fixed", minQ=1e-3), "`minQ` must not exceed the fixed process Q"),
+                       (dict(initialBackground=np.zeros(3)), "`initialBackground` must have length 64"),
+                       (dict(initialProcessQ=np.eye(3)), "`initialProcessQ` must have shape (2, 2)"),
+                       (dict(observationMask=np.ones((2, 2), bool)), "observationMask must match matrixData shape"),
+                       (dict(backgroundNegativePenaltyMultiplier=float("inf")), "must be finite or None"),
+                       (dict(projectStateDuringFiltering=True), "not supported")):
+        with pytest.raises(ValueError, match=text.replace("(", r"\(").replace(")", r"\)")):
+            call(**over)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_contract_cases_on_the_cpu_twin(name):
+    data, munc, kw = CASES[name]()
+    _, out = _twin_call(data, munc, kw)
+    _check_contract(name, out, data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_contract_cases_on_the_device_match_the_twin(name):
+    """The literal invocations through `core_api.runConsenrich` (device-resident fit) == the CPU twin: same tuple length,
+    the discrete history (passes, ECM iterations, stop reason) equal, arrays within the parity tolerance."""
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import core_api
+
+    data, munc, kw = CASES[name]()
+    k = dict(kw)
+    out = core_api.runConsenrich(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
+    _check_contract(name, out, data)
+    _, ref = _twin_call(data, munc, kw)
+    assert len(out) == len(ref)
+    for i, (a, b) in enumerate(zip(out, ref)):
+        if isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and a.shape == b.shape, i
+            if a.dtype.kind == "f":
+                lvl = 1.0 if i != 0 else np.maximum(np.abs(b[:, :1]).astype(np.float64), 1.0)
+                tol = 1e-4 if i != 3 else 5e-2                   # NIS amplifies one ulp of the level (close_mostly elsewhere)
+                assert float((np.abs(a.astype(np.float64) - b) / (lvl * (np.abs(b) if i != 0 else 1.0) + 1e-3)).max()) <= tol, (name, i)
+            else:
+                np.testing.assert_array_equal(a, b)
+    if kw.get("returnDiagnostics"):
+        dg, dr = out[-1], ref[-1]
+        pg, pr = dg["post_process_noise_fit"], dr["post_process_noise_fit"]
+        for key in ("planned_outer_passes", "actual_outer_passes", "outer_stop_reason", "outer_converged"):
+            assert pg[key] == pr[key], (name, key, pg[key], pr[key])
+        assert [r["iters_done"] for r in pg["fixed_background_ecm"]] == [r["iters_done"] for r in pr["fixed_background_ecm"]]
+        assert dg["final_nll"] == pytest.approx(dr["final_nll"], rel=1e-6)
+        assert dg["process_q_diagnostics"]["policy"] == dr["process_q_diagnostics"]["policy"]
+        np.testing.assert_allclose(dg["process_q_diagnostics"]["baseQLevel"], dr["process_q_diagnostics"]["baseQLevel"], rtol=1e-6)
