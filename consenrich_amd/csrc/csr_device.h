@@ -2821,25 +2821,32 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     unsigned seen = 0, runs = 0, aborts = 0;
     unsigned dbgBatches = 0, dbgRounds = 0, dbgFb = 0;
     unsigned long long dbgTicks = 0;
+    unsigned long long dbgSec[4] = {0, 0, 0, 0};      // s_memtime ticks: group top, batch prologue, rounds, batch epilogue (debug only)
+    const bool dbgOn = p.sbDbg != nullptr;
     int brk = 0;                                    // first bin of the stored trajectory's last piece
     unsigned *const ring = sbRing + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SB_WAVE_W;
     unsigned *const pollRow = ring + 2 * SBG * SB_SLOT_W;
     const unsigned long long *pvf = a.vf + (b - 1), *pcarry = a.carry + (b - 1);
     const int ng = (nb + SBG - 1) / SBG;
+    // (uniform base + 32-bit lane offset: the DMA instructions take their address as SGPR pair + VGPR offset, so a group's 31
+    // DMAs cost one scalar add each instead of 64-bit vector address arithmetic)
+    const int64_t bx = (int64_t)__builtin_amdgcn_readfirstlane(bi.x);
+    const unsigned offG = (unsigned)lane * 16u, offX = (unsigned)lane * 8u;
     auto issue_group = [&](int g) {
         unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
 #pragma unroll
         for (int u = 0; u < SBG; ++u) {
             const int t = g * SBG + u;
-            const int64_t i = g0 + (int64_t)(t < nb ? t : nb - 1) * 64;     // (a batch beyond the end re-reads the last one: the count of DMAs per group is fixed)
+            const int64_t i = bx + (int64_t)(t < nb ? t : nb - 1) * 64;     // (a batch beyond the end re-reads the last one: the count of DMAs per group is fixed)
             unsigned *slot = half + u * SB_SLOT_W;
-            dma16(natGain + i, slot);
-            const float *z = reinterpret_cast<const float *>(natSZ + i) + 2;
-            dma4(z, slot + 256);
-            dma4(z + 1, slot + 320);
-            const float *x = reinterpret_cast<const float *>(natXf + i);
-            dma4(x, slot + 384);
-            dma4(x + 1, slot + 448);
+            const char *pg = reinterpret_cast<const char *>(natGain + i);
+            const char *pz = reinterpret_cast<const char *>(natSZ + i) + 8;
+            const char *px = reinterpret_cast<const char *>(natXf + i);
+            dma16(pg + offG, slot);
+            dma4(pz + offG, slot + 256);
+            dma4(pz + 4 + offG, slot + 320);
+            dma4(px + offX, slot + 384);
+            dma4(px + 4 + offX, slot + 448);
         }
         // the predecessor's {version, final} word (low half: versions stay far below 2^31), agent scope
         __builtin_amdgcn_global_load_lds((gbl_cvptr)pvf, (lds_vptr)pollRow, 4, 0, 16 /* sc1 */);
@@ -2879,6 +2886,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
             issue_group(0);
 #pragma unroll 1
             for (int g = 0; g < ng && !merged && !newer; ++g) {
+                long long dbgA = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
                 if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SBG) : "memory");
                 // news from the predecessor (as of the moment this group's records were asked for)?
@@ -2899,10 +2907,12 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                 if (g + 1 < ng) issue_group(g + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
+                if (dbgOn) { const long long nowA = (long long)__builtin_readcyclecounter(); dbgSec[0] += (unsigned long long)(nowA - dbgA); }
 #pragma unroll
                 for (int u = 0; u < SBG; ++u) {
                     const int t = g * SBG + u;
                     if (t < nb && !merged) {
+                        const long long dbgB = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
                         const unsigned *slot = half + u * SB_SLOT_W;
                         const uint4 gr = lds_rd128(slot + lane * 4);
                         const unsigned zl = lds_rd32(slot + 256 + lane), zh = lds_rd32(slot + 320 + lane);
@@ -2919,38 +2929,43 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                         // bits and pass; the first failing lane f had a proven predecessor: its step result n_f is true.  The
                         // second step m = step(shift(n)) is issued while the scalar unit digests the comparison: m_k = n_k up
                         // to f, and m_{f+1} is true as well (from n_f), so the round settles through f + 1 and re-bases there.
-                        // ONE backward branch per round: the re-base is computed unconditionally (a round without a failing
-                        // lane re-bases at the batch's last bin, where m = n: nothing changes), rare paths sit behind the loop --
-                        // at one wavefront per SIMD every taken branch costs an instruction-buffer refill (~30 cycles; the
-                        // first version of this loop took five per round and 160 ns per round instead of 90).
+                        // What a round costs is its INSTRUCTION COUNT: one wavefront per SIMD issues one instruction every
+                        // ~5 ticks whatever its type or dependencies (scripts/ubench/issue_cost.hip).  Hence: ONE backward branch
+                        // per round, the re-base computed unconditionally (a sentinel bit at the batch's last bin makes a round
+                        // without a failing lane re-base there, where m = n: nothing changes), rare paths behind the loop, the
+                        // shifted vectors loop-carried so that their lane 0 keeps the true carry without a copy per round, one
+                        // 64-bit comparison of the packed pair.
                         float d0 = t0 - sc0, d1 = t1 - sc1;
                         float h0 = so0 + d0, h1 = so1 + d1;
+                        float q0 = t0, q1 = t1, r0 = t0, r1 = t1;           // lane 0 of the shifted vectors: the true carry, for the whole batch
+                        const unsigned long long sentinel = 1ull << (left - 1);
+                        const int rmax = a.advFrom;
                         int rounds = 0, s;
                         unsigned long long fail;
-                        bool giveUp;
+                        const long long dbgC = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
+                        if (dbgOn) dbgSec[1] += (unsigned long long)(dbgC - dbgB);
 #pragma unroll 1
                         do {
-                            const float q0 = dpp_shr1_keep0(t0, h0), q1 = dpp_shr1_keep0(t1, h1);
+                            q0 = dpp_shr1_keep0(q0, h0); q1 = dpp_shr1_keep0(q1, h1);
                             float n0, n1;
                             sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, gz, gw, n0, n1);
-                            const unsigned long long ne0 = __builtin_amdgcn_uicmp(f2u(n0), f2u(h0), 33 /* ICMP_NE */);
-                            const unsigned long long ne1 = __builtin_amdgcn_uicmp(f2u(n1), f2u(h1), 33);
+                            const unsigned long long ne = __builtin_amdgcn_uicmpl(((unsigned long long)f2u(n1) << 32) | f2u(n0),
+                                                                                  ((unsigned long long)f2u(h1) << 32) | f2u(h0), 33 /* ICMP_NE */);
                             __builtin_amdgcn_sched_barrier(0);
-                            const float r0 = dpp_shr1_keep0(t0, n0), r1 = dpp_shr1_keep0(t1, n1);
+                            r0 = dpp_shr1_keep0(r0, n0); r1 = dpp_shr1_keep0(r1, n1);
                             float m0, m1;
                             sys_step<MODE>(p, r0, r1, gs, zbar, p00, p10, gz, gw, m0, m1);
                             const float e0 = m0 - so0, e1 = m1 - so1;
                             __builtin_amdgcn_sched_barrier(0);
-                            fail = (ne0 | ne1) & leftMask;
+                            fail = ne & leftMask;
                             // bins 0 .. s are settled: m holds their true states (s = f + 1 behind a failing lane f)
-                            s = fail != 0ull ? min((int)__builtin_ctzll(fail) + 1, left - 1) : left - 1;
+                            s = min((int)__builtin_ctzll(fail | sentinel) + 1, left - 1);
                             d0 = rl32(e0, s); d1 = rl32(e1, s);
                             const bool le = lane <= s;
                             h0 = le ? m0 : so0 + d0;
                             h1 = le ? m1 : so1 + d1;
                             ++rounds;
-                            giveUp = rounds >= a.advFrom && s + 1 < a.advMin * rounds;
-                        } while (fail != 0ull && !giveUp);
+                        } while (fail != 0ull && rounds < rmax);
                         if (fail != 0ull) {
                             // delta changes at (nearly) every bin here: walk the rest of the batch as a shift register
                             float x0v = h0, x1v = h1;
@@ -2962,6 +2977,8 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                             h0 = x0v; h1 = x1v;
                             ++dbgFb;
                         }
+                        const long long dbgD = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
+                        if (dbgOn) dbgSec[2] += (unsigned long long)(dbgD - dbgC);
                         if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
                         dbgRounds += (unsigned)rounds; ++dbgBatches;
                         if (t == 0) { trj0 = cin0; trj1 = cin1; }
@@ -2973,6 +2990,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                         // met the stored trajectory inside its last piece: what lies behind is right and ends in `out`
                         merged = done > brk && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
                         if (done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }
+                        if (dbgOn) dbgSec[3] += (unsigned long long)((long long)__builtin_readcyclecounter() - dbgD);
                     }
                 }
             }
@@ -2997,6 +3015,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
             atomicAdd(p.sbDbg + 5, (unsigned long long)dbgFb);
             atomicAdd(p.sbDbg + 6, dbgTicks);
             atomicMax(p.sbDbg + 7, (dbgTicks << 24) | (unsigned long long)(dbgBatches & 0xffffff));
+            for (int q = 0; q < 4; ++q) atomicAdd(p.sbDbg + 8 + p.nchains + q, dbgSec[q]);
             if (b == (int64_t)bi.w) p.sbDbg[8 + p.blkChain[b]] = (unsigned long long)wall_clock64();     // the chain is final
         }
     }

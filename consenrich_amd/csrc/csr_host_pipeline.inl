@@ -445,8 +445,8 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     const int grid = (int)((v.NB + 3) / 4);
     q.sbDbg = nullptr;
     if (getenv("CONSENRICH_AMD_SB_DEBUG")) {
-        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 8 + (int64_t)c->chains.size()));
-        if (!resume) HIPOK(hipMemsetAsync(c->sbDbg, 0, 8 * (8 + c->chains.size()), c->stream));
+        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 12 + (int64_t)c->chains.size()));
+        if (!resume) HIPOK(hipMemsetAsync(c->sbDbg, 0, 8 * (12 + c->chains.size()), c->stream));
         q.sbDbg = c->sbDbg;
     }
     auto launch = [&](int which, int fix) {
@@ -516,6 +516,13 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             fprintf(stderr, "[csr]   delta runs: %llu batches, %.2f rounds per batch, %llu walked to the end; %.0f ns per batch inside the runs; busiest wavefront %.1f us in runs over %llu batches\n",
                     h[3], h[3] ? (double)h[4] / (double)h[3] : 0.0, h[5], h[3] ? (double)h[6] * 10.0 / (double)h[3] : 0.0,
                     (double)(h[7] >> 24) * 0.01, h[7] & 0xffffffull);
+            {
+                unsigned long long sec[4];
+                HIPOK(hipMemcpy(sec, c->sbDbg + 8 + c->chains.size(), 32, hipMemcpyDeviceToHost));
+                const double nbt = h[3] ? (double)h[3] : 1.0;
+                fprintf(stderr, "[csr]   s_memtime ticks per batch: group top %.0f, batch prologue %.0f, rounds %.0f, batch epilogue %.0f\n",
+                        (double)sec[0] / nbt, (double)sec[1] / nbt, (double)sec[2] / nbt, (double)sec[3] / nbt);
+            }
             std::vector<unsigned long long> fin(c->chains.size());
             HIPOK(hipMemcpy(fin.data(), c->sbDbg + 8, 8 * fin.size(), hipMemcpyDeviceToHost));
             fprintf(stderr, "[csr]   chains final at (us, bins):");

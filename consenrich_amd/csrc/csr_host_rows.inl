@@ -946,7 +946,8 @@ extern "C" int csr_batch_make_fold(csr_ctx *c, int32_t src, int32_t dst, int64_t
     CHECK(need(c));
     CHECK(settle(c));
     const int nc = (int)c->chains.size();
-    if (src < 0 || src >= nc || dst < 0 || dst >= nc || src == dst) return fail("bad chain index");
+    // (src == dst: the fold is made in place -- both kernels are per bin and read every cell of a bin before they overwrite it)
+    if (src < 0 || src >= nc || dst < 0 || dst >= nc) return fail("bad chain index");
     if (!block_fold || !reps_count || !reps || !kept || !heldout || !h) return fail("null argument");
     const ChainInfo &cs = c->chains[src], &cd = c->chains[dst];
     if (cs.n != cd.n) return fail("fold chain must have the length of its source chain");

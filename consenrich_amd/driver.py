@@ -63,7 +63,9 @@ class FitConfig:
     nu: float = 8.0
     use_lambda: bool = False
     use_kappa: bool = True
-    use_apn: bool = False                        # adaptive process noise (pyx:510-527; the sequential kernel); excludes use_kappa (core.py:3975)
+    use_apn: bool = False                        # ECM_useAPN as `runConsenrich` passes it: ALWAYS together with processQScale = ones
+                                                 # (core.py:3282, 4296), which switches the adaptation itself off (pyx:510: `useAPN and
+                                                 # not useProcessQScale`); what remains is kappa off (core.py:3975) and qScale = 1
     fit_background: bool = True
     zero_center: bool = False
     use_nonnegative: bool = True
@@ -188,7 +190,7 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
             fits[c].warm_start_passes = int(info[c]["passes"])
     prev_obj = [float("nan")] * nc
     fwd_flags = (L.RETURN_NLL | (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
-                 | (L.USE_APN if cfg.use_apn else 0))
+                 | ((L.USE_APN | L.USE_QSCALE) if cfg.use_apn else 0))
     have_stats = False
     planned = planned_outer_passes(cfg)
     last_inner = [False] * nc
@@ -204,7 +206,8 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
         if not have_stats:
             batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, chain_mask=active)
+                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn,
+                            chain_mask=active)
         for c in range(nc):
             if active[c]:
                 fits[c].ecm_iters.append(int(outs[c].iters_done))
@@ -348,12 +351,12 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     fits = fit_batch(batch, cfg, keep_background=initial_background is not None)
 
     mult_flags = (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
-    apn_flag = L.USE_APN if cfg.use_apn else 0
+    apn_flag = (L.USE_APN | L.USE_QSCALE) if cfg.use_apn else 0      # (the resident qScale track is all ones: core.py:5688)
     if cfg.fit_background:
         # final fixed-background ECM phase (core.py:5385-5440): every chain, converged background, warm-started multipliers
         batch.stats()
         outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn)
+                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn)
         for c in range(nc):
             fits[c].final_ecm_iters = int(outs[c].iters_done)
             fits[c].final_ecm_nll = float(outs[c].final_nll)
@@ -368,7 +371,7 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags | apn_flag)
     batch.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
     if return_precision_diagnostics:
-        batch.diagnostics(mult_flags)
+        batch.diagnostics(mult_flags | (L.USE_QSCALE if cfg.use_apn else 0))
     for c in range(nc):
         fits[c].final_nll = float(sum_nll[c])
         fits[c].final_forward_nis = float(sum_d[c]) / float(batch.chain_lens[c])      # phiHat = sumD / n (pyx:6627)
@@ -394,3 +397,48 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
             res.append(precision_diagnostics(batch, cfg, c, q0, state_model))
         results.append(tuple(res))
     return fits, results
+
+
+def fold_chain_lengths(specs) -> List[int]:
+    """Chain lengths of the batch `run_folds_batch` expects: chromosome c's folds are consecutive chains of its length."""
+    out: List[int] = []
+    for sp in specs:
+        out += [int(np.asarray(sp["data"]).shape[1])] * int(sp["folds"])
+    return out
+
+
+def run_folds_batch(batch: DeviceBatch, cfg: FitConfig, specs, *, block_len_intervals: int, model_q0=None,
+                    return_precision_diagnostics: bool = False):
+    """The delete-block calibration fold loop (uncertainty.py:1370-1419: per fold `cmakeFoldMaskAndInformation`, then a FULL
+    `runConsenrich(matrixData, matrixMunc, observationMask=mask, **fitKwargs)`) for every fold of every chromosome as ONE
+    device-resident batch: each (chromosome, fold) is a chain; its masked variance matrix (1e30 in the deleted (replicate,
+    block) cells, core.py:2759-2780) is made on the device from one upload per chromosome; `run_consenrich_batch` then runs
+    every chain as a full fit -- its own Q0 seed on its masked matrices (cfg.seed_q), background warm start, alternation,
+    final ECM phase, final pass.  Chains are independent fits, so a fold's result equals the single-chain fit of the
+    host-masked matrices (tests: bit for bit in the default mode).
+
+    specs: one dict per chromosome -- data, munc (float32 (m, n)), folds, fold_block_len, block_fold (int32 per block),
+    reps_count (int64 per block), reps (int64 (blocks, slots)) as `cmakeFoldSpec` returns them, pad, rho (default 0).
+    The batch must be configured with `fold_chain_lengths(specs)`.
+    Returns (fits, results, info): fits / results per chain as `run_consenrich_batch` (background always returned),
+    info[c][f] = (keptInformation, heldoutInformation, h) float64 tracks of fold f of chromosome c."""
+    want = fold_chain_lengths(specs)
+    if list(batch.chain_lens) != want:
+        raise ValueError("the batch must be configured with fold_chain_lengths(specs)")
+    info = []
+    first = 0
+    for sp in specs:
+        nf = int(sp["folds"])
+        if nf < 1:
+            raise ValueError("folds must be positive")
+        batch.upload(first, np.ascontiguousarray(sp["data"], np.float32), np.ascontiguousarray(sp["munc"], np.float32))
+        tracks = [None] * nf
+        # folds 1 .. nf-1 are masked copies of the uploaded matrices, fold 0 is then made in place
+        for f in list(range(1, nf)) + [0]:
+            tracks[f] = batch.make_fold(first, first + f, int(sp["fold_block_len"]), f, sp["block_fold"], sp["reps_count"],
+                                        sp["reps"], pad=float(sp["pad"]), rho=float(sp.get("rho", 0.0)))
+        info.append(tracks)
+        first += nf
+    fits, results = run_consenrich_batch(batch, cfg, block_len_intervals=block_len_intervals, model_q0=model_q0,
+                                         return_background=True, return_precision_diagnostics=return_precision_diagnostics)
+    return fits, results, info

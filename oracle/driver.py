@@ -96,11 +96,12 @@ def planned_outer_passes(cfg):
     return max(int(cfg["min_outer"]), max(1, int(cfg["outer_passes"])))
 
 
-def _apn_kwargs(cfg):
+def _apn_kwargs(cfg, n=None):
     """adaptive process noise (core.py:3273-3279: APN_minQ = minQ, APN_maxQ = max(maxQ, minQ) or inf); off unless cfg asks"""
     if not cfg.get("use_apn"):
         return {}
-    return {"ECM_useAPN": True, "APN_minQ": float(cfg["apn"][0]), "APN_maxQ": float(cfg["apn"][1])}
+    # (the reference passes processQScale = ones with it, core.py:3282 / 4296: that disables the adaptation itself, pyx:510)
+    return {"ECM_useAPN": True, "APN_minQ": float(cfg["apn"][0]), "APN_maxQ": float(cfg["apn"][1]), "processQScale": np.ones(int(n), np.float32)}
 
 
 def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, initial_kappa=None):
@@ -125,7 +126,7 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
               ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
               obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
               procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
-              logIterations=False, **_apn_kwargs(cfg))
+              logIterations=False, **_apn_kwargs(cfg, n))
     if d == 2:
         kw["matrixF"] = np.asarray(cfg["F"], np.float32)
     out = None
@@ -159,7 +160,7 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
                    ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
                    obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
                    procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
-                   **_apn_kwargs(cfg))
+                   **_apn_kwargs(cfg, n))
         if d == 2:
             fkw["matrixF"] = kw["matrixF"]
         obj = penalized_objective(float(fwd(**fkw)[3]), munc, bg, lam, kap, cfg)
@@ -229,7 +230,7 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
                   ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
                   obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
                   procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
-                  **_apn_kwargs(cfg))
+                  **_apn_kwargs(cfg, n))
     if d == 2:
         common["matrixF"] = np.asarray(cfg["F"], np.float32)
     adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)
@@ -247,7 +248,7 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
     fwd = orc.cforwardPass if d == 2 else orc.cforwardPassLevel
     phi, _, D, nll = fwd(matrixData=adj, matrixPluginMuncInit=munc, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
                          vectorD=D, returnNLL=True, storeNLLInD=False, lambdaExp=lam if cfg["use_lambda"] else None,
-                         processPrecExp=kap if cfg["use_kappa"] else None, processQScale=np.ones(n, np.float32), **common)
+                         processPrecExp=kap if cfg["use_kappa"] else None, **{"processQScale": np.ones(n, np.float32), **common})
     bkw = dict(matrixData=adj, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
     if d == 2:
         bkw["matrixF"] = common["matrixF"]

@@ -1411,6 +1411,74 @@ def test_folds_as_extra_chains_of_a_batch(product, oracle):
     assert not np.array_equal(xs[0], xs[1])
 
 
+def test_fold_loop_as_one_batch_of_full_fits(product, oracle):
+    """`driver.run_folds_batch` (uncertainty.py:1370-1419): every (chromosome, fold) of the delete-block calibration is a chain
+    of ONE device-resident batch and runs as a FULL fit -- its own Q0 seed on its masked matrices, background warm start, outer
+    alternation, final ECM phase, final pass.  Each fold chain must equal (a) the single-chain device fit of the host-masked
+    matrices BIT FOR BIT (default mode: chains are independent of how a batch is composed) with the same discrete history,
+    and (b) the CPU twin run on the host-masked matrices within the parity tolerance."""
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.driver import FitConfig, fold_chain_lengths, run_consenrich_batch, run_folds_batch
+    from oracle import background as bgo
+    from oracle import driver as odrv
+    from oracle import qseed as oq
+
+    m, folds, fbl = 5, 2, 40
+    mp = ModelParams(state_dim=2)
+    pad = float(np.float32(mp.pad))
+    ins = _bg_batch_fixture([2600, 1500], m, 7300, bg_amp=0.3)
+    specs = []
+    for c, (data, munc) in enumerate(ins):
+        bf, rc, rb = unc_cases.fold_spec(m, data.shape[1], fbl, folds, 0.4, 90 + c)
+        specs.append(dict(data=data, munc=munc, folds=folds, fold_block_len=fbl, block_fold=bf, reps_count=rc, reps=rb, pad=pad))
+    pen = bgo.penalties(40, 2.0)
+    cfg = FitConfig(penalties=pen, ecm_iters=4, ecm_rtol=1e-4, inner_iters=3, outer_passes=3, min_outer=1, patience=1,
+                    shift_rtol=2e-2, neg_multiplier=2.0, seed_q=True)
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, fold_chain_lengths(specs))
+        fits, results, info = run_folds_batch(b, cfg, specs, block_len_intervals=500)
+    assert len(fits) == len(results) == folds * len(ins)
+    worst = {}
+    chain = 0
+    for c, (data, munc) in enumerate(ins):
+        n = data.shape[1]
+        act = np.ones((m, n), np.uint8)
+        tot = oracle.cobservationTotalInformation(munc, act, np.ones(n), False, pad, 0.0)
+        for f in range(folds):
+            mask, kept, held, h = oracle.cmakeFoldMaskAndInformation(m, n, fbl, f, specs[c]["block_fold"], specs[c]["reps_count"],
+                                                                     specs[c]["reps"], munc, act, tot, np.ones(n), False, pad, 0.0)
+            for got, ref in zip(info[c][f], (kept, held, h)):
+                assert np.array_equal(got, ref, equal_nan=True)
+            masked = munc.copy()
+            masked[mask == 0] = np.float32(1.0e30)                     # core.py:2759-2780
+            # (a) the same fit as a batch of its own
+            with DeviceBatch(0) as b1:
+                b1.configure(mp, m, [n])
+                b1.upload(0, data, masked)
+                f1, r1 = run_consenrich_batch(b1, cfg, block_len_intervals=500, return_precision_diagnostics=False)
+            fa, fb = fits[chain], f1[0]
+            assert (fa.passes, fa.ecm_iters, fa.irls_passes, fa.outer_stop_reason, fa.final_ecm_iters) == \
+                   (fb.passes, fb.ecm_iters, fb.irls_passes, fb.outer_stop_reason, fb.final_ecm_iters), (c, f)
+            assert np.array_equal(fa.q0, fb.q0)
+            for a_, b_ in zip(results[chain], r1[0]):
+                assert np.array_equal(a_, b_), (c, f)
+            # (b) the CPU twin on the host-masked matrices, with the oracle's seed for THOSE matrices
+            Q, _ = oq.estimate_initial_process_noise(oq, matrixData=data, matrixMunc=masked, pad=cfg.pad, stateModel="levelTrend",
+                                                     minQ=cfg.min_q, maxQ=cfg.max_q, deltaF=cfg.delta_f, robustTNu=cfg.nu)
+            assert np.array_equal(Q, fa.q0), (c, f, Q, fa.q0)
+            ref = odrv.run_consenrich_chain(data, masked, _twin_cfg(mp, cfg, pen, Q0=Q))
+            assert fa.passes == ref["passes"] and fa.ecm_iters == ref["ecm_iters"], (c, f, fa.ecm_iters, ref["ecm_iters"])
+            xs, Ps, resid, nis, bmap, bg = results[chain]
+            lvl = np.maximum(np.abs(ref["out_xs"][:, :1]).astype(np.float64), 1.0)
+            worst[f"c{c}f{f}:xs"] = float((np.abs(xs.astype(np.float64) - ref["out_xs"]) / lvl).max())
+            worst[f"c{c}f{f}:bg"] = float(np.abs(bg - ref["out_background"]).max() / max(float(np.abs(ref["out_background"]).max()), 1e-3))
+            assert worst[f"c{c}f{f}:xs"] <= 1e-4 and worst[f"c{c}f{f}:bg"] <= 2e-5, worst
+            chain += 1
+    # folds of one chromosome really differ (different cells masked)
+    assert not np.array_equal(results[0][0], results[1][0])
+    print("run_folds_batch worst relative errors vs the CPU twin:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+
+
 @pytest.mark.parametrize("d", [2, 1])
 def test_per_chain_process_noise(product, oracle, d):
     """csr_batch_set_chain_q: every chain of a batch with its own base process noise (the reference seeds Q0 per
