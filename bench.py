@@ -13,10 +13,14 @@ resident in HBM:  per-bin sufficient statistics of (data, munc)  ->  forward fil
 With N > 1 the chains are LPT-sharded over the ranks (strong scaling: the genome is fixed); there is no data-path
 collective -- the one RCCL call is the final track gather, done once after the timed region and reported separately.
 
-`value` is measured in the library's DEFAULT validation mode (bit-exact sequential semantics, x_tol_ulps = 0: every output of
-the forward pass equals the reference's bit for bit -- the only mode that holds the 1e-5 gate through the ECM loop on
-ill-conditioned data, tests/test_hard_data.py).  The opt-in 2-ulp throughput mode (a single pass stays within a few float32
-ulps of the reference, gated on hard data by the same test file) is reported beside it as `throughput_mode`.
+`value` is measured in the library's DEFAULT validation mode (x_tol_ulps = 0): the SEQUENTIAL semantics of the library's own
+arithmetic -- every speculative block is repaired to the fixed point bit for bit, so results do not depend on blocking.  Against
+the REFERENCE that arithmetic differs at ~2^-50 per operation (sufficient statistics hoisted out of the recursion, pyx:271-282;
+Newton-refined reciprocals), which flips a float32 rounding about once per 1e7 stored values: measured 0 differing elements of
+8.7e6 in one forward pass over a chr1-sized hard chain, and after a 6-iteration kappa-ECM at that size every bin within 0.10 x
+the 1e-5 gate (tests/test_hard_data.py, profiles/r04_parity_worst_hard_*.json).  The opt-in 2-ulp throughput mode (a single pass
+within a few float32 ulps of the reference -- 33 % of the filtered values differ in the last bits --, gated on hard data by the
+same test file) is reported beside it as `throughput_mode`.
 
 No PyTorch: a launcher only provides the rank environment; the barrier and the max-over-ranks of the timed region are RCCL
 all-reduces on the library's stream (consenrich_amd.sharding.RcclComm -> csr_comm_* in libconsenrich_amd.so, librccl
@@ -100,7 +104,7 @@ def cpu_baseline(m: int, max_seconds: float = 15.0):
         spent += dt
         reps += 1
     return {
-        "value": n / best, "unit": "genomic bins/s", "cores": 1, "kind": "port",
+        "value": n / best, "unit": "genomic bins/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
         "sample": f"oracle C port (forward store+NLL, backward+residuals), 1 thread, chr1-sized chain "
                   f"({n} bins x {m} samples), best of {reps} passes after warm-up ({spent:.1f} s of CPU work)",
     }
@@ -278,15 +282,19 @@ def main() -> int:
                "alg_bytes_per_bin": kernel_alg_bytes(dom, m, 2), "bins_per_launch": my_bins,
                "avg_launch_ms": crit[dom]["avg_ms"], "launches_per_step": crit[dom]["launches"] / max(args.steps, 1)}
         if dom == "fwd_state":
-            out["limit"] = ("dependent fp64 latency, not bandwidth: the exact float32-rounded state recursion is sequential per "
-                            "chain; one wavefront per superblock walks it once as a 64-lane shift register (~25 ns per bin) and "
-                            "re-runs it in delta form (~12 ns per bin) whenever its predecessor publishes a new carry; the launch "
-                            "lasts as long as the true trajectory needs to meet a speculative one on the slowest chain "
-                            "(DESIGN.md section 3)")
+            out["limit"] = ("instruction issue of ONE wavefront per SIMD, not bandwidth: the exact float32-rounded state recursion is "
+                            "sequential per chain; a wavefront issues one instruction per ~5 cycles whatever its type "
+                            "(scripts/ubench/issue_cost.hip), the walk costs 12 instructions per bin (~30 ns), a re-run in delta "
+                            "form ~5 per bin (~14 ns); the launch lasts as long as the true trajectory needs to meet a speculative "
+                            "one on the slowest chain (DESIGN.md section 3)")
         return out
 
     # ---- the headline: the library's default mode --------------------------------------------------------------------
-    elapsed = timed(batch, lambda: batch.step(flags, what), args.warmup, args.steps)
+    # three timed windows of exactly K steps each (every one bracketed by barrier + synchronize, max over ranks); the line
+    # carries the MEDIAN window (a latency-bound step's time depends on which chain is the unlucky one: box-to-box and
+    # window-to-window spread is several per cent) and the spread beside it
+    windows = sorted(timed(batch, lambda: batch.step(flags, what), args.warmup if w == 0 else 0, args.steps) for w in range(3))
+    elapsed = windows[1]
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = total_bins * args.steps / elapsed
     per_kernel = profile_kernels(batch, args.steps)
@@ -331,6 +339,10 @@ def main() -> int:
                                             "value": total_bins * (folds + 1) * fsteps / ef, "unit": "genomic bins/s",
                                             "note": "every chromosome three times in the batch (fit + 2 fold refits, "
                                                     "synthetic data of the same shape); bins of all refits counted"}
+        fb.stats()
+        efe = timed(fb, lambda: ecm_once(fb), 1, 1)
+        extras["with_calibration_folds"]["ecm_ms_per_iter"] = 1000.0 * efe / ecm_iters
+        extras["with_calibration_folds"]["ecm_bin_sweeps_per_s"] = total_bins * (folds + 1) * ecm_iters * inner / efe
         fb.close()
         # (3) the opt-in throughput mode (2-ulp carry acceptance): same step, same outputs within a few float32 ulps
         tb = DeviceBatch(local_rank, x_tol_ulps=2)
@@ -357,6 +369,17 @@ def main() -> int:
                         "reference's own sensitivity to ulp-level perturbations, which is why it is not the default"}
         tb.close()
 
+    # what a measured scaling curve has to be read against: every rank's state-chain time and longest chromosome
+    def per_rank(v: float):
+        if comm is None:
+            return [v]
+        return [comm.allreduce_sum(v if r == rank else 0.0) for r in range(world)]
+
+    state_ms = (roofline or {}).get("avg_launch_ms", 0.0) if (roofline or {}).get("kernel") == "fwd_state" else \
+        per_kernel.get("fwd_state_chain", {}).get("ms_per_step", 0.0)
+    ranks_info = {"fwd_state_ms": per_rank(float(state_ms)), "longest_chain_bins": [int(v) for v in per_rank(float(max(my_lens)))],
+                  "bins": [int(v) for v in per_rank(float(my_bins))]}
+
     gather_ms, gather_note = None, comm_note
     if comm_kind == "rccl" and not args.no_gather:
         # final track gather (state + its variance): once per job, packed on the device from the exported arrays and
@@ -380,12 +403,16 @@ def main() -> int:
         out = {
             "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples",
             "value": value, "unit": "genomic bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_min": 1000.0 * windows[0] / max(args.steps, 1),
+            "ms_per_step_median": ms_per_step, "ms_per_step_max": 1000.0 * windows[2] / max(args.steps, 1), "timed_windows": 3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 arithmetic on f32 storage", "data": "synthetic",
             "config": {
                 "workload": f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
                             "stats + forward(store,NLL) + RTS backward + lagCov + reference-layout tracks + residuals, "
-                            "levelTrend",
+                            "levelTrend, constant process noise (no per-bin lambda / kappa / qScale, one Q0 for every chain: "
+                            "the case of a plain forward + backward call; the ECM loop's sweeps carry kappa per bin and are "
+                            "reported under `ecm`)",
                 "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"], "q0_diag": [q00, q11],
                 "warm_bins": [rs["warm_p"], rs["warm_x"], rs["warm_b"]], "x_tol_ulps": rs["x_tol_ulps"],
                 "validation": "bit-exact sequential semantics (library default)" if rs["x_tol_ulps"] == 0
@@ -406,6 +433,7 @@ def main() -> int:
                             # launches of the state chain that gave up on a bounded wait (the pass form ran instead)
                             "tail_groups": rs.get("tail_groups", 0), "state_chain_bailouts": rs.get("sb_bailouts", 0)},
             "gather_ms": gather_ms,
+            "per_rank": ranks_info,
         }
         out.update(extras)
         if gather_note:

@@ -51,7 +51,6 @@ struct Prm {
     uint32_t flags;     // CSR_* bits
     int warm;           // warm-up length in blocks for the kernel being launched
     int debugForce;     // debugging aid: validation treats every carry as mismatching
-    int probeTiled;     // measurement probe only (wrong results): k_stats reads [tile][sample][64 bins] addresses
     int predCompact;    // fused forward chain: only the NIS epilogue reads the gain record, and only P00pred of it --
                         // store that float (tPP, 4 B/bin) instead of the 16-byte record
     float *tPP;
@@ -133,8 +132,6 @@ struct Prm {
     unsigned int *localFixCount;    // blocks repaired inside the speculative kernel (wave_local_repair): statistics only
     // superblock view of the bit-exact state chain (k_sb_state_*): widened {gs, zbar, P00pred, P10pred} records in the view's
     // blocking, and the index of a padding block behind the last group that lanes without a block of their own walk
-    const double4 *sbRec;
-    int64_t sbPad;
     unsigned long long *sbDbg;      // CONSENRICH_AMD_SB_DEBUG: counters of the delta-form repair passes (blocks, batches, rounds, fallback batches, merged exits), else null
     int prevKind;
     const void *prevCarryIn, *prevCarryOut;
@@ -343,57 +340,6 @@ __device__ __forceinline__ BinStats bin_stats(const float *__restrict__ data, co
     o.s2c = s2 > 0.0 ? s2 : 0.0;
     o.logr = log(mant) + (double)ex * 0.693147180559945309417232121458;
     return o;
-}
-
-// One workgroup = one tile of TS steps x TL lanes (blocks) of a wave-group: TL runs of TS consecutive bins are read
-// from every sample row (TS*4-byte contiguous segments), reduced over the m samples, transposed through LDS and
-// written as TS rows of TL*8 bytes (a full 128-B line for TL = 16).  TS*TL/256 passes of 256 threads per tile; the tile
-// is kept small (<= 35 KB of LDS) so that >= 4 waves/SIMD are resident to cover the HBM latency.
-template <int TS, int TL, int UN = 8>
-__global__ __launch_bounds__(256) void k_stats(Prm p) {
-    constexpr int RP = 256 / TS;            // runs handled per pass (TS <= 256)
-    constexpr int LT = 64 / TL;             // lane-tiles per wave-group
-    constexpr int NP = TS * TL / 256;       // passes
-    __shared__ double tile[4][TS][TL + 1];
-    const int tilesPerGroup = (p.B / TS) * LT;
-    const int64_t G = blockIdx.x / tilesPerGroup;
-    const int rem = (int)(blockIdx.x % tilesPerGroup);
-    const int s0 = (rem / LT) * TS;
-    const int l0 = (rem % LT) * TL;
-    const int t = threadIdx.x;
-    const int si = t % TS, r = t / TS;
-#pragma unroll 1
-    for (int pass = 0; pass < NP; ++pass) {
-        const int ll = pass * RP + r;
-        const int64_t b = G * 64 + l0 + ll;
-        BinStats o = {0.0, 0.0, 0.0, 0.0};
-        if (b < p.NB) {
-            const int4 bi = p.blk[b];
-            if (s0 + si < bi.y && chain_on(p, b)) {
-                const int64_t g = (int64_t)bi.x + s0 + si;
-                if (p.probeTiled) {
-                    const int64_t gt = (g >> 6) * ((int64_t)p.m << 6) + (g & 63);
-                    o = bin_stats<UN>(p.data, p.munc, 64, gt, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
-                } else
-                o = bin_stats<UN>(p.data, p.munc, p.Npad, g, p.m, p.pad, p.bg ? p.bg[g] : 0.f);
-            }
-        }
-        tile[0][si][ll] = o.s0;
-        tile[1][si][ll] = o.zbar;
-        tile[2][si][ll] = o.s2c;
-        tile[3][si][ll] = o.logr;
-    }
-    __syncthreads();
-    const int64_t rowBase = (G * (int64_t)p.B + s0) * 64 + l0;
-#pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        const int idx = it * 256 + t;
-        const int row = idx / TL, ll = idx % TL;
-        const int64_t o = rowBase + (int64_t)row * 64 + ll;
-        p.tSZ[o] = make_double2(tile[0][row][ll], tile[1][row][ll]);
-        p.tS2c[o] = tile[2][row][ll];
-        p.tLogR[o] = tile[3][row][ll];
-    }
 }
 
 // Four consecutive bins per thread, 16-byte loads (same sums in the same order as bin_stats: results are bit-identical).
@@ -2157,236 +2103,6 @@ __global__ __launch_bounds__(64) void k_state_seq_trend(Prm p, const int64_t *ch
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bit-exact state chain on SUPERBLOCKS (levelTrend).  Two float32-rounded state trajectories that start apart agree to
-// an ulp after ~10^2 bins but need ~10^4 to coincide bit for bit (the trend's ulps are far finer than the level's, so a
-// trend difference is only ever corrected when the level happens to round differently: scripts/ubench/merge_time.c), so
-// bitwise validation never passes on the batch's own 32..256-bin blocks.  This chain therefore works on a second
-// blocking of the batch: pd.B = thousands of bins per lane, window p.warm of the same order.  The machinery is that of
-// k_chain_spec / k_chain_fix (carry-in recorded, carry-out ping-pong, passes to the fixed point = the sequential
-// recursion); the walker is specialised the way k_state_seq_trend is, because a launch has only tens of wavefronts and
-// each is bound by instruction issue: records arrive widened (double4 {gs, zbar, P00pred, P10pred}), EVERY lane of a
-// wavefront walks every step (no predicates: lanes without work walk a padding block, sbPad, or recompute what they
-// already hold), loads run a register buffer ahead.
-// ---------------------------------------------------------------------------------------------------------------
-// F1: F01 == 1 as well (deltaF = 1, the reference's default, constants.py:146): the predicted level r32(x0 + x1) of two
-// float32 values IS their float32 sum -- double rounding through the 53-bit sum is innocuous for an addition when
-// 53 >= 2 * 24 + 2 (Figueroa) -- so it is ONE v_add_f32 instead of fma + two conversions.  The conversions are what the
-// dependent path of a step mostly consists of (scripts/ubench/step_lat.hip: a v_cvt pair costs as much as three fp64
-// operations), and the carries therefore stay float32 between steps: the same bits with 6 instead of 8 dependent instructions.
-template <bool UF, bool F1>
-__device__ __forceinline__ void sb_step(const Prm &p, float &x0, float &x1, const double4 &r, float2 &out) {
-    if constexpr (UF && F1) {
-        const float xpf = x0 + x1;
-        const double xp0 = (double)xpf, x1d = (double)x1;
-        const double dl = r.x * (r.y - xp0);
-        out.x = (float)fma(r.z, dl, xp0);
-        out.y = (float)fma(r.w, dl, x1d);
-    } else if constexpr (UF) {
-        const double x1d = (double)x1;
-        const double xp0 = r32(fma(p.F01, x1d, (double)x0));
-        const double dl = r.x * (r.y - xp0);
-        out.x = (float)fma(r.z, dl, xp0);
-        out.y = (float)fma(r.w, dl, x1d);
-    } else {
-        FwdXTrend::Carry c{x0, x1};
-        FwdXTrend::In in;
-        in.gs = r.x; in.zbar = r.y;
-        in.cp = make_float2((float)r.z, (float)r.w);       // exact round trip of float32 values
-        FwdXTrend::step<false>(p, c, in, 0, 0, 0, 0);
-        out = make_float2(c.x0, c.x1);
-    }
-    x0 = out.x;
-    x1 = out.y;
-}
-// Steps [sLo, sHi) (multiples of 2 * SB_U) of the block whose slot base is `base`, all 64 lanes.  Two register buffers of
-// SB_U records; hipcc drains the memory counter (loads AND stores, one counter on gfx9) at the loop's back-edge, so the
-// body ends with SB_U steps that issue nothing: the outputs of the second half are held in registers and stored at the
-// top of the next iteration, and everything still in flight at the back-edge was issued >= SB_U steps (~0.7 us) earlier.
-// (With the stores where the results are produced the drain waited for the acknowledgement of a store issued a few
-// instructions earlier, once per 2 * SB_U steps: 73 instead of ~50 ns per step.)
-#define SB_U 16
-template <bool UF, bool F1, bool STORE>
-__device__ __forceinline__ void sb_walk(const Prm &p, float &x0, float &x1, int64_t base, int sLo, int sHi) {
-    const double4 *r = p.sbRec + base + (int64_t)sLo * 64;
-    float2 *o = p.tXf + base + (int64_t)sLo * 64;
-    const int cnt = sHi - sLo;
-    double4 A[SB_U], Bq[SB_U];
-    float2 held[SB_U];
-#pragma unroll
-    for (int u = 0; u < SB_U; ++u) {
-        A[u] = r[(int64_t)u * 64];
-        held[u] = make_float2(0.f, 0.f);
-    }
-#pragma unroll 1
-    for (int i0 = 0; i0 < cnt; i0 += 2 * SB_U) {
-        if constexpr (STORE) {
-            if (i0 > 0) {
-#pragma unroll
-                for (int u = 0; u < SB_U; ++u) o[(int64_t)(i0 - SB_U + u) * 64] = held[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) Bq[u] = r[(int64_t)(i0 + SB_U + u) * 64];
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) {
-            float2 v;
-            sb_step<UF, F1>(p, x0, x1, A[u], v);
-            if constexpr (STORE) o[(int64_t)(i0 + u) * 64] = v;
-        }
-        if (i0 + 2 * SB_U < cnt) {
-#pragma unroll
-            for (int u = 0; u < SB_U; ++u) A[u] = r[(int64_t)(i0 + 2 * SB_U + u) * 64];
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) sb_step<UF, F1>(p, x0, x1, Bq[u], held[u]);
-    }
-    if constexpr (STORE) {
-        if (cnt > 0) {
-#pragma unroll
-            for (int u = 0; u < SB_U; ++u) o[(int64_t)(cnt - SB_U + u) * 64] = held[u];
-        }
-    }
-}
-
-// The same walk for the lane's OWN block with wave-uniform addressing: all 64 blocks of a wavefront belong to one wave-group
-// G, so the row of step s starts at the uniform address (G * B + s) * 64 and a lane adds its own index.  The records and the
-// outputs go through BUFFER instructions (resource descriptor of the group's region in SGPRs, the lane's byte offset in one
-// VGPR computed once, the row offset in an SGPR advanced by the scalar unit): the per-step 64-bit vector address arithmetic
-// of sb_walk -- 3-4 of its ~18 instructions per step, on a wavefront that is bound by instruction issue -- disappears.
-// Lanes without a block of their own (past the batch's last block, inactive chains) walk their natural slots of the group:
-// zeroed records, outputs nobody reads.
-typedef unsigned int csr_u4 __attribute__((ext_vector_type(4)));
-typedef unsigned int csr_u2 __attribute__((ext_vector_type(2)));
-#define CSR_RSRC_FLAGS 0x00020000     /* raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950) */
-__device__ __forceinline__ double4 sb_rec_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    const csr_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    const csr_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0);
-    return make_double4(words2double(a.x, a.y), words2double(a.z, a.w), words2double(b.x, b.y), words2double(b.z, b.w));
-}
-__device__ __forceinline__ void sb_out_store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, float2 v) {
-    csr_u2 w;
-    w.x = __float_as_uint(v.x);
-    w.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, ws, voff, soff, 0);
-}
-template <bool UF, bool F1, bool STORE>
-__device__ __forceinline__ void sb_walk_u(const Prm &p, float &x0, float &x1, unsigned G, unsigned lane, int B) {
-    // the group's region: B rows of 64 records (32 B each: <= 16 MB for 8192-bin superblocks) / 64 outputs (8 B each)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double4 *>(p.sbRec) + (size_t)G * (size_t)B * 64u, 0, B * 64 * 32, CSR_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.tXf + (size_t)G * (size_t)B * 64u, 0, B * 64 * 8,
-                                                                        CSR_RSRC_FLAGS);
-    const int vr = (int)lane * 32, vo = (int)lane * 8;
-    double4 A[SB_U], Bq[SB_U];
-    float2 held[SB_U];
-#pragma unroll
-    for (int u = 0; u < SB_U; ++u) {
-        A[u] = sb_rec_load(rs, vr, u * 2048);
-        held[u] = make_float2(0.f, 0.f);
-    }
-#pragma unroll 1
-    for (int i0 = 0; i0 < B; i0 += 2 * SB_U) {
-        if constexpr (STORE) {
-            if (i0 > 0) {
-#pragma unroll
-                for (int u = 0; u < SB_U; ++u) sb_out_store(ws, vo, (i0 - SB_U + u) * 512, held[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) Bq[u] = sb_rec_load(rs, vr, (i0 + SB_U + u) * 2048);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) {
-            float2 v;
-            sb_step<UF, F1>(p, x0, x1, A[u], v);
-            if constexpr (STORE) sb_out_store(ws, vo, (i0 + u) * 512, v);
-        }
-        if (i0 + 2 * SB_U < B) {
-#pragma unroll
-            for (int u = 0; u < SB_U; ++u) A[u] = sb_rec_load(rs, vr, (i0 + 2 * SB_U + u) * 2048);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) sb_step<UF, F1>(p, x0, x1, Bq[u], held[u]);
-    }
-    if constexpr (STORE) {
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) sb_out_store(ws, vo, (B - SB_U + u) * 512, held[u]);
-    }
-}
-
-template <bool UF, bool F1>
-__global__ __launch_bounds__(64) void k_sb_state_spec(Prm p) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b < p.NB && chain_on(p, b);
-    int4 bi = make_int4(0, 0, 0, 0);
-    if (b < p.NB) bi = p.blk[b];
-    const int64_t bfirst = bi.z;
-    const int B = p.B;
-    using Carry = FwdXTrend::Carry;
-    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
-    Carry *cout = reinterpret_cast<Carry *>(p.carryOutA);
-    float x0 = (float)p.init, x1 = 0.0f;       // FwdXTrend::init_true == init_cold
-    // window: the last p.warm bins before the block (qmax blocks, the farthest one from step lo); a lane whose chain starts
-    // inside the window walks from the chain's first bin, i.e. from the true prior (k_chain_spec's rule)
-    const int qmax = (p.warm + B - 1) / B;
-    const int rem = p.warm - (qmax - 1) * B;
-    const int lo = B - rem;
-    const int avail = live ? (int)(b - bfirst) : 0;
-    for (int q = qmax; q >= 1; --q) {
-        const bool act = live && q <= avail;
-        if (!__any(act)) continue;
-        const int64_t base = tbase(act ? b - q : p.sbPad, B);
-        if (q == qmax && lo > 0 && __any(act && avail == qmax)) {
-            // lanes at their chain's first block need its head too
-            const bool head = act && avail == qmax;
-            float y0 = x0, y1 = x1;
-            sb_walk<UF, F1, false>(p, y0, y1, tbase(head ? b - q : p.sbPad, B), 0, lo);
-            x0 = head ? y0 : x0;
-            x1 = head ? y1 : x1;
-        }
-        float y0 = x0, y1 = x1;
-        sb_walk<UF, F1, false>(p, y0, y1, base, (q == qmax) ? lo : 0, B);
-        x0 = act ? y0 : x0;
-        x1 = act ? y1 : x1;
-    }
-    if (live) cin[b] = Carry{x0, x1};
-    // own block (a chain's last block is walked past its end into zeroed records: those slots are nobody's, and a chain's
-    // last carry-out is never read)
-    sb_walk_u<UF, F1, true>(p, x0, x1, blockIdx.x, threadIdx.x, B);
-    if (live) cout[b] = Carry{x0, x1};
-}
-
-template <bool UF, bool F1>
-__global__ __launch_bounds__(64) void k_sb_state_fix(Prm p, int which) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b < p.NB && chain_on(p, b);
-    using Carry = FwdXTrend::Carry;
-    Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
-    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
-    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
-    int4 bi = make_int4(0, 0, 0, 0);
-    if (b < p.NB) bi = p.blk[b];
-    const bool check = live && b != (int64_t)bi.z;
-    const Carry prev = ocur[check ? b - 1 : 0];
-    const Carry mine = cin[live ? b : 0];
-    const bool rerun = check & (((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) != 0u);
-    if (rerun) cin[b] = prev;
-    if (live && !rerun) onxt[b] = ocur[b];
-    if (!__any(rerun)) return;
-    // the whole wavefront walks: lanes that need no re-run recompute their block from the carry-in they hold (same bits)
-    float x0 = rerun ? prev.x0 : mine.x0, x1 = rerun ? prev.x1 : mine.x1;
-    sb_walk_u<UF, F1, true>(p, x0, x1, blockIdx.x, threadIdx.x, p.B);
-    if (rerun) {
-        onxt[b] = Carry{x0, x1};
-        atomicAdd(p.rerunCount, 1u);
-        atomicAdd(p.rerunCountPass, 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // SYSTOLIC walker of the bit-exact state chain (round 3; replaces the lane-per-superblock walker above by default).
 // One wavefront per superblock; its 64 lanes are 64 CONSECUTIVE BINS of the chain, so the records are read and the filtered
 // state is written in the natural (reference) layout, fully coalesced, once per 64 steps -- the lane-per-superblock walker
@@ -2409,29 +2125,17 @@ __device__ __forceinline__ float dpp_shr1_keep0(float keepLane0, float src) {
 // stayed empty: 47-70 instead of 25 ns per step).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_sys(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
-                                                float2 *__restrict__ natXf, int which, int fix) {
+                                                float2 *__restrict__ natXf) {
+    // (the speculative pass of the PASS form, CONSENRICH_AMD_SB_ASYNC=0 and the fallback of a bailed-out single launch:
+    // every superblock from the prior -- true for a chain's first one, cold otherwise; repairs: k_sb_delta)
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= p.NB || !chain_on(p, b)) return;                 // wave-uniform
     const int lane = threadIdx.x & 63;
     const int4 bi = p.blk[b];
     using Carry = FwdXTrend::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
-    const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
-    Carry *onxt = fix ? reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB) : reinterpret_cast<Carry *>(p.carryOutA);
+    Carry *onxt = reinterpret_cast<Carry *>(p.carryOutA);
     float c0 = (float)p.init, c1 = 0.0f;                      // FwdXTrend::init_true == init_cold
-    if (fix) {
-        if (b == (int64_t)bi.z) {                             // a chain's first superblock starts from the true prior: never re-run
-            if (lane == 0) onxt[b] = ocur[b];
-            return;
-        }
-        const Carry prev = ocur[b - 1], mine = cin[b];
-        const bool differ = ((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) != 0u;
-        if (!differ) {
-            if (lane == 0) onxt[b] = ocur[b];
-            return;
-        }
-        c0 = prev.x0; c1 = prev.x1;
-    }
     if (lane == 0) cin[b] = Carry{c0, c1};
     const int n = bi.y;
     const int64_t g0 = (int64_t)bi.x + lane;
@@ -2483,13 +2187,7 @@ __global__ __launch_bounds__(256) void k_sb_sys(Prm p, const float4 *__restrict_
         c1 = rl32(x1v, last);
         ga = gb; sa = sb_; gb = gc; sb_ = sc;
     }
-    if (lane == 0) {
-        onxt[b] = Carry{c0, c1};
-        if (fix) {
-            atomicAdd(p.rerunCount, 1u);
-            atomicAdd(p.rerunCountPass, 1u);
-        }
-    }
+    if (lane == 0) onxt[b] = Carry{c0, c1};
 }
 
 // One state step of a lane from a given predecessor state with the lane's own record (the systolic walker's step body)
@@ -2539,44 +2237,30 @@ __device__ __forceinline__ void sys_step(const Prm &p, float s0, float s1, doubl
 #ifndef SB_DELTA_DEPTH
 #define SB_DELTA_DEPTH 8
 #endif
-// spec = 1: the FIRST pass, against the trajectory of the 2-ulp state chain that the natural xf array holds (a few ulps from the
-// truth everywhere, self-consistent inside each of its own blocks): every superblock takes that trajectory's state at the bin
-// before it as its carry guess (delta = 0 to begin with) -- a round then proves whole stretches of the guess right and re-bases at
-// the guess's own block boundaries -- instead of walking all its bins from a cold prior.
+// (This is the PASS form's repair kernel -- CONSENRICH_AMD_SB_ASYNC=0 and the fallback of a bailed-out single launch; the
+// barrier-free k_sb_async carries the round-4 form of the same rounds: LDS ring, h-vector, shadow step.)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
-                                                  float2 *__restrict__ natXf, int which, int specAndRule) {
+                                                  float2 *__restrict__ natXf, int which, int rule) {
     // (readfirstlane: the wavefront's index is uniform, and telling the compiler so keeps the superblock's table entry, the
     // carries and the whole round control -- pos, f, delta -- in scalar registers)
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= p.NB || !chain_on(p, b)) return;
     const int lane = threadIdx.x & 63;
-    const int advMin = (specAndRule >> 8) & 0xff, advFrom = (specAndRule >> 16) & 0xff;     // the fallback rule (see batch())
-    const int spec = specAndRule & 1;
+    const int advMin = (rule >> 8) & 0xff, advFrom = (rule >> 16) & 0xff;     // the fallback rule (see batch())
     const int4 bi = p.blk[b];
     using Carry = FwdXTrend::Carry;
     Carry *cin = reinterpret_cast<Carry *>(p.carryIn);
     const Carry *ocur = reinterpret_cast<const Carry *>(which ? p.carryOutB : p.carryOutA);
-    Carry *onxt = spec ? reinterpret_cast<Carry *>(p.carryOutA) : reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
-    Carry prev, mine, oldOut;
-    if (spec) {
-        // carry guess = the resident (2-ulp) trajectory at the bin before the superblock; a chain's first superblock starts
-        // from the true prior, which is also where that trajectory started
-        const bool first = b == (int64_t)bi.z;
-        const float2 g = first ? make_float2((float)p.init, 0.0f) : natXf[(int64_t)bi.x - 1];
-        prev = Carry{g.x, g.y};
-        mine = prev;
-        oldOut = prev;                                          // (never used: spec never exits early)
-    } else {
-        if (b == (int64_t)bi.z) {                             // a chain's first superblock started from the true prior
-            if (lane == 0) onxt[b] = ocur[b];
-            return;
-        }
-        prev = ocur[b - 1]; mine = cin[b]; oldOut = ocur[b];
-        if ((((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) == 0u)) {
-            if (lane == 0) onxt[b] = oldOut;
-            return;
-        }
+    Carry *onxt = reinterpret_cast<Carry *>(which ? p.carryOutA : p.carryOutB);
+    if (b == (int64_t)bi.z) {                             // a chain's first superblock started from the true prior
+        if (lane == 0) onxt[b] = ocur[b];
+        return;
+    }
+    const Carry prev = ocur[b - 1], mine = cin[b], oldOut = ocur[b];
+    if ((((f2u(prev.x0) ^ f2u(mine.x0)) | (f2u(prev.x1) ^ f2u(mine.x1))) == 0u)) {
+        if (lane == 0) onxt[b] = oldOut;
+        return;
     }
     if (lane == 0) cin[b] = prev;
     if (p.sbDbg != nullptr && lane == 0) atomicAdd(p.sbDbg, 1ull);
@@ -2656,7 +2340,7 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
         sc0 = rl32(so.x, left - 1);
         sc1 = rl32(so.y, left - 1);
         // the true trajectory has met the old one bit for bit: everything behind this bin is already right
-        merged = !spec && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
+        merged = ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
         dbgFb += fallback ? 1u : 0u; dbgRounds += (unsigned)rounds; dbgBatches += 1u;
     };
 #pragma unroll 1
@@ -2677,10 +2361,8 @@ __global__ __launch_bounds__(256) void k_sb_delta(Prm p, const float4 *__restric
     }
     if (lane == 0) {
         onxt[b] = merged ? oldOut : Carry{t0, t1};
-        if (!spec) {
-            atomicAdd(p.rerunCount, 1u);
-            atomicAdd(p.rerunCountPass, 1u);
-        }
+        atomicAdd(p.rerunCount, 1u);
+        atomicAdd(p.rerunCountPass, 1u);
         if (p.sbDbg != nullptr) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - dbgT0);
             // slowest superblock of the launch sequence: ticks (10 ns), packed with its batches / rounds / fallbacks
@@ -2725,8 +2407,12 @@ struct SbAsync {
 // a chain is final (its whole filtered state stands in the reference layout): tell the host, which may start that chain's
 // smoother / residuals on another stream while other chains are still being repaired
 __device__ __forceinline__ void sb_chain_done(const Prm &p, const SbAsync &a, int64_t b, const int4 &bi, int lane) {
-    if (a.hostDone != nullptr && lane == 0 && b == (int64_t)bi.w)
-        __hip_atomic_store(a.hostDone + p.blkChain[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.hostDone != nullptr && b == (int64_t)bi.w) {          // (wave-uniform)
+        // every lane stored a part of the chain's last track: the WHOLE wavefront releases its stores at system scope, then
+        // lane 0 publishes (the scoped memory model orders a release only behind the releasing thread's own writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0) __hip_atomic_store(a.hostDone + p.blkChain[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
@@ -2734,6 +2420,10 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ void sb_publish(const SbAsync &a, int64_t b, int lane, float o0, float o1, unsigned ver, bool fin) {
+    // the trajectory this carry-out belongs to was stored by all 64 lanes: the whole wavefront releases at agent scope before
+    // lane 0 publishes {carry, version} (round-3 review: lane 0's release alone covers only lane 0's writes in the scoped model;
+    // it worked because s_waitcnt is per wavefront)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
         __hip_atomic_store(a.carry + b, ((unsigned long long)f2u(o1) << 32) | f2u(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.vf + b, ((unsigned long long)ver << 1) | (fin ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2754,7 +2444,9 @@ __device__ __forceinline__ unsigned lds_rd32_wait(const unsigned *q) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(q)) : "memory");
     return v;
 }
-template <int MODE>
+// DBG: the instance with the section timers and counters of CONSENRICH_AMD_SB_DEBUG (they cost a dozen instructions and five
+// branches per batch: not in the production instance)
+template <int MODE, bool DBG = false>
 __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restrict__ natGain, const float4 *__restrict__ natSZ,
                                                   float2 *__restrict__ natXf, SbAsync a) {
     extern __shared__ __attribute__((aligned(16))) unsigned sbRing[];
@@ -2771,7 +2463,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     const int nb = (n + 63) >> 6;
     // ---- the speculative walk: from the prior (true for a chain's first superblock, cold otherwise)
     float out0 = (float)p.init, out1 = 0.0f;
-    if (p.sbDbg != nullptr && b == 0 && lane == 0) p.sbDbg[0] = (unsigned long long)wall_clock64();
+    if (DBG && b == 0 && lane == 0) p.sbDbg[0] = (unsigned long long)wall_clock64();
     {
         float4 ga = natGain[g0], sa = natSZ[g0];
         float4 gb = ga, sb_ = sa;
@@ -2803,7 +2495,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     }
     unsigned ver = 1;
     sb_publish(a, b, lane, out0, out1, ver, first);
-    if (p.sbDbg != nullptr && lane == 0) atomicMax(p.sbDbg + 1, (unsigned long long)wall_clock64());
+    if (DBG && lane == 0) atomicMax(p.sbDbg + 1, (unsigned long long)wall_clock64());
     if (first) {
         sb_chain_done(p, a, b, bi, lane);
         return;
@@ -2822,7 +2514,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     unsigned dbgBatches = 0, dbgRounds = 0, dbgFb = 0;
     unsigned long long dbgTicks = 0;
     unsigned long long dbgSec[4] = {0, 0, 0, 0};      // s_memtime ticks: group top, batch prologue, rounds, batch epilogue (debug only)
-    const bool dbgOn = p.sbDbg != nullptr;
+    constexpr bool dbgOn = DBG;
     int brk = 0;                                    // first bin of the stored trajectory's last piece
     unsigned *const ring = sbRing + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SB_WAVE_W;
     unsigned *const pollRow = ring + 2 * SBG * SB_SLOT_W;
@@ -2881,7 +2573,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
             bool newer = false;
             unsigned long long cwNew = cw;
             int done = 0;
-            const long long dbgT0 = p.sbDbg != nullptr ? wall_clock64() : 0;
+            const long long dbgT0 = DBG ? wall_clock64() : 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's earlier stores of the trajectory are out; the ring is free
             issue_group(0);
 #pragma unroll 1
@@ -2995,7 +2687,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA of this run still lands in the ring
-            if (p.sbDbg != nullptr) dbgTicks += (unsigned long long)(wall_clock64() - dbgT0);
+            if (DBG) dbgTicks += (unsigned long long)(wall_clock64() - dbgT0);
             if (!newer) break;
             ++aborts;
             cw = cwNew;
@@ -3008,7 +2700,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     if (lane == 0) {
         atomicAdd(a.ctl + 2, runs);
         atomicAdd(a.ctl + 3, aborts);
-        if (p.sbDbg != nullptr) {
+        if (DBG) {
             atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
             atomicAdd(p.sbDbg + 3, (unsigned long long)dbgBatches);
             atomicAdd(p.sbDbg + 4, (unsigned long long)dbgRounds);
@@ -3053,32 +2745,6 @@ __global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__
         const int row = it * 4 + r0;
         if (s0 + row < len) dst[rowBase + (int64_t)row * 64 + lane] = tile[row][lane];
     }
-}
-
-// gain + statistics records of the batch's blocking -> widened records of the superblock view (one thread per destination slot)
-__global__ __launch_bounds__(256) void k_sb_records(Prm pd, const int64_t *srcChainFirst, int srcB, const int64_t *chainOff,
-                                                    const float4 *__restrict__ gain, const double2 *__restrict__ sz,
-                                                    double4 *__restrict__ dst) {
-    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int l = (int)(slot & 63);
-    const int64_t row = slot >> 6;
-    const int64_t G = row / pd.B;
-    const int s = (int)(row % pd.B);
-    const int64_t b = G * 64 + l;
-    if (b >= pd.NB || !chain_on(pd, b)) return;
-    const int4 bi = pd.blk[b];
-    if (s >= bi.y) return;
-    const int ch = pd.blkChain[b];
-    const int64_t rel = (int64_t)bi.x + s - chainOff[ch];
-    const int64_t i = tidx(srcChainFirst[ch] + rel / srcB, (int)(rel % srcB), srcB);
-    const float4 r = gain[i];
-    dst[slot] = make_double4(unpack_d(r.x, r.y), sz[i].y, (double)r.z, (double)r.w);
-}
-
-// diagnostic: a near-empty kernel (used to attribute kernel-boundary costs when profiling)
-__global__ __launch_bounds__(64) void k_probe(Prm p) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b < p.NB && p.blk[b].y < 0) p.rerunCount[3] = 1u;
 }
 
 // Validation / fix-up pass: a block whose recorded carry-in differs from its neighbour's current carry-out is re-run
@@ -3476,26 +3142,6 @@ __global__ __launch_bounds__(256) void k_import_f32(Prm p, const float *nat, int
     if (s >= bi.y) return;
     const int64_t g = (int64_t)bi.x + s;
     dst[slot * dstStride + dstComp] = nat[g * ncomp + comp];
-}
-
-// Records of a per-bin array from one blocking of the batch to another (same chains, same bin offsets; block lengths
-// srcB -> pd.B).  One thread per DESTINATION slot: coalesced stores, 64 scattered loads per instruction -- this moves
-// ~40 B per bin once per bit-exact forward pass (superblock view of the state chain), not worth an LDS transposition.
-template <class T>
-__global__ __launch_bounds__(256) void k_reblock(Prm pd, const int64_t *srcChainFirst, int srcB, const int64_t *chainOff,
-                                                 const T *__restrict__ src, T *__restrict__ dst) {
-    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int l = (int)(slot & 63);
-    const int64_t row = slot >> 6;
-    const int64_t G = row / pd.B;
-    const int s = (int)(row % pd.B);
-    const int64_t b = G * 64 + l;
-    if (b >= pd.NB || !chain_on(pd, b)) return;
-    const int4 bi = pd.blk[b];
-    if (s >= bi.y) return;
-    const int ch = pd.blkChain[b];
-    const int64_t rel = (int64_t)bi.x + s - chainOff[ch];          // bin index inside its chain
-    dst[slot] = src[tidx(srcChainFirst[ch] + rel / srcB, (int)(rel % srcB), srcB)];
 }
 
 // blocked -> blocked copy of a per-bin float array, active chains only (ECM: the kappa of a validated iteration becomes

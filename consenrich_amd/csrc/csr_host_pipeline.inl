@@ -4,34 +4,17 @@
 // ---------------------------------------------------------------------------------------------------------------
 // compute
 // ---------------------------------------------------------------------------------------------------------------
-template <int TS, int TL, int UN = 8>
-static void launch_stats(csr_ctx *c, const Prm &p) {
-    const int grid = (int)(c->NG * (c->B / TS) * (64 / TL));
-    hipLaunchKernelGGL((k_stats<TS, TL, UN>), dim3(grid), dim3(256), 0, c->stream, p);
-}
-
 extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
     CHECK(settle(c));
     Prm p = c->p;
-    p.probeTiled = getenv("CONSENRICH_AMD_PROBE_TILED") ? 1 : 0;
     {
+        // 16-byte loads, four bins per thread; 64-bin tiles (32 when the block length is not a multiple of 64)
         Scope sc(c, "stats");
-        int ts = c->statsTile;
-        if (ts == 0) ts = 64;
-        if (c->B % ts != 0) ts = 32;
-        if (c->statsWide && (ts == 64 || ts == 32)) {
-            // 16-byte loads, four bins per thread
-            const int grid = (int)(c->NG * (c->B / ts) * (ts == 64 ? 4 : 2));
-            if (ts == 64 && c->statsWideUnroll == 8) hipLaunchKernelGGL((k_stats_v4<64, 8>), dim3(grid), dim3(256), 0, c->stream, p);
-            else if (ts == 64 && c->statsWideUnroll == 2) hipLaunchKernelGGL((k_stats_v4<64, 2>), dim3(grid), dim3(256), 0, c->stream, p);
-            else if (ts == 64) hipLaunchKernelGGL((k_stats_v4<64, 4>), dim3(grid), dim3(256), 0, c->stream, p);
-            else hipLaunchKernelGGL((k_stats_v4<32, 4>), dim3(grid), dim3(256), 0, c->stream, p);
-        } else if (ts == 128) launch_stats<128, 16>(c, p);
-        else if (ts == 64 && c->statsUnroll == 16) launch_stats<64, 16, 16>(c, p);
-        else if (ts == 64 && c->statsUnroll == 32) launch_stats<64, 16, 32>(c, p);
-        else if (ts == 64) launch_stats<64, 16>(c, p);
-        else launch_stats<32, 16>(c, p);
+        const int ts = (c->B % 64 == 0) ? 64 : 32;
+        const int grid = (int)(c->NG * (c->B / ts) * (ts == 64 ? 4 : 2));
+        if (ts == 64) hipLaunchKernelGGL((k_stats_v4<64, 4>), dim3(grid), dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((k_stats_v4<32, 4>), dim3(grid), dim3(256), 0, c->stream, p);
     }
     LAUNCH_CHECK("k_stats");
     c->statsValid = true;
@@ -47,7 +30,15 @@ enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
 // step: poll first, block only if the stream is still busy after ~200 us.
 static hipError_t wait_stream(csr_ctx *c) {
     if (c->spinWait) {
-        for (int i = 0; i < 20000; ++i) {
+        // a short burst of polls (the waits on a shard's critical path are tens of microseconds), then polls 20 us apart for
+        // ~2 ms, then a blocking wait: a rank never burns a core for the length of a latency-bound launch (8 ranks per node)
+        for (int i = 0; i < 128; ++i) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        }
+        for (int i = 0; i < 100; ++i) {
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) return hipSuccess;
             if (q != hipErrorNotReady) return q;
@@ -123,11 +114,6 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     p.xTolUlps = c->xTolUlps;
     p.rerunCount = reinterpret_cast<unsigned int *>(c->dMail) + stage;
     const int grid = (int)c->NG;
-    if (c->dbgPoison) {
-        HIPOK(hipMemsetAsync(p.carryIn, 0xFF, c->NB * 32, c->stream));
-        HIPOK(hipMemsetAsync(p.carryOutA, 0xFF, c->NB * 32, c->stream));
-        HIPOK(hipMemsetAsync(p.carryOutB, 0xFF, c->NB * 32, c->stream));
-    }
     const bool pcq = CH::USES_Q && p.chainQ != nullptr;      // per-chain base process noise: per-lane model copy
     // consecutive stages alternate between two carry sets; the previous stage's pending check (if any) rides in this
     // stage's speculative kernel
@@ -212,7 +198,6 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         }
     }
     LAUNCH_CHECK(name);
-    if (c->dbgProbe) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(64), 0, c->stream, c->p);
     int which = 0;
     unsigned int *const cnt = reinterpret_cast<unsigned int *>(c->dMail);
     auto launch_fix = [&](unsigned int *passCounter) {
@@ -233,7 +218,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         c->rs.fix_launches++;
         which ^= 1;
     };
-    if (defer && c->foldCheck && c->nPasses[stage] <= 1 && c->dbgForceIters == 0) {
+    if (defer && c->nPasses[stage] <= 1) {
         // clean so far: no validation kernel -- the next speculative kernel (or read_mail) checks this stage's carries
         c->pendChk.valid = true;
         c->pendChk.kind = CH::KIND;
@@ -247,7 +232,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     if (defer) {
         // optimistic: nPasses validation passes back to back, no host round trip; the stage stands iff the last one re-ran
         // nothing (checked at the next settle point through its own counter)
-        p.debugForce = c->dbgFence ? 2 : 0;
+        p.debugForce = 0;
         const int np = std::max(1, std::min(MAX_DEFER_PASSES, c->nPasses[stage]));
         for (int j = 0; j < np; ++j) launch_fix(cnt + MAIL_PASS0 + 4 * stage + j);
         LAUNCH_CHECK(fixName);
@@ -260,8 +245,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
     // carries unchanged, so all later ones are empty too); at most burst-1 empty passes are wasted.
     int burst = 1;
     for (int64_t it = 0; it <= c->NB + 1; ++it) {
-        p.debugForce = (it < c->dbgForceIters) ? 1 : 0;
-        if (c->dbgFence) p.debugForce |= 2;
+        p.debugForce = 0;
         for (int rep = 0; rep < burst; ++rep) launch_fix(cnt + MAIL_DUMMY);
         LAUNCH_CHECK(fixName);
         CHECK(read_mail(c, MAIL_HDR));
@@ -279,7 +263,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
         }
         stage_reruns(c, stage) += fresh;
         if (it == 0) grow_warm(c, warmRef, fresh);
-        if (c->dbgForceIters == 0) burst = it == 0 ? 2 : std::min(32, burst * 2);
+        burst = it == 0 ? 2 : std::min(32, burst * 2);
     }
     return fail("%s: speculative fix-up did not reach a fixed point", name);
 }
@@ -324,7 +308,7 @@ static int ensure_sb_view(csr_ctx *c) {
     if (v.ready) return 0;
     int B = c->sbBins;
     const int nc = (int)c->chains.size();
-    if (c->sbSystolic && !c->sbBinsPinned) {
+    if (!c->sbBinsPinned) {
         // one wavefront per superblock, at most one wavefront per SIMD: the shortest superblock (a multiple of 8192 bins) that
         // leaves no more superblocks than 5/8 of the device's SIMDs (measured at genome scale: 16 384 bins 7.2 ms, 24 576 / 32 768
         // bins 7.0 ms, 8 192 bins 8.3 ms per step -- fewer, longer repair passes win slightly while a pass costs the slowest
@@ -365,13 +349,6 @@ static int ensure_sb_view(csr_ctx *c) {
     HIPOK(hipMemcpyAsync(v.blkChain, bch.data(), sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemcpyAsync(v.chainFirst, first.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
-    // (+ one padding group: lanes without a block of their own walk block NG * 64, zero records)
-    if (!c->sbSystolic) {
-        const int64_t TP = v.TN + (int64_t)B * 64;
-        CHECK(dalloc(c, &v.rec, TP)); CHECK(dalloc(c, &v.tXf, TP));
-        HIPOK(hipMemsetAsync(v.rec, 0, sizeof(double4) * TP, c->stream));
-        HIPOK(hipMemsetAsync(v.tXf, 0, sizeof(float2) * TP, c->stream));
-    }
     char *q[3];
     for (char *&x : q) CHECK(dalloc(c, &x, nb * 32));
     v.carryIn = q[0]; v.carryOutA = q[1]; v.carryOutB = q[2];
@@ -398,19 +375,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
     c->sbp.active = false;
-    // First-pass guess: the state chain in its 2-ulp form on the batch's own blocks (one bandwidth-bound launch, validated with
-    // the k = 2 rule), converted to the natural layout together with the records.  The delta-form first pass then proves and
-    // corrects that trajectory instead of walking every superblock from a cold prior.
-    const bool seeded = c->sbDelta && c->sbSeed;
-    if (seeded && !resume) {
-        const int keep = c->xTolUlps;
-        c->xTolUlps = 2;
-        int rc;
-        if (unit_f(c, p)) rc = run_chain<FwdXTrendT<true>>(c, p, "fwd_state_seed", "fwd_state_seed_fix", ST_X, false);
-        else rc = run_chain<FwdXTrend>(c, p, "fwd_state_seed", "fwd_state_seed_fix", ST_X, false);
-        c->xTolUlps = keep;
-        CHECK(rc);
-    }
     if (!resume) {
         Scope sc(c, "state_records_natural");
         ExpList L;
@@ -425,10 +389,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             e.src = reinterpret_cast<const float *>(p.tSZ); e.dst = reinterpret_cast<float *>(c->sbNatSZ); e.E = 4; e.n = 4;
             pe.chainActive = nullptr;       // the statistics of EVERY chain (csr_batch_stats computed them all), whatever this pass masks
             c->natSZValid = true;
-        }
-        if (seeded) {
-            ExpDesc &e = L.d[L.count++];
-            e.src = reinterpret_cast<const float *>(p.tXf); e.dst = natXf; e.E = 2; e.n = 2;
         }
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pe, L);
     }
@@ -451,19 +411,19 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     }
     auto launch = [&](int which, int fix) {
         float2 *xf = reinterpret_cast<float2 *>(natXf);
-        if ((fix || seeded) && c->sbDelta) {        // delta form (k_sb_delta): repair passes, and the first pass when a 2-ulp trajectory is resident
-            const int spec = (fix ? 0 : 1) | (c->sbAdvMin << 8) | (c->sbAdvFrom << 16);
+        if (fix) {        // repair passes in delta form (k_sb_delta)
+            const int spec = (c->sbAdvMin << 8) | (c->sbAdvFrom << 16);
             if (mode == 2) hipLaunchKernelGGL(k_sb_delta<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             else if (mode == 1) hipLaunchKernelGGL(k_sb_delta<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             else hipLaunchKernelGGL(k_sb_delta<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, spec);
             return;
         }
-        if (mode == 2) hipLaunchKernelGGL(k_sb_sys<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
-        else if (mode == 1) hipLaunchKernelGGL(k_sb_sys<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
-        else hipLaunchKernelGGL(k_sb_sys<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, which, fix);
+        if (mode == 2) hipLaunchKernelGGL(k_sb_sys<2>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf);
+        else if (mode == 1) hipLaunchKernelGGL(k_sb_sys<1>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf);
+        else hipLaunchKernelGGL(k_sb_sys<0>, dim3(grid), dim3(256), 0, c->stream, q, c->sbNatGain, c->sbNatSZ, xf);
     };
     bool done = false;
-    if (c->sbAsync && !seeded) {
+    if (c->sbAsync) {
         // the whole chain in one launch, no barrier between passes (k_sb_async); a bail-out (a bounded wait ran out) falls
         // through to the pass form below, which starts over from the cold prior
         if (!v.pub) { CHECK(dalloc(c, &v.pub, 2 * v.NB + 2)); }
@@ -487,16 +447,17 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             Scope sc(c, "fwd_state_chain");
             float2 *xf = reinterpret_cast<float2 *>(natXf);
             // (the repair runs' LDS ring: > 64 KB of dynamic LDS has to be asked for once per kernel)
-            static bool ldsOk[3] = {false, false, false};
-            if (!ldsOk[mode]) {
-                const void *fn = mode == 2 ? reinterpret_cast<const void *>(&k_sb_async<2>)
-                                 : mode == 1 ? reinterpret_cast<const void *>(&k_sb_async<1>) : reinterpret_cast<const void *>(&k_sb_async<0>);
-                HIPOK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_ASYNC_LDS));
-                ldsOk[mode] = true;
+            static bool ldsOk[6] = {false, false, false, false, false, false};
+            const bool dbg = q.sbDbg != nullptr;
+            using KFn = void (*)(Prm, const float4 *, const float4 *, float2 *, SbAsync);
+            const KFn fns[6] = {&k_sb_async<0, false>, &k_sb_async<1, false>, &k_sb_async<2, false>,
+                                &k_sb_async<0, true>, &k_sb_async<1, true>, &k_sb_async<2, true>};
+            const int which = mode + (dbg ? 3 : 0);
+            if (!ldsOk[which]) {
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[which]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_ASYNC_LDS));
+                ldsOk[which] = true;
             }
-            if (mode == 2) hipLaunchKernelGGL(k_sb_async<2>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
-            else if (mode == 1) hipLaunchKernelGGL(k_sb_async<1>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
-            else hipLaunchKernelGGL(k_sb_async<0>, dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
+            hipLaunchKernelGGL(fns[which], dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
         }
         LAUNCH_CHECK("k_sb_async");
         if (phase == 1) {
@@ -582,69 +543,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     }
     LAUNCH_CHECK("k_import_tiled_f2");
     c->xfNat = true;
-    return 0;
-}
-
-// Bit-exact state chain of the levelTrend model on the superblock view (k_sb_state_*): widen + re-block the (gain,
-// statistics) records, speculate, validate / repair to the fixed point, re-block the filtered state back.  The fixed point
-// is the sequential recursion whatever the block length.
-template <bool UF>
-static int state_chain_superblocks(csr_ctx *c, const Prm &p) {
-    CHECK(ensure_sb_view(c));
-    CHECK(flush_pending_check(c));
-    csr_ctx::SbView &v = c->sb;
-    Prm q = p;
-    q.B = v.B; q.NB = v.NB; q.NG = v.NG; q.blk = v.blk; q.blkChain = v.blkChain;
-    q.sbRec = v.rec; q.sbPad = v.NG * 64; q.tXf = v.tXf;
-    q.carryIn = v.carryIn; q.carryOutA = v.carryOutA; q.carryOutB = v.carryOutB;
-    q.warm = c->sbWarm;
-    unsigned int *const cnt = reinterpret_cast<unsigned int *>(c->dMail);
-    q.rerunCount = cnt + ST_X;
-    q.rerunCountPass = cnt + MAIL_DUMMY;
-    q.prevKind = CK_NONE;
-    const int grid = (int)v.NG;
-    const bool f1 = UF && p.F01 == 1.0 && c->unitF1Enabled;     // deltaF = 1: the predicted level is one float32 add (sb_step)
-    {
-        Scope sc(c, "state_reblock_in");
-        hipLaunchKernelGGL(k_sb_records, dim3((int)((v.TN + 255) / 256)), dim3(256), 0, c->stream, q, c->dChainFirst, c->B,
-                           c->dChainOff, p.tXin, p.tSZ, v.rec);
-    }
-    LAUNCH_CHECK("k_sb_records");
-    {
-        Scope sc(c, "fwd_state_chain");
-        if (f1) hipLaunchKernelGGL((k_sb_state_spec<UF, UF>), dim3(grid), dim3(64), 0, c->stream, q);
-        else hipLaunchKernelGGL((k_sb_state_spec<UF, false>), dim3(grid), dim3(64), 0, c->stream, q);
-    }
-    LAUNCH_CHECK("k_sb_state_spec");
-    // validation / repair passes in bursts (run_chain's rule: a burst that re-ran nothing is the fixed point; a pass that
-    // finds nothing to do costs microseconds)
-    int which = 0, burst = 1;
-    bool done = false;
-    for (int64_t it = 0; it <= v.NB + 1 && !done; ++it) {
-        {
-            Scope sc(c, "fwd_state_fix");
-            for (int rep = 0; rep < burst; ++rep) {
-                if (f1) hipLaunchKernelGGL((k_sb_state_fix<UF, UF>), dim3(grid), dim3(64), 0, c->stream, q, which);
-                else hipLaunchKernelGGL((k_sb_state_fix<UF, false>), dim3(grid), dim3(64), 0, c->stream, q, which);
-                which ^= 1;
-                c->rs.fix_launches++;
-            }
-        }
-        LAUNCH_CHECK("k_sb_state_fix");
-        CHECK(read_mail(c, MAIL_HDR));
-        const unsigned int fresh = take_fresh(c, ST_X);
-        if (c->dbgLog) fprintf(stderr, "[csr] fwd_state_fix (superblocks) iter %lld reruns %u\n", (long long)it, fresh);
-        if (fresh == 0) done = true;
-        c->rs.reruns_x += fresh;
-        burst = c->dbgLog ? 1 : (it == 0 ? 2 : std::min(32, burst * 2));      // (debug log: one pass per read-back)
-    }
-    if (!done) return fail("fwd_state_chain (superblocks): fix-up did not reach a fixed point");
-    {
-        Scope sc(c, "state_reblock_out");
-        hipLaunchKernelGGL(k_reblock<float2>, dim3(grid_slots(c)), dim3(256), 0, c->stream, p, v.chainFirst, v.B, c->dChainOff,
-                           v.tXf, p.tXf);
-    }
-    LAUNCH_CHECK("k_reblock");
     return 0;
 }
 
@@ -844,9 +742,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             } else if (sbX) {
                 // (the early covariance exports fork off behind the state chain's own record conversion)
                 const bool early = natOut && c->earlyPf && active == nullptr && c->natOutEnabled;
-                if (c->sbSystolic) CHECK(state_chain_systolic(c, p, early, flags, split ? 1 : 0));
-                else if (unit_f(c, p)) CHECK(state_chain_superblocks<true>(c, p));
-                else CHECK(state_chain_superblocks<false>(c, p));
+                CHECK(state_chain_systolic(c, p, early, flags, split ? 1 : 0));
                 dX = false;
             } else
             if (unit_f(c, p)) CHECK(run_chain<FwdXTrendT<true>>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
@@ -1455,8 +1351,8 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
 static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handled) {
     *handled = false;
     const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA | F_LAMBDA)) && c->p.chainQ == nullptr;
-    if (!(c->tailSplit && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState && c->sbSystolic && c->sbAsync &&
-          !(c->sbDelta && c->sbSeed) && c->natOutEnabled && c->natOutD && c->earlyPf && c->deferEnabled && constQ &&
+    if (!(c->tailSplit && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState && c->sbAsync &&
+          c->deferEnabled && constQ &&
           !(what & CSR_EXPORT_MULT) && c->chains.size() >= 2 && c->chains.size() <= 4096))
         return 0;
     CHECK(settle(c));
@@ -1517,7 +1413,9 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
     for (;;) {
         const hipError_t qs = hipStreamQuery(mainStream);
         if (qs != hipErrorNotReady) { if (qs != hipSuccess) rc = fail("state chain: %s", hipGetErrorString(qs)); break; }
-        if (phase >= 6) { std::this_thread::yield(); continue; }
+        // (bounded sleep-poll: the launch lasts milliseconds and a tail group is worth launching 20-50 us late; round 3 spun here)
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (phase >= 6) continue;
         std::vector<unsigned char> grp((size_t)nc, 0);
         int64_t bins = 0;
         for (int i = 0; i < nc; ++i)

@@ -138,7 +138,6 @@ extern "C" int csr_solve_background(int32_t n_chains, const int64_t *n, const do
     if (!std::isfinite(lam_first) || lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
     if (!std::isfinite(lam) || lam < 0.0) return fail("lam must be finite and nonnegative");
     int Bp = block_len > 0 ? block_len : 1024;
-    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
     if (Bp < 8) return fail("block_len must be at least 8");
     csr_ctx *c = default_ctx();
     if (!c) return -1;
@@ -356,7 +355,6 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     if (!std::isfinite(cfg->lam_first) || cfg->lam_first < 0.0) return fail("lamFirst must be finite and nonnegative");
     if (!std::isfinite(cfg->lam) || cfg->lam < 0.0) return fail("lam must be finite and nonnegative");
     int Bp = cfg->block_len > 0 ? cfg->block_len : 1024;
-    if (const char *e = getenv("CONSENRICH_AMD_BG_BLOCK")) Bp = atoi(e);
     if (Bp < 8) return fail("block_len must be at least 8");
     CHECK(bg_setup(c, Bp));
     csr_ctx::BgState &S = c->bg;

@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -123,8 +124,8 @@ struct csr_ctx {
     bool wsEnabled = true;      // CONSENRICH_AMD_WARMSTART=0: off
     bool wsActive = false;      // set by the ECM loop around its sweeps
     bool wsCold = false;        // replay of a failed iteration: record checkpoints, do not start from them
-    int wsWarmF = 32, wsWarmB = 32;         // CONSENRICH_AMD_WS_WARM_F / _B
-    int wsMaxBlock = 32;                    // CONSENRICH_AMD_WS_MAX_BLOCK: largest block length (= batch size class) that warm-starts
+    int wsWarmF = 32, wsWarmB = 32;         // warm-started windows (widen themselves when an edge block fails)
+    static constexpr int wsMaxBlock = 32;   // largest block length (= batch size class) that warm-starts
     int wsSavedF = 0, wsSavedB = 0;         // window length the resident checkpoints were recorded for (0: none)
     int wsSweepF = 0, wsSweepB = 0;         // parity of the double buffers
     void *ckF[2] = {nullptr, nullptr}, *ckB[2] = {nullptr, nullptr};
@@ -137,11 +138,7 @@ struct csr_ctx {
     int xTolUlps = 0;           // carry validation: 0 = bit-exact sequential semantics (DEFAULT of every context since round 3: the
                                 // only mode that holds the parity gate through the ECM loop on ill-conditioned data, tests/test_hard_data.py);
                                 // k > 0 = k-ulp acceptance, the opt-in throughput mode (csr_set_validation / CONSENRICH_AMD_XTOL_ULPS)
-    bool statsWide = true;  // statistics kernel with 16-byte loads (four bins per thread)
-    int statsWideUnroll = 4;    // ... sample rows it loads together (2, 4, 8)
-    int statsUnroll = 8;    // sample rows loaded together by the statistics kernel (8, 16, 32)
-    int residTile = 2;      // residual kernel: 64-bin sub-tiles per workgroup (1, 2, 4); 2 measured best (0.665 vs 0.684 ms)
-    int statsTile = 0;      // 0 = auto (128 when block_len allows), else 32 / 128 / 256
+    static constexpr int residTile = 2;     // residual kernel: 64-bin sub-tiles per workgroup; 2 measured best (0.665 vs 0.684 ms)
     // batch
     bool configured = false;
     csr_model mdl{};
@@ -156,10 +153,10 @@ struct csr_ctx {
     bool pendNatOut = false;
     bool fwdNat = false, pendFwdNat = false;   // the last forward pass wrote xf / Pf in the reference layout too
     bool dNat = false;          // ... and its NIS/NLL epilogue wrote D there (nothing left to convert)
-    bool natOutD = true;        // CONSENRICH_AMD_NATOUT_D=0: D through tD + the export pass
+    static constexpr bool natOutD = true;       // the NIS / NLL epilogue writes D in the reference layout itself
     bool dstatLdsRaised = false;
     int pendEstep = 0;
-    bool fuseEstep = true;      // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
+    static constexpr bool fuseEstep = true;     // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
     uint32_t fwdFlags = 0;
     Prm p{};
@@ -186,9 +183,9 @@ struct csr_ctx {
     // pass + one validation pass, no host round trip); the counters are checked at the next settle point and the
     // pipeline is re-run synchronously from the first stage that did re-run blocks.
     bool deferEnabled = true;
-    bool spinWait = true;
+    static constexpr bool spinWait = true;
     bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
-    bool unitF1Enabled = true;  // CONSENRICH_AMD_UNITF1=0: the superblock walker's fma + conversion form of the predicted level even for F01 == 1
+    static constexpr bool unitF1Enabled = true; // F01 == 1: the superblock walker's predicted level is one float32 add
     bool unitFEnabled = true;   // CONSENRICH_AMD_UNITF=0: the general-F instances of the levelTrend chains even for F = [[1, f], [0, 1]]
     bool seqState = false;      // bit-exact validation, levelTrend: one wavefront per chain walks the state chain sequentially (CONSENRICH_AMD_SEQ_STATE=1)
     // bit-exact validation, levelTrend (default): the state chain speculates on SUPERBLOCKS of sbBins bins with an sbWarm-bin
@@ -196,7 +193,7 @@ struct csr_ctx {
     // so the batch's own 32..256-bin blocks never validate; the gain / statistics records are re-blocked into a second view
     // of the batch (own block table and carries) for this one chain and the filtered state is re-blocked back
     bool sbState = true;        // CONSENRICH_AMD_SB_STATE=0: off (speculation on the batch's own blocks, or seqState)
-    int sbBins = 8192, sbWarm = 16384;      // CONSENRICH_AMD_SB_BINS / CONSENRICH_AMD_SB_WARM
+    int sbBins = 8192;          // CONSENRICH_AMD_SB_BINS (default: chosen from the batch, ensure_sb_view)
     // k_sb_delta's fallback rule (CONSENRICH_AMD_SB_ADV = "min,from"): walk the rest of a batch when, from round `from` on, the
     // rounds have settled fewer than `min` bins each.  Measured flat between "give up after 20 rounds" (4,20) and "walk as soon
     // as a round is worth less than its six steps" (6,2): 3.75-3.95 ms of repairs either way (profiles/r03_sb_sweeps.txt) -- where
@@ -204,13 +201,10 @@ struct csr_ctx {
     int sbAdvMin = 4, sbAdvFrom = 20;
     bool sbBinsPinned = false;  // CONSENRICH_AMD_SB_BINS given: no automatic choice of the superblock length
     unsigned long long *sbDbg = nullptr;
-    bool sbSeed = false;        // CONSENRICH_AMD_SB_SEED=1: the first pass of the exact state chain corrects the 2-ulp trajectory in delta form instead of walking every superblock from the cold prior (measured slower while a round costs ~170 ns: 1.07 + 0.36 vs 0.94 ms; bit-identical, tests/fuzz run with it once)
     // CONSENRICH_AMD_SB_ASYNC=0: speculative pass + repair passes as separate launches (k_sb_sys / k_sb_delta) instead of the
     // barrier-free single launch (k_sb_async); sbSpinLimit bounds every wait inside it (polls of ~2 us; then: bail out to the pass form)
     bool sbAsync = true;
     int sbSpinLimit = 1 << 19;
-    bool sbDelta = true;        // CONSENRICH_AMD_SB_DELTA=0: repair passes as plain systolic walks (k_sb_sys) instead of the delta form (k_sb_delta)
-    bool sbSystolic = true;     // CONSENRICH_AMD_SB_SYSTOLIC=0: the round-2 lane-per-superblock walker (re-blocked records, window sbWarm)
     bool natSZValid = false;    // sbNatSZ holds the current statistics of every chain
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
     bool xfNat = false;         // the resident forward pass left xf in the reference layout already (systolic walker)
@@ -221,16 +215,13 @@ struct csr_ctx {
         int4 *blk = nullptr;
         int *blkChain = nullptr;
         int64_t *chainFirst = nullptr;
-        double4 *rec = nullptr;     // {gs, zbar, P00pred, P10pred} per bin, + one padding group
-        float2 *tXf = nullptr;
         void *carryIn = nullptr, *carryOutA = nullptr, *carryOutB = nullptr;
         unsigned long long *pub = nullptr;      // k_sb_async: carry[NB], {version, final}[NB], control words
     } sb;
-    bool natOutEnabled = true;  // smoother writes the reference layout directly (CONSENRICH_AMD_NATOUT=0: via export)
-    bool natOutFwd = true;      // ... and so does the fused forward chain (CONSENRICH_AMD_NATOUT_FWD=0: via export)
+    static constexpr bool natOutEnabled = true; // the smoother writes the reference layout directly
+    static constexpr bool natOutFwd = true;     // ... and so does the fused forward chain
     // debugging switches, read once from the environment at creation (never on the launch path)
-    bool dbgPoison = false, dbgProbe = false, dbgFence = false, dbgLog = false;
-    int dbgForceIters = 0;
+    bool dbgLog = false;
     bool optimistic[3] = {true, true, true};
     bool pendFwd = false, pendBwd = false, sidePending = false;
     double *dChainQ = nullptr;  // per-chain base process noise (csr_batch_set_chain_q), freed with the batch
@@ -239,7 +230,7 @@ struct csr_ctx {
     // (nullptr = the resident array).  Allocated on first use, freed with the batch.
     float *kapScratch[2] = {nullptr, nullptr};
     float *kapIn = nullptr, *kapOut = nullptr;
-    bool deferIteration = true; // ECM (fused E-step): one settle point per iteration, replay on a failed validation
+    static constexpr bool deferIteration = true;    // ECM (fused E-step): one settle point per iteration, replay on a failed validation
     bool sweepSkipQ = false;    // the forward pass being launched is an inner ECM sweep (Prm::qFromKappa, storePP)
     bool fwdQCompact = false;   // the resident forward pass stored the diagonal of pNoise (tQ2) instead of pNoise (tQ)
     bool qDiagonal = true;      // the base process noise in use (model's, or every chain's) is diagonal
@@ -274,7 +265,6 @@ struct csr_ctx {
     } pendChk;
     void *carrySet[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [set][carryIn, carryOutA]
     int carryToggle = 0;
-    bool foldCheck = true;              // CONSENRICH_AMD_FOLD_CHECK=0: every stage launches its own validation kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipEvent_t evFork2 = nullptr, evPf = nullptr;      // early covariance exports on the side stream (bit-exact mode)
     // step_pipelined: tails of the chains whose filtered state stands, on a stream of their own while the state chain runs
@@ -287,7 +277,7 @@ struct csr_ctx {
     int tailFirstPct = 50, tailNextPct = 15;     // CONSENRICH_AMD_TAIL_PCT="first,next": share of the batch's bins a group must reach
     bool tailSplit = true;      // CONSENRICH_AMD_TAIL_SPLIT=0: a step's tail follows the state chain for all chains at once
     bool pfPending = false, pfNat = false, pnNat = false;
-    bool earlyPf = true;        // CONSENRICH_AMD_EARLY_PF=0: Pf / constant pNoise exported after the smoother like the other tracks
+    static constexpr bool earlyPf = true;       // Pf / constant pNoise are exported underneath the state chain
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -387,60 +377,38 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     }
     const char *e;
     if ((e = getenv("CONSENRICH_AMD_BLOCK"))) { c->B = atoi(e); c->Bfixed = c->B != 0; }
-    if ((e = getenv("CONSENRICH_AMD_WARM_P"))) { c->warmP = atoi(e); c->pinP = true; }
-    if ((e = getenv("CONSENRICH_AMD_WARM_X"))) { c->warmX = atoi(e); c->pinX = true; }
-    if ((e = getenv("CONSENRICH_AMD_WARM_B"))) { c->warmB = atoi(e); c->pinB = true; }
-    if ((e = getenv("CONSENRICH_AMD_WARM_FM"))) { c->warmFM = atoi(e); c->pinFM = true; }
+    if ((e = getenv("CONSENRICH_AMD_WARM"))) {
+        // "p,x,b[,fm]": warm-up windows (bins) of the covariance / state / smoother chains and of the fused forward chain with
+        // per-bin multipliers; -1 leaves one at its default (csr_set_tuning is the API for the first three)
+        int w[4] = {-1, -1, -1, -1};
+        (void)sscanf(e, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]);
+        if (w[0] >= 0) { c->warmP = w[0]; c->pinP = true; }
+        if (w[1] >= 0) { c->warmX = w[1]; c->pinX = true; }
+        if (w[2] >= 0) { c->warmB = w[2]; c->pinB = true; }
+        if (w[3] >= 0) { c->warmFM = w[3]; c->pinFM = true; }
+    }
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_ADAPT"))) c->adaptWarm = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_SPIN"))) c->spinWait = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_WARMSTART"))) c->wsEnabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_WS_MAX_BLOCK"))) c->wsMaxBlock = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_WS_WARM_F"))) c->wsWarmF = std::max(16, (atoi(e) + 15) / 16 * 16);
-    if ((e = getenv("CONSENRICH_AMD_WS_WARM_B"))) c->wsWarmB = std::max(16, (atoi(e) + 15) / 16 * 16);
     if ((e = getenv("CONSENRICH_AMD_SB_ADV"))) {
         int a = 4, f = 20;
         if (sscanf(e, "%d,%d", &a, &f) >= 1) { c->sbAdvMin = std::min(255, std::max(0, a)); c->sbAdvFrom = std::min(255, std::max(1, f)); }
     }
     if ((e = getenv("CONSENRICH_AMD_SB_BINS"))) { c->sbBins = std::max(64, (atoi(e) + 63) / 64 * 64); c->sbBinsPinned = true; }
-    if ((e = getenv("CONSENRICH_AMD_SB_WARM"))) c->sbWarm = std::max(0, (atoi(e) + 63) / 64 * 64);
-    if ((e = getenv("CONSENRICH_AMD_SB_SYSTOLIC"))) c->sbSystolic = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_SB_DELTA"))) c->sbDelta = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_ASYNC"))) c->sbAsync = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_EARLY_PF"))) c->earlyPf = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_TAIL_SPLIT"))) c->tailSplit = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_TAIL_PCT"))) {
         int a = 50, b = 15;
         if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->tailFirstPct = std::min(100, std::max(1, a)); c->tailNextPct = std::min(100, std::max(1, b)); }
     }
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
-    if ((e = getenv("CONSENRICH_AMD_SB_SEED"))) c->sbSeed = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_UNITF1"))) c->unitF1Enabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_FOLD_CHECK"))) c->foldCheck = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_NATOUT"))) c->natOutEnabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_NATOUT_FWD"))) c->natOutFwd = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_NATOUT_D"))) c->natOutD = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_FUSE_ESTEP"))) c->fuseEstep = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_DEFER_ITER"))) c->deferIteration = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_FORCE_ITERS"))) { c->dbgForceIters = atoi(e); c->deferEnabled = false; }
-    c->dbgPoison = getenv("CONSENRICH_AMD_POISON") != nullptr;
-    c->dbgProbe = getenv("CONSENRICH_AMD_PROBE") != nullptr;
-    c->dbgFence = getenv("CONSENRICH_AMD_FENCE") != nullptr;
     c->dbgLog = getenv("CONSENRICH_AMD_DEBUG") != nullptr;
     mode_warm_defaults(c);
-    if ((e = getenv("CONSENRICH_AMD_STATS_TILE"))) c->statsTile = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_RESID_TILE"))) c->residTile = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_STATS_UNROLL"))) c->statsUnroll = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_STATS_WIDE"))) c->statsWide = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_STATS_WIDE_UNROLL"))) c->statsWideUnroll = atoi(e);
-    if ((e = getenv("CONSENRICH_AMD_DMA_FUSED"))) c->useDmaFused = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_DMA_WARM"))) c->useDmaWarm = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = c->useDmaFused = c->useDmaWarm = atoi(e) != 0;     // 0: the plain-load forms of the chains (yardstick of the LDS-DMA ring tests)
     if (c->B != 0 && (c->B < 32 || (c->B % 32) != 0)) c->B = 0;
     return c;
 }

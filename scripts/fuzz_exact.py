@@ -12,7 +12,7 @@ from consenrich_amd.batch import DeviceBatch, ModelParams
 
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 def run(n_list, m, seed, mult, F01, env):
-    for k in ("CONSENRICH_AMD_SEQ_STATE", "CONSENRICH_AMD_SB_BINS", "CONSENRICH_AMD_SB_WARM", "CONSENRICH_AMD_TAIL_PCT"):
+    for k in ("CONSENRICH_AMD_SEQ_STATE", "CONSENRICH_AMD_SB_BINS", "CONSENRICH_AMD_TAIL_PCT"):
         os.environ.pop(k, None)
     os.environ.update({k: v for k, v in env.items() if k.startswith("CONSENRICH_")})
     mp = ModelParams(state_dim=2, F=((1.0, F01), (0.0, 1.0)) if F01 != "gen" else ((0.98, 0.7), (0.01, 0.97)), Q0=((1e-3, 0.0), (0.0, 1e-4)))
@@ -48,7 +48,7 @@ for trial in range(int(os.environ.get("TRIALS", "12"))):
     m = int(rng.choice([1, 3, 8])); mult = bool(rng.integers(0, 2)); F01 = [1.0, 0.5, "gen"][int(rng.integers(0, 3))]
     seed = int(rng.integers(1, 10000))
     ref = run(n_list, m, seed, mult, F01, {"CONSENRICH_AMD_SEQ_STATE": "1"})
-    got = run(n_list, m, seed, mult, F01, {"CONSENRICH_AMD_SB_BINS": str(sbb), "CONSENRICH_AMD_SB_WARM": str(sbw)})
+    got = run(n_list, m, seed, mult, F01, {"CONSENRICH_AMD_SB_BINS": str(sbb)})
     for key, val in ref.items():
         if key == "stats": continue
         if key == "sums":
@@ -56,7 +56,7 @@ for trial in range(int(os.environ.get("TRIALS", "12"))):
         else:
             assert np.array_equal(val, got[key]), (trial, key, n_list, sbb, sbw, m, mult, F01)
     # the same batch through csr_batch_step (twice), thresholds that make small groups of finished chains
-    stp = run(n_list, m, seed, mult, F01, {"CONSENRICH_AMD_SB_BINS": str(sbb), "CONSENRICH_AMD_SB_WARM": str(sbw),
+    stp = run(n_list, m, seed, mult, F01, {"CONSENRICH_AMD_SB_BINS": str(sbb),
                                            "CONSENRICH_AMD_TAIL_PCT": str(int(rng.choice([1, 10, 50]))) + ",1", "USE_STEP": "1"})
     for key, val in ref.items():
         if key == "stats": continue
