@@ -2518,6 +2518,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     int brk = 0;                                    // first bin of the stored trajectory's last piece
     unsigned *const ring = sbRing + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SB_WAVE_W;
     unsigned *const pollRow = ring + 2 * SBG * SB_SLOT_W;
+    const unsigned ldsLaneG = lds_off(ring) + (unsigned)lane * 16u, ldsLaneW = lds_off(ring) + (unsigned)lane * 4u;
     const unsigned long long *pvf = a.vf + (b - 1), *pcarry = a.carry + (b - 1);
     const int ng = (nb + SBG - 1) / SBG;
     // (uniform base + 32-bit lane offset: the DMA instructions take their address as SGPR pair + VGPR offset, so a group's 31
@@ -2598,18 +2599,21 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 1 < ng) issue_group(g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
+                if (g == 0) { trj0 = cin0; trj1 = cin1; }          // (this group rewrites batch 0 of the stored trajectory from cin)
                 if (dbgOn) { const long long nowA = (long long)__builtin_readcyclecounter(); dbgSec[0] += (unsigned long long)(nowA - dbgA); }
 #pragma unroll
                 for (int u = 0; u < SBG; ++u) {
                     const int t = g * SBG + u;
                     if (t < nb && !merged) {
                         const long long dbgB = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
-                        const unsigned *slot = half + u * SB_SLOT_W;
-                        const uint4 gr = lds_rd128(slot + lane * 4);
-                        const unsigned zl = lds_rd32(slot + 256 + lane), zh = lds_rd32(slot + 320 + lane);
-                        const unsigned sx0 = lds_rd32(slot + 384 + lane), sx1 = lds_rd32(slot + 448 + lane);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        // (two vector adds form the lane's addresses in the slot; the five reads carry immediate offsets)
+                        const unsigned slotOff = (unsigned)(((g & 1) * SBG + u) * SB_SLOT_W * 4);
+                        const unsigned aG = ldsLaneG + slotOff, aW = ldsLaneW + slotOff;
+                        uint4 gr;
+                        unsigned zl, zh, sx0, sx1;
+                        asm volatile("ds_read_b128 %0, %5\n\tds_read_b32 %1, %6 offset:1024\n\tds_read_b32 %2, %6 offset:1280\n\t"
+                                     "ds_read_b32 %3, %6 offset:1536\n\tds_read_b32 %4, %6 offset:1792\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(gr), "=&v"(zl), "=&v"(zh), "=&v"(sx0), "=&v"(sx1) : "v"(aG), "v"(aW) : "memory");
                         const double gs = words2double(gr.x, gr.y), zbar = words2double(zl, zh);
                         const float gz = __uint_as_float(gr.z), gw = __uint_as_float(gr.w);
                         const double p00 = (double)gz, p10 = (double)gw;
@@ -2673,7 +2677,6 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                         if (dbgOn) dbgSec[2] += (unsigned long long)(dbgD - dbgC);
                         if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
                         dbgRounds += (unsigned)rounds; ++dbgBatches;
-                        if (t == 0) { trj0 = cin0; trj1 = cin1; }
                         t0 = rl32(h0, left - 1);
                         t1 = rl32(h1, left - 1);
                         sc0 = rl32(so0, left - 1);
@@ -2681,12 +2684,12 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                         done = (t << 6) + left;                    // bins of the superblock settled by this run
                         // met the stored trajectory inside its last piece: what lies behind is right and ends in `out`
                         merged = done > brk && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
-                        if (done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }
                         if (dbgOn) dbgSec[3] += (unsigned long long)((long long)__builtin_readcyclecounter() - dbgD);
                     }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA of this run still lands in the ring
+            if (!newer && done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }      // the run reached the superblock's end
             if (DBG) dbgTicks += (unsigned long long)(wall_clock64() - dbgT0);
             if (!newer) break;
             ++aborts;

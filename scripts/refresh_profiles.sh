@@ -6,7 +6,7 @@
 # follows `--` (python3, no env / shell hop).
 set -e
 export TMPDIR=/tmp
-R=${R:-r03}
+R=${R:-r04}
 O=gpurun_out/p
 rm -rf $O && mkdir -p $O
 timeout -k 10 600 python3 bench.py > $O/${R}_bench.json 2> $O/bench.err

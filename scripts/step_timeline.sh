@@ -1,9 +1,9 @@
-mkdir -p gpurun_out/r3
+mkdir -p gpurun_out/r4
 export TMPDIR=/tmp
-STEPS=2 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r3/tr -o t -- python3 scripts/one_step.py > gpurun_out/r3/tr.log 2>&1
+STEPS=2 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r4/tr -o t -- python3 scripts/one_step.py > gpurun_out/r4/tr.log 2>&1
 python3 - <<'PY'
 import csv,glob
-f=glob.glob('gpurun_out/r3/tr/**/*kernel_trace.csv',recursive=True)[0]
+f=glob.glob('gpurun_out/r4/tr/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 t0=int(rows[0]['Start_Timestamp'])
