@@ -2402,7 +2402,7 @@ struct SbAsync {
     unsigned long long *vf;         // [NB] (version << 1) | final; 0 = nothing published yet
     unsigned int *ctl;              // [0] ticket, [1] bail-out flag, [2] delta runs, [3] abandoned runs
     unsigned int *hostDone;         // [chains], host-visible, or nullptr: set to 1 when a chain's last superblock is final
-    int advMin, advFrom, spinLimit;
+    int spinLimit;
 };
 // a chain is final (its whole filtered state stands in the reference layout): tell the host, which may start that chain's
 // smoother / residuals on another stream while other chains are still being repaired
@@ -2635,7 +2635,6 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                         float h0 = so0 + d0, h1 = so1 + d1;
                         float q0 = t0, q1 = t1, r0 = t0, r1 = t1;           // lane 0 of the shifted vectors: the true carry, for the whole batch
                         const unsigned long long sentinel = 1ull << (left - 1);
-                        const int rmax = a.advFrom;
                         int rounds = 0, s;
                         unsigned long long fail;
                         const long long dbgC = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
@@ -2660,23 +2659,15 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                             const bool le = lane <= s;
                             h0 = le ? m0 : so0 + d0;
                             h1 = le ? m1 : so1 + d1;
-                            ++rounds;
-                        } while (fail != 0ull && rounds < rmax);
-                        if (fail != 0ull) {
-                            // delta changes at (nearly) every bin here: walk the rest of the batch as a shift register
-                            float x0v = h0, x1v = h1;
-#pragma unroll 1
-                            for (int q = s + 1; q < left; ++q) {
-                                const float w0 = dpp_shr1_keep0(t0, x0v), w1 = dpp_shr1_keep0(t1, x1v);
-                                sys_step<MODE>(p, w0, w1, gs, zbar, p00, p10, gz, gw, x0v, x1v);
-                            }
-                            h0 = x0v; h1 = x1v;
-                            ++dbgFb;
-                        }
+                            if constexpr (DBG) ++rounds;
+                            // (no give-up rule: a round settles at least two more bins -- the lane behind the settled ones has a
+                            // proven predecessor, so the next failing lane lies beyond it -- i.e. at most 32 rounds per batch, which
+                            // costs what the round-3 rule "20 rounds, then walk the rest" cost where the levels flip densely)
+                        } while (fail != 0ull);
                         const long long dbgD = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
                         if (dbgOn) dbgSec[2] += (unsigned long long)(dbgD - dbgC);
                         if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
-                        dbgRounds += (unsigned)rounds; ++dbgBatches;
+                        if constexpr (DBG) { dbgRounds += (unsigned)rounds; ++dbgBatches; if (rounds > 20) ++dbgFb; }
                         t0 = rl32(h0, left - 1);
                         t1 = rl32(h1, left - 1);
                         sc0 = rl32(so0, left - 1);

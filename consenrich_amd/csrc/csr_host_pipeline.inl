@@ -429,7 +429,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         if (!v.pub) { CHECK(dalloc(c, &v.pub, 2 * v.NB + 2)); }
         SbAsync a;
         a.carry = v.pub; a.vf = v.pub + v.NB; a.ctl = reinterpret_cast<unsigned int *>(v.pub + 2 * v.NB);
-        a.advMin = c->sbAdvMin; a.advFrom = c->sbAdvFrom; a.spinLimit = c->sbSpinLimit;
+        a.spinLimit = c->sbSpinLimit;
         a.hostDone = nullptr;
         if (phase == 1) {
             // (nothing of this context is in flight that writes these words: the previous launch was waited for)
@@ -474,7 +474,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             HIPOK(hipMemcpy(h, c->sbDbg, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "[csr] barrier-free state chain: last speculative walk ends %.1f us after the start, last wavefront leaves at %.1f us; %u delta runs, %u abandoned\n",
                     (double)(h[1] - h[0]) * 0.01, (double)(h[2] - h[0]) * 0.01, ctl[2], ctl[3]);
-            fprintf(stderr, "[csr]   delta runs: %llu batches, %.2f rounds per batch, %llu walked to the end; %.0f ns per batch inside the runs; busiest wavefront %.1f us in runs over %llu batches\n",
+            fprintf(stderr, "[csr]   delta runs: %llu batches, %.2f rounds per batch, %llu with more than 20 rounds; %.0f ns per batch inside the runs; busiest wavefront %.1f us in runs over %llu batches\n",
                     h[3], h[3] ? (double)h[4] / (double)h[3] : 0.0, h[5], h[3] ? (double)h[6] * 10.0 / (double)h[3] : 0.0,
                     (double)(h[7] >> 24) * 0.01, h[7] & 0xffffffull);
             {
