@@ -2429,16 +2429,20 @@ __device__ __forceinline__ void sb_publish(const SbAsync &a, int64_t b, int lane
         __hip_atomic_store(a.vf + b, ((unsigned long long)ver << 1) | (fin ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// LDS ring of the repair runs: per wavefront two halves of SBG batch slots + one row for the poll word.
-// A slot (words): gain record 64 x 4 | zbar low 64 | zbar high 64 | stored x0 64 | stored x1 64.
+// LDS ring of the repair runs: per wavefront two halves + one row for the poll word.  A half holds a GROUP of SBG batches
+// as three regions in the natural layout, each filled by 1-KiB DMAs (64 lanes x 16 B): the gain records (SBG KiB), the
+// statistics records {S0, zbar} (SBG KiB; zbar is read back at +8) and the stored trajectory (SBG/2 KiB: one DMA brings
+// the float2 states of TWO batches): 2.5 DMAs per batch.
 #ifndef SB_GROUP
 #define SB_GROUP 6
 #endif
 constexpr int SBG = SB_GROUP;
-constexpr int SB_SLOT_W = 512;
-constexpr int SB_WAVE_W = 2 * SBG * SB_SLOT_W + 64;
+static_assert(SBG % 2 == 0, "the stored trajectory travels two batches per DMA");
+constexpr int SB_HALF_W = SBG * 256 + SBG * 256 + SBG * 128;     // words per half
+constexpr int SB_WAVE_W = 2 * SB_HALF_W + 64;
 constexpr size_t SB_ASYNC_LDS = 4 * (size_t)SB_WAVE_W * sizeof(unsigned);
-static_assert(5 * SBG + 1 + SBG <= 63, "the group's DMAs and stores must fit the 6-bit vmcnt");
+static_assert(SBG * 1024 + 8 < 65536 && 2 * SBG * 1024 < 65536, "immediate offsets of the ring's reads");
+static_assert(2 * SBG + SBG / 2 + 1 + SBG <= 63, "the group's DMAs and stores must fit the 6-bit vmcnt");
 __device__ __forceinline__ unsigned lds_rd32_wait(const unsigned *q) {
     unsigned v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(q)) : "memory");
@@ -2517,29 +2521,21 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     constexpr bool dbgOn = DBG;
     int brk = 0;                                    // first bin of the stored trajectory's last piece
     unsigned *const ring = sbRing + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SB_WAVE_W;
-    unsigned *const pollRow = ring + 2 * SBG * SB_SLOT_W;
-    const unsigned ldsLaneG = lds_off(ring) + (unsigned)lane * 16u, ldsLaneW = lds_off(ring) + (unsigned)lane * 4u;
+    unsigned *const pollRow = ring + 2 * SB_HALF_W;
+    const unsigned ldsLaneG = lds_off(ring) + (unsigned)lane * 16u, ldsLaneX = lds_off(ring) + (unsigned)lane * 8u + 2u * SBG * 1024u;
     const unsigned long long *pvf = a.vf + (b - 1), *pcarry = a.carry + (b - 1);
     const int ng = (nb + SBG - 1) / SBG;
-    // (uniform base + 32-bit lane offset: the DMA instructions take their address as SGPR pair + VGPR offset, so a group's 31
-    // DMAs cost one scalar add each instead of 64-bit vector address arithmetic)
     const int64_t bx = (int64_t)__builtin_amdgcn_readfirstlane(bi.x);
-    const unsigned offG = (unsigned)lane * 16u, offX = (unsigned)lane * 8u;
     auto issue_group = [&](int g) {
-        unsigned *half = ring + (size_t)(g & 1) * (SBG * SB_SLOT_W);
+        unsigned *half = ring + (size_t)(g & 1) * SB_HALF_W;
 #pragma unroll
         for (int u = 0; u < SBG; ++u) {
             const int t = g * SBG + u;
-            const int64_t i = bx + (int64_t)(t < nb ? t : nb - 1) * 64;     // (a batch beyond the end re-reads the last one: the count of DMAs per group is fixed)
-            unsigned *slot = half + u * SB_SLOT_W;
-            const char *pg = reinterpret_cast<const char *>(natGain + i);
-            const char *pz = reinterpret_cast<const char *>(natSZ + i) + 8;
-            const char *px = reinterpret_cast<const char *>(natXf + i);
-            dma16(pg + offG, slot);
-            dma4(pz + offG, slot + 256);
-            dma4(pz + 4 + offG, slot + 320);
-            dma4(px + offX, slot + 384);
-            dma4(px + 4 + offX, slot + 448);
+            const int64_t i = bx + (int64_t)(t < nb ? t : nb - 1) * 64 + lane;   // (a batch beyond the end re-reads the last one: the count of DMAs per group is fixed)
+            dma16(natGain + i, half + u * 256);
+            dma16(natSZ + i, half + SBG * 256 + u * 256);
+            if ((u & 1) == 0)       // lane k brings bins 2k, 2k + 1 of the 128 bins from batch t on (the array ends in 64 spare bins)
+                dma16(reinterpret_cast<const float4 *>(natXf + (bx + (int64_t)(t < nb ? t : nb - 1) * 64)) + lane, half + 2 * SBG * 256 + (u >> 1) * 256);
         }
         // the predecessor's {version, final} word (low half: versions stay far below 2^31), agent scope
         __builtin_amdgcn_global_load_lds((gbl_cvptr)pvf, (lds_vptr)pollRow, 4, 0, 16 /* sc1 */);
@@ -2606,18 +2602,17 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                     const int t = g * SBG + u;
                     if (t < nb && !merged) {
                         const long long dbgB = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
-                        // (two vector adds form the lane's addresses in the slot; the five reads carry immediate offsets)
-                        const unsigned slotOff = (unsigned)(((g & 1) * SBG + u) * SB_SLOT_W * 4);
-                        const unsigned aG = ldsLaneG + slotOff, aW = ldsLaneW + slotOff;
+                        // (two vector adds form the lane's addresses; zbar sits SBG KiB + 8 B behind the lane's gain record)
+                        const unsigned halfOff = (unsigned)((g & 1) * SB_HALF_W * 4);
+                        const unsigned aG = ldsLaneG + halfOff + (unsigned)(u * 1024), aX = ldsLaneX + halfOff + (unsigned)(u * 512);
                         uint4 gr;
-                        unsigned zl, zh, sx0, sx1;
-                        asm volatile("ds_read_b128 %0, %5\n\tds_read_b32 %1, %6 offset:1024\n\tds_read_b32 %2, %6 offset:1280\n\t"
-                                     "ds_read_b32 %3, %6 offset:1536\n\tds_read_b32 %4, %6 offset:1792\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(gr), "=&v"(zl), "=&v"(zh), "=&v"(sx0), "=&v"(sx1) : "v"(aG), "v"(aW) : "memory");
-                        const double gs = words2double(gr.x, gr.y), zbar = words2double(zl, zh);
+                        uint2 zw, sx;
+                        asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(gr), "=&v"(zw), "=&v"(sx) : "v"(aG), "v"(aX), "n"(SBG * 1024 + 8) : "memory");
+                        const double gs = words2double(gr.x, gr.y), zbar = words2double(zw.x, zw.y);
                         const float gz = __uint_as_float(gr.z), gw = __uint_as_float(gr.w);
                         const double p00 = (double)gz, p10 = (double)gw;
-                        const float so0 = __uint_as_float(sx0), so1 = __uint_as_float(sx1);
+                        const float so0 = __uint_as_float(sx.x), so1 = __uint_as_float(sx.y);
                         const int left = min(64, n - (t << 6));
                         const unsigned long long leftMask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
                         // h: lane k holds the TRUE state of its bin once settled, the hypothesis S_k + delta otherwise.  Every

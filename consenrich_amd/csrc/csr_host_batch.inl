@@ -267,8 +267,9 @@ static int64_t arr_comps(csr_ctx *c, int id);
 static int nat_array(csr_ctx *c, int id, float **out) {
     if (!c->nat[id]) {
         const int64_t per = arr_comps(c, id);
-        CHECK(dalloc(c, &c->nat[id], per * c->Npad));
-        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * c->Npad, c->stream));
+        // (+ 64 spare bins: the bit-exact state chain's ring DMAs fetch the stored trajectory 128 bins at a time)
+        CHECK(dalloc(c, &c->nat[id], per * (c->Npad + 64)));
+        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * (c->Npad + 64), c->stream));
     }
     *out = c->nat[id];
     return 0;
