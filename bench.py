@@ -40,8 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILES = {0: os.path.join("profiles", "r03_pmc_traffic_exact.json"),      # PMC passes of THIS workload (scripts/pmc_traffic.py)
-                 2: os.path.join("profiles", "r03_pmc_traffic.json")}
+TRAFFIC_FILES = {0: os.path.join("profiles", "r04_pmc_traffic_exact.json"),      # PMC passes of THIS workload (scripts/pmc_traffic.py)
+                 2: os.path.join("profiles", "r04_pmc_traffic.json")}
 EXIT_RCCL_FAILED = 3
 
 
