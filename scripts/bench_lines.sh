@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other bench lines kept under profiles/ (R = round tag): BASELINE configs 3 and 5 on one GPU, the long-memory regime.
 set -e
-R=${R:-r03}
+R=${R:-r04}
 O=gpurun_out/p
 mkdir -p $O
 python3 bench.py --samples 8 --no-cpu-baseline > $O/${R}_bench_c3_hg38_200bp_x8.json
