@@ -274,7 +274,9 @@ struct csr_ctx {
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<unsigned char> hMaskStage[8];
-    int tailFirstPct = 50, tailNextPct = 15;     // CONSENRICH_AMD_TAIL_PCT="first,next": share of the batch's bins a group must reach
+    // CONSENRICH_AMD_TAIL_PCT="first,next": share of the batch's bins a group of finished chains must reach.  Round 4: 60 / 40 (round 3:
+    // 50 / 15) -- tail kernels take issue slots from the walking wavefronts, so fewer, later groups win (profiles/r04_tail_sweep.txt)
+    int tailFirstPct = 60, tailNextPct = 40;
     bool tailSplit = true;      // CONSENRICH_AMD_TAIL_SPLIT=0: a step's tail follows the state chain for all chains at once
     bool pfPending = false, pfNat = false, pnNat = false;
     static constexpr bool earlyPf = true;       // Pf / constant pNoise are exported underneath the state chain
@@ -401,7 +403,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_SB_ASYNC"))) c->sbAsync = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_TAIL_SPLIT"))) c->tailSplit = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_TAIL_PCT"))) {
-        int a = 50, b = 15;
+        int a = 60, b = 40;
         if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->tailFirstPct = std::min(100, std::max(1, a)); c->tailNextPct = std::min(100, std::max(1, b)); }
     }
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
