@@ -149,6 +149,11 @@ class RcclComm:
         self._L.check(self._lib.csr_comm_allreduce_sum(self._comm, C.byref(v)))
         return int(round(v.value))
 
+    def allreduce_sum(self, value: float) -> float:
+        v = C.c_double(float(value))
+        self._L.check(self._lib.csr_comm_allreduce_sum(self._comm, C.byref(v)))
+        return float(v.value)
+
     def barrier(self):
         self._L.check(self._lib.csr_comm_barrier(self._comm))
 

@@ -1120,6 +1120,7 @@ def test_track_gather_over_rccl_single_rank(product):
         with RcclComm(b, world=1, rank=0) as comm:
             comm.barrier()
             assert comm.allreduce_max(3.25) == 3.25
+            assert comm.allreduce_sum(2.5) == 2.5 and comm.ranks_seen() == 1
             b.step(L.RETURN_NLL, L.EXPORT_SMOOTH)
             out = comm.gather_batch_tracks(lengths)
             assert comm.gather_batch_tracks(lengths, to_host=False) is None

@@ -96,3 +96,14 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
                        timeout=100)
     assert r.returncode == 2 and "WORLD_SIZE is 2" in r.stderr
+
+
+def test_both_transports_offer_the_reductions_bench_py_uses():
+    """bench.py's barrier, max-over-ranks and per-rank reductions go through `comm`, which is an RcclComm or, on the fallback
+    path, the job's JobFiles: both must offer the same three calls (round 4: `per_rank` needs allreduce_sum on both)."""
+    from consenrich_amd.launch import JobFiles
+    from consenrich_amd.sharding import RcclComm
+
+    for cls in (RcclComm, JobFiles):
+        for name in ("barrier", "allreduce_max", "allreduce_sum"):
+            assert callable(getattr(cls, name, None)), (cls.__name__, name)
