@@ -229,3 +229,101 @@ def test_reference_contract_cases_on_the_device_match_the_twin(name):
         assert dg["final_nll"] == pytest.approx(dr["final_nll"], rel=1e-6)
         assert dg["process_q_diagnostics"]["policy"] == dr["process_q_diagnostics"]["policy"]
         np.testing.assert_allclose(dg["process_q_diagnostics"]["baseQLevel"], dr["process_q_diagnostics"]["baseQLevel"], rtol=1e-6)
+
+
+def _variant_cases():
+    data, munc, kw = _case_outer_pass_smoke()
+    n = data.shape[1]
+    base = {k: v for k, v in kw.items() if k not in ("returnPrecisionDiagnostics", "returnDiagnostics", "trackOptimizationPath")}
+    rng = np.random.default_rng(5)
+    return {
+        "background_and_bounds": dict(base, returnBackground=True, boundState=True, stateLowerBound=-0.5, stateUpperBound=0.6),
+        "no_background_fit": dict(base, fitBackground=False, returnBackground=True, returnScales=False),
+        "fixed_q_and_mask": dict(base, processNoiseCalibration="fixed", minQ=1.0e-6, observationMask=rng.random((3, n)) > 0.2,
+                                 ECM_useObsPrecisionReweighting=False),
+        "given_q_and_warm_starts": dict(base, initialProcessQ=np.asarray([[2e-3, 1e-4], [1e-4, 5e-4]], np.float32),
+                                        initialBackground=np.linspace(-0.2, 0.2, n).astype(np.float32),
+                                        initialProcessPrecision=np.full(n, 1.5, np.float32),
+                                        initialObservationPrecision=np.full(n, 0.8, np.float32), returnPrecisionDiagnostics=True),
+    }, data, munc
+
+
+@pytest.mark.parametrize("name", ["background_and_bounds", "no_background_fit", "fixed_q_and_mask", "given_q_and_warm_starts"])
+def test_argument_variants_on_the_cpu_twin(name):
+    variants, data, munc = _variant_cases()
+    kw = variants[name]
+    _, out = _twin_call(data, munc, kw)
+    n = data.shape[1]
+    want = 4 + int(kw.get("returnScales", True)) + int(kw.get("returnBackground", False)) + int(kw.get("returnPrecisionDiagnostics", False))
+    assert len(out) == want
+    assert out[0].shape == (n, 2) and all(np.all(np.isfinite(np.asarray(a, np.float64))) for a in out[:4])
+    if kw.get("boundState"):
+        assert out[0][:, 0].min() >= np.float32(-0.5) and out[0][:, 0].max() <= np.float32(0.6)
+    if name == "no_background_fit":
+        np.testing.assert_array_equal(out[4], np.zeros(n, np.float32))          # background stays zero (core.py:5038-5040)
+    if name == "given_q_and_warm_starts":
+        np.testing.assert_allclose(out[-1]["matrixQ0"], [[2e-3, 1e-4], [1e-4, 5e-4]], rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["background_and_bounds", "no_background_fit", "fixed_q_and_mask", "given_q_and_warm_starts"])
+def test_argument_variants_on_the_device_match_the_twin(name):
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import core_api
+
+    variants, data, munc = _variant_cases()
+    kw = dict(variants[name])
+    out = core_api.runConsenrich(data, munc, kw.pop("deltaF"), kw.pop("minQ"), kw.pop("maxQ"), **kw)
+    _, ref = _twin_call(data, munc, variants[name])
+    assert len(out) == len(ref)
+    for i, (a, b) in enumerate(zip(out, ref)):
+        if isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and a.shape == b.shape, (name, i)
+            if a.dtype.kind == "f" and i != 3:
+                np.testing.assert_allclose(a.astype(np.float64), b, rtol=1e-4, atol=2e-5, err_msg=f"{name} item {i}")
+            elif a.dtype.kind != "f":
+                np.testing.assert_array_equal(a, b)
+    if isinstance(out[-1], dict):
+        for k in TRACK_KEYS:
+            np.testing.assert_allclose(out[-1]["outputTracks"][k], ref[-1]["outputTracks"][k], rtol=5e-2, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_the_references_fold_loop_call_by_call_equals_the_batch_of_folds():
+    """uncertainty.py:1370-1419 calls `runConsenrich(matrixData, matrixMunc, observationMask=mask, **fitKwargs)` once per fold.
+    Through `core_api.runConsenrich` (one device-resident fit per call) and through `driver.run_folds_batch` (all folds as
+    chains of one batch, masks made on the device) the tuples must be the same arrays bit for bit."""
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import cases
+    import unc_cases
+    from consenrich_amd import core_api
+    from consenrich_amd.batch import DeviceBatch
+    from consenrich_amd.driver import fold_chain_lengths, run_folds_batch
+    from oracle import oracle as orc
+
+    m, n, folds, fbl = 4, 2300, 2, 50
+    data, munc = cases.synth(n, m, 8800)
+    data = (data + (0.3 * np.sin(np.arange(n) / 300.0)).astype(np.float32)[None, :]).astype(np.float32)
+    bf, rc, rb = unc_cases.fold_spec(m, n, fbl, folds, 0.4, 12)
+    kw = dict(deltaF=1.0, minQ=1.0e-6, maxQ=1000.0, stateInit=0.0, stateCovarInit=1000.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=40, ECM_fixedBackgroundIters=4, ECM_outerIters=2, ECM_minOuterIters=1,
+              ECM_useObsPrecisionReweighting=False, returnScales=True, returnBackground=True)
+    k = dict(kw)
+    plan = core_api.resolve_call(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
+    spec = dict(data=data, munc=munc, folds=folds, fold_block_len=fbl, block_fold=bf, reps_count=rc, reps=rb, pad=float(np.float32(plan.model.pad)))
+    with DeviceBatch(0) as b:
+        b.configure(plan.model, m, fold_chain_lengths([spec]))
+        fits, results, info = run_folds_batch(b, plan.cfg, [spec], block_len_intervals=plan.block_len_intervals)
+    act = np.ones((m, n), np.uint8)
+    tot = orc.cobservationTotalInformation(munc, act, np.ones(n), False, float(np.float32(plan.model.pad)), 0.0)
+    for f in range(folds):
+        mask = orc.cmakeFoldMaskAndInformation(m, n, fbl, f, bf, rc, rb, munc, act, tot, np.ones(n), False, float(np.float32(plan.model.pad)), 0.0)[0]
+        k = dict(kw)
+        out = core_api.runConsenrich(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), observationMask=mask != 0, **k)
+        assert len(out) == 6
+        for a, b_ in zip(out, results[f]):
+            assert np.array_equal(a, b_), f
