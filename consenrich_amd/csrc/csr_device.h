@@ -2115,6 +2115,9 @@ __global__ __launch_bounds__(64) void k_state_seq_trend(Prm p, const int64_t *ch
 // v_readlane and no memory instruction on the step path: 2 DPP moves + 9 arithmetic instructions, ~20 ns per bin.
 // MODE 2: F = [[1, 1], [0, 1]] (predicted level = one float32 add, see sb_step); 1: F = [[1, f], [0, 1]]; 0: any F.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_ror1(float src) {          // lane k <- lane k - 1, lane 0 <- lane 63
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, src), __builtin_bit_cast(int, src), 0x13C /* wave_ror:1 */, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float dpp_shr1_keep0(float keepLane0, float src) {
     // lanes 1..63 <- src of the lane below; lane 0 keeps keepLane0 (bound_ctrl = 0: an out-of-range source leaves the destination)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keepLane0), __builtin_bit_cast(int, src),
@@ -2565,12 +2568,95 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         for (;;) {
             cin0 = __uint_as_float((unsigned)cw); cin1 = __uint_as_float((unsigned)(cw >> 32));
             ++runs;
-            float t0 = cin0, t1 = cin1;                    // TRUE state at the bin before the next batch
-            float sc0 = trj0, sc1 = trj1;                  // the stored trajectory's state at the bin before the batch
+            float qi0 = cin0, qi1 = cin1;                  // lane 0: TRUE state at the bin before the next batch
+            float d0 = cin0 - trj0, d1 = cin1 - trj1;      // the hypothesis T - S (trj: the stored trajectory's state at the bin before batch 0)
             bool newer = false;
             unsigned long long cwNew = cw;
             int done = 0;
             const long long dbgT0 = DBG ? wall_clock64() : 0;
+            // one 64-bin batch of the run.  Carried from batch to batch: qi (lane 0: the TRUE state at the bin before the batch),
+            // d (the current hypothesis T - S as two scalars), `done`, `merged`.
+            auto batch = [&](auto fullTag, int g, int u) {
+                constexpr bool FULL = decltype(fullTag)::value;
+                const int t = g * SBG + u;
+                const long long dbgB = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
+                // (two vector adds form the lane's addresses; zbar sits SBG KiB + 8 B behind the lane's gain record)
+                const unsigned halfOff = (unsigned)((g & 1) * SB_HALF_W * 4);
+                const unsigned aG = ldsLaneG + halfOff + (unsigned)(u * 1024), aX = ldsLaneX + halfOff + (unsigned)(u * 512);
+                uint4 gr;
+                uint2 zw, sx;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(gr), "=&v"(zw), "=&v"(sx) : "v"(aG), "v"(aX), "n"(SBG * 1024 + 8) : "memory");
+                const double gs = words2double(gr.x, gr.y), zbar = words2double(zw.x, zw.y);
+                const float gz = __uint_as_float(gr.z), gw = __uint_as_float(gr.w);
+                const double p00 = (double)gz, p10 = (double)gw;
+                const float so0 = __uint_as_float(sx.x), so1 = __uint_as_float(sx.y);
+                const int left = FULL ? 64 : min(64, n - (t << 6));
+                const unsigned long long leftMask = (FULL || left >= 64) ? ~0ull : ((1ull << (left & 63)) - 1ull);
+                // h: lane k holds the TRUE state of its bin once settled, the hypothesis S_k + delta otherwise.  Every
+                // lane's predecessor is a wave shift of h (lane 0: the true carry), so settled lanes recompute their own
+                // bits and pass; the first failing lane f had a proven predecessor: its step result n_f is true.  The
+                // second step m = step(shift(n)) is issued while the scalar unit digests the comparison: m_k = n_k up
+                // to f, and m_{f+1} is true as well (from n_f), so the round settles through f + 1 and re-bases there.
+                // What a round costs is its INSTRUCTION COUNT: one wavefront per SIMD issues one instruction every
+                // ~5 ticks whatever its type or dependencies (scripts/ubench/issue_cost.hip).  Hence: ONE backward branch
+                // per round, the re-base computed unconditionally (a sentinel bit at the batch's last bin makes a round
+                // without a failing lane re-base there, where m = n: nothing changes), rare paths behind the loop, the
+                // shifted vectors loop-carried so that their lane 0 keeps the true carry without a copy per round, one
+                // 64-bit comparison of the packed pair.
+                float h0 = so0 + d0, h1 = so1 + d1;
+                float q0 = qi0, q1 = qi1, r0 = qi0, r1 = qi1;         // lane 0 of the shifted vectors: the true carry, for the whole batch
+                const unsigned long long sentinel = 1ull << (left - 1);
+                int rounds = 0, s;
+                unsigned long long fail;
+                const long long dbgC = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
+                if (dbgOn) dbgSec[1] += (unsigned long long)(dbgC - dbgB);
+#pragma unroll 1
+                do {
+                    q0 = dpp_shr1_keep0(q0, h0); q1 = dpp_shr1_keep0(q1, h1);
+                    float n0, n1;
+                    sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, gz, gw, n0, n1);
+                    const unsigned long long ne = __builtin_amdgcn_uicmpl(((unsigned long long)f2u(n1) << 32) | f2u(n0),
+                                                                          ((unsigned long long)f2u(h1) << 32) | f2u(h0), 33 /* ICMP_NE */);
+                    __builtin_amdgcn_sched_barrier(0);
+                    r0 = dpp_shr1_keep0(r0, n0); r1 = dpp_shr1_keep0(r1, n1);
+                    float m0, m1;
+                    sys_step<MODE>(p, r0, r1, gs, zbar, p00, p10, gz, gw, m0, m1);
+                    const float e0 = m0 - so0, e1 = m1 - so1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    fail = FULL ? ne : (ne & leftMask);
+                    // bins 0 .. s are settled: m holds their true states (s = f + 1 behind a failing lane f)
+                    s = min((int)__builtin_ctzll(fail | sentinel) + 1, left - 1);
+                    d0 = rl32(e0, s); d1 = rl32(e1, s);
+                    const bool le = lane <= s;
+                    h0 = le ? m0 : so0 + d0;
+                    h1 = le ? m1 : so1 + d1;
+                    if constexpr (DBG) ++rounds;
+                    // (no give-up rule: a round settles at least two more bins -- the lane behind the settled ones has a
+                    // proven predecessor, so the next failing lane lies beyond it -- i.e. at most 32 rounds per batch, which
+                    // costs what the round-3 rule "20 rounds, then walk the rest" cost where the levels flip densely)
+                } while (fail != 0ull);
+                const long long dbgD = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
+                if (dbgOn) dbgSec[2] += (unsigned long long)(dbgD - dbgC);
+                if (FULL || lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
+                if constexpr (DBG) { dbgRounds += (unsigned)rounds; ++dbgBatches; if (rounds > 20) ++dbgFb; }
+                // the batch's last bin: its true state becomes lane 0 of the next batch's shifted vectors (a full batch: one wave
+                // rotation per component), T - S there the next hypothesis (after the loop d is the delta of lane s <= left - 1; the
+                // settled lanes hold m, so it is read again at the last bin), and T == S there means the run has met the stored
+                // trajectory: what lies behind is right and ends in `out`, provided the stored trajectory is one piece from here
+                const unsigned long long eq = __builtin_amdgcn_uicmpl(((unsigned long long)f2u(h1) << 32) | f2u(h0),
+                                                                      ((unsigned long long)f2u(so1) << 32) | f2u(so0), 32 /* ICMP_EQ */);
+                const float dv0 = h0 - so0, dv1 = h1 - so1;
+                d0 = rl32(dv0, left - 1); d1 = rl32(dv1, left - 1);
+                if constexpr (FULL) {
+                    qi0 = dpp_ror1(h0); qi1 = dpp_ror1(h1);
+                } else {
+                    qi0 = rl32(h0, left - 1); qi1 = rl32(h1, left - 1);
+                }
+                done = (t << 6) + left;                    // bins of the superblock settled by this run
+                merged = done > brk && ((eq >> (left - 1)) & 1ull) != 0ull;
+                if (dbgOn) dbgSec[3] += (unsigned long long)((long long)__builtin_readcyclecounter() - dbgD);
+            };
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's earlier stores of the trajectory are out; the ring is free
             issue_group(0);
 #pragma unroll 1
@@ -2597,85 +2683,20 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                 __builtin_amdgcn_sched_barrier(0);
                 if (g == 0) { trj0 = cin0; trj1 = cin1; }          // (this group rewrites batch 0 of the stored trajectory from cin)
                 if (dbgOn) { const long long nowA = (long long)__builtin_readcyclecounter(); dbgSec[0] += (unsigned long long)(nowA - dbgA); }
+                // (a group whose SBG batches are all full -- every group but a superblock's last -- runs the instance of the batch
+                // with left = 64 folded in: no length mask in the round, an unpredicated store, constant lane indices)
+                if ((g * SBG + SBG) * 64 <= n) {
 #pragma unroll
-                for (int u = 0; u < SBG; ++u) {
-                    const int t = g * SBG + u;
-                    if (t < nb && !merged) {
-                        const long long dbgB = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
-                        // (two vector adds form the lane's addresses; zbar sits SBG KiB + 8 B behind the lane's gain record)
-                        const unsigned halfOff = (unsigned)((g & 1) * SB_HALF_W * 4);
-                        const unsigned aG = ldsLaneG + halfOff + (unsigned)(u * 1024), aX = ldsLaneX + halfOff + (unsigned)(u * 512);
-                        uint4 gr;
-                        uint2 zw, sx;
-                        asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(gr), "=&v"(zw), "=&v"(sx) : "v"(aG), "v"(aX), "n"(SBG * 1024 + 8) : "memory");
-                        const double gs = words2double(gr.x, gr.y), zbar = words2double(zw.x, zw.y);
-                        const float gz = __uint_as_float(gr.z), gw = __uint_as_float(gr.w);
-                        const double p00 = (double)gz, p10 = (double)gw;
-                        const float so0 = __uint_as_float(sx.x), so1 = __uint_as_float(sx.y);
-                        const int left = min(64, n - (t << 6));
-                        const unsigned long long leftMask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-                        // h: lane k holds the TRUE state of its bin once settled, the hypothesis S_k + delta otherwise.  Every
-                        // lane's predecessor is a wave shift of h (lane 0: the true carry), so settled lanes recompute their own
-                        // bits and pass; the first failing lane f had a proven predecessor: its step result n_f is true.  The
-                        // second step m = step(shift(n)) is issued while the scalar unit digests the comparison: m_k = n_k up
-                        // to f, and m_{f+1} is true as well (from n_f), so the round settles through f + 1 and re-bases there.
-                        // What a round costs is its INSTRUCTION COUNT: one wavefront per SIMD issues one instruction every
-                        // ~5 ticks whatever its type or dependencies (scripts/ubench/issue_cost.hip).  Hence: ONE backward branch
-                        // per round, the re-base computed unconditionally (a sentinel bit at the batch's last bin makes a round
-                        // without a failing lane re-base there, where m = n: nothing changes), rare paths behind the loop, the
-                        // shifted vectors loop-carried so that their lane 0 keeps the true carry without a copy per round, one
-                        // 64-bit comparison of the packed pair.
-                        float d0 = t0 - sc0, d1 = t1 - sc1;
-                        float h0 = so0 + d0, h1 = so1 + d1;
-                        float q0 = t0, q1 = t1, r0 = t0, r1 = t1;           // lane 0 of the shifted vectors: the true carry, for the whole batch
-                        const unsigned long long sentinel = 1ull << (left - 1);
-                        int rounds = 0, s;
-                        unsigned long long fail;
-                        const long long dbgC = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
-                        if (dbgOn) dbgSec[1] += (unsigned long long)(dbgC - dbgB);
-#pragma unroll 1
-                        do {
-                            q0 = dpp_shr1_keep0(q0, h0); q1 = dpp_shr1_keep0(q1, h1);
-                            float n0, n1;
-                            sys_step<MODE>(p, q0, q1, gs, zbar, p00, p10, gz, gw, n0, n1);
-                            const unsigned long long ne = __builtin_amdgcn_uicmpl(((unsigned long long)f2u(n1) << 32) | f2u(n0),
-                                                                                  ((unsigned long long)f2u(h1) << 32) | f2u(h0), 33 /* ICMP_NE */);
-                            __builtin_amdgcn_sched_barrier(0);
-                            r0 = dpp_shr1_keep0(r0, n0); r1 = dpp_shr1_keep0(r1, n1);
-                            float m0, m1;
-                            sys_step<MODE>(p, r0, r1, gs, zbar, p00, p10, gz, gw, m0, m1);
-                            const float e0 = m0 - so0, e1 = m1 - so1;
-                            __builtin_amdgcn_sched_barrier(0);
-                            fail = ne & leftMask;
-                            // bins 0 .. s are settled: m holds their true states (s = f + 1 behind a failing lane f)
-                            s = min((int)__builtin_ctzll(fail | sentinel) + 1, left - 1);
-                            d0 = rl32(e0, s); d1 = rl32(e1, s);
-                            const bool le = lane <= s;
-                            h0 = le ? m0 : so0 + d0;
-                            h1 = le ? m1 : so1 + d1;
-                            if constexpr (DBG) ++rounds;
-                            // (no give-up rule: a round settles at least two more bins -- the lane behind the settled ones has a
-                            // proven predecessor, so the next failing lane lies beyond it -- i.e. at most 32 rounds per batch, which
-                            // costs what the round-3 rule "20 rounds, then walk the rest" cost where the levels flip densely)
-                        } while (fail != 0ull);
-                        const long long dbgD = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
-                        if (dbgOn) dbgSec[2] += (unsigned long long)(dbgD - dbgC);
-                        if (lane < left) natXf[g0 + (int64_t)t * 64] = make_float2(h0, h1);
-                        if constexpr (DBG) { dbgRounds += (unsigned)rounds; ++dbgBatches; if (rounds > 20) ++dbgFb; }
-                        t0 = rl32(h0, left - 1);
-                        t1 = rl32(h1, left - 1);
-                        sc0 = rl32(so0, left - 1);
-                        sc1 = rl32(so1, left - 1);
-                        done = (t << 6) + left;                    // bins of the superblock settled by this run
-                        // met the stored trajectory inside its last piece: what lies behind is right and ends in `out`
-                        merged = done > brk && ((f2u(t0) ^ f2u(sc0)) | (f2u(t1) ^ f2u(sc1))) == 0u;
-                        if (dbgOn) dbgSec[3] += (unsigned long long)((long long)__builtin_readcyclecounter() - dbgD);
-                    }
+                    for (int u = 0; u < SBG; ++u)
+                        if (!merged) batch(std::true_type{}, g, u);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SBG; ++u)
+                        if (g * SBG + u < nb && !merged) batch(std::false_type{}, g, u);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA of this run still lands in the ring
-            if (!newer && done >= n) { completed = true; out0 = t0; out1 = t1; brk = 0; }      // the run reached the superblock's end
+            if (!newer && done >= n) { completed = true; out0 = rl32(qi0, 0); out1 = rl32(qi1, 0); brk = 0; }      // the run reached the superblock's end
             if (DBG) dbgTicks += (unsigned long long)(wall_clock64() - dbgT0);
             if (!newer) break;
             ++aborts;
