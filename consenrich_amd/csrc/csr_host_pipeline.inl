@@ -1318,8 +1318,11 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     pt.prevKind = CK_NONE;
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
-    for (const ChainRun &r : runs) {        // (only the wavefront-groups that hold blocks of these chains; the mask trims the edges)
-        const int64_t g0 = r.b0 / 64, g1 = (r.b1 + 63) / 64;
+    if (!runs.empty()) {
+        // ONE launch over the wavefront-groups from the first to the last block of these chains: the mask trims what lies between
+        // (round 4: a launch per run of chains serialised four 60-us launches behind the state chain for a scattered last group)
+        int64_t g0 = runs.front().b0 / 64, g1 = (runs.front().b1 + 63) / 64;
+        for (const ChainRun &r : runs) { g0 = std::min(g0, r.b0 / 64); g1 = std::max(g1, (r.b1 + 63) / 64); }
         Scope sc(c, "state_reblock_out");
         hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, c->stream, pt,
                            reinterpret_cast<const float2 *>(natXf), pt.tXf, g0);
@@ -1384,6 +1387,12 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
     int64_t total = 0;
     for (const ChainInfo &ci : c->chains) total += ci.n;
     if (!c->dMask[0]) for (auto &m : c->dMask) CHECK(dalloc(c, &m, nc));
+    if (c->hMaskPinChains < (size_t)nc) {
+        if (c->hMaskPin) HIPOK(hipHostFree(c->hMaskPin));
+        c->hMaskPin = nullptr;
+        HIPOK(hipHostMalloc((void **)&c->hMaskPin, 8 * (size_t)nc, hipHostMallocDefault));
+        c->hMaskPinChains = (size_t)nc;
+    }
     std::vector<unsigned char> tailed((size_t)nc, 0);
     int phase = 0;
     bool any = false;
@@ -1401,8 +1410,9 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
             } else runs.push_back(ChainRun{ci.off, l, ci.b0, ci.b0 + ci.nb});
         }
         unsigned char *dm = c->dMask[phase];
-        c->hMaskStage[phase].assign(grp.begin(), grp.end());
-        HIPOK(hipMemcpyAsync(dm, c->hMaskStage[phase].data(), (size_t)nc, hipMemcpyHostToDevice, c->stream));
+        unsigned char *hm = c->hMaskPin + (size_t)phase * (size_t)nc;
+        std::copy(grp.begin(), grp.end(), hm);
+        HIPOK(hipMemcpyAsync(dm, hm, (size_t)nc, hipMemcpyHostToDevice, c->stream));
         CHECK(step_tail(c, pf, dm, runs, what));
         ++phase;
         any = true;

@@ -273,7 +273,8 @@ struct csr_ctx {
     struct SbPending { bool active = false; Prm p{}; } sbp;     // a state chain launched and not yet waited for (step_pipelined)
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<unsigned char> hMaskStage[8];
+    unsigned char *hMaskPin = nullptr;          // pinned staging of the eight masks (an upload from pageable memory may hold the host)
+    size_t hMaskPinChains = 0;
     // CONSENRICH_AMD_TAIL_PCT="first,next": share of the batch's bins a group of finished chains must reach.  Round 4: 60 / 40 (round 3:
     // 50 / 15) -- tail kernels take issue slots from the walking wavefronts, so fewer, later groups win (profiles/r04_tail_sweep.txt)
     int tailFirstPct = 60, tailNextPct = 40;
@@ -328,6 +329,7 @@ static void free_batch(csr_ctx *c) {
     c->sbDbg = nullptr;
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     if (c->hDone) { (void)hipHostFree(c->hDone); c->hDone = nullptr; c->dDone = nullptr; }
+    if (c->hMaskPin) { (void)hipHostFree(c->hMaskPin); c->hMaskPin = nullptr; c->hMaskPinChains = 0; }
     for (auto &m : c->dMask) m = nullptr;
     c->sbp.active = false;
     c->pfPending = false;
@@ -437,6 +439,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (c->evTailJoin) (void)hipEventDestroy(c->evTailJoin);
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->hDone) (void)hipHostFree(c->hDone);
+    if (c->hMaskPin) (void)hipHostFree(c->hMaskPin);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
