@@ -601,26 +601,40 @@ static void join_pf(csr_ctx *c) {
 // is one constant matrix -- are written on the side stream underneath it instead of after the smoother.
 static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool withPf = true) {
     const int nm = c->mdl.state_dim * c->mdl.state_dim;
-    const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA)) && p.chainQ == nullptr;
+    const bool constFlags = !(flags & (F_APN | F_QSCALE | F_KAPPA));
+    const bool constQ = constFlags && p.chainQ == nullptr;
+    // (round 4: with Pf also the process noise that is NOT one constant matrix -- per-bin multipliers: the covariance chain
+    // stored it; per-chain base matrices: a table -- so that a step with multipliers pipelines its tail as well)
+    const bool convQ = withPf && !constQ;
     if (!withPf && !constQ) return 0;
     // (a reference-layout array is allocated -- and zeroed ON THE MAIN STREAM -- at its first use: before the fork, so that the
     // side stream's writes are ordered behind the zeroing)
     float *dstPf = nullptr, *dstPn = nullptr;
     if (withPf) CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
-    if (constQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
+    if (constQ || convQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
     HIPOK(hipEventRecord(c->evFork2, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
     if (withPf) {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        float *dst = dstPf;
         L.count = 1;
-        L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dst; L.d[0].E = 4; L.d[0].n = nm;
+        L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dstPf; L.d[0].E = 4; L.d[0].n = nm;
+        if (convQ) {            // (as export_impl describes it)
+            ExpDesc &e = L.d[L.count++];
+            e.src = constFlags ? nullptr : reinterpret_cast<const float *>(p.tQ); e.dst = dstPn; e.E = 4; e.n = nm; e.skipLast = 1;
+            if (constFlags) {
+                e.cval[0] = (float)p.Q00;
+                e.cval[1] = c->mdl.state_dim == 2 ? (float)p.Q01 : 0.f;
+                e.cval[2] = c->mdl.state_dim == 2 ? (float)p.Q10 : 0.f;
+                e.cval[3] = c->mdl.state_dim == 2 ? (float)p.Q11 : 0.f;
+            }
+        }
         Scope sc(c, "export_natural", c->side);
         hipLaunchKernelGGL(k_export_tiled, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->side, p, L);
     }
     LAUNCH_CHECK("k_export_tiled (early Pf)");
     if (withPf) c->pfNat = true;
+    if (convQ) c->pnNat = true;
     if (constQ) {
         float *dst = dstPn;
         const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
@@ -1354,9 +1368,10 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
 // chain has ended.  Same kernels, same results; a chain's tail simply starts when ITS filtered state stands.
 static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handled) {
     *handled = false;
-    const bool constQ = !(flags & (F_APN | F_QSCALE | F_KAPPA | F_LAMBDA)) && c->p.chainQ == nullptr;
+    // (round 4: per-bin multipliers and per-chain base matrices pipeline as well -- their process noise goes to the reference
+    // layout underneath the state chain with Pf, early_cov_exports; the sequential APN pass has no state chain to hide behind)
     if (!(c->tailSplit && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState && c->sbAsync &&
-          c->deferEnabled && constQ &&
+          c->deferEnabled && !((flags & F_APN) && !(flags & F_QSCALE)) &&
           !(what & CSR_EXPORT_MULT) && c->chains.size() >= 2 && c->chains.size() <= 4096))
         return 0;
     CHECK(settle(c));

@@ -271,12 +271,15 @@ def test_exact_state_chain_on_superblocks_equals_the_sequential_kernel(product, 
             assert sb["stats"]["sb_bailouts"] > 0, sb["stats"]
 
 
-def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(product, monkeypatch):
+@pytest.mark.parametrize("variant", ["constant_q", "multipliers", "per_chain_q"])
+def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(product, monkeypatch, variant):
     """csr_batch_step in the bit-exact mode launches the smoother / residuals of the chains whose filtered state stands while
     the state chain of the others is still running (step_pipelined, csr_host_pipeline.inl): groups of chains under masks, on
     a second stream.  Same kernels, so every output must equal the step run in order, bit for bit -- with the default
     thresholds, with thresholds that make (nearly) every finished chain a group of its own, and when the single launch bails
-    out under the groups already in flight (everything is then redone behind the pass form)."""
+    out under the groups already in flight (everything is then redone behind the pass form).  Round 4: also with per-bin
+    multipliers (lambda, kappa, qScale: the final pass of a fit, pyx:8151-8300) and with per-chain base process noise
+    (core.py:5667) -- their process noise reaches the reference layout underneath the state chain."""
     from consenrich_amd import _lib as L
     from consenrich_amd.batch import DeviceBatch, ModelParams
 
@@ -284,6 +287,9 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
     m = 4
     sets = [cases.synth(n, m, 7300 + c, mask_frac=0.01, outlier_frac=0.01) for c, n in enumerate(n_list)]
     what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+    flags = L.RETURN_NLL
+    if variant == "multipliers":
+        flags |= L.USE_LAMBDA | L.USE_KAPPA | L.USE_QSCALE
 
     def run(env):
         for k in ("CONSENRICH_AMD_TAIL_SPLIT", "CONSENRICH_AMD_TAIL_PCT", "CONSENRICH_AMD_SB_SPIN_LIMIT"):
@@ -295,15 +301,20 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
             b.configure(ModelParams(state_dim=2), m, n_list)
             for c, (d_, v_) in enumerate(sets):
                 b.upload(c, d_, v_)
+                if variant == "multipliers":
+                    lam, kap, qs = cases.multipliers(n_list[c], 7400 + c)
+                    b.upload_multipliers(c, lam, np.clip(kap, 0.25, 4.0), qs)
+            if variant == "per_chain_q":
+                b.set_chain_q([np.diag([1e-3 * (1 + c), 1e-4 * (1 + 0.5 * c)]).astype(np.float32) for c in range(len(n_list))])
             for rep in range(2):        # the second step re-uses every buffer of the first
-                sd, sn = b.step(L.RETURN_NLL, what)
+                sd, sn = b.step(flags, what)
             out["sd"], out["sn"] = np.array(sd), np.array(sn)
             for c in range(len(n_list)):
                 for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
                     out[(c, name)] = b.download(c, name)
             out["stats"] = b.run_stats()
             # a step that exports nothing, the exports asked for afterwards (the residuals were not part of the pipelined tails)
-            b.step(L.RETURN_NLL, 0)
+            b.step(flags, 0)
             b.export(what)
             for c in range(len(n_list)):
                 for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
@@ -312,15 +323,17 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
 
     ref = run({"CONSENRICH_AMD_TAIL_SPLIT": "0"})
     assert ref["stats"]["tail_groups"] == 0
+    if variant != "constant_q":         # the process noise really varies (per bin / per chain)
+        assert not np.array_equal(ref[(0, "pnoise")][:100], ref[(1, "pnoise")][:100])
     for env in ({}, {"CONSENRICH_AMD_TAIL_PCT": "1,1"}, {"CONSENRICH_AMD_TAIL_PCT": "1,1", "CONSENRICH_AMD_SB_SPIN_LIMIT": "1"}):
         got = run(env)
         if os.environ.get("CONSENRICH_AMD_TAIL_SPLIT", "1") != "0" and os.environ.get("CONSENRICH_AMD_SB_ASYNC", "1") != "0" \
                 and os.environ.get("CONSENRICH_AMD_SB_STATE", "1") != "0" and os.environ.get("CONSENRICH_AMD_SEQ_STATE", "0") == "0" \
                 and os.environ.get("CONSENRICH_AMD_DEFER", "1") != "0":
-            assert got["stats"]["tail_groups"] >= 2, (env, got["stats"])       # two steps, at least one group each
+            assert got["stats"]["tail_groups"] >= 2, (env, variant, got["stats"])       # two steps, at least one group each
         for key, val in ref.items():
             if key != "stats":
-                assert np.array_equal(val, got[key]), (env, key)
+                assert np.array_equal(val, got[key]), (env, variant, key)
 
 
 def _full_chain(mod, d, n, m, seed=4242):
