@@ -11,7 +11,7 @@ if os.environ.get("SHARD"):      # "8:0" = the contigs rank 0 of 8 would own
     from consenrich_amd.sharding import lpt_assign
     w, r = map(int, os.environ["SHARD"].split(":")); lengths = [lengths[i] for i in lpt_assign(lengths, w)[r]]
 b = DeviceBatch(0, block_len=B)
-b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
+b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(int(os.environ.get("SEED", "1234")))
 what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
 def step():
     if os.environ.get("SPLIT_CALLS"):
