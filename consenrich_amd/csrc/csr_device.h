@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include <stdint.h>
 
 namespace csr {
@@ -250,6 +251,13 @@ __device__ __forceinline__ void dma4(const void *g, unsigned *ldsRow) {
 }
 __device__ __forceinline__ void dma16(const void *g, unsigned *ldsRow) {
     __builtin_amdgcn_global_load_lds((gbl_cvptr)g, (lds_vptr)ldsRow, 16, 0, 0);
+}
+// N consecutive 1-KiB rows (64 lanes x 16 B) from g (this lane's address of row 0) into the LDS rows from ldsRow on: ONE address
+// pair and ONE M0, the row index in the instruction's immediate offset (it is applied to the global and the LDS address alike;
+// 13 bits signed: rows 0..3)
+template <int... U>
+__device__ __forceinline__ void dma16_rows(const void *g, unsigned *ldsRow, std::integer_sequence<int, U...>) {
+    (__builtin_amdgcn_global_load_lds((gbl_cvptr)g, (lds_vptr)ldsRow, 16, U * 1024, 0), ...);
 }
 __device__ __forceinline__ unsigned lds_off(const unsigned *q) {
     return (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned *)q);
@@ -2543,6 +2551,26 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
         // the predecessor's {version, final} word (low half: versions stay far below 2^31), agent scope
         __builtin_amdgcn_global_load_lds((gbl_cvptr)pvf, (lds_vptr)pollRow, 4, 0, 16 /* sc1 */);
     };
+    // a group whose SBG batches all exist: per region one or two base addresses, the batch in the immediate offset (the generic
+    // form above spends ~100 instructions on its 16 addresses; this one ~35)
+    const float4 *const laneGain = natGain + bx + lane, *const laneSZ = natSZ + bx + lane;
+    const float4 *const laneXf = reinterpret_cast<const float4 *>(natXf + bx) + lane;
+    auto issue_group_full = [&](int g) {
+        unsigned *half = ring + (size_t)(g & 1) * SB_HALF_W;
+        const int64_t r0 = (int64_t)g * (SBG * 64);               // records (bins) before the group
+        constexpr int LO = SBG < 4 ? SBG : 4, HI = SBG - LO;      // rows reachable from the first base, from the second (+ 4 KiB)
+        dma16_rows(laneGain + r0, half, std::make_integer_sequence<int, LO>{});
+        if constexpr (HI > 0) dma16_rows(laneGain + r0 + 256, half + 1024, std::make_integer_sequence<int, HI>{});
+        dma16_rows(laneSZ + r0, half + SBG * 256, std::make_integer_sequence<int, LO>{});
+        if constexpr (HI > 0) dma16_rows(laneSZ + r0 + 256, half + SBG * 256 + 1024, std::make_integer_sequence<int, HI>{});
+        // (the stored trajectory: 8 B per bin, a row = two batches)
+        dma16_rows(laneXf + (r0 >> 1), half + 2 * SBG * 256, std::make_integer_sequence<int, SBG / 2>{});
+        __builtin_amdgcn_global_load_lds((gbl_cvptr)pvf, (lds_vptr)pollRow, 4, 0, 16 /* sc1 */);
+    };
+    auto issue = [&](int g) {
+        if ((g + 1) * SBG <= nb) issue_group_full(g);
+        else issue_group(g);
+    };
     for (;;) {
         // wait for news from the predecessor
         unsigned long long vf;
@@ -2658,7 +2686,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                 if (dbgOn) dbgSec[3] += (unsigned long long)((long long)__builtin_readcyclecounter() - dbgD);
             };
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's earlier stores of the trajectory are out; the ring is free
-            issue_group(0);
+            issue(0);
 #pragma unroll 1
             for (int g = 0; g < ng && !merged && !newer; ++g) {
                 long long dbgA = dbgOn ? (long long)__builtin_readcyclecounter() : 0;
@@ -2679,7 +2707,7 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (g + 1 < ng) issue_group(g + 1);
+                if (g + 1 < ng) issue(g + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g == 0) { trj0 = cin0; trj1 = cin1; }          // (this group rewrites batch 0 of the stored trajectory from cin)
                 if (dbgOn) { const long long nowA = (long long)__builtin_readcyclecounter(); dbgSec[0] += (unsigned long long)(nowA - dbgA); }
