@@ -1,7 +1,7 @@
 """One-off robustness run: the bit-exact mode on the superblock state chain against the sequential kernel (k_state_seq_trend),
 bit for bit, over random ragged batches whose chain lengths sit on and around multiples of the superblock length, random
 superblock / window settings, per-bin multipliers on and off, a general F; every batch also through csr_batch_step (twice), whose
-tail is pipelined per chain when there are no multipliers."""
+tail is pipelined per chain."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (R, os.path.join(R, "tests", "golden")): sys.path.insert(0, p)
