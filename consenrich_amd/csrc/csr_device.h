@@ -2513,6 +2513,10 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
     if (DBG && lane == 0) atomicMax(p.sbDbg + 1, (unsigned long long)wall_clock64());
     if (first) {
         sb_chain_done(p, a, b, bi, lane);
+        if (DBG && lane == 0) {
+            atomicMax(p.sbDbg + 2, (unsigned long long)wall_clock64());
+            if (b == (int64_t)bi.w) p.sbDbg[8 + p.blkChain[b]] = (unsigned long long)wall_clock64();     // a one-superblock chain is final
+        }
         return;
     }
     // ---- repairs
