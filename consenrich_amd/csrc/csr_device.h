@@ -89,6 +89,8 @@ struct Prm {
                         // one LDS-DMA instruction per step of the serial chains instead of two / four)
     double *tS2c;       // sum_j (z_j - zbar)^2 / R_j
     double *tLogR;      // sum_j log R_j
+    double2 *natSZ;     // statistics kernel: non-null = the {S0u, zbar} records ALSO in the reference layout (where the superblock
+                        // state chain reads them: no conversion launch in front of it)
     // blocked multipliers
     float *tLam, *tKap, *tQs;
     float *tKapOut;     // where the smoother's fused kappa E-step writes (the ECM loop ping-pongs scratch buffers so that a
@@ -452,6 +454,11 @@ __global__ __launch_bounds__(256) void k_stats_v4(Prm p) {
             const float4 bg = p.bg ? *reinterpret_cast<const float4 *>(p.bg + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             bin_stats4<UN>(p.data, p.munc, p.Npad, g, p.m, p.pad, bg, o);
             valid = bi.y - (s0 + si);
+            if (p.natSZ != nullptr) {           // (the thread's four bins are consecutive there: 64 contiguous bytes)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < valid) p.natSZ[g + q] = make_double2(o[q].s0, o[q].zbar);
+            }
         }
     }
 #pragma unroll
@@ -512,7 +519,10 @@ struct FwdPTrendT {
     static constexpr int FAMILY = FAM_OTHER;
     static constexpr int KIND = CK_FWDP_TREND;
     static constexpr bool USES_Q = true;      // reads the base process noise (per-chain Q0 needs the PCQ kernels)
-    static constexpr bool NATOUT_FWD = false;
+    // default mode, superblock state chain: the main phase can write the gain records (and Pf) in the reference layout through
+    // LDS tiles (walk_nat_gain) -- the state chain reads them there, a conversion launch less in front of it
+    static constexpr bool NATOUT_FWD = true;
+    static constexpr bool GAIN_NAT = true;
     static constexpr bool NATOUT = false;
     static constexpr bool DMA = false;
     static constexpr int NW = 1, ND = 1;
@@ -1611,6 +1621,82 @@ __device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::C
     }
 }
 
+// Covariance chain of the default mode with the superblock state chain: the gain records go to the reference layout (that is
+// where k_sb_async / k_sb_sys read them; Prm::natLag points at them HERE) and, when Prm::natPs is set, Pf as well, through the
+// LDS tiles of walk_nat (ps: Pf, lag: gain record).  The blocked Pf / pNoise stores of the step stay (the smoother reads them);
+// the blocked gain record is not written in this mode (Prm::predCompact: the NIS epilogue reads P00pred from tPP).
+template <class CH, class = void>
+struct GainNatOf : std::false_type {};
+template <class CH>
+struct GainNatOf<CH, std::void_t<decltype(CH::GAIN_NAT)>> : std::bool_constant<CH::GAIN_NAT> {};
+template <class CH>
+__device__ __forceinline__ void walk_nat_gain(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                              int64_t bfirst, int gbase, NatTiles &T) {
+    const int lane = threadIdx.x;
+    const int B = p.B;
+    const int64_t base = tbase(bq, B);
+    T.gbase[lane] = gbase;
+    T.len[lane] = act ? len : 0;
+    float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
+    float4 *natGn = reinterpret_cast<float4 *>(p.natLag);
+    typename CH::In cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (act && u < len) cur[u] = CH::load(p, base + (int64_t)u * 64, bq, u, len);
+#pragma unroll 1
+    for (int s8 = 0; s8 < B; s8 += 8) {
+        if (s8 + 8 < B) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 + 8 + u;
+                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            }
+        }
+        if (__any(act && s8 < len)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s8 + u;
+                if (act && s < len) {
+                    typename CH::Gain g;
+                    CH::template advance<true>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst, g);
+                    T.lag[u][lane] = pack_gain_trend(g.gs, g.p00, g.p10);
+                    T.ps[u][lane] = make_float4(c.c00, c.c01, c.c01, c.c11);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int L = k * 8 + (lane >> 3), r = lane & 7, s = s8 + r;
+                if (s < T.len[L]) {
+                    natGn[(int64_t)T.gbase[L] + s] = T.lag[r][L];
+                    if (natPf != nullptr) natPf[(int64_t)T.gbase[L] + s] = T.ps[r][L];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+}
+// re-run path (validation kernel): scattered natural stores, no LDS
+template <class CH>
+__device__ __forceinline__ void walk_nat_gain_direct(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                                     int64_t bfirst, int gbase) {
+    const int64_t base = tbase(bq, p.B);
+    float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
+    float4 *natGn = reinterpret_cast<float4 *>(p.natLag);
+#pragma unroll 1
+    for (int s = 0; s < p.B; ++s) {
+        if (act && s < len) {
+            const typename CH::In in = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+            typename CH::Gain g;
+            CH::template advance<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst, g);
+            natGn[(int64_t)gbase + s] = pack_gain_trend(g.gs, g.p00, g.p10);
+            if (natPf != nullptr) natPf[(int64_t)gbase + s] = make_float4(c.c00, c.c01, c.c01, c.c11);
+        }
+    }
+}
+
 // Folded validation of the PREVIOUS stage (Prm::prevKind), run by every lane for its own block in the prologue of a
 // speculative kernel.
 template <class PCH>
@@ -1752,7 +1838,8 @@ __global__ __launch_bounds__(64) void k_chain_spec(Prm p_) {
         if constexpr (!WS) { if (live) cin[b] = c; }
         if constexpr (NAT && CH::NATOUT_FWD) {
             extern __shared__ __attribute__((aligned(16))) unsigned char natTileMemF[];
-            walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
+            if constexpr (GainNatOf<CH>::value) walk_nat_gain<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
+            else walk_nat_fwd<CH>(p, c, b, bi.y, live, bfirst, bi.x, *reinterpret_cast<NatTiles *>(natTileMemF));
         } else if (WS && svq > 0 && p.ckptOut != nullptr) {
             if (svSplit > 0) walk_block<CH, true>(p, c, b, bi.y, live, bfirst, 0, svSplit);
             if (live && b != blast) reinterpret_cast<typename CH::Carry *>(p.ckptOut)[b] = c;
@@ -2830,7 +2917,8 @@ __global__ __launch_bounds__(64) void k_chain_fix(Prm p_, int which) {
     if constexpr (NAT && CH::NATOUT) {
         walk_nat_direct<CH>(p, c, b, bi.y, rerun, b == blast, bi.x);
     } else if constexpr (NAT && CH::NATOUT_FWD) {
-        walk_nat_fwd_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
+        if constexpr (GainNatOf<CH>::value) walk_nat_gain_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
+        else walk_nat_fwd_direct<CH>(p, c, b, bi.y, rerun, bfirst, bi.x);
     } else {
         walk_block<CH, true>(p, c, b, bi.y, rerun, bfirst, 0, p.B);
     }

@@ -8,6 +8,13 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
     CHECK(settle(c));
     Prm p = c->p;
+    // default mode with the superblock state chain: that chain reads {S0u, zbar} in the reference layout -- written here directly
+    const bool natSZ = CSR_GAIN_NAT && CSR_STATS_NATSZ && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState;
+    p.natSZ = nullptr;
+    if (natSZ) {
+        if (!c->sbNatGain) { CHECK(dalloc(c, &c->sbNatGain, c->Npad)); CHECK(dalloc(c, &c->sbNatSZ, c->Npad)); }
+        p.natSZ = reinterpret_cast<double2 *>(c->sbNatSZ);
+    }
     {
         // 16-byte loads, four bins per thread; 64-bin tiles (32 when the block length is not a multiple of 64)
         Scope sc(c, "stats");
@@ -18,7 +25,7 @@ extern "C" int csr_batch_stats(csr_ctx *c) {
     }
     LAUNCH_CHECK("k_stats");
     c->statsValid = true;
-    c->natSZValid = false;
+    c->natSZValid = natSZ;
     c->haveFwd = c->haveBwd = false;
     return 0;
 }
@@ -375,14 +382,18 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
     c->sbp.active = false;
-    if (!resume) {
+    if (!resume && !(c->gainNat && c->natSZValid)) {
         Scope sc(c, "state_records_natural");
         ExpList L;
         memset(&L, 0, sizeof(L));
-        // the gain records of this pass; the statistics records {S0, zbar} only when the statistics changed since they were last
-        // converted (csr_batch_stats): the sweeps of an ECM iteration share them
-        L.count = 1;
-        L.d[0].src = reinterpret_cast<const float *>(p.tXin); L.d[0].dst = reinterpret_cast<float *>(c->sbNatGain); L.d[0].E = 4; L.d[0].n = 4;
+        // the gain records of this pass unless the covariance chain wrote them in the reference layout itself (forward_impl); the
+        // statistics records {S0, zbar} only when the statistics changed since they were last converted (csr_batch_stats): the
+        // sweeps of an ECM iteration share them
+        L.count = 0;
+        if (!c->gainNat) {
+            L.count = 1;
+            L.d[0].src = reinterpret_cast<const float *>(p.tXin); L.d[0].dst = reinterpret_cast<float *>(c->sbNatGain); L.d[0].E = 4; L.d[0].n = 4;
+        }
         Prm pe = p;
         if (!c->natSZValid) {
             ExpDesc &e = L.d[L.count++];
@@ -607,18 +618,23 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool with
     // stored it; per-chain base matrices: a table -- so that a step with multipliers pipelines its tail as well)
     const bool convQ = withPf && !constQ;
     if (!withPf && !constQ) return 0;
+    const bool doPf = withPf && !c->pfNat;          // (the covariance chain may have written Pf in the reference layout itself)
+    if (!doPf && !constQ && !convQ) return 0;
     // (a reference-layout array is allocated -- and zeroed ON THE MAIN STREAM -- at its first use: before the fork, so that the
     // side stream's writes are ordered behind the zeroing)
     float *dstPf = nullptr, *dstPn = nullptr;
-    if (withPf) CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
+    if (doPf) CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
     if (constQ || convQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
     HIPOK(hipEventRecord(c->evFork2, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
-    if (withPf) {
+    if (doPf || convQ) {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        L.count = 1;
-        L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dstPf; L.d[0].E = 4; L.d[0].n = nm;
+        L.count = 0;
+        if (doPf) {
+            L.count = 1;
+            L.d[0].src = reinterpret_cast<const float *>(p.tPf); L.d[0].dst = dstPf; L.d[0].E = 4; L.d[0].n = nm;
+        }
         if (convQ) {            // (as export_impl describes it)
             ExpDesc &e = L.d[L.count++];
             e.src = constFlags ? nullptr : reinterpret_cast<const float *>(p.tQ); e.dst = dstPn; e.E = 4; e.n = nm; e.skipLast = 1;
@@ -660,6 +676,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     c->sbp.active = false;
     join_pf(c);         // (an early export nobody asked for afterwards still reads the arrays this pass overwrites)
     c->pfNat = c->pnNat = false;
+    c->gainNat = false;
     Prm p = c->p;
     p.flags = flags;
     p.chainActive = active;
@@ -740,8 +757,26 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             // millisecond state chains -- one host round trip, ~0.1 ms per forward pass -- although a failed validation is as
             // rare here as in the 2-ulp mode and costs the same replay of the pass.  The sequential yardstick keeps the round trip.)
             if (seqX) dP = false;
-            if (unit_f(c, p)) CHECK(run_chain<FwdPTrendT<true>>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
-            else CHECK(run_chain<FwdPTrend>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            c->gainNat = false;
+            Prm pc = p;
+            if (sbX && CSR_GAIN_NAT) {
+                // the superblock state chain reads its records in the reference layout: the covariance chain writes the gain
+                // records there itself (and Pf, when this pass's Pf is an output), through LDS tiles -- no conversion launch
+                // between the two chains; the NIS epilogue reads P00pred from the compact track instead of the blocked record
+                if (!c->sbNatGain) { CHECK(dalloc(c, &c->sbNatGain, c->Npad)); CHECK(dalloc(c, &c->sbNatSZ, c->Npad)); }
+                p.predCompact = 1;
+                pc = p;
+                pc.natOut = 1;
+                pc.natLag = reinterpret_cast<float *>(c->sbNatGain);
+                pc.natPs = nullptr;
+                if (natOut && c->earlyPf && active == nullptr && c->natOutEnabled) {
+                    CHECK(nat_array(c, CSR_ARR_PF, &pc.natPs));
+                    c->pfNat = true;
+                }
+                c->gainNat = true;
+            }
+            if (unit_f(c, p)) CHECK(run_chain<FwdPTrendT<true>>(c, pc, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
+            else CHECK(run_chain<FwdPTrend>(c, pc, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             if (seqX) {
                 // bit-exact mode: the state recursion cannot be validated speculatively in reasonable time (see
                 // k_state_seq_trend) -- one wavefront per chain runs it sequentially on the validated gains

@@ -21,6 +21,12 @@
 #include <mutex>
 #include <string>
 #include <chrono>
+#ifndef CSR_GAIN_NAT
+#define CSR_GAIN_NAT 1       // 0: gain records through the blocked layout and a conversion launch (yardstick; scripts/ sweeps)
+#endif
+#ifndef CSR_STATS_NATSZ
+#define CSR_STATS_NATSZ 1    // 0: the statistics records reach the reference layout through the conversion launch
+#endif
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -206,6 +212,7 @@ struct csr_ctx {
     bool sbAsync = true;
     int sbSpinLimit = 1 << 19;
     bool natSZValid = false;    // sbNatSZ holds the current statistics of every chain
+    bool gainNat = false;       // this forward pass's covariance chain wrote sbNatGain itself (walk_nat_gain)
     float4 *sbNatGain = nullptr, *sbNatSZ = nullptr;    // natural-layout records of the systolic walker (freed with the batch)
     bool xfNat = false;         // the resident forward pass left xf in the reference layout already (systolic walker)
     struct SbView {
