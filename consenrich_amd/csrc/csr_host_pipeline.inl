@@ -1410,6 +1410,16 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
           !(what & CSR_EXPORT_MULT) && c->chains.size() >= 2 && c->chains.size() <= 4096))
         return 0;
     CHECK(settle(c));
+    {
+        // The reference-layout arrays the tails write are allocated -- and zeroed -- HERE, on the main stream ahead of the forward
+        // pass.  A first use inside a tail queues the zeroing on THAT group's stream behind its kernels, where it can land on top
+        // of what the next group has already written from the other stream: seen (round 4, one run in five under
+        // CONSENRICH_AMD_SB_BINS=4096, where the groups follow each other closely) as zeroed residuals of the last chromosome
+        // in the first step of a batch.
+        float *q;
+        for (int id : {CSR_ARR_XS, CSR_ARR_PS, CSR_ARR_LAG}) CHECK(nat_array(c, id, &q));
+        if (what & CSR_EXPORT_RESID) CHECK(nat_array(c, CSR_ARR_RESID, &q));
+    }
     CHECK(forward_impl(c, flags, true, nullptr, true, false, true, true));
     if (!c->sbp.active) {               // the state chain did not go out as one launch: the pass is complete, carry on as usual
         CHECK(backward_impl(c, true, nullptr, true, true));

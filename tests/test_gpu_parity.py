@@ -308,6 +308,13 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
                 b.set_chain_q([np.diag([1e-3 * (1 + c), 1e-4 * (1 + 0.5 * c)]).astype(np.float32) for c in range(len(n_list))])
             for rep in range(2):        # the second step re-uses every buffer of the first
                 sd, sn = b.step(flags, what)
+                if rep == 0:
+                    # the FIRST step of a batch allocates (and zeroes) its reference-layout arrays: that zeroing must be ordered
+                    # ahead of every group's writes, whichever stream a group runs on (round 4: it was queued on the first
+                    # group's stream and could wipe what the next group had already written)
+                    for c in range(len(n_list)):
+                        for name in ("xs", "Ps", "lag", "resid"):
+                            out[(c, name, "first step")] = b.download(c, name)
             out["sd"], out["sn"] = np.array(sd), np.array(sn)
             for c in range(len(n_list)):
                 for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
@@ -1700,7 +1707,13 @@ def _genome_workload_against_oracle(oracle, bin_bp, m, full, x_tol_ulps=None, se
                         np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL, err_msg=f"chain {c} {name}")
                     res = b.download(c, "resid").astype(np.float64)
                     worst["resid_rel"] = max(worst.get("resid_rel", 0.0), float((np.abs(res - bw[3]) / lvl).max()))
-                    assert np.all(np.abs(res - bw[3]) <= RTOL * lvl + ATOL), c
+                    bad = np.abs(res - bw[3]) > RTOL * lvl + ATOL
+                    if bad.any():           # (say WHERE: a stale or half-written track shows as a contiguous run of rows)
+                        rows = np.nonzero(bad.any(axis=1))[0]
+                        xs_now = b.download(c, "xs").astype(np.float64)
+                        raise AssertionError(f"chain {c} residuals: {int(bad.sum())} cells in {rows.size} rows [{rows[0]} .. {rows[-1]}] of {n}; "
+                                             f"xs agrees there now: {bool(np.all(np.abs(xs_now[rows] - bw[0][rows]) <= RTOL * lvl[rows] + ATOL))}; "
+                                             f"first bad row: got {res[rows[0], :3]}, want {bw[3][rows[0], :3]}; run stats {b.run_stats()}")
                     gD = b.download(c, "D").astype(np.float64)
                     relD = np.abs(gD - D) / (np.abs(D) + ATOL / RTOL)
                     worst["D_rel_max"] = max(worst.get("D_rel_max", 0.0), float(relD.max()))
