@@ -263,13 +263,19 @@ extern "C" int csr_batch_download_inputs(csr_ctx *c, int32_t chain, float *data,
 static int grid_slots(csr_ctx *c) { return (int)((c->TN + 255) / 256); }
 
 static int64_t arr_comps(csr_ctx *c, int id);
-// natural device scratch for per-bin float arrays (import/export); lazily allocated
+// Reference-layout ("natural") device arrays of per-bin floats (import / export), allocated at first use.
+// First use zeroes the array on the context's own zeroing stream and WAITS for it on the host before the pointer is handed
+// out: the zeroing is ordered against no caller's stream, so whichever stream `c->stream` is at that moment (step_pipelined
+// swaps it to a tail group's stream) nothing queued later -- on any stream -- can be overtaken by it.  (Round 4 zeroed on
+// `c->stream`: a first use inside a tail group wiped what the next group had already written from the other stream.)
 static int nat_array(csr_ctx *c, int id, float **out) {
     if (!c->nat[id]) {
         const int64_t per = arr_comps(c, id);
         // (+ 64 spare bins: the bit-exact state chain's ring DMAs fetch the stored trajectory 128 bins at a time)
         CHECK(dalloc(c, &c->nat[id], per * (c->Npad + 64)));
-        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * (c->Npad + 64), c->stream));
+        HIPOK(hipMemsetAsync(c->nat[id], 0, sizeof(float) * per * (c->Npad + 64), c->zeroStream));
+        HIPOK(hipStreamSynchronize(c->zeroStream));
+        if (c->mainStream && c->stream != c->mainStream) ++c->rs.nat_first_use_off_main;
     }
     *out = c->nat[id];
     return 0;

@@ -458,15 +458,14 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             Scope sc(c, "fwd_state_chain");
             float2 *xf = reinterpret_cast<float2 *>(natXf);
             // (the repair runs' LDS ring: > 64 KB of dynamic LDS has to be asked for once per kernel)
-            static bool ldsOk[6] = {false, false, false, false, false, false};
             const bool dbg = q.sbDbg != nullptr;
             using KFn = void (*)(Prm, const float4 *, const float4 *, float2 *, SbAsync);
             const KFn fns[6] = {&k_sb_async<0, false>, &k_sb_async<1, false>, &k_sb_async<2, false>,
                                 &k_sb_async<0, true>, &k_sb_async<1, true>, &k_sb_async<2, true>};
             const int which = mode + (dbg ? 3 : 0);
-            if (!ldsOk[which]) {
+            if (!c->sbAsyncLdsRaised[which]) {
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[which]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_ASYNC_LDS));
-                ldsOk[which] = true;
+                c->sbAsyncLdsRaised[which] = true;
             }
             hipLaunchKernelGGL(fns[which], dim3(grid), dim3(256), SB_ASYNC_LDS, c->stream, q, c->sbNatGain, c->sbNatSZ, xf, a);
         }
@@ -1410,16 +1409,6 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
           !(what & CSR_EXPORT_MULT) && c->chains.size() >= 2 && c->chains.size() <= 4096))
         return 0;
     CHECK(settle(c));
-    {
-        // The reference-layout arrays the tails write are allocated -- and zeroed -- HERE, on the main stream ahead of the forward
-        // pass.  A first use inside a tail queues the zeroing on THAT group's stream behind its kernels, where it can land on top
-        // of what the next group has already written from the other stream: seen (round 4, one run in five under
-        // CONSENRICH_AMD_SB_BINS=4096, where the groups follow each other closely) as zeroed residuals of the last chromosome
-        // in the first step of a batch.
-        float *q;
-        for (int id : {CSR_ARR_XS, CSR_ARR_PS, CSR_ARR_LAG}) CHECK(nat_array(c, id, &q));
-        if (what & CSR_EXPORT_RESID) CHECK(nat_array(c, CSR_ARR_RESID, &q));
-    }
     CHECK(forward_impl(c, flags, true, nullptr, true, false, true, true));
     if (!c->sbp.active) {               // the state chain did not go out as one launch: the pass is complete, carry on as usual
         CHECK(backward_impl(c, true, nullptr, true, true));

@@ -161,6 +161,7 @@ struct csr_ctx {
     bool dNat = false;          // ... and its NIS/NLL epilogue wrote D there (nothing left to convert)
     static constexpr bool natOutD = true;       // the NIS / NLL epilogue writes D in the reference layout itself
     bool dstatLdsRaised = false;
+    bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
     int pendEstep = 0;
     static constexpr bool fuseEstep = true;     // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
@@ -277,6 +278,10 @@ struct csr_ctx {
     // step_pipelined: tails of the chains whose filtered state stands, on a stream of their own while the state chain runs
     hipStream_t tail = nullptr;
     hipEvent_t evTailJoin = nullptr;
+    // first-use zeroing of a reference-layout array (nat_array) runs HERE and is waited for by the host before the array is
+    // handed out: it is ordered against no other stream, so it does not matter which stream the caller is on at that moment
+    hipStream_t zeroStream = nullptr;
+    hipStream_t mainStream = nullptr;   // what `stream` is outside step_pipelined's tail groups (csr_run_stats.nat_first_use_off_main)
     struct SbPending { bool active = false; Prm p{}; } sbp;     // a state chain launched and not yet waited for (step_pipelined)
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -375,12 +380,14 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         delete c;
         return nullptr;
     }
+    c->mainStream = c->stream;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evFork2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPf, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->zeroStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTailJoin, hipEventDisableTiming) != hipSuccess) {
         fail("cannot create the side stream of device %d", device_ordinal);
         delete c;
@@ -447,6 +454,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->hDone) (void)hipHostFree(c->hDone);
     if (c->hMaskPin) (void)hipHostFree(c->hMaskPin);
+    if (c->zeroStream) (void)hipStreamDestroy(c->zeroStream);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

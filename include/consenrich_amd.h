@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSR_ABI_VERSION 3
+#define CSR_ABI_VERSION 4
 
 /* ---- model / flags ------------------------------------------------------------------------------------- */
 
@@ -486,6 +486,9 @@ typedef struct csr_run_stats {
                                    form then ran instead (same results) */
     int64_t tail_groups;        /* bit-exact steps: groups of chains whose smoother / residuals were launched on their own (the
                                    first ones while the state chain of the other chains was still running) */
+    int64_t nat_first_use_off_main; /* reference-layout arrays whose first use (allocation + zeroing) happened while a tail group's
+                                   stream was current; harmless since ABI 4 (the zeroing is waited for on the host before the
+                                   array is handed out) -- counted so that a test can show the path was exercised */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 
