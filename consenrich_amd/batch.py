@@ -105,10 +105,12 @@ class DeviceBatch:
                                               lens.ctypes.data_as(L.I64P)))
         self.chain_lens = [int(v) for v in lens]
         self.m, self.d = int(m), int(model.state_dim)
+        self.model = model
 
     def set_model(self, model: ModelParams):
         mdl = model.to_c()
         L.check(self._lib.csr_batch_set_model(self._ctx, C.byref(mdl)))
+        self.model = model
 
     def set_chain_q(self, q_list):
         """Per-chain base process noise: one (2,2) (or (1,1) for the level model) matrix per chain, values taken as

@@ -15,8 +15,13 @@ Three layers, so that the same call can be replayed on the CPU twin in the tests
 
 Arguments that the reference's own body never reads (processNoiseWarmupECMIters, processNoiseWarmupOuterPasses: signature
 only, core.py:3900-3901) and its logging knobs (logIndentLevel, logRunRole) are accepted and have no effect, like there.
-`intervalSizeBP` is validated like there; the one diagnostic it feeds (relative sign changes per kb, core.py:4980) is reported
-as None.  `projectStateDuringFiltering=True` is refused: the kernels filter unprojected (the reference's default)."""
+`projectStateDuringFiltering` is accepted and has no effect, like there too: the reference only forwards it to
+`cforwardPass` / `cforwardPassLevel` (core.py:4284, 4391), whose loops never read it (pyx:6393-6632) -- this
+package's own `cforwardPass` mirror accepts and ignores it the same way.  `intervalSizeBP` feeds the one diagnostic it
+feeds there (relative sign changes per kb, core.py:2647-2700, 4980).
+The run-diagnostics mapping carries the reference's complete key set (core.py:5943-5999); the only values reported as None
+that the reference computes are the `background_objective*` entries of `post_process_noise_fit` (a diagnostic of the background
+solve that enters no stop rule; `ChainFit.post_process_noise_fit`)."""
 from __future__ import annotations
 
 import operator
@@ -195,6 +200,8 @@ class RunPlan:
     initial_kappa: Optional[np.ndarray]
     requested_kappa: bool
     ret: dict = field(default_factory=dict)
+    interval_size_bp: Optional[int] = None
+    q_given: bool = False                       # initialProcessQ was passed (process-noise calibration "skipped", core.py:5689-5700)
 
 
 def resolve_call(matrixData, matrixMunc, deltaF, minQ, maxQ, *, stateInit, stateCovarInit, boundState, stateLowerBound,
@@ -241,9 +248,7 @@ def resolve_call(matrixData, matrixMunc, deltaF, minQ, maxQ, *, stateInit, state
         raise ValueError("need at least 2 intervals for smoothing")
     if intervalSizeBP is not None and int(intervalSizeBP) <= 0:
         raise ValueError("intervalSizeBP must be positive when provided")
-    if bool(projectStateDuringFiltering):
-        raise ValueError("projectStateDuringFiltering=True is not supported by consenrich_amd.core_api.runConsenrich "
-                         "(the device kernels filter unprojected, the reference's default)")
+    # projectStateDuringFiltering: forwarded to the forward passes by the reference (core.py:4284, 4391), read by neither loop
     requested_kappa = bool(ECM_useProcessPrecisionReweighting)
     use_apn = bool(ECM_useAPN)
     use_kappa = requested_kappa and not use_apn                                     # core.py:3974-3976
@@ -334,7 +339,190 @@ def resolve_call(matrixData, matrixMunc, deltaF, minQ, maxQ, *, stateInit, state
     return RunPlan(data=data, munc=munc, state_model=state_model, model=model, cfg=cfg,
                    block_len_intervals=int(blockLenIntervals), q0=q0, q_policy=policy, initial_background=bg0,
                    initial_lambda=lam0 if cfg.use_lambda else None, initial_kappa=kap0 if use_kappa else None,
-                   requested_kappa=requested_kappa, ret=ret)
+                   requested_kappa=requested_kappa, ret=ret,
+                   interval_size_bp=None if intervalSizeBP is None else int(intervalSizeBP), q_given=q_given is not None)
+
+
+# ---- host restatements of the reference's diagnostics helpers (pure NumPy on downloaded / host arrays) ---------------------------
+def metadata_float(value):
+    """diagnostics.metadataFloat (diagnostics.py:19-23): None for a non-finite value."""
+    v = float(value)
+    return v if np.isfinite(v) else None
+
+
+def process_noise_calibration_support(data, munc, pad) -> dict:
+    """core._processNoiseCalibrationSupport (core.py:2989-3055): counts of usable cells / transitions."""
+    d64, m64 = np.asarray(data, np.float64), np.asarray(munc, np.float64)
+    obs_var = m64 + float(pad)
+    unmasked = np.isfinite(m64) & (m64 < 0.5 * float(MASKED_OBSERVATION_VARIANCE))
+    positive = np.isfinite(obs_var) & (obs_var > 0.0)
+    active = np.isfinite(d64) & unmasked & positive
+    act_iv = np.any(active, axis=0)
+    adjacent = act_iv[1:] & act_iv[:-1] if act_iv.size >= 2 else np.zeros(0, bool)
+    same_track = np.any(active[:, 1:] & active[:, :-1], axis=0) if active.shape[1] >= 2 else np.zeros(0, bool)
+    finite_n, pos_n = int(np.count_nonzero(np.isfinite(d64))), int(np.count_nonzero(unmasked & positive))
+    act_n, adj_n = int(np.count_nonzero(active)), int(np.count_nonzero(adjacent))
+    reason = None
+    if finite_n <= 0:
+        reason = "no_finite_data"
+    elif pos_n <= 0:
+        reason = "no_positive_observation_variance"
+    elif act_n <= 0:
+        reason = "no_active_observations"
+    elif adj_n <= 0:
+        reason = "no_active_adjacent_transitions"
+    return {"finiteDataCount": finite_n, "positiveObservationVarianceCount": pos_n, "activeObservationCount": act_n,
+            "activeIntervalCount": int(np.count_nonzero(act_iv)), "intervalTransitionCount": int(max(d64.shape[1] - 1, 0)),
+            "activeAdjacentTransitionCount": adj_n, "sameTrackAdjacentTransitionCount": int(np.count_nonzero(same_track)),
+            "processNoiseCalibrationCanRun": bool(reason is None), "processNoiseCalibrationSkipReason": reason}
+
+
+def process_noise_q_boundary_diagnostics(Q0, state_model, minQ, maxQ) -> dict:
+    """core._processNoiseQBoundaryDiagnostics (core.py:3058-3101)."""
+    d = 1 if state_model == STATE_MODEL_LEVEL else 2
+    floor = _finite_positive("minQ", minQ)
+    mq = float(maxQ)
+    cap = float("inf") if (mq < 0.0 or not np.isfinite(mq)) else float(max(mq, floor))
+    q = np.asarray(Q0, np.float64)
+
+    def clamp(v):
+        v = float(v)
+        if not np.isfinite(v):
+            v = floor
+        v = max(v, floor)
+        return float(min(v, cap)) if np.isfinite(cap) else float(v)
+
+    lvl = clamp(q[0, 0])
+    trd = 0.0 if d == 1 else clamp(q[1, 1])
+    hit_lf, hit_tf = bool(lvl <= 1.0001 * floor), bool(d == 2 and trd <= 1.0001 * floor)
+    hit_lc = bool(np.isfinite(cap) and lvl >= 0.9999 * cap)
+    hit_tc = bool(d == 2 and np.isfinite(cap) and trd >= 0.9999 * cap)
+    hit_f, hit_c = bool(hit_lf or hit_tf), bool(hit_lc or hit_tc)
+    status = "floor_and_cap" if (hit_f and hit_c) else "floor" if hit_f else "cap" if hit_c else "interior"
+    return {"preKappaQLevel": lvl, "preKappaQTrend": trd, "qFloor": float(floor), "qCap": float(cap),
+            "hitQLevelFloor": hit_lf, "hitQTrendFloor": hit_tf, "hitQLevelCap": hit_lc, "hitQTrendCap": hit_tc,
+            "hitQFloor": hit_f, "hitQCap": hit_c, "qBoundaryStatus": status}
+
+
+def static_process_noise_calibration_diagnostics(*, policy, status, reason, Q0, state_model, minQ, maxQ, support,
+                                                 warm_start_process_noise) -> dict:
+    """core._staticProcessNoiseCalibrationDiagnostics (core.py:3104-3158)."""
+    d = 1 if state_model == STATE_MODEL_LEVEL else 2
+    bnd = process_noise_q_boundary_diagnostics(Q0, state_model, minQ, maxQ)
+    q_final = clamp_process_noise_matrix(Q0, state_model, minQ, maxQ)
+    lvl, trd = float(bnd["preKappaQLevel"]), float(bnd["preKappaQTrend"])
+    ratio = 0.0 if d == 1 else trd / max(lvl, float(bnd["qFloor"]))
+    out = {"processNoisePolicy": policy, "processNoiseCalibrationStatus": status, "processNoiseCalibrationReason": reason,
+           "stateModel": state_model, "preKappaQLevel": lvl, "preKappaQTrend": trd, "rawTrendLevelRatio": float(ratio),
+           "effectiveTrendLevelRatio": float(ratio), "logQLevel": float(np.log(max(lvl, float(bnd["qFloor"])))),
+           "logQTrend": 0.0 if d == 1 else float(np.log(max(trd, float(bnd["qFloor"])))),
+           "usedInitialProcessQFallback": bool(status != "estimated" and float(warm_start_process_noise) <= 0.0),
+           "matrixQ0Final": q_final.astype(float).tolist(), "warmStartProcessNoise": float(warm_start_process_noise),
+           "globalScale": 1.0, "windowCount": 0, "validTransitionCount": 0, "qScaleClampFraction": 0.0}
+    out.update(bnd)
+    out.update(dict(support))
+    return out
+
+
+def summarize_precision_boundary_hits(*, observationPrecision, observationPrecisionMin, observationPrecisionMax,
+                                      processPrecision, processPrecisionMin, processPrecisionMax) -> dict:
+    """diagnostics.summarizePrecisionBoundaryHits (diagnostics.py:181-247): final multipliers pinned to their bounds."""
+    def one(values, lower, upper, skip_first=False):
+        if values is None:
+            return {"enabled": False, "total": 0, "lower": 0, "upper": 0, "lower_fraction": None, "upper_fraction": None}
+        arr = np.asarray(values, np.float64).reshape(-1)
+        if skip_first and arr.size > 0:
+            arr = arr[1:]
+        fin = arr[np.isfinite(arr)]
+        total = int(fin.size)
+        lo = int(np.sum(np.isclose(fin, float(lower), rtol=0.0, atol=1.0e-6 * max(abs(float(lower)), 1.0))))
+        hi = int(np.sum(np.isclose(fin, float(upper), rtol=0.0, atol=1.0e-6 * max(abs(float(upper)), 1.0))))
+        return {"enabled": True, "total": total, "lower": lo, "upper": hi,
+                "lower_fraction": metadata_float(lo / float(total)) if total > 0 else None,
+                "upper_fraction": metadata_float(hi / float(total)) if total > 0 else None}
+
+    return {"observation": one(observationPrecision, observationPrecisionMin, observationPrecisionMax),
+            "process": one(processPrecision, processPrecisionMin, processPrecisionMax, skip_first=True),
+            "bounds": {"observation": [float(observationPrecisionMin), float(observationPrecisionMax)],
+                       "process": [float(processPrecisionMin), float(processPrecisionMax)]}}
+
+
+def precision_bound_hits(values, lower, upper, skip_first=False):
+    """core._precisionBoundHits (core.py:2591-2611): fractions of the finite multipliers at or beyond each bound."""
+    if values is None:
+        return None, None
+    arr = np.asarray(values, np.float64).reshape(-1)
+    if skip_first and arr.size > 1:
+        arr = arr[1:]
+    fin = arr[np.isfinite(arr)]
+    if fin.size == 0:
+        return None, None
+    lo = int(np.count_nonzero(fin <= float(lower))) if np.isfinite(float(lower)) else 0
+    hi = int(np.count_nonzero(fin >= float(upper))) if np.isfinite(float(upper)) else 0
+    return metadata_float(lo / float(fin.size)), metadata_float(hi / float(fin.size))
+
+
+def relative_sign_change_per_kb(state_level, data, munc, *, interval_size_bp, background=None, pad=0.0):
+    """core._relativeSignChangePerKB + _signChangePerKB (core.py:2614-2700): sign changes per kb of (smoothed level - the
+    inverse-variance weighted mean of the background-adjusted observations), ignoring values below 1 % of the mean magnitude."""
+    if state_level is None or interval_size_bp is None or int(interval_size_bp) <= 0:
+        return None
+    x = np.asarray(state_level, np.float64).reshape(-1)
+    d, v = np.asarray(data), np.asarray(munc)
+    if d.ndim != 2 or v.shape != d.shape or d.shape[1] != x.size:
+        return None
+    bg = np.zeros(x.size) if background is None else np.asarray(background, np.float64).reshape(-1)
+    if bg.size != x.size:
+        return None
+    tot, wsum, x_ok = np.zeros(x.size), np.zeros(x.size), np.isfinite(x)
+    for j in range(d.shape[0]):
+        row, den = np.asarray(d[j], np.float64), np.asarray(v[j], np.float64) + float(pad)
+        ok = x_ok & np.isfinite(row) & np.isfinite(den) & (den > 0.0)
+        if not np.any(ok):
+            continue
+        w = 1.0 / np.maximum(den[ok], 1.0e-12)
+        tot[ok] += (row[ok] - bg[ok]) * w
+        wsum[ok] += w
+    mean = np.full(x.size, np.nan)
+    has = wsum > 0.0
+    mean[has] = tot[has] / wsum[has]
+    arr = x - mean
+    if arr.size == 0:
+        return None
+    fin = arr[np.isfinite(arr)]
+    if fin.size == 0:
+        return None
+    mean_abs = float(np.mean(np.abs(fin), dtype=np.float64))
+    if not np.isfinite(mean_abs):
+        return None
+    if 0.01 * mean_abs > 0.0:
+        fin = fin[np.abs(fin) >= 0.01 * mean_abs]
+    sg = np.sign(fin)
+    sg = sg[sg != 0.0]
+    changes = int(np.count_nonzero(sg[1:] * sg[:-1] < 0.0)) if sg.size >= 2 else 0
+    span_kb = float(arr.size) * float(int(interval_size_bp)) / 1000.0
+    if not np.isfinite(span_kb) or span_kb <= 0.0:
+        return None
+    return metadata_float(float(changes) / span_kb)
+
+
+def _metadata_value(value):
+    """core.runConsenrich._processNoiseCalibrationMetadataValue + _diagnosticScalar (core.py:5921-5931, 2315-2327)."""
+    if isinstance(value, np.ndarray):
+        return value.astype(float).tolist()
+    if isinstance(value, dict):
+        return {str(k): _metadata_value(v) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_metadata_value(v) for v in value]
+    if isinstance(value, np.generic):
+        value = value.item()
+    if isinstance(value, bool):
+        return bool(value)
+    if isinstance(value, int):
+        return int(value)
+    if isinstance(value, float):
+        return value if np.isfinite(value) else None
+    return value
 
 
 def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
@@ -391,15 +579,47 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
             qd[f"effectiveQ{name}{stat.capitalize()}"] = s[stat]
     nis = np.asarray(final["NIS"], np.float64)
     nis = nis[np.isfinite(nis)]
-    post = fit.post_process_noise_fit(cfg)
-    post["relative_sign_change_per_kb"] = None
-    calib = {"processNoisePolicy": plan.q_policy, "resolvedMinQ": float(plan.ret["min_q"]),
-             "resolvedMaxQ": float(plan.ret["max_q_apn"]), "transitionCount": float(max(n - 1, 0)),
-             "preKappaQLevel": float(q0[0, 0]), "preKappaQTrend": float(q0[1, 1]) if d == 2 else 0.0}
-    calib.update({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in (fit.q_seed or {}).items()})
-    return {"state_model": plan.state_model, "final_nll": fit.final_nll,
-            "final_forward_nis": float(nis.mean()) if nis.size else float("nan"),
-            "final_forward_gain_contig_summary": gain, "process_noise_calibration": calib,
+    lam_b, kap_b = plan.model.lambda_bounds, plan.model.kappa_bounds
+    # the multipliers of the last ECM phase are the final ones (the final pass runs WITH them): bound-hit fractions (core.py:5473-5484)
+    lam_lo, lam_hi = precision_bound_hits(lam, *lam_b)
+    kap_lo, kap_hi = precision_bound_hits(kap, *kap_b, skip_first=True)
+    post = fit.post_process_noise_fit(cfg, extras={
+        "observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
+        "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
+        "relative_sign_change_per_kb": relative_sign_change_per_kb(
+            fit.ecm_state_level, plan.data, plan.munc, interval_size_bp=plan.interval_size_bp,
+            background=final.get("background"), pad=float(cfg.pad))})
+    # process-noise calibration record (core.py:5686-5737, 5921-5942)
+    support = process_noise_calibration_support(plan.data, plan.munc, float(cfg.pad))
+    q_full = np.zeros((2, 2), np.float64)
+    q_full[:d, :d] = q0[:d, :d]
+    common = dict(Q0=q_full if d == 2 else q_full[:1, :1], state_model=plan.state_model, minQ=float(plan.ret["min_q"]),
+                  maxQ=float(cfg.max_q), support=support)
+    if plan.q_given:
+        calib = static_process_noise_calibration_diagnostics(policy=PROCESS_NOISE_CALIBRATION_FIXED, status="skipped",
+                                                             reason="initial_process_q", warm_start_process_noise=1.0, **common)
+    elif cfg.seed_q:
+        calib = static_process_noise_calibration_diagnostics(policy=plan.q_policy, status="estimated",
+                                                             reason="data_derived_q_estimate", warm_start_process_noise=1.0,
+                                                             **common)
+        calib.update(dict(fit.q_seed or {}))
+        calib["validTransitionCount"] = int((fit.q_seed or {}).get("qSeedTransitionCount", 0))
+    else:
+        calib = static_process_noise_calibration_diagnostics(policy=plan.q_policy, status="skipped", reason=plan.q_policy,
+                                                             warm_start_process_noise=0.0, **common)
+    calib.update(support)
+    calib["resolvedMinQ"] = float(plan.ret["min_q"])
+    calib["resolvedMaxQ"] = float(plan.ret["max_q_apn"])
+    calib["transitionCount"] = float(max(n - 1, 0))
+    calib["processQScaleSummary"] = track_summary(np.ones(n, np.float32))
+    calib = {k: _metadata_value(v) for k, v in calib.items() if not str(k).startswith("_")}
+    return {"state_model": plan.state_model, "final_nll": metadata_float(fit.final_nll),
+            "final_forward_nis": metadata_float(float(nis.mean()) if nis.size else float("nan")),
+            "final_forward_gain_contig_summary": gain,
+            "precision_reweighting_boundary_hits": summarize_precision_boundary_hits(
+                observationPrecision=lam, observationPrecisionMin=lam_b[0], observationPrecisionMax=lam_b[1],
+                processPrecision=kap if not use_apn else None, processPrecisionMin=kap_b[0], processPrecisionMax=kap_b[1]),
+            "process_noise_calibration": calib,
             "post_process_noise_fit": post, "optimization_path_tracked": bool(plan.ret["track_path"]),
             "process_precision_reweighting_requested": bool(plan.requested_kappa),
             "process_precision_reweighting_effective": bool(cfg.use_kappa),
@@ -521,7 +741,9 @@ def run_plan(plan: RunPlan, device: int = 0):
         fits, results = run_consenrich_batch(
             b, cfg, block_len_intervals=plan.block_len_intervals, model_q0=None if plan.q0 is None else _pad_q(plan.q0),
             initial_background=None if plan.initial_background is None else [plan.initial_background],
-            return_background=True, return_precision_diagnostics=True, download=True)
+            return_background=True, return_precision_diagnostics=True, download=True,
+            initial_lambda=plan.initial_lambda is not None, initial_kappa=plan.initial_kappa is not None,
+            keep_ecm_state=bool(plan.ret["diagnostics"]) and plan.interval_size_bp is not None)
         fit, res = fits[0], results[0]
         final = {"stateSmoothed": res[0], "stateCovarSmoothed": res[1], "postFitResiduals": res[2], "NIS": res[3],
                  "intervalToBlockMap": res[4], "background": res[5], "outputTracks": res[6]["outputTracks"],

@@ -133,38 +133,83 @@ class ChainFit:
     final_ecm_converged: Optional[bool] = None
     final_nll: Optional[float] = None                         # sumNLL of the final forward pass (core.py:5583)
     final_forward_nis: Optional[float] = None                 # mean NIS of the final forward pass (core.py:5824)
+    ecm_state_level: object = None                            # smoothed level of the LAST ECM phase (host float32 (n,)), kept on request:
+                                                              # what the reference's sign-change diagnostic reads (core.py:4980, 5485)
 
-    def post_process_noise_fit(self, cfg: "FitConfig") -> dict:
+    def post_process_noise_fit(self, cfg: "FitConfig", extras: Optional[dict] = None) -> dict:
         """The reference's `diagnostics["post_process_noise_fit"]` summary of this chain (`_fitDiagnosticsMetadata`,
-        core.py:3355-3417), the keys its own tests read (test_core.py:4528-4530, 4604-4609, 4665-4672)."""
+        core.py:3355-3417) with its complete key set.  `extras`: values only the caller can compute from host arrays (the
+        multiplier bound-hit fractions, the sign-change rate).  The `background_objective*` keys -- a diagnostic of the
+        background solve alone that enters no stop rule (core.py:5160-5197; the rule reads the shift, the OUTER objective and the
+        inner convergence, :5252-5376) -- are not computed on this path and are reported as None."""
+        def finite(v):
+            return None if (v is None or not math.isfinite(float(v))) else float(v)
+
         loop = [r for r in self.loop_diagnostics if not r.get("final_fixed_background_ecm")]
         last = loop[-1] if loop else {}
         conv = [bool(r["converged"]) for r in self.loop_diagnostics if r.get("converged") is not None]
-        return {
+        incr = [int(r["nll_increase_count"]) for r in self.loop_diagnostics if r.get("nll_increase_count") is not None]
+        # outer_nll*: the forward NLL of the adopted background and its pass-to-pass change (core.py:4781-4797)
+        fwd = [r.get("outer_forward_nll") for r in loop if r.get("outer_forward_nll") is not None]
+        nll_change = nll_tol = None
+        nll_stable = False
+        if len(fwd) >= 2 and math.isfinite(fwd[-1]) and math.isfinite(fwd[-2]):
+            nll_change = abs(fwd[-1] - fwd[-2])
+            nll_tol = cfg.outer_nll_rtol * max(abs(fwd[-1]), abs(fwd[-2]), 1.0)
+            nll_stable = bool(nll_change <= nll_tol)
+        out = {
             "requested_outer_passes": max(1, int(cfg.outer_passes)) if cfg.fit_background else 1,
             "min_outer_passes": int(cfg.min_outer) if cfg.fit_background else 1,
             "planned_outer_passes": int(self.planned_passes),
             "actual_outer_passes": int(self.passes),
             "outer_converged": bool(self.converged),
             "outer_stop_reason": str(self.outer_stop_reason),
-            "background_shift": last.get("background_shift", 0.0),
-            "background_shift_threshold": last.get("background_shift_threshold"),
-            "outer_objective_per_cell": last.get("outer_objective_per_cell"),
+            "background_shift": finite(last.get("background_shift", 0.0)),
+            "background_shift_threshold": finite(last.get("background_shift_threshold")),
+            "background_objective": None, "background_objective_per_cell": None,
+            "background_objective_change_per_cell": None, "background_objective_threshold_per_cell": None,
+            "background_objective_stable": False,
+            "outer_nll": finite(fwd[-1]) if fwd else None, "outer_nll_change": finite(nll_change),
+            "outer_nll_threshold": finite(nll_tol), "outer_nll_stable": nll_stable,
+            "outer_objective": finite(last.get("outer_objective")),
+            "outer_objective_per_cell": finite(last.get("outer_objective_per_cell")),
+            "outer_objective_change_per_cell": finite(last.get("outer_objective_change_per_cell")),
+            "outer_objective_threshold_per_cell": finite(last.get("outer_objective_threshold_per_cell")),
             "outer_objective_stable": bool(last.get("outer_objective_stable", False)),
+            "outer_effective_observation_count": int(last.get("outer_effective_observation_count", 0) or 0),
+            "observation_lambda_lower_bound_hits": None, "observation_lambda_upper_bound_hits": None,
+            "process_kappa_lower_bound_hits": None, "process_kappa_upper_bound_hits": None,
+            "relative_sign_change_per_kb": None,
             "outer_stable_iters": int(last.get("outer_stable_iters", 0)),
             "outer_patience_target": int(cfg.patience),
             "inner_ecm_converged": bool(self.loop_diagnostics[-1].get("converged")) if self.loop_diagnostics else False,
             "warm_start": dict(self.warm_start),
             "all_ecm_converged": (bool(conv) and all(conv)) if conv else None,
+            "max_nll_increase_count": max(incr) if incr else None,
             "fixed_background_ecm": [dict(r) for r in self.loop_diagnostics],
         }
+        if extras:
+            out.update(extras)
+        return out
 
 
-def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False) -> List[ChainFit]:
+def warm_start_source(cfg: "FitConfig") -> str:
+    """`source` of `_estimateBackgroundWarmStart` (core.py:2866-2884), reported as warm_start["background_prepass_source"]."""
+    if cfg.use_nonnegative:
+        return "asymmetric_irls_zero_centered_weighted_data" if cfg.zero_center else "asymmetric_irls_weighted_data"
+    return "zero_centered_banded_weighted_data" if cfg.zero_center else "banded_weighted_data"
+
+
+def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False, initial_lambda: bool = False,
+              initial_kappa: bool = False) -> List[ChainFit]:
     """Steps 0-2 (the alternation loop, core.py:4860-5376) on a configured batch with data uploaded.  The fit that is
     resident afterwards is the one of each chain's last in-loop ECM phase against the background of THAT phase -- the
     reference never returns it: `run_consenrich_batch` continues with the final phases.  keep_background: start from the
-    background that is resident (an initial background uploaded with set_background) instead of zeros."""
+    background that is resident (an initial background uploaded with set_background) instead of zeros.
+    initial_lambda / initial_kappa: the caller uploaded warm-start multipliers (`upload_multipliers`; the reference's
+    initialObservationPrecision / initialProcessPrecision): the first ECM phase starts from them either way (they are the
+    resident multipliers); an initial lambda also weights the background warm start (core.py:4663-4676 passes
+    observationPrecision = lambdaExpLocal), and both are recorded in the warm-start summary (core.py:4689-4695)."""
     nc = len(batch.chain_lens)
     fits = [ChainFit() for _ in range(nc)]
     active = [True] * nc
@@ -183,7 +228,8 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
         # core.py:4663-4690: asymmetric-IRLS (or plain) solve of the weighted data themselves, no initial background
         info = batch.background_update(cfg.penalties[0], cfg.penalties[1], zero_center=cfg.zero_center,
                                        use_nonnegative=cfg.use_nonnegative,
-                                       negative_penalty_multiplier=cfg.neg_multiplier, use_lambda=False,
+                                       negative_penalty_multiplier=cfg.neg_multiplier,
+                                       use_lambda=bool(cfg.use_lambda and initial_lambda),
                                        use_initial=False, zero_state=True)
         batch.background_apply(None)
         for c in range(nc):
@@ -195,13 +241,14 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False)
     planned = planned_outer_passes(cfg)
     last_inner = [False] * nc
     last_obj_stable = [False] * nc
+    prepass = bool(cfg.fit_background and cfg.background_warm_start and not keep_background)
     for c in range(nc):
         fits[c].planned_passes = planned
         fits[c].warm_start = {"background": bool(keep_background),                       # core.py:4689-4695
-                              "background_prepass": bool(cfg.fit_background and cfg.background_warm_start and not keep_background),
-                              "background_prepass_source": "banded_weighted_data" if (cfg.fit_background and cfg.background_warm_start
-                                                                                     and not keep_background) else "",
-                              "observation_precision": False, "process_precision": False}
+                              "background_prepass": prepass,
+                              "background_prepass_source": warm_start_source(cfg) if prepass else "",
+                              "observation_precision": bool(cfg.use_lambda and initial_lambda),
+                              "process_precision": bool(cfg.use_kappa and not cfg.use_apn and initial_kappa)}
     for p in range(planned):
         if not have_stats:
             batch.stats()
@@ -328,7 +375,8 @@ def precision_diagnostics(batch: DeviceBatch, cfg: FitConfig, chain: int, q0, st
 
 def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_intervals: int, model_q0=None,
                          initial_background=None, return_background: bool = True,
-                         return_precision_diagnostics: bool = True, download: bool = True):
+                         return_precision_diagnostics: bool = True, download: bool = True,
+                         initial_lambda: bool = False, initial_kappa: bool = False, keep_ecm_state: bool = False):
     """Steps 0-5 of the module docstring.  Returns (fits, results): `fits` the per-chain history, `results` one tuple per
     chain in the reference's order (core.py:6126-6142 with returnScales=True): (stateSmoothed (n,2) float32,
     stateCovarSmoothed (n,2,2), postFitResiduals (n,m), NIS (n,), intervalToBlockMap (n,) int32[, background (n,)]
@@ -338,7 +386,10 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     model_q0: the batch-wide matrixQ0 (2,2) used when cfg.seed_q is False (for the diagnostics dict; default: the
     reference's 1e-4 fixed diagonal is NOT assumed -- pass what the batch was configured with).
     initial_background: optional list of per-chain float32 tracks (the reference's `initialBackground`); None = background
-    warm start from the weighted data when the background is fitted (core.py:4663), zeros otherwise."""
+    warm start from the weighted data when the background is fitted (core.py:4663), zeros otherwise.
+    initial_lambda / initial_kappa: warm-start multipliers were uploaded (`fit_batch`).
+    keep_ecm_state: keep the smoothed level of every chain's LAST ECM phase on the host (`ChainFit.ecm_state_level`; the
+    reference's sign-change diagnostic reads that state, core.py:4980 / 5485 -- not the final pass's)."""
     nc = len(batch.chain_lens)
     d = batch.d
     cfg = FitConfig(**{**cfg.__dict__})
@@ -348,7 +399,8 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
         cfg.background_warm_start = False
     else:
         cfg.background_warm_start = bool(cfg.fit_background)
-    fits = fit_batch(batch, cfg, keep_background=initial_background is not None)
+    fits = fit_batch(batch, cfg, keep_background=initial_background is not None, initial_lambda=initial_lambda,
+                     initial_kappa=initial_kappa)
 
     mult_flags = (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
     apn_flag = (L.USE_APN | L.USE_QSCALE) if cfg.use_apn else 0      # (the resident qScale track is all ones: core.py:5688)
@@ -366,6 +418,12 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
                                              "converged": fits[c].final_ecm_converged,
                                              "nll_increase_count": int(outs[c].nll_increase_count),
                                              "diagnostics_source": "cfixedBackgroundECM", "final_fixed_background_ecm": True})
+    if keep_ecm_state:
+        # every chain's last ECM phase: the final one, or (no background fit) the loop's single phase -- a chain that left
+        # the alternation early still took part in the final phase when there is one
+        batch.export(L.EXPORT_SMOOTH)
+        for c in range(nc):
+            fits[c].ecm_state_level = np.ascontiguousarray(batch.download(c, "xs")[:, 0])
     # final store-all forward / backward on data - background with the final multipliers (core.py:5560-5600).  The
     # statistics of the final background are resident (the ECM phase above or, without a background fit, the loop's)
     sum_d, sum_nll = batch.forward_backward(L.RETURN_NLL | mult_flags | apn_flag)

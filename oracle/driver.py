@@ -197,11 +197,21 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
     return hist
 
 
-def background_warm_start(data, munc, cfg):
+def warm_start_source(cfg):
+    """`source` of `_estimateBackgroundWarmStart`'s diagnostics (core.py:2866-2884), reported as
+    warm_start["background_prepass_source"] (core.py:4687-4692)."""
+    if cfg["use_nonnegative"]:
+        return "asymmetric_irls_zero_centered_weighted_data" if cfg["zero_center"] else "asymmetric_irls_weighted_data"
+    return "zero_centered_banded_weighted_data" if cfg["zero_center"] else "banded_weighted_data"
+
+
+def background_warm_start(data, munc, cfg, lam=None):
     """core.py:2809-2910 `_estimateBackgroundWarmStart` (called at core.py:4663 when the background is fitted and no initial
-    background is given): the background solve of the weighted DATA (residual = data, float32 inverse variances, no
-    observation precision unless an initial lambda is supplied, no initial background)."""
-    w, r, _, _ = bgo.weight_rhs_tracks(data, munc, np.zeros(np.asarray(data).shape[1], np.float32), np.float32(cfg["pad"]))
+    background is given): the background solve of the weighted DATA (residual = data, float32 inverse variances times the
+    INITIAL observation precision clipped to its bounds when one is supplied -- core.py:4669 passes lambdaExpLocal, :2847-2856 --
+    no initial background)."""
+    w, r, _, _ = bgo.weight_rhs_tracks(data, munc, np.zeros(np.asarray(data).shape[1], np.float32), np.float32(cfg["pad"]),
+                                       lam, cfg.get("lambda_bounds", (0.25, 4.0)))
     out, info = bgo.solve_background(w, r, 0, zero_center=cfg["zero_center"], use_nonnegative=cfg["use_nonnegative"],
                                      multiplier=cfg["neg_multiplier"], initial=None, penalties_override=cfg["penalties"],
                                      return_info=True)
@@ -219,10 +229,13 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
     d = cfg["state_dim"]
     warm_passes = None
     bg0 = initial_background
+    lam0 = initial_lambda if cfg["use_lambda"] else None                                    # core.py:4639-4643
+    kap0 = initial_kappa if (cfg["use_kappa"] and not cfg.get("use_apn")) else None         # core.py:4644-4650
     if bg0 is None and cfg["fit_background"]:
-        bg0, warm_passes = background_warm_start(data, munc, cfg)
-    hist = fit_chain(data, munc, cfg, initial_background=bg0, initial_lambda=initial_lambda, initial_kappa=initial_kappa)
+        bg0, warm_passes = background_warm_start(data, munc, cfg, lam0)
+    hist = fit_chain(data, munc, cfg, initial_background=bg0, initial_lambda=lam0, initial_kappa=kap0)
     bg, lam, kap = hist["background"], hist["lam"], hist["kap"]
+    ecm_xs_level = np.asarray(hist["xs"], np.float32)[:, 0].copy()          # smoothed level of the last ECM phase (core.py:4980)
     bm = (np.arange(n, dtype=np.int32) // cfg["block_len_intervals"]).astype(np.int32)
     Q0 = np.asarray(cfg["Q0"], np.float32)
     common = dict(matrixQ0=Q0, intervalToBlockMap=bm, blockCount=int(bm.max()) + 1, stateInit=cfg["state_init"],
@@ -242,6 +255,7 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
                   t_innerIters=cfg["inner_iters"], ECM_robustTNu=cfg["nu"], returnIntermediates=True,
                   returnDiagnostics=True, logIterations=False, **common)
         iters, nll, _xs, _Ps, _lag, _res, lam, kap, diag = out
+        ecm_xs_level = np.asarray(_xs, np.float32)[:, 0].copy()             # ... of the final phase (core.py:5485)
         final = dict(final_ecm_iters=int(iters), final_ecm_nll=float(nll), final_ecm_converged=bool(diag["converged"]))
     xf, Pf, pn = np.empty((n, d), np.float32), np.empty((n, d, d), np.float32), np.empty((n, d, d), np.float32)
     D = np.empty(n, np.float32)
@@ -257,8 +271,11 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
         xs2, Ps2 = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32)
         xs2[:, 0], Ps2[:, 0, 0] = xs[:, 0], Ps[:, 0, 0]
         xs, Ps = xs2, Ps2
+    prepass = bool(initial_background is None and cfg["fit_background"])
     hist["warm_start"] = {"background": initial_background is not None,                       # core.py:4689-4695
-                          "background_prepass": bool(initial_background is None and cfg["fit_background"])}
+                          "background_prepass": prepass,
+                          "background_prepass_source": warm_start_source(cfg) if prepass else "",
+                          "observation_precision": lam0 is not None, "process_precision": kap0 is not None}
     hist["ecm_calls"] = len(hist["ecm_iters"]) + (1 if cfg["fit_background"] else 0)
     if cfg["fit_background"]:
         hist["loop"].append({"outer_pass": hist["passes"] + 1, "iters_done": final["final_ecm_iters"],
@@ -267,5 +284,5 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
     hist.update(final, warm_start_passes=warm_passes, final_nll=float(nll), final_forward_nis=float(phi),
                 out_xs=np.asarray(xs, np.float32), out_Ps=np.asarray(Ps, np.float32), out_resid=np.asarray(res, np.float32),
                 out_NIS=np.asarray(D, np.float32), out_block_map=bm, out_background=bg, out_lam=lam, out_kap=kap,
-                out_Pf=Pf, out_pn=pn)
+                out_Pf=Pf, out_pn=pn, ecm_xs_level=ecm_xs_level)
     return hist

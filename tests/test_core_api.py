@@ -183,10 +183,375 @@ def test_argument_mapping_and_the_references_errors():
                        (dict(initialBackground=np.zeros(3)), "`initialBackground` must have length 64"),
                        (dict(initialProcessQ=np.eye(3)), "`initialProcessQ` must have shape (2, 2)"),
                        (dict(observationMask=np.ones((2, 2), bool)), "observationMask must match matrixData shape"),
-                       (dict(backgroundNegativePenaltyMultiplier=float("inf")), "must be finite or None"),
-                       (dict(projectStateDuringFiltering=True), "not supported")):
+                       (dict(backgroundNegativePenaltyMultiplier=float("inf")), "must be finite or None")):
         with pytest.raises(ValueError, match=text.replace("(", r"\(").replace(")", r"\)")):
             call(**over)
+
+
+    # accepted without effect, like the reference (core.py:4284, 4391 forward it to loops that never read it)
+    assert call(projectStateDuringFiltering=True).cfg == call().cfg
+
+
+# ---- three more contract cases the reference's tests hold (test_core.py:4289-4353, 4356-4467, 6094-6150), mirrored literally.
+# The reference spies on `cconsenrich.cfixedBackgroundECM` and fakes `core._estimateInitialProcessNoiseFromData` with
+# monkeypatch.setattr; the same seams exist here: the twin calls `oracle.oracle.cfixedBackgroundECM` and
+# `oracle.qseed.estimate_initial_process_noise`, the product `DeviceBatch.ecm` and `DeviceBatch.qseed`.
+SEED_Q = np.diag([2.0e-5, 3.0e-5]).astype(np.float32)                  # test_core.py:4370
+
+
+def _case_initial_process_q():
+    """test_core.py:4290-4337"""
+    rng = np.random.default_rng(17)
+    n, m = 30, 3
+    grid = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    data = np.vstack([grid + 0.02 * rng.normal(size=n) + offset for offset in (-0.01, 0.0, 0.01)]).astype(np.float32)
+    munc = np.full((m, n), 0.10, dtype=np.float32)
+    kw = dict(deltaF=1.0, minQ=1.0e-4, maxQ=0.5, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=8, ECM_fixedBackgroundIters=2, ECM_useProcessPrecisionReweighting=True,
+              ECM_useAPN=False, fitBackground=False, initialProcessQ=np.diag([1.0e-3, 1.0e-4]).astype(np.float32),
+              returnDiagnostics=True)
+    return data, munc, kw
+
+
+def _case_fixed_diagonal_uses_data_q():
+    """test_core.py:4357-4417"""
+    rng = np.random.default_rng(3)
+    n, m = 36, 3
+    grid = np.linspace(0.0, 2.0 * np.pi, n, dtype=np.float32)
+    data = np.vstack([np.sin(grid) + 0.2 * rng.normal(size=n) + offset for offset in (-0.1, 0.0, 0.1)]).astype(np.float32)
+    munc = np.full((m, n), 0.05, dtype=np.float32)
+    kw = dict(deltaF=0.2, minQ=1.0e-6, maxQ=1.0, processNoiseCalibration="fixedDiagonal", stateInit=0.0, stateCovarInit=1.0,
+              boundState=False, stateLowerBound=0.0, stateUpperBound=0.0, blockLenIntervals=6, ECM_fixedBackgroundIters=1,
+              ECM_outerIters=1, ECM_minOuterIters=1, fitBackground=False, ECM_useProcessPrecisionReweighting=True,
+              initialProcessPrecision=np.linspace(0.5, 1.8, n, dtype=np.float32), qSeedPriorLevel=7.0e-6,
+              returnPrecisionDiagnostics=True, returnDiagnostics=True)
+    return data, munc, kw
+
+
+def _case_always_runs_ecm_with_apn():
+    """test_core.py:6097-6138"""
+    rng = np.random.default_rng(321)
+    n, m = 40, 3
+    sig = np.cos(np.linspace(0.0, 2.0 * np.pi, n, dtype=np.float32))
+    data = np.vstack([sig + 0.05 * rng.normal(size=n) - 0.02, sig + 0.05 * rng.normal(size=n),
+                      sig + 0.05 * rng.normal(size=n) + 0.01]).astype(np.float32)
+    munc = np.full((m, n), 0.2, dtype=np.float32)
+    kw = dict(deltaF=0.1, minQ=1.0e-6, maxQ=0.5, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=8, ECM_useAPN=True, ECM_useProcessPrecisionReweighting=True,
+              processNoiseCalibration="fixedDiagonal")
+    return data, munc, kw
+
+
+def _fake_seed(n):
+    return SEED_Q.copy(), {"qSeedSource": "test", "qSeedTransitionCount": n - 1, "qSeedLevelFinal": float(SEED_Q[0, 0]),
+                           "qSeedTrendFinal": float(SEED_Q[1, 1])}
+
+
+def _check_initial_process_q(out, ecm_modes, kw):
+    """test_core.py:4339-4353"""
+    diagnostics = out[-1]
+    assert ecm_modes == [(True, False)]                    # ONE phase, (process re-weighting, APN)
+    q_info = diagnostics["process_noise_calibration"]
+    assert q_info["processNoiseCalibrationStatus"] == "skipped"
+    assert q_info["processNoiseCalibrationReason"] == "initial_process_q"
+    assert q_info["warmStartProcessNoise"] == 1.0
+    np.testing.assert_allclose(q_info["matrixQ0Final"], kw["initialProcessQ"], rtol=0.0, atol=0.0)
+    assert diagnostics["post_process_noise_fit"]["warm_start"]["background"] is False
+
+
+def _check_fixed_diagonal_uses_data_q(out, seed_calls, ecm_calls, data, munc):
+    """test_core.py:4419-4467"""
+    n = data.shape[1]
+    prec, run = out[-2], out[-1]
+    q_info = run["process_noise_calibration"]
+    assert len(seed_calls) == 1
+    call = seed_calls[0]
+    if "matrixData" in call:                               # (the twin's seed estimator takes the matrices; the device's reads the resident ones)
+        np.testing.assert_array_equal(call["matrixData"], data)
+        np.testing.assert_array_equal(call["matrixMunc"], munc)
+    assert call["pad"] == pytest.approx(1.0e-4)
+    assert call["stateModel"] == "levelTrend"
+    assert call["minQ"] == pytest.approx(1.0e-6) and call["maxQ"] == pytest.approx(1.0)
+    assert call["deltaF"] == pytest.approx(0.2) and call["robustTNu"] == pytest.approx(8.0)
+    assert call["qSeedPriorLevel"] == pytest.approx(7.0e-6)
+    assert len(ecm_calls) == 1
+    np.testing.assert_allclose(ecm_calls[0]["matrixQ0"], SEED_Q, rtol=0.0, atol=1.0e-10)
+    assert ecm_calls[0]["useAPN"] is False and ecm_calls[0]["useProcPrec"] is True
+    assert "process_noise_warmup_fit" not in run
+    assert q_info["processNoisePolicy"] == "fixedDiagonal"
+    assert q_info["processNoiseCalibrationStatus"] == "estimated"
+    assert q_info["processNoiseCalibrationReason"] == "data_derived_q_estimate"
+    assert q_info["qSeedSource"] == "test"
+    assert q_info["validTransitionCount"] == n - 1
+    np.testing.assert_allclose(q_info["matrixQ0Final"], SEED_Q, rtol=0.0, atol=1.0e-10)
+    tracks = prec["outputTracks"]
+    np.testing.assert_allclose(tracks["processQScale"], np.ones(n))
+    np.testing.assert_allclose(tracks["baseQLevel"], SEED_Q[0, 0])
+    np.testing.assert_allclose(tracks["baseQTrend"], SEED_Q[1, 1])
+    np.testing.assert_allclose(tracks["preKappaQLevel"], SEED_Q[0, 0])
+    np.testing.assert_allclose(tracks["preKappaQTrend"], SEED_Q[1, 1])
+    assert np.any(np.abs(tracks["effectiveQLevel"] - tracks["preKappaQLevel"]) > 1.0e-9)
+
+
+def _check_always_runs_ecm_with_apn(out, calls, data):
+    """test_core.py:6140-6150"""
+    m, n = data.shape
+    assert calls
+    assert calls[-1] == (True, False)                      # (APN, process re-weighting): kappa is off under APN (core.py:3974)
+    xs, Ps, resid, nis, *_ = out
+    assert xs.shape == (n, 2) and Ps.shape == (n, 2, 2) and resid.shape == (n, m) and nis.shape == (n,)
+    assert np.all(np.isfinite(xs))
+
+
+def _spy_twin(monkeypatch, n):
+    """the reference's two seams on the twin: every cfixedBackgroundECM call recorded, the seed estimator faked"""
+    from oracle import oracle as orc
+    from oracle import qseed as oq
+
+    ecm_calls, seed_calls = [], []
+    original = orc.cfixedBackgroundECM
+
+    def spy_ecm(*args, **kwargs):
+        ecm_calls.append({"matrixQ0": np.asarray(kwargs["matrixQ0"], np.float64).copy(), "useAPN": bool(kwargs.get("ECM_useAPN", False)),
+                          "useProcPrec": bool(kwargs["ECM_useProcessPrecisionReweighting"])})
+        return original(*args, **kwargs)
+
+    def fake_seed(_natives, **kwargs):
+        seed_calls.append(kwargs)
+        return _fake_seed(n)
+
+    monkeypatch.setattr(orc, "cfixedBackgroundECM", spy_ecm)
+    return ecm_calls, seed_calls, lambda: monkeypatch.setattr(oq, "estimate_initial_process_noise", fake_seed)
+
+
+def test_initial_process_q_skips_the_seed_on_the_cpu_twin(monkeypatch):
+    from oracle import qseed as oq
+
+    data, munc, kw = _case_initial_process_q()
+    ecm_calls, _seed_calls, _ = _spy_twin(monkeypatch, data.shape[1])
+
+    def fail_seed(*_a, **_k):
+        raise AssertionError("explicit process Q must bypass data estimation")
+
+    monkeypatch.setattr(oq, "estimate_initial_process_noise", fail_seed)
+    _, out = _twin_call(data, munc, kw)
+    _check_initial_process_q(out, [(c["useProcPrec"], c["useAPN"]) for c in ecm_calls], kw)
+
+
+def test_fixed_diagonal_uses_the_data_q_on_the_cpu_twin(monkeypatch):
+    data, munc, kw = _case_fixed_diagonal_uses_data_q()
+    ecm_calls, seed_calls, install_fake_seed = _spy_twin(monkeypatch, data.shape[1])
+    install_fake_seed()
+    _, out = _twin_call(data, munc, kw)
+    _check_fixed_diagonal_uses_data_q(out, seed_calls, ecm_calls, data, munc)
+
+
+def test_apn_always_runs_the_ecm_on_the_cpu_twin(monkeypatch):
+    data, munc, kw = _case_always_runs_ecm_with_apn()
+    ecm_calls, _s, _ = _spy_twin(monkeypatch, data.shape[1])
+    _, out = _twin_call(data, munc, kw)
+    _check_always_runs_ecm_with_apn(out, [(c["useAPN"], c["useProcPrec"]) for c in ecm_calls], data)
+
+
+def _spy_device(monkeypatch, n, fake_seed=False, forbid_seed=False):
+    """the same seams on the product: DeviceBatch.ecm recorded (with the base process noise the batch holds), DeviceBatch.qseed faked"""
+    from consenrich_amd.batch import DeviceBatch
+
+    ecm_calls, seed_calls, chain_q = [], [], []
+    original_ecm, original_set_q = DeviceBatch.ecm, DeviceBatch.set_chain_q
+
+    def spy_set_q(self, qs):
+        chain_q[:] = [np.asarray(q, np.float64).copy() for q in qs]
+        return original_set_q(self, qs)
+
+    def spy_ecm(self, *args, **kwargs):
+        q = chain_q[0] if chain_q else np.asarray(self.model.Q0, np.float64)
+        ecm_calls.append({"matrixQ0": np.asarray(q, np.float64)[:2, :2].copy(), "useAPN": bool(kwargs.get("use_apn", False)),
+                          "useProcPrec": bool(kwargs.get("use_kappa", True))})
+        return original_ecm(self, *args, **kwargs)
+
+    def fake(self, **kwargs):
+        if forbid_seed:
+            raise AssertionError("explicit process Q must bypass data estimation")
+        seed_calls.append(kwargs)
+        return [_fake_seed(n)]
+
+    monkeypatch.setattr(DeviceBatch, "ecm", spy_ecm)
+    monkeypatch.setattr(DeviceBatch, "set_chain_q", spy_set_q)
+    if fake_seed or forbid_seed:
+        monkeypatch.setattr(DeviceBatch, "qseed", fake)
+    return ecm_calls, seed_calls
+
+
+def _device_call(data, munc, kw):
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import core_api
+
+    k = dict(kw)
+    return core_api.runConsenrich(data, munc, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
+
+
+@pytest.mark.gpu
+def test_initial_process_q_skips_the_seed_on_the_device(monkeypatch):
+    data, munc, kw = _case_initial_process_q()
+    ecm_calls, _ = _spy_device(monkeypatch, data.shape[1], forbid_seed=True)
+    out = _device_call(data, munc, kw)
+    _check_initial_process_q(out, [(c["useProcPrec"], c["useAPN"]) for c in ecm_calls], kw)
+    np.testing.assert_allclose(ecm_calls[0]["matrixQ0"], kw["initialProcessQ"], rtol=0.0, atol=0.0)
+
+
+@pytest.mark.gpu
+def test_fixed_diagonal_uses_the_data_q_on_the_device(monkeypatch):
+    data, munc, kw = _case_fixed_diagonal_uses_data_q()
+    ecm_calls, seed_calls = _spy_device(monkeypatch, data.shape[1], fake_seed=True)
+    out = _device_call(data, munc, kw)
+    _check_fixed_diagonal_uses_data_q(out, seed_calls, ecm_calls, data, munc)
+
+
+@pytest.mark.gpu
+def test_apn_always_runs_the_ecm_on_the_device(monkeypatch):
+    data, munc, kw = _case_always_runs_ecm_with_apn()
+    ecm_calls, _ = _spy_device(monkeypatch, data.shape[1])
+    out = _device_call(data, munc, kw)
+    _check_always_runs_ecm_with_apn(out, [(c["useAPN"], c["useProcPrec"]) for c in ecm_calls], data)
+    _, ref = _twin_call(data, munc, kw)
+    for a, b in zip(out[:3], ref[:3]):
+        np.testing.assert_allclose(a.astype(np.float64), b, rtol=1e-4, atol=2e-5)
+
+
+# the reference's run-diagnostics key set (core.py:5943-5999; post_process_noise_fit: core.py:3373-3417; process_noise_calibration:
+# core.py:3133-3158 + 3046-3055 + 3088-3100 + 5731-5737; precision_reweighting_boundary_hits: diagnostics.py:233-247)
+RUN_DIAGNOSTICS_KEYS = {
+    "state_model", "final_nll", "final_forward_nis", "final_forward_gain_contig_summary",
+    "precision_reweighting_boundary_hits", "process_noise_calibration", "post_process_noise_fit", "optimization_path_tracked",
+    "process_precision_reweighting_requested", "process_precision_reweighting_effective",
+    "process_precision_reweighting_disabled_by_apn", "adaptive_process_noise_effective", "process_q_policy",
+    "process_q_diagnostics", "observation_r_trace"}
+POST_FIT_KEYS = {
+    "requested_outer_passes", "min_outer_passes", "planned_outer_passes", "actual_outer_passes", "outer_converged",
+    "outer_stop_reason", "background_shift", "background_shift_threshold", "background_objective",
+    "background_objective_per_cell", "background_objective_change_per_cell", "background_objective_threshold_per_cell",
+    "background_objective_stable", "outer_nll", "outer_nll_change", "outer_nll_threshold", "outer_nll_stable", "outer_objective",
+    "outer_objective_per_cell", "outer_objective_change_per_cell", "outer_objective_threshold_per_cell",
+    "outer_objective_stable", "outer_effective_observation_count", "observation_lambda_lower_bound_hits",
+    "observation_lambda_upper_bound_hits", "process_kappa_lower_bound_hits", "process_kappa_upper_bound_hits",
+    "relative_sign_change_per_kb", "outer_stable_iters", "outer_patience_target", "inner_ecm_converged", "warm_start",
+    "all_ecm_converged", "max_nll_increase_count", "fixed_background_ecm"}
+CALIBRATION_KEYS = {
+    "processNoisePolicy", "processNoiseCalibrationStatus", "processNoiseCalibrationReason", "stateModel", "preKappaQLevel",
+    "preKappaQTrend", "rawTrendLevelRatio", "effectiveTrendLevelRatio", "logQLevel", "logQTrend", "usedInitialProcessQFallback",
+    "matrixQ0Final", "warmStartProcessNoise", "globalScale", "windowCount", "validTransitionCount", "qScaleClampFraction",
+    "qFloor", "qCap", "hitQLevelFloor", "hitQTrendFloor", "hitQLevelCap", "hitQTrendCap", "hitQFloor", "hitQCap",
+    "qBoundaryStatus", "finiteDataCount", "positiveObservationVarianceCount", "activeObservationCount", "activeIntervalCount",
+    "intervalTransitionCount", "activeAdjacentTransitionCount", "sameTrackAdjacentTransitionCount",
+    "processNoiseCalibrationCanRun", "processNoiseCalibrationSkipReason", "resolvedMinQ", "resolvedMaxQ", "transitionCount",
+    "processQScaleSummary"}
+WARM_START_KEYS = {"background", "background_prepass", "background_prepass_source", "observation_precision", "process_precision"}
+
+
+def test_run_diagnostics_carry_the_references_key_set():
+    data, munc, kw = _case_outer_pass_smoke()
+    _, out = _twin_call(data, munc, kw)
+    diag = out[-1]
+    n = data.shape[1]
+    assert set(diag) == RUN_DIAGNOSTICS_KEYS
+    assert set(diag["post_process_noise_fit"]) == POST_FIT_KEYS
+    assert set(diag["post_process_noise_fit"]["warm_start"]) == WARM_START_KEYS
+    assert CALIBRATION_KEYS <= set(diag["process_noise_calibration"])            # (+ the seed estimator's own qSeed* keys)
+    hits = diag["precision_reweighting_boundary_hits"]
+    assert set(hits) == {"observation", "process", "bounds"} and hits["bounds"] == {"observation": [0.25, 4.0], "process": [5.0e-3, 5.0e3]}
+    assert hits["observation"]["enabled"] and hits["observation"]["total"] == n
+    assert hits["process"]["enabled"] and hits["process"]["total"] == n - 1       # the first kappa multiplies nothing (skipFirst)
+    post = diag["post_process_noise_fit"]
+    assert post["warm_start"] == {"background": False, "background_prepass": True,
+                                  "background_prepass_source": "asymmetric_irls_weighted_data",
+                                  "observation_precision": False, "process_precision": False}
+    rate = post["relative_sign_change_per_kb"]                                    # intervalSizeBP = 1000: changes per interval
+    assert rate is not None and 0.0 <= rate <= 1.0
+    cal = diag["process_noise_calibration"]
+    assert cal["processNoiseCalibrationStatus"] == "estimated" and cal["intervalTransitionCount"] == n - 1
+    assert cal["activeObservationCount"] == data.size and cal["processNoiseCalibrationCanRun"] is True
+    import json
+    json.dumps(diag["process_noise_calibration"])                                 # metadata: plain Python values only (core.py:5921-5942)
+
+
+def test_host_restatements_of_the_diagnostics_helpers():
+    """the reference's small pure-NumPy helpers restated in core_api, on hand-made inputs with answers worked out by hand"""
+    from consenrich_amd import core_api as ca
+
+    hits = ca.summarize_precision_boundary_hits(observationPrecision=[0.25, 1.0, 4.0, 4.0, np.nan], observationPrecisionMin=0.25,
+                                                observationPrecisionMax=4.0, processPrecision=[5e-3, 5e-3, 1.0, 5e3],
+                                                processPrecisionMin=5e-3, processPrecisionMax=5e3)
+    assert hits["observation"] == {"enabled": True, "total": 4, "lower": 1, "upper": 2, "lower_fraction": 0.25, "upper_fraction": 0.5}
+    assert hits["process"] == {"enabled": True, "total": 3, "lower": 1, "upper": 1, "lower_fraction": 1 / 3, "upper_fraction": 1 / 3}
+    off = ca.summarize_precision_boundary_hits(observationPrecision=None, observationPrecisionMin=0.25, observationPrecisionMax=4.0,
+                                               processPrecision=None, processPrecisionMin=5e-3, processPrecisionMax=5e3)
+    assert off["observation"]["enabled"] is False and off["process"]["lower_fraction"] is None
+    assert ca.precision_bound_hits([0.1, 0.25, 1.0, 5.0], 0.25, 4.0) == (0.5, 0.25)
+    assert ca.precision_bound_hits([9.0, 0.25, 1.0, 5.0], 0.25, 4.0, skip_first=True) == (1 / 3, 1 / 3)
+    assert ca.precision_bound_hits(None, 0.25, 4.0) == (None, None)
+    # sign changes: state - weighted mean = [+1, -1, +1, +1, -0.001 (below 1 % of the mean magnitude: dropped), -1] -> 3 changes
+    data = np.zeros((2, 6), np.float32)
+    munc = np.ones((2, 6), np.float32)
+    state = np.asarray([1.0, -1.0, 1.0, 1.0, -0.001, -1.0])
+    assert ca.relative_sign_change_per_kb(state, data, munc, interval_size_bp=500) == pytest.approx(3 / 3.0)
+    assert ca.relative_sign_change_per_kb(state, data, munc, interval_size_bp=None) is None
+    bnd = ca.process_noise_q_boundary_diagnostics(np.diag([1e-6, 0.5]), "levelTrend", 1e-6, 0.5)
+    assert bnd["qBoundaryStatus"] == "floor_and_cap" and bnd["hitQLevelFloor"] and bnd["hitQTrendCap"] and not bnd["hitQLevelCap"]
+    assert ca.process_noise_q_boundary_diagnostics(np.diag([1e-3, 1e-4]), "levelTrend", 1e-6, -1.0)["qCap"] == float("inf")
+    sup = ca.process_noise_calibration_support(np.asarray([[1.0, np.nan, 2.0, 3.0]]), np.asarray([[0.1, 0.1, 1e30, 0.1]]), 1e-4)
+    assert sup["finiteDataCount"] == 3 and sup["activeObservationCount"] == 2 and sup["activeAdjacentTransitionCount"] == 0
+    assert sup["processNoiseCalibrationSkipReason"] == "no_active_adjacent_transitions"
+
+
+def test_an_initial_lambda_weights_the_background_warm_start():
+    """core.py:4663-4676: the background prepass is weighted by the INITIAL observation precision (clipped to its bounds) when
+    one is given and no initial background is -- a different start than the unweighted prepass."""
+    from oracle import driver as odrv
+
+    data, munc, kw = _case_outer_pass_smoke()
+    n = data.shape[1]
+    munc = (munc * np.linspace(0.5, 2.0, 3, dtype=np.float32)[:, None]).astype(np.float32)
+    lam0 = np.where(np.arange(n) % 2 == 0, 0.1, 9.0).astype(np.float32)         # outside the bounds on both sides
+    k = dict(kw, initialObservationPrecision=lam0)
+    plan, out = _twin_call(data, munc, k)
+    assert plan.initial_lambda.min() == np.float32(0.25) and plan.initial_lambda.max() == np.float32(4.0)
+    ws = out[-1]["post_process_noise_fit"]["warm_start"]
+    assert ws["observation_precision"] is True and ws["background_prepass"] is True and ws["background"] is False
+    cfg = __import__("twin_core").twin_cfg(plan)
+    with_lam, _ = odrv.background_warm_start(data, munc, cfg, plan.initial_lambda)
+    without, _ = odrv.background_warm_start(data, munc, cfg)
+    assert float(np.abs(with_lam - without).max()) > 1e-3
+    # the formula itself (core.py:2842-2857): weights = lambda / max(munc + pad, 1e-8), residual = data
+    w = (lam0.clip(0.25, 4.0)[None, :] / np.maximum(munc + np.float32(1e-4), np.float32(1e-8))).astype(np.float32)
+    from oracle import background as bgo
+    want, _ = bgo.solve_background(w.sum(axis=0, dtype=np.float64), np.einsum("ij,ij->j", w, data, dtype=np.float64), 0,
+                                   zero_center=False, use_nonnegative=True, multiplier=1.0, initial=None,
+                                   penalties_override=cfg["penalties"], return_info=True)
+    np.testing.assert_allclose(with_lam, want, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_an_initial_lambda_weights_the_background_warm_start_on_the_device():
+    """the device prepass hard-coded use_lambda=False.  Device == twin with an initial lambda and no initial
+    background (the prepass runs), and the warm-start summary says what was uploaded."""
+    data, munc, kw = _case_outer_pass_smoke()
+    n = data.shape[1]
+    munc = (munc * np.linspace(0.5, 2.0, 3, dtype=np.float32)[:, None]).astype(np.float32)
+    lam0 = np.where(np.arange(n) % 2 == 0, 0.1, 9.0).astype(np.float32)
+    k = dict(kw, initialObservationPrecision=lam0, initialProcessPrecision=np.full(n, 1.3, np.float32), returnBackground=True)
+    out = _device_call(data, munc, k)
+    _, ref = _twin_call(data, munc, k)
+    ws = out[-1]["post_process_noise_fit"]["warm_start"]
+    assert ws == ref[-1]["post_process_noise_fit"]["warm_start"]
+    assert ws["observation_precision"] is True and ws["process_precision"] is True and ws["background_prepass"] is True
+    pg, pr = out[-1]["post_process_noise_fit"], ref[-1]["post_process_noise_fit"]
+    assert [r["iters_done"] for r in pg["fixed_background_ecm"]] == [r["iters_done"] for r in pr["fixed_background_ecm"]]
+    np.testing.assert_allclose(out[5].astype(np.float64), ref[5], rtol=1e-4, atol=2e-5)        # the fitted background
+    np.testing.assert_allclose(out[0].astype(np.float64), ref[0], rtol=1e-4, atol=2e-5)
+    assert pg["relative_sign_change_per_kb"] == pytest.approx(pr["relative_sign_change_per_kb"], abs=2.0 / n)
+    assert out[-1]["precision_reweighting_boundary_hits"] == ref[-1]["precision_reweighting_boundary_hits"]
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -351,6 +351,32 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
                 assert np.array_equal(val, got[key]), (env, variant, key)
 
 
+def test_two_contexts_in_one_process_each_raise_their_own_launch_attributes(product):
+    """The default-mode state chain launches with ~124 KB of dynamic LDS, which has to be asked for once per kernel AND PER
+    DEVICE (hipFuncSetAttribute).  Round 4 remembered that in a process-wide static: a second context on another GPU of the
+    same process skipped the call and its launch failed.  The flag lives in the context now: two contexts of one process --
+    on two devices where the box has them, else both on device 0 -- step the same batch to the same bits."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list = [70000, 33000]
+    sets = [cases.synth(n, 3, 7800 + c) for c, n in enumerate(n_list)]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH
+    second = 1 if L.device_count() > 1 else 0
+    outs = []
+    with DeviceBatch(0) as b0, DeviceBatch(second) as b1:
+        for b in (b0, b1):
+            b.configure(ModelParams(state_dim=2), 3, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+        for b in (b0, b1, b0):
+            b.step(L.RETURN_NLL, what)
+            outs.append({(c, k): b.download(c, k) for c in range(2) for k in ("xf", "xs", "Ps", "D")})
+    for o in outs[1:]:
+        for key, val in outs[0].items():
+            assert np.array_equal(val, o[key]), key
+
+
 def test_a_pipelined_step_whose_covariance_chain_fails_validation_is_replayed_whole(product, monkeypatch):
     """In the default mode the covariance chain is validated OPTIMISTICALLY and writes the gain records the state chain, the
     pipelined tail groups and the exports run on.  With a deliberately short covariance window (16 bins) that validation

@@ -49,9 +49,7 @@ def twin_run(plan):
         procPrecisionMultiplierMin=mp.kappa_bounds[0], procPrecisionMultiplierMax=mp.kappa_bounds[1])
     fit = ChainFit(passes=ref["passes"], converged=bool(ref["converged"]), outer_stop_reason=ref["stop_reason"],
                    loop_diagnostics=list(ref["loop"]), planned_passes=odrv.planned_outer_passes(ocfg),
-                   warm_start={**ref["warm_start"], "background_prepass_source": "banded_weighted_data" if ref["warm_start"]["background_prepass"] else "",
-                               "observation_precision": plan.initial_lambda is not None,
-                               "process_precision": plan.initial_kappa is not None},
+                   warm_start=dict(ref["warm_start"]), ecm_state_level=ref["ecm_xs_level"],
                    ecm_iters=list(ref["ecm_iters"]), nll=list(ref["nll"]), q_seed=dict(q_seed),
                    final_ecm_iters=ref.get("final_ecm_iters"), final_nll=ref["final_nll"],
                    final_forward_nis=ref["final_forward_nis"])
