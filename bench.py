@@ -5,9 +5,14 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W         (the launcher provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT)
 
-Workload (BASELINE.json metric "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples"):
+  python bench.py --config c2|c3|c4|c5                  (one line per BASELINE config; default c4 = the headline)
+
+Default workload = BASELINE config 4 (BASELINE.json metric "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples"):
 22 synthetic chains with the hg38 autosome bin counts at 200 bp (14 375 018 bins), m = 32 samples, levelTrend model,
-SURVEY 8(d) parameters.  One STEP = one full pass of the hot path over every chain the rank owns, inputs already
+SURVEY 8(d) parameters.  c3 = the same chains x 8 samples; c5 = the chains at 50 bp (57 500 042 bins) x 64 samples; c2 = ONE
+chain of 1e6 bins x 4 samples, FORWARD FILTER ONLY (statistics + forward(store, NLL) + reference-layout D / xf / Pf / pNoise;
+no smoother, no residuals; B_alg = 8 m + 60 bytes per bin; `cpu_baseline` = the port's forward pass alone).
+One STEP = one full pass of the hot path over every chain the rank owns, inputs already
 resident in HBM:  per-bin sufficient statistics of (data, munc)  ->  forward filter (store, NLL)  ->  RTS smoother
 ->  lag-one covariances  ->  D, xf, Pf, pNoise, xs, Ps, lagCov in the reference layouts  ->  residuals (n, m).
 With N > 1 the chains are LPT-sharded over the ranks (strong scaling: the genome is fixed); there is no data-path
@@ -40,14 +45,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILES = {0: os.path.join("profiles", "r04_pmc_traffic_exact.json"),      # PMC passes of THIS workload (scripts/pmc_traffic.py)
+TRAFFIC_FILES = {0: os.path.join("profiles", "r04_pmc_traffic_exact.json"),      # PMC passes of the c4 workload (scripts/pmc_traffic.py)
                  2: os.path.join("profiles", "r04_pmc_traffic.json")}
 EXIT_RCCL_FAILED = 3
 
+# BASELINE.json `configs` 2-5 (config 1 is the reference's own CPU-runnable plumbing case: a parity test, not a bench line)
+CONFIGS = {
+    "c2": {"bin_bp": 200, "samples": 4, "single_chain": 1000000, "forward_only": True,
+           "metric": "genomic bins/sec (forward filter only), 1 chromosome of 1e6 x 200bp bins x 4 samples"},
+    "c3": {"bin_bp": 200, "samples": 8, "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 8 samples"},
+    "c4": {"bin_bp": 200, "samples": 32, "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples"},
+    "c5": {"bin_bp": 50, "samples": 64, "metric": "genomic bins/sec (forward+backward pass), hg38 50bp x 64 samples"},
+}
 
-def b_alg(m: int) -> int:
-    """algorithmic bytes per bin, forward + backward, data read once."""
-    return 12 * m + 100
+# What a rank's step costs as a function of the bins it owns, per validation mode: ms = fixed + per_mbin * (bins / 1e6), fitted to
+# the LPT shards of 2 / 4 / 8 ranks emulated on ONE GPU (scripts/shards.sh -> SCALING_MODEL_SOURCE; c4 shape).  The default mode's
+# fixed part is the state chain's critical path on the rank's longest chromosome (every rank of <= 8 holds one of chr1..chr8:
+# 0.73-1.24 M bins); the throughput mode's is launch / drain latency of its serial kernels.  Used for `expected` at N > 1 only.
+SCALING_MODEL = {"default": {"fixed_ms": 1.47, "per_mbin_ms": 0.174}, "ulp2": {"fixed_ms": 0.116, "per_mbin_ms": 0.151}}
+SCALING_MODEL_SOURCE = "profiles/r04_shards_exact_mode.txt, profiles/r03_shards_throughput_mode.txt"
+
+
+def b_alg(m: int, forward_only: bool = False) -> int:
+    """algorithmic bytes per bin, data read once: forward + backward 12 m + 100; forward only 8 m + 60."""
+    return 8 * m + 60 if forward_only else 12 * m + 100
+
+
+def expected_speedup(bins_per_rank, total_bins):
+    """`expected` of an N > 1 line: the speed-up over ONE GPU that SCALING_MODEL gives the job's LPT table (slowest rank)."""
+    out = {}
+    for mode, c in SCALING_MODEL.items():
+        t1 = c["fixed_ms"] + c["per_mbin_ms"] * total_bins / 1e6
+        tn = max(c["fixed_ms"] + c["per_mbin_ms"] * b / 1e6 for b in bins_per_rank)
+        out[mode] = {"speedup_vs_1gpu": t1 / tn, "ms_per_step": tn}
+    out["model"] = "ms = fixed + per_mbin * Mbins of the slowest rank; " + json.dumps(SCALING_MODEL)
+    out["source"] = SCALING_MODEL_SOURCE
+    out["bound"] = ("LPT makespan bound: %.2f x" % (total_bins / max(bins_per_rank)))
+    out["note"] = ("default (bit-exact) mode: bounded by the state chain's critical path on each rank's longest chromosome, ~2 x at "
+                   "8 GPUs; the opt-in 2-ulp mode (`throughput_mode`) is the one that approaches north_star's >= 6 x")
+    return out
 
 
 # algorithmic bytes per bin of each kernel (DESIGN.md "Kernels"): only traffic the reference layouts require
@@ -66,8 +102,9 @@ def kernel_alg_bytes(name: str, m: int, d: int) -> float:
     }.get(name, 0.0)
 
 
-def cpu_baseline(m: int, max_seconds: float = 15.0):
-    """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload: a chr1-sized chain.
+def cpu_baseline(m: int, max_seconds: float = 15.0, forward_only: bool = False, n_bins: int = 0):
+    """Oracle (C port of the reference loop, 1 thread) on a bounded sample of the same workload: a chr1-sized chain (c2: THE
+    1e6-bin chain, forward pass alone).
     (scripts/cpu_port_vs_reference.py, build container only: the port runs within 3 % of the compiled reference.)"""
     import numpy as np
 
@@ -77,7 +114,7 @@ def cpu_baseline(m: int, max_seconds: float = 15.0):
     from oracle import oracle as orc
 
     orc.lib()
-    n = hg38_chain_lengths(200)[0]    # chr1-sized chain: 1 244 783 bins
+    n = int(n_bins) if n_bins else hg38_chain_lengths(200)[0]    # chr1-sized chain: 1 244 783 bins
     data, munc = cases.synth(n, m, 21)
     F = np.asarray(cases.F_TREND, np.float32)
     Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
@@ -91,8 +128,9 @@ def cpu_baseline(m: int, max_seconds: float = 15.0):
         orc.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0, intervalToBlockMap=bm,
                          blockCount=int(bm.max()) + 1, stateInit=0.0, stateCovarInit=1000.0, stateForward=xf,
                          stateCovarForward=Pf, pNoiseForward=pn, vectorD=D, returnNLL=True)
-        orc.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
-                          stateSmoothed=xs, stateCovarSmoothed=Ps, lagCovSmoothed=lag, postFitResiduals=res)
+        if not forward_only:
+            orc.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                              stateSmoothed=xs, stateCovarSmoothed=Ps, lagCovSmoothed=lag, postFitResiduals=res)
 
     one()  # warm-up (first-touch page faults)
     best, spent, reps = float("inf"), 0.0, 0
@@ -105,7 +143,8 @@ def cpu_baseline(m: int, max_seconds: float = 15.0):
         reps += 1
     return {
         "value": n / best, "unit": "genomic bins/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
-        "sample": f"oracle C port (forward store+NLL, backward+residuals), 1 thread, chr1-sized chain "
+        "sample": f"oracle C port ({'forward store+NLL only' if forward_only else 'forward store+NLL, backward+residuals'}), "
+                  f"1 thread, {'the' if n_bins else 'chr1-sized'} chain "
                   f"({n} bins x {m} samples), best of {reps} passes after warm-up ({spent:.1f} s of CPU work)",
     }
 
@@ -115,8 +154,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=32)
-    ap.add_argument("--bin-bp", type=int, default=200)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4",
+                    help="BASELINE config: c2 = 1 chain of 1e6 bins x 4, forward filter only; c3 = hg38 @200bp x 8; "
+                         "c4 = hg38 @200bp x 32 (default, the headline); c5 = hg38 @50bp x 64")
+    ap.add_argument("--samples", type=int, default=None, help="override the config's sample count")
+    ap.add_argument("--bin-bp", type=int, default=None, help="override the config's bin size")
     ap.add_argument("--q0", default="1e-3,1e-4", help="diagonal of the base process noise Q0 (long-memory regime: 1e-5,1e-6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -124,7 +166,17 @@ def parse_args(argv=None):
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (no RCCL: file barrier)")
     ap.add_argument("--fake-ranks", action="store_true",
                     help="CPU rehearsal of the launcher and control plane: no GPU, no measurement; rank 0 prints a stub line")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    if args.samples is None:
+        args.samples = cfg["samples"]
+    if args.bin_bp is None:
+        args.bin_bp = cfg["bin_bp"]
+    args.forward_only = bool(cfg.get("forward_only"))
+    args.single_chain = int(cfg.get("single_chain", 0))
+    args.metric = cfg["metric"] if (args.samples == cfg["samples"] and args.bin_bp == cfg["bin_bp"]) else \
+        f"genomic bins/sec (forward+backward pass), hg38 {args.bin_bp}bp x {args.samples} samples"
+    return args
 
 
 def fake_rank(args) -> int:
@@ -169,7 +221,10 @@ def main() -> int:
     L.require_gpu()          # no GPU, no number: there is no CPU fallback to time
     m = args.samples
     q00, q11 = (float(v) for v in args.q0.split(","))
-    lengths = hg38_chain_lengths(args.bin_bp)
+    lengths = [args.single_chain] if args.single_chain else hg38_chain_lengths(args.bin_bp)
+    if world > len(lengths):
+        print(f"bench.py: --config {args.config} has {len(lengths)} chain(s): nothing to shard over {world} GPUs", file=sys.stderr)
+        return 2
     total_bins = int(sum(lengths))
     mine = lpt_assign(lengths, world)[rank]
     my_lens = [lengths[i] for i in mine]
@@ -214,7 +269,12 @@ def main() -> int:
     batch.configure(model, m, my_lens)
     batch.synthesize(seed=1234 + rank)
     flags = L.RETURN_NLL
-    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+    what = L.EXPORT_FORWARD if args.forward_only else (L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+    bytes_per_bin = b_alg(m, args.forward_only)
+
+    def one_step(b):
+        # c2: the forward filter alone (statistics + forward(store, NLL) + its tracks in the reference layouts)
+        return b.step_forward(flags, what) if args.forward_only else b.step(flags, what)
 
     def fence(b=batch):
         # device-wide synchronize of this rank, then the barrier over all ranks (an RCCL all-reduce on the library's
@@ -240,7 +300,7 @@ def main() -> int:
         """per-kernel durations: HIP events on the library's stream, separate (untimed) pass of the same steps"""
         b.profile(True)
         for _ in range(steps):
-            b.step(flags, what)
+            one_step(b)
         times = b.kernel_times()
         b.profile(False)
         return {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1), "ms_per_step": v[1] / max(steps, 1)} for k, v in times.items()}
@@ -269,7 +329,7 @@ def main() -> int:
         traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, TRAFFIC_FILES.get(xtol, ""))
         # a committed PMC pass describes the default workload at N = 1 only
-        if os.path.isfile(pmc_path) and world == 1 and m == 32 and args.bin_bp == 200 and args.q0 == "1e-3,1e-4":
+        if os.path.isfile(pmc_path) and world == 1 and args.config == "c4" and m == 32 and args.bin_bp == 200 and args.q0 == "1e-3,1e-4":
             try:
                 with open(pmc_path) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
@@ -293,7 +353,7 @@ def main() -> int:
     # three timed windows of exactly K steps each (every one bracketed by barrier + synchronize, max over ranks); the line
     # carries the MEDIAN window (a latency-bound step's time depends on which chain is the unlucky one: box-to-box and
     # window-to-window spread is several per cent) and the spread beside it
-    windows = sorted(timed(batch, lambda: batch.step(flags, what), args.warmup if w == 0 else 0, args.steps) for w in range(3))
+    windows = sorted(timed(batch, lambda: one_step(batch), args.warmup if w == 0 else 0, args.steps) for w in range(3))
     elapsed = windows[1]
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = total_bins * args.steps / elapsed
@@ -313,22 +373,28 @@ def main() -> int:
                               "avg_launch_ms": stream[sk]["avg_ms"]}
 
     extras = {}
-    if not args.no_extras:
+    ecm_iters, inner = 3, 5
+
+    def ecm_once(b=batch):
+        b.ecm(max_iters=ecm_iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
+
+    # what fits: c2 is a forward-only line (no ECM, no folds); three more copies of c5 (59 GB each) beside the two resident
+    # batches would not leave headroom in 288 GB
+    do_ecm = not args.no_extras and not args.forward_only
+    do_folds = do_ecm and my_bins * (16.0 * m + 400.0) * 4.0 < 200e9
+    if do_ecm:
         # (1) the ECM loop -- what real runs execute: 5 x [forward, smoother + kappa E-step] + 1 NLL forward
-        ecm_iters, inner = 3, 5
         batch.stats()
-
-        def ecm_once(b=batch):
-            b.ecm(max_iters=ecm_iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
-
         e = timed(batch, ecm_once, 1, 2) / 2.0
         extras["ecm"] = {"x_tol_ulps": rs["x_tol_ulps"], "ms_per_iter": 1000.0 * e / ecm_iters, "iters": ecm_iters,
                          "inner_sweeps": inner, "bin_sweeps_per_s": total_bins * ecm_iters * inner / e,
                          "note": "per ECM iteration over all chains: 5 x (forward + smoother + kappa E-step) + 1 NLL "
                                  "forward; bin_sweeps = forward+backward+E-step sweeps; default (bit-exact) mode"}
+    if do_folds:
         # (2) the same step with the delete-block calibration folds of every chromosome as extra chains of the batch
         # (uncertainty.py:1370-1419: folds = 2 independent refits per chromosome, constants.py:437; DeviceBatch.make_fold):
-        # independent chains fill the GPU the latency-bound exact state chain leaves idle
+        # independent chains fill the GPU the latency-bound exact state chain leaves idle -- also the weak-scaling line of an
+        # N > 1 job (every rank triples its own chains)
         folds = 2
         fb = DeviceBatch(local_rank)
         fb.configure(model, m, [n for n in my_lens for _ in range(folds + 1)])
@@ -344,22 +410,26 @@ def main() -> int:
         extras["with_calibration_folds"]["ecm_ms_per_iter"] = 1000.0 * efe / ecm_iters
         extras["with_calibration_folds"]["ecm_bin_sweeps_per_s"] = total_bins * (folds + 1) * ecm_iters * inner / efe
         fb.close()
+    if not args.no_extras:
         # (3) the opt-in throughput mode (2-ulp carry acceptance): same step, same outputs within a few float32 ulps
         tb = DeviceBatch(local_rank, x_tol_ulps=2)
         tb.configure(model, m, my_lens)
         tb.synthesize(seed=1234 + rank)
-        et = timed(tb, lambda: tb.step(flags, what), args.warmup, args.steps)
+        et = timed(tb, lambda: one_step(tb), args.warmup, args.steps)
         tk = profile_kernels(tb, args.steps)
         trs = tb.run_stats()
         tvalue = total_bins * args.steps / et
-        tb.stats()
-        ete = timed(tb, lambda: ecm_once(tb), 1, 2) / 2.0
+        ete = None
+        if do_ecm:
+            tb.stats()
+            ete = timed(tb, lambda: ecm_once(tb), 1, 2) / 2.0
         extras["throughput_mode"] = {
             "x_tol_ulps": 2, "ms_per_step": 1000.0 * et / max(args.steps, 1), "value": tvalue, "unit": "genomic bins/s",
             "roofline": roofline_of(tk, 2),
-            "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": tvalue * b_alg(m) / 1e9, "peak": HBM_PEAK_GBS * world,
-                              "unit": "GB/s", "frac": tvalue * b_alg(m) / 1e9 / (HBM_PEAK_GBS * world)},
-            "ecm_ms_per_iter": 1000.0 * ete / ecm_iters,
+            "path_roofline": {"alg_bytes_per_bin": bytes_per_bin, "achieved": tvalue * bytes_per_bin / 1e9,
+                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                              "frac": tvalue * bytes_per_bin / 1e9 / (HBM_PEAK_GBS * world)},
+            "ecm_ms_per_iter": None if ete is None else 1000.0 * ete / ecm_iters,
             "block_len": trs["block_len"], "warm_bins": [trs["warm_p"], trs["warm_x"], trs["warm_b"]],
             "reruns": [trs["reruns_p"], trs["reruns_x"], trs["reruns_b"]], "pipeline_redos": trs["pipeline_redos"],
             "kernels_rank0": tk,
@@ -385,7 +455,7 @@ def main() -> int:
         # final track gather (state + its variance): once per job, packed on the device from the exported arrays and
         # all-gathered over RCCL / xGMI; not part of `value`.  A failure here must not cost the measurement its JSON line.
         try:
-            batch.step(flags, what)
+            batch.step(flags, L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
             fence()
             tg = time.perf_counter()
             gathered = comm.gather_batch_tracks(lengths, to_host=True)
@@ -401,18 +471,24 @@ def main() -> int:
 
     if rank == 0:
         out = {
-            "metric": "genomic bins/sec (forward+backward pass), hg38 200bp x 32 samples",
+            "metric": args.metric,
             "value": value, "unit": "genomic bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_min": 1000.0 * windows[0] / max(args.steps, 1),
             "ms_per_step_median": ms_per_step, "ms_per_step_max": 1000.0 * windows[2] / max(args.steps, 1), "timed_windows": 3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 arithmetic on f32 storage", "data": "synthetic",
             "config": {
-                "workload": f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
-                            "stats + forward(store,NLL) + RTS backward + lagCov + reference-layout tracks + residuals, "
-                            "levelTrend, constant process noise (no per-bin lambda / kappa / qScale, one Q0 for every chain: "
-                            "the case of a plain forward + backward call; the ECM loop's sweeps carry kappa per bin and are "
-                            "reported under `ecm`)",
+                "baseline_config": args.config,
+                "workload": (f"ONE chain of {total_bins} bins @{args.bin_bp}bp x {m} samples; FORWARD FILTER ONLY: stats + "
+                             "forward(store,NLL) + D / xf / Pf / pNoise in the reference layouts (no smoother, no residuals), "
+                             "levelTrend, constant process noise" if args.forward_only else
+                             f"hg38 autosomes, 22 chains / {total_bins} bins @{args.bin_bp}bp x {m} samples; "
+                             "stats + forward(store,NLL) + RTS backward + lagCov + reference-layout tracks + residuals, "
+                             "levelTrend, constant process noise (no per-bin lambda / kappa / qScale, one Q0 for every chain: "
+                             "the case of a plain forward + backward call; the ECM loop's sweeps carry kappa per bin and are "
+                             "reported under `ecm`)"),
+                "mfma": "not eligible: the observation update is a length-m weighted reduction per bin (pyx:443-456), no dense "
+                        "contraction at any m; the bound is HBM",
                 "chains_per_rank": "LPT over contigs", "block_len": rs["block_len"], "q0_diag": [q00, q11],
                 "warm_bins": [rs["warm_p"], rs["warm_x"], rs["warm_b"]], "x_tol_ulps": rs["x_tol_ulps"],
                 "validation": "bit-exact sequential semantics (library default)" if rs["x_tol_ulps"] == 0
@@ -422,9 +498,9 @@ def main() -> int:
             "build": L.build_id(),
             "roofline": roofline,
             "roofline_streaming": roofline_streaming,
-            "path_roofline": {"alg_bytes_per_bin": b_alg(m), "achieved": value * b_alg(m) / 1e9,
+            "path_roofline": {"alg_bytes_per_bin": bytes_per_bin, "achieved": value * bytes_per_bin / 1e9,
                               "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                              "frac": value * b_alg(m) / 1e9 / (HBM_PEAK_GBS * world)},
+                              "frac": value * bytes_per_bin / 1e9 / (HBM_PEAK_GBS * world)},
             "kernels_rank0": per_kernel,
             "speculation": {"blocks": rs["blocks"], "reruns_cov": rs["reruns_p"], "reruns_state": rs["reruns_x"],
                             "reruns_bwd": rs["reruns_b"], "fix_launches": rs["fix_launches"],
@@ -436,10 +512,12 @@ def main() -> int:
             "per_rank": ranks_info,
         }
         out.update(extras)
+        if world > 1 and args.config == "c4":
+            out["expected"] = expected_speedup(ranks_info["bins"], total_bins)
         if gather_note:
             out["gather_note"] = gather_note
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(m)
+            out["cpu_baseline"] = cpu_baseline(m, forward_only=args.forward_only, n_bins=args.single_chain)
         print(json.dumps(out))
         sys.stdout.flush()
     status = EXIT_RCCL_FAILED if rccl_failed else 0

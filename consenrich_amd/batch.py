@@ -215,6 +215,17 @@ class DeviceBatch:
         L.check(self._lib.csr_batch_step(self._ctx, int(flags), int(what), L.dp(sd), L.dp(sn)))
         return sd, sn
 
+    def step_forward(self, flags: int = L.RETURN_NLL, what: int = L.EXPORT_FORWARD, want_sums: bool = True):
+        """stats() + forward(flags) + export(what & EXPORT_FORWARD) + sums() in one C-ABI call: the forward filter alone
+        (`cforwardPass` without `cbackwardPass`, pyx:6393-6632; BASELINE config 2)."""
+        if not want_sums:
+            L.check(self._lib.csr_batch_step_forward(self._ctx, int(flags), int(what), None, None))
+            return None, None
+        nc = len(self.chain_lens)
+        sd, sn = np.zeros(nc), np.zeros(nc)
+        L.check(self._lib.csr_batch_step_forward(self._ctx, int(flags), int(what), L.dp(sd), L.dp(sn)))
+        return sd, sn
+
     def forward_masked(self, flags: int, chain_mask):
         """forward() for the chains with chain_mask[c] true only; returns (sum_d, sum_nll) (masked chains: stale)."""
         nc = len(self.chain_lens)

@@ -1531,6 +1531,15 @@ extern "C" int csr_batch_step(csr_ctx *c, uint32_t flags, uint32_t what, double 
     return 0;
 }
 
+extern "C" int csr_batch_step_forward(csr_ctx *c, uint32_t flags, uint32_t what, double *sum_d, double *sum_nll) {
+    CHECK(csr_batch_stats(c));
+    CHECK(settle(c));
+    CHECK(forward_impl(c, flags, true, nullptr, true, false, true));
+    if (what & CSR_EXPORT_FORWARD) CHECK(csr_batch_export(c, CSR_EXPORT_FORWARD));
+    if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
+    return 0;
+}
+
 extern "C" int csr_batch_device_array(csr_ctx *c, int32_t id, void **dev_ptr, int64_t *n_elems) {
     CHECK(need(c));
     CHECK(settle(c));

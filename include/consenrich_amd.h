@@ -183,6 +183,10 @@ int csr_batch_forward_backward(csr_ctx *ctx, uint32_t flags, double *sum_d, doub
  * noise, >= 2 chains) start the smoother / residuals of every chain as soon as THAT chain's filtered state stands, while the
  * state chain of slower chains is still running (csr_run_stats.tail_groups counts the groups). */
 int csr_batch_step(csr_ctx *ctx, uint32_t flags, uint32_t what, double *sum_d, double *sum_nll);
+/* The FORWARD FILTER ALONE in one call (cforwardPass without cbackwardPass, pyx:6393-6632 -- BASELINE config 2): csr_batch_stats +
+ * csr_batch_forward + csr_batch_export(what & CSR_EXPORT_FORWARD) + csr_batch_sums.  Same kernels and results as the separate
+ * calls; no smoother, no residuals. */
+int csr_batch_step_forward(csr_ctx *ctx, uint32_t flags, uint32_t what, double *sum_d, double *sum_nll);
 /* Per-chain sumD / sumNLL of the resident forward pass (n_chains doubles each, either may be NULL).  Lets a caller
  * queue csr_batch_export behind csr_batch_forward_backward(…, NULL, NULL) and synchronise once, here. */
 int csr_batch_sums(csr_ctx *ctx, double *sum_d, double *sum_nll);

@@ -1897,6 +1897,58 @@ def test_config1_two_sample_plumbing_end_to_end(product, oracle):
     assert sum(a != b_ for a, b_ in zip(got_rows, ref_rows)) <= max(1, n // 1000)
 
 
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+def test_config2_forward_only_step_matches_oracle(product, oracle, xtol):
+    """BASELINE config 2 = `bench.py --config c2`: ONE chromosome of 1e6 bins x 4 samples, the forward filter alone
+    (`cforwardPass` with store + NLL and no `cbackwardPass`, pyx:6393-6632) through `csr_batch_step_forward` on device-synthesised
+    inputs (seed 1234): phiHat, NLL and every stored array against the oracle on the inputs read back; the one-call entry equals
+    the separate stats / forward / export calls bit for bit; nothing of a smoother is exported."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n, m = 1000000, 4
+    F = np.asarray(cases.F_TREND, np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+    with DeviceBatch(0, x_tol_ulps=xtol) as b:
+        b.configure(ModelParams(state_dim=2), m, [n])
+        b.synthesize(1234)
+        sd, sn = b.step_forward(L.RETURN_NLL, L.EXPORT_FORWARD)
+        got = {k: b.download(0, k) for k in ("xf", "Pf", "pnoise", "D")}
+        with pytest.raises(L.ConsenrichAMDError, match="not exported"):
+            b.download(0, "xs")
+        data, munc = b.download_inputs(0)
+        b.stats()
+        sd2, sn2 = b.forward(L.RETURN_NLL)
+        b.export(L.EXPORT_FORWARD)
+        for k, v in got.items():
+            assert np.array_equal(v, b.download(0, k)), k
+        assert sd2[0] == sd[0] and sn2[0] == sn[0]
+    xf, Pf, pn = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+    D = np.zeros(n, np.float32)
+    r = oracle.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0,
+                            intervalToBlockMap=(np.arange(n) // 500).astype(np.int32), blockCount=(n + 499) // 500,
+                            stateInit=0.0, stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                            vectorD=D, returnNLL=True)
+    assert sd[0] / n == pytest.approx(r[0], rel=1e-6) and sn[0] == pytest.approx(r[3], rel=1e-8 if xtol else 1e-11)
+    lvl = np.maximum(np.abs(xf[:, :1].astype(np.float64)), 1.0)
+    worst = {"xf_level_rel": float((np.abs(got["xf"].astype(np.float64) - xf)[:, 0] / lvl[:, 0]).max()),
+             "xf_values_differing": float(np.count_nonzero(got["xf"] != xf)),
+             "Pf_values_differing": float(np.count_nonzero(got["Pf"] != Pf))}
+    assert np.all(np.abs(got["xf"].astype(np.float64) - xf) <= RTOL * lvl + ATOL)
+    np.testing.assert_allclose(got["Pf"], Pf, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got["pnoise"], pn[: n - 1], rtol=RTOL, atol=ATOL)
+    if xtol == 0:
+        np.testing.assert_allclose(got["D"], D, rtol=2e-5, atol=ATOL)
+        assert worst["xf_level_rel"] == 0.0 and worst["xf_values_differing"] <= 2000
+    else:
+        # NIS amplifies ONE float32 ulp of the level by ~2 ulp(x0) / |zbar - x0|: with |level| up to ~30 on this 1e6-bin walk
+        # and m = 4 that is ~1e-5 relative on a few per cent of the bins (measured 3.2 %), never beyond the conditioning bound
+        worst["D_frac_outside_1e-5"] = float((np.abs(got["D"].astype(np.float64) - D) > RTOL * np.abs(D) + ATOL).mean())
+        close_mostly(got["D"], D, frac=1e-1, cap=5e-4, msg="D")
+        assert worst["xf_level_rel"] <= 2e-6
+    _record_worst(f"c2_1e6_x4_forward_only_{'exact' if xtol == 0 else 'ulp2'}", worst)
+
+
 def test_bench_workload_matches_oracle(product, oracle):
     """BASELINE config 4 = the exact workload bench.py times (its `throughput_mode` line) -- hg38 autosomes @200 bp x 32
     samples, device-synthesised inputs (seed 1234), csr_batch_step in the THROUGHPUT mode, `x_tol_ulps = 2` passed explicitly
