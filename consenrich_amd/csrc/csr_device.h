@@ -89,6 +89,21 @@ struct Prm {
                         // one LDS-DMA instruction per step of the serial chains instead of two / four)
     double *tS2c;       // sum_j (z_j - zbar)^2 / R_j
     double *tLogR;      // sum_j log R_j
+    // 2-ulp throughput mode: the two statistics only the NIS / NLL terms read travel as ONE float32 pair {S2c, log R} (8 B per
+    // bin written and read instead of 16 + 16; statsF32 says which form the resident statistics have -- load_s2l() reads either)
+    float2 *tS2L;
+    int statsF32;
+    // fused forward chain with reference-layout outputs (2-ulp mode): the tile walker evaluates the NIS / NLL terms of the bins it
+    // filters (it holds S0, zbar - xpred and 1 + P00pred S0 in registers), writes D in the reference layout through its LDS tile
+    // and the block's partial sums -- no epilogue kernel, no predicted-variance track, no second read of the statistics
+    int nisInChain;
+    double rM;          // 1 / m
+    // ... and when the process noise is one constant matrix its tile walker writes xf / Pf ONLY in the reference layout (natOnly: no
+    // blocked copies, 24 B per bin less); the smoother then reads them THERE through its LDS tiles (natIn, k_smooth_natin)
+    int natOnly;
+    int natIn;
+    const float2 *natXfIn;
+    const float4 *natPfIn;
     double2 *natSZ;     // statistics kernel: non-null = the {S0u, zbar} records ALSO in the reference layout (where the superblock
                         // state chain reads them: no conversion launch in front of it)
     // blocked multipliers
@@ -478,9 +493,20 @@ __global__ __launch_bounds__(256) void k_stats_v4(Prm p) {
         const int row = idx / TL, l2 = idx % TL;
         const int64_t oo = rowBase + (int64_t)row * 64 + l2;
         p.tSZ[oo] = make_double2(tile[0][row][l2], tile[1][row][l2]);
-        p.tS2c[oo] = tile[2][row][l2];
-        p.tLogR[oo] = tile[3][row][l2];
+        if (p.statsF32) {
+            p.tS2L[oo] = make_float2((float)tile[2][row][l2], (float)tile[3][row][l2]);
+        } else {
+            p.tS2c[oo] = tile[2][row][l2];
+            p.tLogR[oo] = tile[3][row][l2];
+        }
     }
+}
+
+// {S2c, log R} of slot i in whichever form the resident statistics have (Prm::statsF32)
+__device__ __forceinline__ double load_s2c(const Prm &p, int64_t i) { return p.statsF32 ? (double)p.tS2L[i].x : p.tS2c[i]; }
+__device__ __forceinline__ double load_logr(const Prm &p, int64_t i) { return p.statsF32 ? (double)p.tS2L[i].y : p.tLogR[i]; }
+__device__ __forceinline__ float2 load_s2l(const Prm &p, int64_t i) {
+    return p.statsF32 ? p.tS2L[i] : make_float2((float)p.tS2c[i], (float)p.tLogR[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -567,6 +593,7 @@ struct FwdPTrendT {
     struct Gain {            // what the state update of the same bin needs (also the content of the gain record)
         double gs;
         float p00, p10;
+        double is, lam;      // 1 + P00pred S0 and the clamped observation-precision multiplier (NIS / NLL terms inside the fused chain)
     };
     // b, s: block / step of this bin (for the shifted pNoise store)
     template <bool STORE>
@@ -620,6 +647,8 @@ struct FwdPTrendT {
         gout.gs = gG;
         gout.p00 = (float)a00;
         gout.p10 = (float)a10;
+        gout.is = is;
+        gout.lam = lam;
         if constexpr (STORE) {
             if (p.predCompact) { if (p.storePP) p.tPP[i] = (float)a00; }
             else p.tXin[i] = pack_gain_trend(gG, (float)a00, (float)a10);
@@ -771,7 +800,14 @@ struct FwdXTrendT {
         return bits | near;
     }
     template <bool STORE>
-    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t) {
+    __device__ static __forceinline__ void step(const Prm &p, Carry &c, const In &in, int64_t b, int s, int64_t i, int64_t bf) {
+        double dz, dl;
+        step_d<STORE>(p, c, in, b, s, i, bf, dz, dl);
+    }
+    // the same step; also hands out the innovation dz = zbar - xpred and dl = gs dz (NIS = (lam S2c + dl dz) / m)
+    template <bool STORE>
+    __device__ static __forceinline__ void step_d(const Prm &p, Carry &c, const In &in, int64_t, int, int64_t i, int64_t,
+                                                  double &dz, double &dl) {
         const double x0 = (double)c.x0, x1 = (double)c.x1;
         double xp0, xp1;
         if constexpr (UF) {
@@ -781,7 +817,8 @@ struct FwdXTrendT {
             xp0 = r32(fma(p.F01, x1, p.F00 * x0));
             xp1 = r32(fma(p.F11, x1, p.F10 * x0));
         }
-        const double dl = in.gs * (in.zbar - xp0);            // S1/innovScale with S1 = S0 (zbar - x)
+        dz = in.zbar - xp0;
+        dl = in.gs * dz;                                      // S1/innovScale with S1 = S0 (zbar - x)
         c.x0 = (float)fma((double)in.cp.x, dl, xp0);
         c.x1 = (float)fma((double)in.cp.y, dl, xp1);
         if constexpr (STORE) p.tXf[i] = make_float2(c.x0, c.x1);
@@ -911,6 +948,51 @@ struct FwdTrendFusedT {
         xin.gs = g.gs;
         xin.cp = make_float2(g.p00, g.p10);
         XT::template step<STORE>(p, c.X, xin, b, s, i, bfirst);
+    }
+    // The step with the NIS / NLL terms of its bin (pyx:458-475) from what it holds in registers anyway.  With S1 = S0 dz,
+    // S2 = lam S2c + S0 dz^2 and is = 1 + P00pred S0 the reference's quadForm = S2 - (P00pred / is) S1^2 is lam S2c + (S0 / is) dz^2
+    // = lam S2c + gs dz^2 -- the cancellation-free form, one fma on top of the state update's own dl = gs dz.  The log terms of
+    // the NLL never enter the serial path: sum_k log(is_k) and sum_k log(lam_k) are the logs of running PRODUCTS (renormalised
+    // by the walker every 8 steps, NisAcc::renorm), evaluated once per block.
+    struct NisAcc {
+        double sumD = 0.0, sumQ = 0.0, sumSL = 0.0, prodIs = 1.0, prodLam = 1.0;
+        int exIs = 0, exLam = 0, bins = 0;
+        __device__ __forceinline__ void renorm(const Prm &p) {
+            int e;
+            prodIs = frexp(prodIs, &e); exIs += e;
+            if (p.flags & F_LAMBDA) { prodLam = frexp(prodLam, &e); exLam += e; }
+        }
+        __device__ __forceinline__ double nll(const Prm &p) const {
+            const double ln2 = 0.693147180559945309417232121458, log2pi = 1.8378770664093454835606594728112;
+            const double mD = (double)p.m;
+            double sl = sumSL;
+            if (p.flags & F_LAMBDA) sl -= mD * (log_pos(prodLam) + (double)exLam * ln2);
+            return 0.5 * (sl + (log_pos(prodIs) + (double)exIs * ln2) + sumQ + (double)bins * mD * log2pi);
+        }
+    };
+    template <bool STORE>
+    __device__ static __forceinline__ float step_nis(const Prm &p, Carry &c, const In &in, float2 s2l, int64_t b, int s, int64_t i,
+                                                     int64_t bfirst, NisAcc &acc) {
+        typename PT::Gain g;
+        PT::template advance<STORE>(p, c.P, in, b, s, i, bfirst, g);
+        typename XT::In xin;
+        xin.zbar = in.zbar;
+        xin.gs = g.gs;
+        xin.cp = make_float2(g.p00, g.p10);
+        double dz, dl;
+        XT::template step_d<STORE>(p, c.X, xin, b, s, i, bfirst, dz, dl);
+        double quad = fma(dl, dz, g.lam * (double)s2l.x);
+        if (quad < 0.0) quad = 0.0;
+        const float D = (float)(quad * p.rM);
+        acc.sumD += (double)D;
+        if (p.flags & F_NLL) {
+            acc.sumQ += quad;
+            acc.sumSL += (double)s2l.y;
+            acc.prodIs *= g.is;
+            if (p.flags & F_LAMBDA) acc.prodLam *= g.lam;
+            acc.bins += 1;
+        }
+        return D;
     }
 };
 using FwdTrendFused = FwdTrendFusedT<false>;
@@ -1088,8 +1170,15 @@ struct BwdTrendT {
     };
     __device__ static __forceinline__ In load(const Prm &p, int64_t i, int64_t bq, int s, int len) {
         In in;
-        in.xf = p.tXf[i];
-        in.pf = p.tPf[i];
+        if (p.natIn) {      // the forward pass left xf / Pf in the reference layout only (a lane's own scattered loads: the
+                            // validation kernel's rare re-runs; the speculative pass reads them through LDS tiles, k_smooth_natin)
+            const int64_t g = (int64_t)p.blk[bq].x + s;
+            in.xf = p.natXfIn[g];
+            in.pf = p.natPfIn[g];
+        } else {
+            in.xf = p.tXf[i];
+            in.pf = p.tPf[i];
+        }
         // without multipliers the stored process noise is the constant float32(Q0): nothing to read
         if (p.qFromMult) in.q = make_float4((float)p.Q00, (float)p.Q01, (float)p.Q10, (float)p.Q11);
         else in.q = p.tQ[i];
@@ -1542,14 +1631,19 @@ __device__ __forceinline__ void walk_nat_direct(const Prm &p, typename CH::Carry
 // Forward counterpart of walk_nat for the fused forward chain: the blocked stores stay (the smoother reads them), and the
 // filtered state / covariance are ALSO written in the reference layout through the same LDS tiles, so the export pass
 // has nothing left to convert but D.  natXs / natPs point at the natural xf / Pf arrays here.
-struct NatTilesFwd {                    // the forward walker's share of NatTiles (no lag tile): 13 KB
+struct NatTilesFwd {                    // the forward walker's share of NatTiles (no lag tile) + the D tile: 15 KB
     float4 ps[8][65];
     float2 xs[8][65];
     int gbase[64], len[64];
+    float d[8][65];                     // NIS of the batch (Prm::nisInChain)
 };
-template <class CH, class TT = NatTiles>
-__device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
-                                             int64_t bfirst, int gbase, TT &T) {
+// where a forward walker stages D: NatTilesFwd has a tile of its own, NatTiles lends its (unused) lag tile
+__device__ __forceinline__ float (*d_tile(NatTilesFwd &T))[65] { return T.d; }
+__device__ __forceinline__ float (*d_tile(NatTiles &T))[65] { return reinterpret_cast<float (*)[65]>(&T.lag[0][0]); }
+
+template <class CH, class TT, bool NIS, bool NATONLY>
+__device__ __forceinline__ void walk_nat_fwd_impl(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                                  int64_t bfirst, int gbase, TT &T) {
     const int lane = threadIdx.x;
     const int B = p.B;
     const int64_t base = tbase(bq, B);
@@ -1557,17 +1651,26 @@ __device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c
     T.len[lane] = act ? len : 0;
     float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
     float2 *natXf = reinterpret_cast<float2 *>(p.natXs);
+    float (*dT)[65] = d_tile(T);
+    typename CH::NisAcc acc;
     typename CH::In cur[8], nxt[8];
+    float2 sl[8], sln[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-        if (act && u < len) cur[u] = CH::load(p, base + (int64_t)u * 64, bq, u, len);
+        if (act && u < len) {
+            cur[u] = CH::load(p, base + (int64_t)u * 64, bq, u, len);
+            if constexpr (NIS) sl[u] = load_s2l(p, base + (int64_t)u * 64);
+        }
 #pragma unroll 1
     for (int s8 = 0; s8 < B; s8 += 8) {
         if (s8 + 8 < B) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int s = s8 + 8 + u;
-                if (act && s < len) nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+                if (act && s < len) {
+                    nxt[u] = CH::load(p, base + (int64_t)s * 64, bq, s, len);
+                    if constexpr (NIS) sln[u] = load_s2l(p, base + (int64_t)s * 64);
+                }
             }
         }
         if (__any(act && s8 < len)) {
@@ -1575,11 +1678,14 @@ __device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c
             for (int u = 0; u < 8; ++u) {
                 const int s = s8 + u;
                 if (act && s < len) {
-                    CH::template step<true>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst);
+                    // NATONLY (constant process noise): the step stores nothing in the blocked layout
+                    if constexpr (NIS) dT[u][lane] = CH::template step_nis<!NATONLY>(p, c, cur[u], sl[u], bq, s, base + (int64_t)s * 64, bfirst, acc);
+                    else CH::template step<!NATONLY>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst);
                     T.xs[u][lane] = make_float2(c.X.x0, c.X.x1);
                     T.ps[u][lane] = make_float4(c.P.c00, c.P.c01, c.P.c01, c.P.c11);
                 }
             }
+            if constexpr (NIS) acc.renorm(p);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1597,11 +1703,41 @@ __device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c
                     natXf[(int64_t)T.gbase[L] + s] = T.xs[r][L];
                 }
             }
+            if constexpr (NIS) {
+                // float array: thread -> (lane L = k*32 + t/2, rows 4*(t%2) .. +3): 16 bytes per thread, 32 bytes per lane
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int L = k * 32 + (lane >> 1), r = (lane & 1) * 4, s = s8 + r;
+                    const int ln = T.len[L];
+                    float *dst = p.natD + (int64_t)T.gbase[L] + s;
+                    if (s + 3 < ln) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(dT[r][L], dT[r + 1][L], dT[r + 2][L], dT[r + 3][L]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (s + e < ln) dst[e] = dT[r + e][L];
+                    }
+                }
+            }
             __syncthreads();
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < 8; ++u) { cur[u] = nxt[u]; if constexpr (NIS) sl[u] = sln[u]; }
     }
+    if constexpr (NIS) {
+        if (act) {
+            p.blkSumD[bq] = acc.sumD;
+            p.blkSumNLL[bq] = (p.flags & F_NLL) ? acc.nll(p) : 0.0;
+        }
+    }
+}
+template <class CH, class TT = NatTiles>
+__device__ __forceinline__ void walk_nat_fwd(const Prm &p, typename CH::Carry &c, int64_t bq, int len, bool act,
+                                             int64_t bfirst, int gbase, TT &T) {
+    if (p.nisInChain && p.natOnly) walk_nat_fwd_impl<CH, TT, true, true>(p, c, bq, len, act, bfirst, gbase, T);
+    else if (p.nisInChain) walk_nat_fwd_impl<CH, TT, true, false>(p, c, bq, len, act, bfirst, gbase, T);
+    else if (p.natOnly) walk_nat_fwd_impl<CH, TT, false, true>(p, c, bq, len, act, bfirst, gbase, T);
+    else walk_nat_fwd_impl<CH, TT, false, false>(p, c, bq, len, act, bfirst, gbase, T);
 }
 // re-run path (validation kernel): scattered natural stores, no LDS
 template <class CH>
@@ -1610,14 +1746,29 @@ __device__ __forceinline__ void walk_nat_fwd_direct(const Prm &p, typename CH::C
     const int64_t base = tbase(bq, p.B);
     float4 *natPf = reinterpret_cast<float4 *>(p.natPs);
     float2 *natXf = reinterpret_cast<float2 *>(p.natXs);
+    typename CH::NisAcc acc;
 #pragma unroll 1
     for (int s = 0; s < p.B; ++s) {
         if (act && s < len) {
             const typename CH::In in = CH::load(p, base + (int64_t)s * 64, bq, s, len);
-            CH::template step<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst);
+            if (p.nisInChain) {
+                const float2 s2l = load_s2l(p, base + (int64_t)s * 64);
+                p.natD[(int64_t)gbase + s] = p.natOnly
+                    ? CH::template step_nis<false>(p, c, in, s2l, bq, s, base + (int64_t)s * 64, bfirst, acc)
+                    : CH::template step_nis<true>(p, c, in, s2l, bq, s, base + (int64_t)s * 64, bfirst, acc);
+                if ((s & 7) == 7) acc.renorm(p);
+            } else if (p.natOnly) {
+                CH::template step<false>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst);
+            } else {
+                CH::template step<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst);
+            }
             natXf[(int64_t)gbase + s] = make_float2(c.X.x0, c.X.x1);
             natPf[(int64_t)gbase + s] = make_float4(c.P.c00, c.P.c01, c.P.c01, c.P.c11);
         }
+    }
+    if (p.nisInChain && act) {
+        p.blkSumD[bq] = acc.sumD;
+        p.blkSumNLL[bq] = (p.flags & F_NLL) ? acc.nll(p) : 0.0;
     }
 }
 
@@ -2080,6 +2231,155 @@ __global__ __launch_bounds__(64) void k_chain_spec_dmawarm_natbwd(Prm p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (live) cin[b] = c;
     walk_nat<typename DCH::Plain>(p, c, b, bi.y, live, b == bi.w, bi.x, tiles);
+    if (live) cout[b] = c;
+}
+
+// Smoother chain whose INPUTS are the reference-layout xf / Pf (Prm::natIn: the forward pass wrote no blocked copies) and whose
+// outputs go there too.  One lane per block as everywhere; a lane's trajectory is its warm-up window (the W bins behind its block,
+// cut at the chain's end) and then its own block, walked downwards 8 steps at a time.  Both directions pass through the SAME LDS
+// tiles: 8 threads fetch one full 128-byte line (8 consecutive bins of one lane's range), deposit it as [row][lane], every lane
+// reads its own column, computes its 8 steps, writes xs / Ps back into the column it has just consumed, and the same 8 threads
+// store full lines -- a thread reads back exactly the tile entries it deposits next, so no barrier separates store and deposit.
+// The next batch's lines are requested before the current batch is computed.  CH = BwdTrendT<UF>.
+// QARR: the process noise varies per bin and is read from the blocked pNoise rows inside the steps (a separate instance: a load in
+// the step code makes hipcc wait for ALL outstanding loads there, i.e. for the next batch's lines it should leave in flight).
+template <class CH, bool QARR>
+__global__ __launch_bounds__(64) void k_smooth_natin(Prm p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char natInMem[];
+    NatTiles &T = *reinterpret_cast<NatTiles *>(natInMem);
+    const int lane = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = b < p.NB && chain_on(p, b);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (b < p.NB) bi = p.blk[b];
+    check_previous_stage(p, b, bi);
+    typename CH::Carry c = CH::init_cold(p);
+    typename CH::Carry *cin = reinterpret_cast<typename CH::Carry *>(p.carryIn);
+    typename CH::Carry *cout = reinterpret_cast<typename CH::Carry *>(p.carryOutA);
+    const int B = p.B, W = p.warm;          // W: multiple of 8 (host)
+    // lim: bins of the trajectory this lane really has -- its block, plus the window unless the chain ends before
+    int lim = 0;
+    if (live) {
+        if (b == (int64_t)bi.w) lim = bi.y;
+        else {
+            const int4 bl = p.blk[bi.w];
+            const int64_t avail = ((int64_t)bl.x + bl.y) - ((int64_t)bi.x + B);
+            lim = B + (int)(avail < (int64_t)W ? avail : (int64_t)W);
+        }
+    }
+    T.gbase[lane] = bi.x;
+    T.len[lane] = lim;
+    T.last[lane] = (live && b == (int64_t)bi.w) ? 1 : 0;
+    __syncthreads();
+    float4 *natPs = reinterpret_cast<float4 *>(p.natPs), *natLag = reinterpret_cast<float4 *>(p.natLag);
+    float2 *natXs = reinterpret_cast<float2 *>(p.natXs);
+    const float4 qc = make_float4((float)p.Q00, (float)p.Q01, (float)p.Q10, (float)p.Q11);
+    // what this thread moves, fixed for the life of the kernel: rows r of the lanes L_k it serves (kept in registers -- the tile's
+    // index arrays are read once).  Every fetch is UNCONDITIONAL (a row past a lane's range is clamped to its last bin: the value
+    // is deposited and never used), so the 12 loads of a batch leave back to back.
+    const int rP = lane & 7, rX = (lane & 3) * 2;
+    int gP[8], gX[4];
+    int lP[8], lX[4], lastP[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int L = k * 8 + (lane >> 3);
+        gP[k] = T.gbase[L]; lP[k] = T.len[L]; lastP[k] = T.last[L];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int L = k * 16 + (lane >> 2);
+        gX[k] = T.gbase[L]; lX[k] = T.len[L];
+    }
+    // (named registers, not arrays behind a lambda: hipcc left such arrays in scratch memory and waited for every line to land
+    // before "spilling" it there -- the prefetch was gone)
+    float4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, rx0, rx1, rx2, rx3;
+#define CSR_FETCH_P(K, S8)                                                                          \
+    {                                                                                               \
+        const int top_ = lP[K] > 0 ? lP[K] - 1 : 0, s_ = (S8) + rP;                                 \
+        rp##K = p.natPfIn[(int64_t)gP[K] + (s_ < top_ ? s_ : top_)];                                \
+    }
+    // (a pair may reach one bin past the lane's range: inside the array -- chains are padded to 64 bins -- and unused)
+#define CSR_FETCH_X(K, S8)                                                                          \
+    {                                                                                               \
+        const int top_ = (lX[K] > 0 ? lX[K] - 1 : 0) & ~1, s_ = (S8) + rX;                          \
+        rx##K = *reinterpret_cast<const float4 *>(p.natXfIn + (int64_t)gX[K] + (s_ < top_ ? s_ : top_)); \
+    }
+#define CSR_FETCH(S8)                                                                               \
+    CSR_FETCH_P(0, S8) CSR_FETCH_P(1, S8) CSR_FETCH_P(2, S8) CSR_FETCH_P(3, S8) CSR_FETCH_P(4, S8) CSR_FETCH_P(5, S8) \
+    CSR_FETCH_P(6, S8) CSR_FETCH_P(7, S8) CSR_FETCH_X(0, S8) CSR_FETCH_X(1, S8) CSR_FETCH_X(2, S8) CSR_FETCH_X(3, S8)
+    const int sTop = B + W - 8;
+    if (W == 0 && live) cin[b] = c;
+    CSR_FETCH(sTop)
+#pragma unroll 1
+    for (int s8 = sTop; s8 >= 0; s8 -= 8) {
+        // deposit the batch's inputs (thread -> the tile entries it fetched)
+        {
+            const int L0 = lane >> 3;
+            T.ps[rP][L0] = rp0; T.ps[rP][8 + L0] = rp1; T.ps[rP][16 + L0] = rp2; T.ps[rP][24 + L0] = rp3;
+            T.ps[rP][32 + L0] = rp4; T.ps[rP][40 + L0] = rp5; T.ps[rP][48 + L0] = rp6; T.ps[rP][56 + L0] = rp7;
+            const int X0 = lane >> 2;
+            T.xs[rX][X0] = make_float2(rx0.x, rx0.y); T.xs[rX + 1][X0] = make_float2(rx0.z, rx0.w);
+            T.xs[rX][16 + X0] = make_float2(rx1.x, rx1.y); T.xs[rX + 1][16 + X0] = make_float2(rx1.z, rx1.w);
+            T.xs[rX][32 + X0] = make_float2(rx2.x, rx2.y); T.xs[rX + 1][32 + X0] = make_float2(rx2.z, rx2.w);
+            T.xs[rX][48 + X0] = make_float2(rx3.x, rx3.y); T.xs[rX + 1][48 + X0] = make_float2(rx3.z, rx3.w);
+        }
+        __syncthreads();
+        if (s8 >= 8) { CSR_FETCH(s8 - 8) }
+        __builtin_amdgcn_sched_barrier(0);          // (the lines of the next batch are requested HERE, not next to their use)
+        const bool main = s8 < B;
+        if (__any(live && s8 < lim)) {
+#pragma unroll
+            for (int u = 7; u >= 0; --u) {
+                const int s = s8 + u;
+                // (the lane's own column, read step by step: all eight held at once cost 48 registers the prefetch needs)
+                typename CH::In in;
+                in.xf = T.xs[u][lane];
+                in.pf = T.ps[u][lane];
+                in.q = qc;
+                if (live && s < lim) {
+                    if constexpr (QARR) {       // stored process noise (per-bin multipliers): blocked rows of the block that owns bin s
+                        const int kq = s / B;
+                        in.q = p.tQ[tidx(b + kq, s - kq * B, B)];
+                    }
+                    typename CH::Out o;
+                    if (main) {
+                        CH::template advance<true>(p, c, in, o);
+                        T.xs[u][lane] = o.xs;
+                        T.ps[u][lane] = o.ps;
+                        if (o.hasLag) T.lag[u][lane] = o.lag;
+                    } else {
+                        CH::template advance<false>(p, c, in, o);
+                    }
+                }
+            }
+        }
+        if (s8 == B && live) cin[b] = c;          // the carry this lane enters its own block with
+        if (main) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int L = k * 8 + (lane >> 3), s = s8 + rP;
+                if (s < lP[k]) {
+                    natPs[(int64_t)gP[k] + s] = T.ps[rP][L];
+                    if (!(lastP[k] && s == lP[k] - 1)) natLag[(int64_t)gP[k] + s] = T.lag[rP][L];     // the chain's last bin has no lag row
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = k * 16 + (lane >> 2), s = s8 + rX;
+                if (s + 1 < lX[k]) {
+                    const float2 a = T.xs[rX][L], b2 = T.xs[rX + 1][L];
+                    *reinterpret_cast<float4 *>(natXs + (int64_t)gX[k] + s) = make_float4(a.x, a.y, b2.x, b2.y);
+                } else if (s < lX[k]) {
+                    natXs[(int64_t)gX[k] + s] = T.xs[rX][L];
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef CSR_FETCH
+#undef CSR_FETCH_X
+#undef CSR_FETCH_P
     if (live) cout[b] = c;
 }
 
@@ -2845,8 +3145,9 @@ __global__ __launch_bounds__(256) void k_sb_async(Prm p, const float4 *__restric
 // natural float2 track -> the batch's blocked layout through LDS tiles (32 steps x 64 blocks per workgroup): coalesced on
 // both sides (the per-slot gather of k_import_f32 reads one 128-byte line per 8 bytes it needs)
 // (g0: first wavefront-group of 64 blocks the launch covers -- a launch for some chains only starts at their blocks)
-__global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__restrict__ nat, float2 *__restrict__ dst, int64_t g0 = 0) {
-    __shared__ float2 tile[32][65];
+template <class V>
+__global__ __launch_bounds__(256) void k_import_tiled(Prm p, const V *__restrict__ nat, V *__restrict__ dst, int64_t g0) {
+    __shared__ V tile[32][65];
     const int tilesPerGroup = p.B >> 5;
     const int64_t G = g0 + blockIdx.x / tilesPerGroup;
     const int s0 = (int)(blockIdx.x % tilesPerGroup) << 5;
@@ -2863,7 +3164,7 @@ __global__ __launch_bounds__(256) void k_import_tiled_f2(Prm p, const float2 *__
     }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
-        float2 v = make_float2(0.f, 0.f);
+        V v{};
         if (s0 + si < bis[pass].y) v = nat[(int64_t)bis[pass].x + s0 + si];
         tile[si][pass * 8 + r] = v;
     }
@@ -2983,8 +3284,8 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
                     { const float4 r = p.tXin[i]; ppv[u] = unpack_d(r.z, r.w); }
                 }
                 { const double2 sz = p.tSZ[i]; s0u[u] = sz.x; zb[u] = sz.y; }
-                s2c[u] = p.tS2c[i];
-                if (wantNLL) slr[u] = p.tLogR[i];
+                s2c[u] = load_s2c(p, i);
+                if (wantNLL) slr[u] = load_logr(p, i);
             }
 #pragma unroll
             for (int u = 0; u < DU; ++u) {
@@ -3106,7 +3407,7 @@ __global__ __launch_bounds__(256) void k_estep_lambda(Prm p) {
     const double2 sz = p.tSZ[slot];
     const double s0u = sz.x;
     const double dz = sz.y - (double)p.tXs[slot].x;
-    const double u2 = fma(p00, s0u, fma(s0u, dz * dz, p.tS2c[slot]));
+    const double u2 = fma(p00, s0u, fma(s0u, dz * dz, load_s2c(p, slot)));
     double w = (p.nu + (double)p.m) / (p.nu + u2);
     if (w < p.wMin) w = p.wMin;
     else if (w > p.wMax) w = p.wMax;
@@ -3192,7 +3493,7 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
                 is = 1.0 + a00 * S0;
                 const double dz = sz.y - xq0;
                 const double S1 = S0 * dz;
-                const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
+                const double S2 = fma(S0, dz * dz, lam * load_s2c(p, i));
                 quad = S2 - (a00 / is) * (S1 * S1);
                 const double delta = S1 / is;
                 x0 = r32(xq0 + a00 * delta);
@@ -3217,7 +3518,7 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
                 is = 1.0 + pl * S0;
                 const double dz = sz.y - xl;
                 const double S1 = S0 * dz;
-                const double S2 = fma(S0, dz * dz, lam * p.tS2c[i]);
+                const double S2 = fma(S0, dz * dz, lam * load_s2c(p, i));
                 quad = S2 - (pl / is) * (S1 * S1);
                 xl += pl * (S1 / is);
                 const double gG = S0 / is, gH = S0 / (is * is);
@@ -3235,7 +3536,7 @@ __global__ __launch_bounds__(64) void k_fwd_apn(Prm p_, const int64_t *chainFirs
             if (quad < 0.0) quad = 0.0;
             double nll = 0.0;
             if (wantNLL) {
-                double SL = p.tLogR[i];
+                double SL = load_logr(p, i);
                 if (p.flags & F_LAMBDA) SL -= mD * log(lam);
                 nll = 0.5 * (SL + log(is) + quad + mD * log2pi);
                 sumN += nll;

@@ -162,7 +162,8 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     p.data = dd; p.munc = dm;
 
     const int64_t T = c->TN;
-    CHECK(dalloc(c, &p.tSZ, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T));
+    CHECK(dalloc(c, &p.tSZ, T)); CHECK(dalloc(c, &p.tS2c, T)); CHECK(dalloc(c, &p.tLogR, T)); CHECK(dalloc(c, &p.tS2L, T));
+    p.statsF32 = 0; p.nisInChain = 0; p.rM = 1.0 / (double)m;
     // (+ one padding wave-group: the smoother's look-ahead at the multipliers of bin k+1 may touch the slot after the batch's
     // last block, csr_device.h BwdTrend::load)
     const int64_t TP = T + (int64_t)B * 64;

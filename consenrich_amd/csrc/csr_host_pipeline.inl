@@ -7,6 +7,9 @@
 extern "C" int csr_batch_stats(csr_ctx *c) {
     CHECK(need(c));
     CHECK(settle(c));
+    // 2-ulp throughput mode: {S2c, log R} as one float32 pair (csr_device.h Prm::tS2L); the form is a property of the RESIDENT
+    // statistics (a later csr_set_validation does not invalidate them: every reader goes through load_s2c / load_logr / load_s2l)
+    c->p.statsF32 = (c->statsF32Enabled && c->xTolUlps > 0) ? 1 : 0;
     Prm p = c->p;
     // default mode with the superblock state chain: that chain reads {S0u, zbar} in the reference layout -- written here directly
     const bool natSZ = CSR_GAIN_NAT && CSR_STATS_NATSZ && c->xTolUlps == 0 && c->mdl.state_dim == 2 && c->sbState && !c->seqState;
@@ -178,9 +181,15 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                 }
             }
             if constexpr (CH::FAMILY == FAM_BWD_TREND) {
+                if (p.natIn && p.natOut && !pcq) {
+                    // reference-layout inputs AND outputs, both through the LDS tiles (the forward pass wrote no blocked xf / Pf)
+                    if (p.qFromMult) hipLaunchKernelGGL((k_smooth_natin<CH, false>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    else hipLaunchKernelGGL((k_smooth_natin<CH, true>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
+                    launched = true;
+                }
                 // smoother with reference-layout outputs: warm-up through the ring
                 // (32-bin blocks: measured slower, 0.063 vs 0.057 ms -- the ring's fill and drain weigh more than they hide)
-                if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->B >= 64) {
+                if (!launched && c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0 && c->B >= 64) {
                     if (p.qFromMult)
                         hipLaunchKernelGGL((k_chain_spec_dmawarm_natbwd<BwdTrendDma<false, CH::UNITF>>), dim3(grid), dim3(64),
                                            std::max(sizeof(unsigned) * DMA_R * 6 * 64, sizeof(NatTiles)), c->stream, p);
@@ -548,8 +557,8 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     }
     if (!resume) {
         Scope sc(c, "state_reblock_out");
-        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
-                           reinterpret_cast<const float2 *>(natXf), p.tXf);
+        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
+                           reinterpret_cast<const float2 *>(natXf), p.tXf, (int64_t)0);
     }
     LAUNCH_CHECK("k_import_tiled_f2");
     c->xfNat = true;
@@ -690,6 +699,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     c->fwdNat = false;
     c->xfNat = false;
     c->dNat = false;
+    c->fwdBlockedStale = false;
     c->pendFwdNat = natOut;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
@@ -699,6 +709,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
         LAUNCH_CHECK("k_fwd_apn");
     } else {
         bool dP = defer && c->optimistic[ST_P], dX = defer && c->optimistic[ST_X];
+        bool nisInChain = false, natOnly = false;
         if (wantD && natOut && c->natOutEnabled && c->natOutD) {        // D straight into the reference layout
             const size_t tileBytes = sizeof(float) * 64 * (size_t)(c->B + 1);
             bool ok = true;
@@ -740,6 +751,19 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 // the constant process noise depends on nothing: its reference-layout rows are filled on the side stream beside
                 // the (latency-bound) forward chain instead of after the smoother
                 if (c->earlyPf && active == nullptr) CHECK(early_cov_exports(c, p, flags, false));
+                // NIS / NLL inside the chain's tile walker (csr_device.h FwdTrendFusedT::step_nis): no epilogue kernel, no
+                // predicted-variance track.  (Per-bin NLL in D keeps the epilogue: its log terms belong off the serial path.)
+                if (c->nisInChainEnabled && wantD && p.natD != nullptr && !(flags & F_NLL_IN_D)) {
+                    p.nisInChain = 1;
+                    p.storePP = 0;
+                    nisInChain = true;
+                }
+                // constant process noise and nobody left to read the blocked xf / Pf but the smoother (which then reads the
+                // reference-layout arrays through its tiles): the tile walker stores nothing in the blocked layout
+                if (c->natOnlyEnabled && p.qFromMult && p.chainQ == nullptr && (nisInChain || !wantD) && (c->B % 8) == 0) {
+                    p.natOnly = 1;
+                    natOnly = true;
+                }
             }
             if (c->mdl.state_dim == 2 && unit_f(c, p)) CHECK(run_chain<FwdTrendFusedT<true>>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
             else if (c->mdl.state_dim == 2) CHECK(run_chain<FwdTrendFused>(c, p, "fwd_chain", "fwd_fix", ST_P, dP));
@@ -748,6 +772,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             p.ckptIn = nullptr; p.ckptOut = nullptr; p.ckptSaveWarm = 0;
             c->lastFwdWindow = c->fwdWindow;
             c->fwdWindow = nullptr;
+            c->fwdBlockedStale = natOnly;
         } else if (c->mdl.state_dim == 2) {
             c->lastFwdWindow = nullptr;
             const bool sbX = c->xTolUlps == 0 && c->sbState && !c->seqState;
@@ -800,6 +825,13 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         }
+        if (wantD && nisInChain) {
+            // the chain kernels left D and the per-block sums: only the per-chain reduction follows (main stream)
+            join_side(c);
+            Scope sc(c, "chain_sums");
+            hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, p, c->dChainFirst, c->dChainNb);
+            LAUNCH_CHECK("k_chain_sums");
+        } else
         if (wantD && !c->sbp.active) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
         if (dP || dX) {
             c->pendFwd = true;
@@ -812,6 +844,25 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     c->haveBwd = false;
     c->fwdInternal = true;
     c->fwdFlags = flags;
+    return 0;
+}
+
+// The resident forward pass left xf / Pf in the reference layout only and a reader needs the blocked copies after all (a
+// smoother pass without reference-layout outputs, per-chain base matrices): bring them back through LDS tiles.
+static int ensure_blocked_fwd(csr_ctx *c) {
+    if (!c->fwdBlockedStale) return 0;
+    float *natXf, *natPf;
+    CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    CHECK(nat_array(c, CSR_ARR_PF, &natPf));
+    Prm p = c->p;
+    p.chainActive = nullptr;
+    Scope sc(c, "state_reblock_out");
+    hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
+                       reinterpret_cast<const float2 *>(natXf), p.tXf, (int64_t)0);
+    hipLaunchKernelGGL(k_import_tiled<float4>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
+                       reinterpret_cast<const float4 *>(natPf), p.tPf, (int64_t)0);
+    LAUNCH_CHECK("k_import_tiled");
+    c->fwdBlockedStale = false;
     return 0;
 }
 
@@ -835,6 +886,19 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
         CHECK(nat_array(c, CSR_ARR_PS, &p.natPs));
         CHECK(nat_array(c, CSR_ARR_LAG, &p.natLag));
         p.natOut = 1;
+    }
+    if (c->fwdBlockedStale) {
+        const bool pcq = p.chainQ != nullptr;
+        if (natOut && !pcq && !p.qFromKappa && (stage_warm(c, ST_B) % 8) == 0) {
+            float *natXf, *natPf;
+            CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+            CHECK(nat_array(c, CSR_ARR_PF, &natPf));
+            p.natIn = 1;
+            p.natXfIn = reinterpret_cast<const float2 *>(natXf);
+            p.natPfIn = reinterpret_cast<const float4 *>(natPf);
+        } else {
+            CHECK(ensure_blocked_fwd(c));
+        }
     }
     c->smoothNat = natOut;
     c->pendNatOut = natOut;
@@ -1372,7 +1436,7 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
         int64_t g0 = runs.front().b0 / 64, g1 = (runs.front().b1 + 63) / 64;
         for (const ChainRun &r : runs) { g0 = std::min(g0, r.b0 / 64); g1 = std::max(g1, (r.b1 + 63) / 64); }
         Scope sc(c, "state_reblock_out");
-        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, c->stream, pt,
+        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, c->stream, pt,
                            reinterpret_cast<const float2 *>(natXf), pt.tXf, g0);
     }
     LAUNCH_CHECK("k_import_tiled_f2");
@@ -1423,8 +1487,8 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
         Prm pt = pf;
         float *natXf;
         CHECK(nat_array(c, CSR_ARR_XF, &natXf));
-        hipLaunchKernelGGL(k_import_tiled_f2, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pt,
-                           reinterpret_cast<const float2 *>(natXf), pt.tXf);
+        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, pt,
+                           reinterpret_cast<const float2 *>(natXf), pt.tXf, (int64_t)0);
         LAUNCH_CHECK("k_import_tiled_f2");
         CHECK(forward_epilogue(c, pf, true));
         CHECK(backward_impl(c, true, nullptr, true, true));

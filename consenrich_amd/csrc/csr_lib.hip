@@ -161,6 +161,11 @@ struct csr_ctx {
     bool dNat = false;          // ... and its NIS/NLL epilogue wrote D there (nothing left to convert)
     static constexpr bool natOutD = true;       // the NIS / NLL epilogue writes D in the reference layout itself
     bool dstatLdsRaised = false;
+    // 2-ulp throughput mode (byte cuts of round 5; CONSENRICH_AMD_LEAN=0 switches all of them off -- the A/B switch of the tests):
+    bool statsF32Enabled = true;        // {S2c, log R} as one float32 pair
+    bool nisInChainEnabled = true;      // NIS / NLL terms inside the fused forward chain's tile walker (no epilogue kernel)
+    bool natOnlyEnabled = true;         // constant process noise: xf / Pf only in the reference layout, the smoother reads them there
+    bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
     bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
     int pendEstep = 0;
     static constexpr bool fuseEstep = true;     // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
@@ -408,6 +413,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_LEAN"))) c->statsF32Enabled = c->nisInChainEnabled = c->natOnlyEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_WARMSTART"))) c->wsEnabled = atoi(e) != 0;
