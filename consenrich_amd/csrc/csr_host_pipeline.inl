@@ -40,19 +40,33 @@ enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
 // step: poll first, block only if the stream is still busy after ~200 us.
 static hipError_t wait_stream(csr_ctx *c) {
     if (c->spinWait) {
-        // a short burst of polls (the waits on a shard's critical path are tens of microseconds), then polls 20 us apart for
-        // ~2 ms, then a blocking wait: a rank never burns a core for the length of a latency-bound launch (8 ranks per node)
+        // a short burst of polls (the waits on a shard's critical path are tens of microseconds), then polls 20 us apart, then
+        // a blocking wait: a rank never burns a core for the length of a latency-bound launch (8 ranks per node).  Two details
+        // keep the wake-up from costing the step tens of microseconds: the calling thread's timer slack is lowered once (the
+        // kernel's default of 50 us turns a 20-us sleep into ~75), and around the moment the PREVIOUS wait of this context ended
+        // (steps repeat) the loop polls without sleeping -- at most ~0.4 ms of spinning per wait.
+        static thread_local bool slackSet = false;
+        if (!slackSet) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slackSet = true; }
+        const auto t0 = std::chrono::steady_clock::now();
+        auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
         for (int i = 0; i < 128; ++i) {
             const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) return hipSuccess;
+            if (q == hipSuccess) { c->lastWaitUs = elapsed_us(); return hipSuccess; }
             if (q != hipErrorNotReady) return q;
         }
-        for (int i = 0; i < 100; ++i) {
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        const double expect = c->lastWaitUs;
+        for (;;) {
+            const double el = elapsed_us();
+            if (el > 8000.0) break;
+            const bool nearEnd = expect > 0.0 && el > expect - 150.0 && el < expect + 250.0;
+            if (!nearEnd) std::this_thread::sleep_for(std::chrono::microseconds(20));
             const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) return hipSuccess;
+            if (q == hipSuccess) { c->lastWaitUs = elapsed_us(); return hipSuccess; }
             if (q != hipErrorNotReady) return q;
         }
+        const hipError_t r = hipStreamSynchronize(c->stream);
+        c->lastWaitUs = elapsed_us();
+        return r;
     }
     return hipStreamSynchronize(c->stream);
 }
@@ -572,6 +586,7 @@ static void join_side(csr_ctx *c) {
     if (c->sidePending) {
         (void)hipStreamWaitEvent(c->stream, c->evJoin, 0);
         c->sidePending = false;
+        if (c->sideSumsDone) { c->sideSumsDone = false; return; }    // the side stream ran the per-chain sums itself
         Scope sc(c, "chain_sums");
         hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, c->sidePrm, c->dChainFirst,
                            c->dChainNb);
@@ -826,11 +841,25 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
         }
         if (wantD && nisInChain) {
-            // the chain kernels left D and the per-block sums: only the per-chain reduction follows (main stream)
+            // the chain kernels left D and the per-block sums: only the per-chain reduction follows -- beside the smoother (side
+            // stream) when one follows, so that its few microseconds leave the critical path
             join_side(c);
-            Scope sc(c, "chain_sums");
-            hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, p, c->dChainFirst, c->dChainNb);
+            hipStream_t st = c->stream;
+            if (side && c->deferEnabled) {
+                HIPOK(hipEventRecord(c->evFork, c->stream));
+                HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+                st = c->side;
+            }
+            {
+                Scope sc(c, "chain_sums", st);
+                hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, st, p, c->dChainFirst, c->dChainNb);
+            }
             LAUNCH_CHECK("k_chain_sums");
+            if (st == c->side) {
+                HIPOK(hipEventRecord(c->evJoin, c->side));
+                c->sidePending = true;
+                c->sideSumsDone = true;         // join_side only waits
+            }
         } else
         if (wantD && !c->sbp.active) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
         if (dP || dX) {
