@@ -1809,7 +1809,12 @@ __device__ __forceinline__ void walk_nat_gain(const Prm &p, typename CH::Carry &
                 const int s = s8 + u;
                 if (act && s < len) {
                     typename CH::Gain g;
-                    CH::template advance<true>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst, g);
+                    if (p.natOnly) {    // Pf leaves in the reference layout only (the smoother reads it there); P00pred for the epilogue
+                        CH::template advance<false>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst, g);
+                        if (p.storePP) p.tPP[base + (int64_t)s * 64] = g.p00;
+                    } else {
+                        CH::template advance<true>(p, c, cur[u], bq, s, base + (int64_t)s * 64, bfirst, g);
+                    }
                     T.lag[u][lane] = pack_gain_trend(g.gs, g.p00, g.p10);
                     T.ps[u][lane] = make_float4(c.c00, c.c01, c.c01, c.c11);
                 }
@@ -1841,7 +1846,12 @@ __device__ __forceinline__ void walk_nat_gain_direct(const Prm &p, typename CH::
         if (act && s < len) {
             const typename CH::In in = CH::load(p, base + (int64_t)s * 64, bq, s, len);
             typename CH::Gain g;
-            CH::template advance<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst, g);
+            if (p.natOnly) {
+                CH::template advance<false>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst, g);
+                if (p.storePP) p.tPP[base + (int64_t)s * 64] = g.p00;
+            } else {
+                CH::template advance<true>(p, c, in, bq, s, base + (int64_t)s * 64, bfirst, g);
+            }
             natGn[(int64_t)gbase + s] = pack_gain_trend(g.gs, g.p00, g.p10);
             if (natPf != nullptr) natPf[(int64_t)gbase + s] = make_float4(c.c00, c.c01, c.c01, c.c11);
         }

@@ -715,6 +715,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     c->xfNat = false;
     c->dNat = false;
     c->fwdBlockedStale = false;
+    c->pfBlockedStale = false;
     c->pendFwdNat = natOut;
     const bool seq = (flags & F_APN) && !(flags & F_QSCALE);
     if (seq) {
@@ -811,6 +812,12 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 if (natOut && c->earlyPf && active == nullptr && c->natOutEnabled) {
                     CHECK(nat_array(c, CSR_ARR_PF, &pc.natPs));
                     c->pfNat = true;
+                    // a pipelined step with one constant process noise: the smoother of every group reads xf / Pf in the reference
+                    // layout (k_smooth_natin) -- no blocked copy of Pf
+                    if (c->natOnlyEnabled && split && p.qFromMult && p.chainQ == nullptr && (c->B % 8) == 0) {
+                        pc.natOnly = 1;
+                        c->pfBlockedStale = true;
+                    }
                 }
                 c->gainNat = true;
             }
@@ -878,27 +885,28 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
 
 // The resident forward pass left xf / Pf in the reference layout only and a reader needs the blocked copies after all (a
 // smoother pass without reference-layout outputs, per-chain base matrices): bring them back through LDS tiles.
-static int ensure_blocked_fwd(csr_ctx *c) {
-    if (!c->fwdBlockedStale) return 0;
+static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active = nullptr) {
+    if (!c->fwdBlockedStale && !c->pfBlockedStale) return 0;
     float *natXf, *natPf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
     CHECK(nat_array(c, CSR_ARR_PF, &natPf));
     Prm p = c->p;
-    p.chainActive = nullptr;
+    p.chainActive = active;
     Scope sc(c, "state_reblock_out");
-    hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
-                       reinterpret_cast<const float2 *>(natXf), p.tXf, (int64_t)0);
+    if (c->fwdBlockedStale)
+        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
+                           reinterpret_cast<const float2 *>(natXf), p.tXf, (int64_t)0);
     hipLaunchKernelGGL(k_import_tiled<float4>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
                        reinterpret_cast<const float4 *>(natPf), p.tPf, (int64_t)0);
     LAUNCH_CHECK("k_import_tiled");
-    c->fwdBlockedStale = false;
+    if (active == nullptr) c->fwdBlockedStale = c->pfBlockedStale = false;      // (a masked import leaves the other chains stale)
     return 0;
 }
 
 // estep: 0 = plain smoother; 1 = ECM sweep whose kappa E-step is evaluated inside the smoother chain, moments stored;
 //        2 = same, but the smoothed moments are not stored (an inner sweep nobody reads them from)
 static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, bool defer = false, bool natOut = false,
-                         int estep = 0) {
+                         int estep = 0, bool preferNatIn = false) {
     if (!c->haveFwd) return fail("forward results are not resident: run csr_batch_forward first");
     Prm p = c->p;
     p.flags = c->fwdFlags;
@@ -916,9 +924,14 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
         CHECK(nat_array(c, CSR_ARR_LAG, &p.natLag));
         p.natOut = 1;
     }
-    if (c->fwdBlockedStale) {
+    // preferNatIn (a group's tail of a pipelined step): the reference-layout xf / Pf of these chains stand -- read them there
+    // even though a blocked xf is on its way for the epilogue
+    if (c->fwdBlockedStale || c->pfBlockedStale || preferNatIn) {
         const bool pcq = p.chainQ != nullptr;
-        if (natOut && !pcq && !p.qFromKappa && (stage_warm(c, ST_B) % 8) == 0) {
+        const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
+        const bool natValid = c->fwdNat || (c->pfNat && (c->xfNat || preferNatIn));
+        const bool need = c->fwdBlockedStale || c->pfBlockedStale;
+        if (natOut && !pcq && !p.qFromKappa && natValid && (need || constQ) && (stage_warm(c, ST_B) % 8) == 0) {
             float *natXf, *natPf;
             CHECK(nat_array(c, CSR_ARR_XF, &natXf));
             CHECK(nat_array(c, CSR_ARR_PF, &natPf));
@@ -926,7 +939,7 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
             p.natXfIn = reinterpret_cast<const float2 *>(natXf);
             p.natPfIn = reinterpret_cast<const float4 *>(natPf);
         } else {
-            CHECK(ensure_blocked_fwd(c));
+            CHECK(ensure_blocked_fwd(c, active));
         }
     }
     c->smoothNat = natOut;
@@ -1459,19 +1472,28 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     pt.prevKind = CK_NONE;
     float *natXf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
+    // one constant process noise: the smoother reads xf / Pf of these chains in the reference layout (k_smooth_natin) and starts
+    // at once; the blocked copy of xf only the NIS / NLL epilogue needs is made on the side stream in front of it
+    const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
+    const bool natTail = c->natOnlyEnabled && c->pfNat && constQ && pf.chainQ == nullptr && (c->B % 8) == 0;
+    HIPOK(hipEventRecord(c->evFork, c->stream));
+    HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+    hipStream_t imp = natTail ? c->side : c->stream;
     if (!runs.empty()) {
         // ONE launch over the wavefront-groups from the first to the last block of these chains: the mask trims what lies between
         // (round 4: a launch per run of chains serialised four 60-us launches behind the state chain for a scattered last group)
         int64_t g0 = runs.front().b0 / 64, g1 = (runs.front().b1 + 63) / 64;
         for (const ChainRun &r : runs) { g0 = std::min(g0, r.b0 / 64); g1 = std::max(g1, (r.b1 + 63) / 64); }
-        Scope sc(c, "state_reblock_out");
-        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, c->stream, pt,
+        Scope sc(c, "state_reblock_out", imp);
+        hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)((g1 - g0) * (c->B / 32))), dim3(256), 0, imp, pt,
                            reinterpret_cast<const float2 *>(natXf), pt.tXf, g0);
     }
     LAUNCH_CHECK("k_import_tiled_f2");
     // the NIS / NLL epilogue beside the (latency-bound) smoother chain, on the side stream
-    HIPOK(hipEventRecord(c->evFork, c->stream));
-    HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+    if (!natTail) {
+        HIPOK(hipEventRecord(c->evFork, c->stream));
+        HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
+    }
     {
         Scope sc(c, "fwd_dstat", c->side);
         if (pt.natD) hipLaunchKernelGGL(k_fwd_dstat<true>, dim3((int)c->NG), dim3(256), sizeof(float) * 64 * (c->B + 1), c->side, pt);
@@ -1479,7 +1501,7 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     }
     LAUNCH_CHECK("k_fwd_dstat");
     HIPOK(hipEventRecord(c->evJoin, c->side));
-    CHECK(backward_impl(c, true, dmask, true, true));
+    CHECK(backward_impl(c, true, dmask, true, true, 0, natTail));
     CHECK(flush_pending_check(c));              // (the residual launches below cover a part of the batch each: no folded check)
     if (what & CSR_EXPORT_RESID)
         for (const ChainRun &r : runs) CHECK(launch_resid(c, r.off, r.len, false));

@@ -167,6 +167,7 @@ struct csr_ctx {
     bool nisInChainEnabled = true;      // NIS / NLL terms inside the fused forward chain's tile walker (no epilogue kernel)
     bool natOnlyEnabled = true;         // constant process noise: xf / Pf only in the reference layout, the smoother reads them there
     bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
+    bool pfBlockedStale = false;        // ... Pf alone (default mode: the covariance chain of a pipelined step writes it in the reference layout only)
     bool sideSumsDone = false;          // the pending side-stream work already includes the per-chain sums (join_side only waits)
     double lastWaitUs = 0.0;            // how long the previous host wait for the stream lasted (wait_stream polls around that moment)
     bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
