@@ -64,6 +64,9 @@ typedef struct {
     float cin0, cin1, out0, out1; int ver, final, seen;
     int walking, wt, running, t, runFinal, brk, sEnd, nb; float x0, x1, pd0, pd1; double clk; int runs, aborts;
 } wave2;
+/* readyUs (may be NULL): per chain, the time at which its statistics and covariance chain are done -- no superblock of the chain
+ * starts its first walk earlier ("head per chain group").  chainEndUs (may be NULL): out, when each chain was final. */
+static const double *g_readyUs = NULL; static double *g_chainEndUs = NULL;
 static double timed(const int64_t *len, int split, int walkAbort, long *runsOut, long *abortsOut, int *okOut) {
     const double WOVH = 50.0, INF = 1e300, WAKE = 2.0 * GHZ * 1e3;
     int64_t nbk = 0;
@@ -79,7 +82,17 @@ static double timed(const int64_t *len, int split, int walkAbort, long *runsOut,
       nbk = b; }
     wave2 *W = calloc(nbk, sizeof(wave2));
     long live = 0, runsAll = 0, abortsAll = 0;
-    for (int64_t b = 0; b < nbk; ++b) { W[b].walking = 1; W[b].nb = (ln[b] + 63) / 64; W[b].clk = 0.0; ++live; }
+    int *chainOfB = malloc(sizeof(int) * nbk);
+    { int64_t b = 0; const int Bs = B / split;
+      for (int c = 0; c < 22; ++c) {
+          const int64_t first = len[c] < B ? len[c] : B;
+          for (int64_t k = 0; k < first; k += Bs, ++b) chainOfB[b] = c;
+          for (int64_t k = first; k < len[c]; k += B, ++b) chainOfB[b] = c;
+      } }
+    for (int64_t b = 0; b < nbk; ++b) {
+        W[b].walking = 1; W[b].nb = (ln[b] + 63) / 64; ++live;
+        W[b].clk = g_readyUs ? g_readyUs[chainOfB[b]] * GHZ * 1e3 : 0.0;
+    }
     double total = 0;
     while (live) {
         int64_t b = -1; double best = INF;
@@ -99,7 +112,7 @@ static double timed(const int64_t *len, int split, int walkAbort, long *runsOut,
             w->clk += WOVH + 64 * STEP; w->wt++;
             if (w->wt == w->nb) {
                 w->walking = 0; w->out0 = w->x0; w->out1 = w->x1; w->ver = 1; w->final = fst[b]; w->sEnd = w->nb; w->brk = 0;
-                if (w->final) { --live; if (w->clk > total) total = w->clk; w->clk = INF; }
+                if (w->final) { --live; if (w->clk > total) total = w->clk; if (g_chainEndUs && w->clk / GHZ / 1e3 > g_chainEndUs[chainOfB[b]]) g_chainEndUs[chainOfB[b]] = w->clk / GHZ / 1e3; w->clk = INF; }
                 if (b + 1 < nbk && !fst[b + 1] && !W[b + 1].final && W[b + 1].clk == INF) W[b + 1].clk = best + WAKE;
             }
             continue;
@@ -111,7 +124,7 @@ static double timed(const int64_t *len, int split, int walkAbort, long *runsOut,
             const int same = p->out0 == w->cin0 && p->out1 == w->cin1;
             if (same) {
                 if (w->running) w->runFinal |= p->final;
-                else if (p->final) { w->final = 1; w->ver++; --live; if (w->clk > total) total = w->clk; w->clk = INF; if (b + 1 < nbk && !fst[b + 1] && W[b + 1].clk == INF && !W[b + 1].final) W[b + 1].clk = best + WAKE; continue; }
+                else if (p->final) { w->final = 1; w->ver++; --live; if (w->clk > total) total = w->clk; if (g_chainEndUs && w->clk / GHZ / 1e3 > g_chainEndUs[chainOfB[b]]) g_chainEndUs[chainOfB[b]] = w->clk / GHZ / 1e3; w->clk = INF; if (b + 1 < nbk && !fst[b + 1] && W[b + 1].clk == INF && !W[b + 1].final) W[b + 1].clk = best + WAKE; continue; }
                 else { w->clk = INF; continue; }
             } else {
                 if (w->running) { if (w->t > w->sEnd) w->sEnd = w->t; if (w->brk != (1 << 30) && w->t * 64 > w->brk) w->brk = w->t * 64; w->aborts++; ++abortsAll; }
@@ -132,7 +145,7 @@ static double timed(const int64_t *len, int split, int walkAbort, long *runsOut,
             w->running = 0;
             if (p->ver != w->seen && p->out0 == w->cin0 && p->out1 == w->cin1) { w->seen = p->ver; w->runFinal |= p->final; }
             w->final = w->runFinal; w->ver++;
-            if (w->final) { --live; if (w->clk > total) total = w->clk; }
+            if (w->final) { --live; if (w->clk > total) total = w->clk; if (g_chainEndUs && w->clk / GHZ / 1e3 > g_chainEndUs[chainOfB[b]]) g_chainEndUs[chainOfB[b]] = w->clk / GHZ / 1e3; }
             const double now = w->clk;
             if (w->final || p->ver == w->seen) w->clk = INF;
             if (b + 1 < nbk && !fst[b + 1] && !W[b + 1].final && W[b + 1].clk == INF) W[b + 1].clk = now + WAKE;
@@ -140,7 +153,7 @@ static double timed(const int64_t *len, int split, int walkAbort, long *runsOut,
     }
     int bad = 0; for (int64_t k = 0; k < 2 * N; ++k) if (cur[k] != truth[k]) { bad = 1; break; }
     *runsOut = runsAll; *abortsOut = abortsAll; *okOut = !bad;
-    free(off); free(ln); free(fst); free(W);
+    free(off); free(ln); free(fst); free(W); free(chainOfB);
     return total / GHZ / 1e3;
 }
 
@@ -289,6 +302,57 @@ int main(int argc, char **argv) {
             printf("walks on the clock, first superblock of a chain in %2d piece(s), walks %s: %.0f us, %ld runs, %ld abandoned; result %s\n",
                    cfg[k][0], cfg[k][1] ? "abandoned for a final carry" : "always finished          ", us, r, a, ok ? "== sequential" : "WRONG");
         }
+    }
+    /* ---- round 5: the head of a step PER GROUP OF CHAINS.  Today every chain waits for the statistics and the covariance chain of
+     * ALL chains (HEAD us, measured) before the single launch of the state chain starts.  With a ready word per chain that gates a
+     * superblock's first walk, the head kernels could be launched per group of chains on a feeder stream; chain c is then ready when
+     * the heads of the groups up to its own are done: head(g) = FIX + HEAD * bins(g) / bins (the two kernels are bandwidth-bound).
+     * Simulated: G groups of about equal bins, chains assigned in the given ORDER; the state chain's cost model is scaled so that
+     * the ungrouped launch lasts what the GPU measures (2.0 ms); SLOW = how much a walking / repairing wavefront slows down while
+     * head kernels of later groups share the chip with it (the statistics kernel fills every CU). */
+    {
+        const double HEAD = 1090.0, FIX = 25.0, TAIL = 790.0, MEASURED = 2000.0;
+        double fin0[22]; for (int c = 0; c < 22; ++c) fin0[c] = 0.0;
+        long r, a; int ok;
+        g_readyUs = NULL; g_chainEndUs = fin0;
+        const double base = timed(len, 1, 1, &r, &a, &ok);
+        const double k = MEASURED / base;        /* cost-model scale */
+        printf("\nhead per chain group (cost model scaled by %.2f so that the single launch lasts %.0f us like on the GPU)\n", k, MEASURED);
+        printf("chain finish times of the ungrouped launch (us, scaled):"); for (int c = 0; c < 22; ++c) printf(" %.0f", fin0[c] * k); printf("\n");
+        printf("today: head %.0f + state chain %.0f + tail %.0f = %.0f us per step\n", HEAD, MEASURED, TAIL, HEAD + MEASURED + TAIL);
+        /* per-chain mean |zbar| (what a cheap pre-pass over the data could know before anything else has run) */
+        double lvl[22]; { int64_t g = 0; for (int c = 0; c < 22; ++c) { double sa = 0; for (int64_t q = 0; q < len[c]; ++q, ++g) sa += fabs(RC[g].zb); lvl[c] = sa / (double)len[c]; } }
+        for (int order = 0; order < 4; ++order) {
+            int idx[22]; for (int c = 0; c < 22; ++c) idx[c] = c;
+            double key[22];
+            for (int c = 0; c < 22; ++c) key[c] = order == 0 ? (double)len[c] : order == 1 ? fin0[c] : order == 2 ? lvl[c] * sqrt((double)len[c]) : -(double)c;
+            for (int i = 0; i < 22; ++i) for (int j = i + 1; j < 22; ++j) if (key[idx[j]] > key[idx[i]]) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+            const char *name = order == 0 ? "longest chain first" : order == 1 ? "slowest chain of the PREVIOUS identical step first (oracle)" : order == 2 ? "mean |level| x sqrt(length) first (predictor)" : "genome order";
+            for (int G = 2; G <= 6; G += (G == 2 ? 1 : (G == 3 ? 1 : 2))) {
+                for (int sl = 0; sl < 3; ++sl) {
+                    const double SLOW = sl == 0 ? 1.0 : sl == 1 ? 1.15 : 1.3;
+                    double ready[22], endc[22]; int grp[22];
+                    { double acc = 0; int g = 0; for (int i = 0; i < 22; ++i) { grp[idx[i]] = g; acc += (double)len[idx[i]]; if (acc >= (double)N * (g + 1) / G && g < G - 1) ++g; } }
+                    double tg[8], t = 0; for (int g = 0; g < G; ++g) { double bins = 0; for (int c = 0; c < 22; ++c) if (grp[c] == g) bins += (double)len[c]; t += FIX + HEAD * bins / (double)N; tg[g] = t; }
+                    /* the simulator runs in unscaled cycles: hand it ready times divided by k * SLOW-on-average.  A chain's work that
+                     * overlaps later heads runs SLOW times slower: approximated by stretching the whole state chain by the share of
+                     * its run that lies before the last head ends (iterated once) */
+                    for (int c = 0; c < 22; ++c) { ready[c] = tg[grp[c]] / k; endc[c] = 0; }
+                    g_readyUs = ready; g_chainEndUs = endc;
+                    (void)timed(len, 1, 1, &r, &a, &ok);
+                    double stepEnd = 0;
+                    for (int c = 0; c < 22; ++c) {
+                        const double start = tg[grp[c]], dur = endc[c] * k - start;              /* this chain's state chain, undisturbed */
+                        const double overlap = tg[G - 1] > start ? (tg[G - 1] - start < dur * SLOW ? tg[G - 1] - start : dur * SLOW) : 0.0;
+                        const double fin = start + dur + overlap * (SLOW - 1.0) / SLOW;
+                        if (fin > stepEnd) stepEnd = fin;
+                    }
+                    printf("  %-62s G=%d slow x%.2f: state chains end at %.0f us -> step %.0f us (%+.1f %%)%s\n", name, G, SLOW, stepEnd, stepEnd + TAIL,
+                           100.0 * (stepEnd + TAIL - (HEAD + MEASURED + TAIL)) / (HEAD + MEASURED + TAIL), ok ? "" : "  WRONG RESULT");
+                }
+            }
+        }
+        g_readyUs = NULL; g_chainEndUs = NULL;
     }
     return 0;
 }
