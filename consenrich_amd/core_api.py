@@ -183,6 +183,38 @@ def track_summary(values) -> dict:
             "mean": float(a.mean()), "q95": float(np.quantile(a, 0.95)), "max": float(a.max())}
 
 
+def _workers() -> int:
+    import os
+
+    try:
+        return max(1, min(8, len(os.sched_getaffinity(0))))
+    except AttributeError:          # not on Linux
+        return max(1, min(8, os.cpu_count() or 1))
+
+
+def _map_rows(fn, rows):
+    """fn over the rows of a matrix, in order; large matrices through a small thread pool (NumPy releases the GIL in its loops)."""
+    rows = list(rows)
+    if len(rows) < 2 or rows[0].size < (1 << 16) or _workers() < 2:
+        return [fn(r) for r in rows]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=_workers()) as pool:
+        return list(pool.map(fn, rows))
+
+
+def _map_cols(fn, n, chunk=1 << 18):
+    """fn(k0, k1) over column ranges that tile [0, n): every range runs the reference's own row-by-row accumulation, so sums keep
+    their order; ranges are independent (thread pool)."""
+    spans = [(k0, min(k0 + chunk, n)) for k0 in range(0, n, chunk)]
+    if len(spans) < 2 or _workers() < 2:
+        return [fn(a, b) for a, b in spans]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=_workers()) as pool:
+        return list(pool.map(lambda ab: fn(*ab), spans))
+
+
 @dataclass
 class RunPlan:
     """One validated `runConsenrich` call: what runs on the device (`model`, `cfg`, the matrices, warm starts) and what shapes
@@ -351,17 +383,28 @@ def metadata_float(value):
 
 
 def process_noise_calibration_support(data, munc, pad) -> dict:
-    """core._processNoiseCalibrationSupport (core.py:2989-3055): counts of usable cells / transitions."""
-    d64, m64 = np.asarray(data, np.float64), np.asarray(munc, np.float64)
-    obs_var = m64 + float(pad)
-    unmasked = np.isfinite(m64) & (m64 < 0.5 * float(MASKED_OBSERVATION_VARIANCE))
-    positive = np.isfinite(obs_var) & (obs_var > 0.0)
-    active = np.isfinite(d64) & unmasked & positive
-    act_iv = np.any(active, axis=0)
-    adjacent = act_iv[1:] & act_iv[:-1] if act_iv.size >= 2 else np.zeros(0, bool)
-    same_track = np.any(active[:, 1:] & active[:, :-1], axis=0) if active.shape[1] >= 2 else np.zeros(0, bool)
-    finite_n, pos_n = int(np.count_nonzero(np.isfinite(d64))), int(np.count_nonzero(unmasked & positive))
-    act_n, adj_n = int(np.count_nonzero(active)), int(np.count_nonzero(adjacent))
+    """core._processNoiseCalibrationSupport (core.py:2989-3055): counts of usable cells / transitions.  (Evaluated range by range
+    with one bin of overlap for the adjacency counts: the float64 copies of two (m, n) matrices are never whole in memory.)"""
+    data, munc = np.asarray(data), np.asarray(munc)
+    n = int(data.shape[1])
+    half = 0.5 * float(MASKED_OBSERVATION_VARIANCE)
+
+    def part(k0, k1):
+        hi = min(k1 + 1, n)                                   # one bin of look-ahead: transitions k -> k + 1 with k in [k0, k1)
+        d64, m64 = np.asarray(data[:, k0:hi], np.float64), np.asarray(munc[:, k0:hi], np.float64)
+        obs_var = m64 + float(pad)
+        unmasked = np.isfinite(m64) & (m64 < half)
+        positive = np.isfinite(obs_var) & (obs_var > 0.0)
+        active = np.isfinite(d64) & unmasked & positive
+        act_iv = np.any(active, axis=0)
+        own = k1 - k0
+        adj = int(np.count_nonzero(act_iv[1:] & act_iv[:-1])) if hi - k0 >= 2 else 0
+        same = int(np.count_nonzero(np.any(active[:, 1:] & active[:, :-1], axis=0))) if hi - k0 >= 2 else 0
+        return (int(np.count_nonzero(np.isfinite(d64[:, :own]))), int(np.count_nonzero((unmasked & positive)[:, :own])),
+                int(np.count_nonzero(active[:, :own])), int(np.count_nonzero(act_iv[:own])), adj, same)
+
+    parts = _map_cols(part, n)
+    finite_n, pos_n, act_n, iv_n, adj_n, same_n = (int(sum(p[i] for p in parts)) for i in range(6))
     reason = None
     if finite_n <= 0:
         reason = "no_finite_data"
@@ -372,8 +415,8 @@ def process_noise_calibration_support(data, munc, pad) -> dict:
     elif adj_n <= 0:
         reason = "no_active_adjacent_transitions"
     return {"finiteDataCount": finite_n, "positiveObservationVarianceCount": pos_n, "activeObservationCount": act_n,
-            "activeIntervalCount": int(np.count_nonzero(act_iv)), "intervalTransitionCount": int(max(d64.shape[1] - 1, 0)),
-            "activeAdjacentTransitionCount": adj_n, "sameTrackAdjacentTransitionCount": int(np.count_nonzero(same_track)),
+            "activeIntervalCount": iv_n, "intervalTransitionCount": int(max(n - 1, 0)),
+            "activeAdjacentTransitionCount": adj_n, "sameTrackAdjacentTransitionCount": same_n,
             "processNoiseCalibrationCanRun": bool(reason is None), "processNoiseCalibrationSkipReason": reason}
 
 
@@ -474,18 +517,25 @@ def relative_sign_change_per_kb(state_level, data, munc, *, interval_size_bp, ba
     bg = np.zeros(x.size) if background is None else np.asarray(background, np.float64).reshape(-1)
     if bg.size != x.size:
         return None
-    tot, wsum, x_ok = np.zeros(x.size), np.zeros(x.size), np.isfinite(x)
-    for j in range(d.shape[0]):
-        row, den = np.asarray(d[j], np.float64), np.asarray(v[j], np.float64) + float(pad)
-        ok = x_ok & np.isfinite(row) & np.isfinite(den) & (den > 0.0)
-        if not np.any(ok):
-            continue
-        w = 1.0 / np.maximum(den[ok], 1.0e-12)
-        tot[ok] += (row[ok] - bg[ok]) * w
-        wsum[ok] += w
     mean = np.full(x.size, np.nan)
-    has = wsum > 0.0
-    mean[has] = tot[has] / wsum[has]
+    x_ok = np.isfinite(x)
+
+    def cols(k0, k1):       # the reference's row-by-row accumulation (core.py:2675-2692) on one range of bins
+        tot, wsum = np.zeros(k1 - k0), np.zeros(k1 - k0)
+        for j in range(d.shape[0]):
+            row, den = np.asarray(d[j, k0:k1], np.float64), np.asarray(v[j, k0:k1], np.float64) + float(pad)
+            ok = x_ok[k0:k1] & np.isfinite(row) & np.isfinite(den) & (den > 0.0)
+            if not np.any(ok):
+                continue
+            w = 1.0 / np.maximum(den[ok], 1.0e-12)
+            tot[ok] += (row[ok] - bg[k0:k1][ok]) * w
+            wsum[ok] += w
+        has = wsum > 0.0
+        out = np.full(k1 - k0, np.nan)
+        out[has] = tot[has] / wsum[has]
+        mean[k0:k1] = out
+
+    _map_cols(cols, x.size)
     arr = x - mean
     if arr.size == 0:
         return None
@@ -537,20 +587,32 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
     p00 = np.maximum(np.asarray(final["stateCovarForward"], np.float64)[:, 0, 0], 0.0)
     prec = np.ones(n) if lam is None else np.clip(np.asarray(lam, np.float64), *plan.model.lambda_bounds)
     gain = {k: [] for k in ("mean", "median", "sd", "iqr", "count")}
-    r_trace = np.zeros(n)
-    for row in plan.munc:
-        var = np.maximum(np.asarray(row, np.float64) + float(cfg.pad), 1.0e-12)
-        r_trace += var
-        g = (p00 * prec) / var
-        g = g[np.isfinite(g)]
-        gain["count"].append(int(g.size))
+    base_gain = p00 * prec
+    pad_f = float(cfg.pad)
+
+    def gain_row(row):      # one replicate: a sort-like pass over n values (the replicates are independent: a small thread pool)
+        var = np.maximum(np.asarray(row, np.float64) + pad_f, 1.0e-12)
+        g = base_gain / var
+        ok = np.isfinite(g)
+        if not ok.all():
+            g = g[ok]
         if g.size == 0:
-            for k in ("mean", "median", "sd", "iqr"):
-                gain[k].append(float("nan"))
-            continue
-        q25, q75 = np.quantile(g, [0.25, 0.75])
-        gain["mean"].append(float(g.mean())); gain["median"].append(float(np.median(g)))
-        gain["sd"].append(float(np.std(g))); gain["iqr"].append(float(q75 - q25))
+            return 0, float("nan"), float("nan"), float("nan"), float("nan")
+        q25, q50, q75 = np.quantile(g, [0.25, 0.5, 0.75])
+        return int(g.size), float(g.mean()), float(q50), float(np.std(g)), float(q75 - q25)
+
+    for cnt, mean, med, sd, iqr in _map_rows(gain_row, plan.munc):
+        gain["count"].append(cnt); gain["mean"].append(mean); gain["median"].append(med); gain["sd"].append(sd); gain["iqr"].append(iqr)
+    # trace of the observation noise: sum over the replicates in their order, bin range by bin range
+    r_trace = np.empty(n)
+
+    def trace_cols(k0, k1):
+        acc = np.zeros(k1 - k0)
+        for row in plan.munc:
+            acc += np.maximum(np.asarray(row[k0:k1], np.float64) + pad_f, 1.0e-12)
+        r_trace[k0:k1] = acc
+
+    _map_cols(trace_cols, n)
     # effective process noise tracks (core.py:2420-2519): base / kappa, or the stored process noise without kappa
     base_l = np.full(n, q0[0, 0])
     base_t = np.full(n, q0[1, 1]) if d == 2 else np.zeros(n)

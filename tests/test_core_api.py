@@ -505,6 +505,49 @@ def test_host_restatements_of_the_diagnostics_helpers():
     assert sup["processNoiseCalibrationSkipReason"] == "no_active_adjacent_transitions"
 
 
+def test_host_diagnostics_in_ranges_equal_the_whole_matrix_formulas():
+    """The per-call entry evaluates its host-side summaries range by range / row by row on a thread pool; on a matrix large enough
+    to take those paths (several 2^18-bin ranges) the results must be what the reference's whole-matrix expressions give."""
+    from consenrich_amd import core_api as ca
+
+    rng = np.random.default_rng(11)
+    m, n = 3, (1 << 18) * 2 + 12345
+    data = rng.normal(size=(m, n)).astype(np.float32)
+    munc = (0.2 * np.exp(rng.normal(0, 0.3, size=(m, n)))).astype(np.float32)
+    data[0, 5:9] = np.nan
+    munc[1, (1 << 18) - 2:(1 << 18) + 3] = np.float32(1.0e30)            # masked cells across a range boundary
+    munc[:, 1 << 18] = np.float32(1.0e30)                                # ... and a wholly inactive bin ON the boundary
+    munc[2, 100] = np.float32(-1.0)                                      # a non-positive variance
+    sup = ca.process_noise_calibration_support(data, munc, 1.0e-4)
+    d64, m64 = data.astype(np.float64), munc.astype(np.float64)
+    ov = m64 + 1.0e-4
+    unmasked = np.isfinite(m64) & (m64 < 0.5e30)
+    active = np.isfinite(d64) & unmasked & np.isfinite(ov) & (ov > 0.0)
+    iv = active.any(axis=0)
+    assert sup["finiteDataCount"] == int(np.isfinite(d64).sum()) and sup["activeObservationCount"] == int(active.sum())
+    assert sup["positiveObservationVarianceCount"] == int((unmasked & np.isfinite(ov) & (ov > 0.0)).sum())
+    assert sup["activeIntervalCount"] == int(iv.sum()) and sup["activeAdjacentTransitionCount"] == int((iv[1:] & iv[:-1]).sum())
+    assert sup["sameTrackAdjacentTransitionCount"] == int((active[:, 1:] & active[:, :-1]).any(axis=0).sum())
+    # sign changes: the reference's expressions on the whole matrix (core.py:2647-2700)
+    state = rng.normal(size=n)
+    bg = (0.1 * np.sin(np.arange(n) / 1000.0)).astype(np.float32)
+    tot, ws = np.zeros(n), np.zeros(n)
+    for j in range(m):
+        den = m64[j] + 1.0e-4
+        ok = np.isfinite(d64[j]) & np.isfinite(den) & (den > 0.0)
+        w = 1.0 / np.maximum(den[ok], 1.0e-12)
+        tot[ok] += (d64[j][ok] - bg.astype(np.float64)[ok]) * w
+        ws[ok] += w
+    arr = state - np.where(ws > 0, tot / np.where(ws > 0, ws, 1.0), np.nan)
+    fin = arr[np.isfinite(arr)]
+    fin = fin[np.abs(fin) >= 0.01 * np.mean(np.abs(fin))]
+    sg = np.sign(fin)
+    want = float(np.count_nonzero(sg[1:] * sg[:-1] < 0.0)) / (n * 25 / 1000.0)
+    assert ca.relative_sign_change_per_kb(state, data, munc, interval_size_bp=25, background=bg, pad=1.0e-4) == want
+    # rows through the pool come back in order
+    assert ca._map_rows(lambda r: float(r[0]), munc) == [float(munc[j, 0]) for j in range(m)]
+
+
 def test_an_initial_lambda_weights_the_background_warm_start():
     """core.py:4663-4676: the background prepass is weighted by the INITIAL observation precision (clipped to its bounds) when
     one is given and no initial background is -- a different start than the unweighted prepass."""
