@@ -931,7 +931,7 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
         const bool natValid = c->fwdNat || (c->pfNat && (c->xfNat || preferNatIn));
         const bool need = c->fwdBlockedStale || c->pfBlockedStale;
-        if (natOut && !pcq && !p.qFromKappa && natValid && (need || constQ) && (stage_warm(c, ST_B) % 8) == 0) {
+        if (c->natInEnabled && natOut && !pcq && !p.qFromKappa && natValid && (need || constQ) && (stage_warm(c, ST_B) % 8) == 0) {
             float *natXf, *natPf;
             CHECK(nat_array(c, CSR_ARR_XF, &natXf));
             CHECK(nat_array(c, CSR_ARR_PF, &natPf));

@@ -166,6 +166,8 @@ struct csr_ctx {
     bool statsF32Enabled = true;        // {S2c, log R} as one float32 pair
     bool nisInChainEnabled = true;      // NIS / NLL terms inside the fused forward chain's tile walker (no epilogue kernel)
     bool natOnlyEnabled = true;         // constant process noise: xf / Pf only in the reference layout, the smoother reads them there
+    bool natInEnabled = true;           // CONSENRICH_AMD_NATIN=0 (tests): the smoother never reads the reference layout -- blocked copies
+                                        // a forward pass did not write are brought back first (ensure_blocked_fwd)
     bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
     bool pfBlockedStale = false;        // ... Pf alone (default mode: the covariance chain of a pipelined step writes it in the reference layout only)
     bool sideSumsDone = false;          // the pending side-stream work already includes the per-chain sums (join_side only waits)
@@ -418,6 +420,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_LEAN"))) c->statsF32Enabled = c->nisInChainEnabled = c->natOnlyEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_NATIN"))) c->natInEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_WARMSTART"))) c->wsEnabled = atoi(e) != 0;

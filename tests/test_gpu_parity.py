@@ -351,6 +351,64 @@ def test_a_step_that_pipelines_its_tail_per_chain_equals_the_step_in_order(produ
                 assert np.array_equal(val, got[key]), (env, variant, key)
 
 
+@pytest.mark.parametrize("xtol", [2, 0], ids=["ulp2", "exact"])
+def test_the_lean_data_flow_changes_no_filtered_or_smoothed_bit(product, monkeypatch, xtol):
+    """Round 5 took bytes out of a step: the NIS / NLL terms are evaluated inside the fused forward chain (2-ulp mode; a running
+    product instead of a log per bin), {S2c, log R} travel as one float32 pair (2-ulp mode), xf / Pf exist only in the reference
+    layout and the smoother reads them there through its LDS tiles (2-ulp mode with one constant process noise; the default
+    mode's pipelined tails).  The recursions are the same instruction sequences on the same values: every filtered and smoothed
+    array must equal the round-4 data flow (CONSENRICH_AMD_LEAN=0) BIT FOR BIT -- also when the blocked copies the forward pass
+    did not write are brought back for a smoother that reads the blocked layout (CONSENRICH_AMD_NATIN=0: ensure_blocked_fwd) --,
+    NIS and the sums within the rounding of their own formula (the in-chain form S2c + gs dz^2 has no cancellation; float32
+    statistics move them by < 1e-6 relative; at a block's first bin the in-chain NIS is predicted from the lane's accepted
+    carry-in -- the state its own xf was computed from -- where the epilogue kernel used the neighbour's stored state)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list = [400000, 130000, 70001, 64, 9]
+    m = 5
+    sets = [cases.synth(n, m, 7900 + c, mask_frac=0.01, outlier_frac=0.005) for c, n in enumerate(n_list)]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+
+    def run(env):
+        for k in ("CONSENRICH_AMD_LEAN", "CONSENRICH_AMD_NATIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = {}
+        with DeviceBatch(0, x_tol_ulps=xtol) as b:
+            b.configure(ModelParams(state_dim=2), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            sd, sn = b.step(L.RETURN_NLL, what)
+            out["sd"], out["sn"] = np.array(sd), np.array(sn)
+            for c in range(len(n_list)):
+                for name in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
+                    out[(c, name)] = b.download(c, name)
+            # the separate entries behind a lean step: a second smoother pass on the resident forward results
+            b.backward()
+            b.export(L.EXPORT_SMOOTH)
+            for c in range(len(n_list)):
+                assert np.array_equal(out[(c, "xs")], b.download(c, "xs")), (env, c)
+        return out
+
+    ref = run({"CONSENRICH_AMD_LEAN": "0"})
+    for env in ({}, {"CONSENRICH_AMD_NATIN": "0"}):
+        got = run(env)
+        for key, val in ref.items():
+            if key in ("sd", "sn"):
+                np.testing.assert_allclose(got[key], val, rtol=2e-6, atol=1e-9, err_msg=str((env, key)))
+            elif key[1] == "D" and xtol > 0:
+                # a block's FIRST bin: the in-chain form predicts from the lane's accepted (<= 2 ulps off) carry-in, the epilogue
+                # kernel from the stored neighbour state -- NIS turns those ulps of the level into ~1e-5 relative (the mode's contract)
+                close_mostly(got[key], val, frac=2e-3, cap=5e-4, msg=str((env, key)))
+                assert float((got[key] != val).mean()) < 0.5
+            elif key[1] == "D":
+                np.testing.assert_allclose(got[key], val, rtol=2e-6, atol=1e-9, err_msg=str((env, key)))
+            else:
+                assert np.array_equal(val, got[key]), (env, key)
+
+
 def test_two_contexts_in_one_process_each_raise_their_own_launch_attributes(product):
     """The default-mode state chain launches with ~124 KB of dynamic LDS, which has to be asked for once per kernel AND PER
     DEVICE (hipFuncSetAttribute).  Round 4 remembered that in a process-wide static: a second context on another GPU of the
