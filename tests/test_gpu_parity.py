@@ -378,6 +378,8 @@ def test_the_lean_data_flow_changes_no_filtered_or_smoothed_bit(product, monkeyp
         out = {}
         with DeviceBatch(0, x_tol_ulps=xtol) as b:
             b.configure(ModelParams(state_dim=2), m, n_list)
+            if xtol:
+                b.set_tuning(0, 96, 96, 64)     # (pinned windows: the 2-ulp mode's results depend on them within its acceptance)
             for c, (d_, v_) in enumerate(sets):
                 b.upload(c, d_, v_)
             sd, sn = b.step(L.RETURN_NLL, what)
@@ -1969,6 +1971,10 @@ def test_config2_forward_only_step_matches_oracle(product, oracle, xtol):
     Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
     with DeviceBatch(0, x_tol_ulps=xtol) as b:
         b.configure(ModelParams(state_dim=2), m, [n])
+        if xtol:
+            # (the 2-ulp mode's results depend on its windows within the acceptance, and windows lengthen themselves when a
+            # validation pass finds many mismatches: pinned, so that two passes over the same inputs are the same computation)
+            b.set_tuning(0, 96, 96, 64)
         b.synthesize(1234)
         sd, sn = b.step_forward(L.RETURN_NLL, L.EXPORT_FORWARD)
         got = {k: b.download(0, k) for k in ("xf", "Pf", "pnoise", "D")}
