@@ -42,11 +42,15 @@ static hipError_t wait_stream(csr_ctx *c) {
     if (c->spinWait) {
         // a short burst of polls (the waits on a shard's critical path are tens of microseconds), then polls 20 us apart, then
         // a blocking wait: a rank never burns a core for the length of a latency-bound launch (8 ranks per node).  Two details
-        // keep the wake-up from costing the step tens of microseconds: the calling thread's timer slack is lowered once (the
-        // kernel's default of 50 us turns a 20-us sleep into ~75), and around the moment the PREVIOUS wait of this context ended
-        // (steps repeat) the loop polls without sleeping -- at most ~0.4 ms of spinning per wait.
-        static thread_local bool slackSet = false;
-        if (!slackSet) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slackSet = true; }
+        // keep the wake-up from costing the step tens of microseconds: the calling thread's timer slack is lowered FOR THE LENGTH OF
+        // THE WAIT (the kernel's default of 50 us turns a 20-us sleep into ~75; the caller's setting is put back on the way out),
+        // and around the moment the PREVIOUS wait of this context ended (steps repeat) the loop polls without sleeping -- at most
+        // ~0.4 ms of spinning per wait.
+        struct Slack {
+            long old;
+            Slack() : old(prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL)) { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
+            ~Slack() { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
+        } slack;
         const auto t0 = std::chrono::steady_clock::now();
         auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
         for (int i = 0; i < 128; ++i) {
@@ -1475,7 +1479,8 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     // one constant process noise: the smoother reads xf / Pf of these chains in the reference layout (k_smooth_natin) and starts
     // at once; the blocked copy of xf only the NIS / NLL epilogue needs is made on the side stream in front of it
     const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
-    const bool natTail = c->natOnlyEnabled && c->pfNat && constQ && pf.chainQ == nullptr && (c->B % 8) == 0;
+    const bool natTail = c->natOnlyEnabled && c->natInEnabled && c->pfNat && constQ && pf.chainQ == nullptr && (c->B % 8) == 0 &&
+                         (stage_warm(c, ST_B) % 8) == 0;
     HIPOK(hipEventRecord(c->evFork, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
     hipStream_t imp = natTail ? c->side : c->stream;
