@@ -107,3 +107,33 @@ def test_both_transports_offer_the_reductions_bench_py_uses():
     for cls in (RcclComm, JobFiles):
         for name in ("barrier", "allreduce_max", "allreduce_sum"):
             assert callable(getattr(cls, name, None)), (cls.__name__, name)
+
+
+def test_bench_configs_name_the_baseline_workloads():
+    """`bench.py --config cN`: one line per BASELINE config (BASELINE.json `configs` 2-5); the default is config 4 and carries
+    BASELINE.json's metric string verbatim; c2 is the forward filter alone with B_alg = 8 m + 60; the N > 1 `expected` block is the
+    fitted model evaluated on the job's LPT table."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(root, "BASELINE.json")) as fh:
+        baseline = json.load(fh)
+    a = bench.parse_args([])
+    assert a.config == "c4" and a.samples == 32 and a.bin_bp == 200 and not a.forward_only
+    assert a.metric.replace("x", "\u00d7") == baseline["metric"] or a.metric == baseline["metric"].replace("\u00d7", "x")
+    c2 = bench.parse_args(["--config", "c2"])
+    assert c2.forward_only and c2.single_chain == 1000000 and c2.samples == 4 and "forward filter only" in c2.metric
+    assert bench.b_alg(4, True) == 92 and bench.b_alg(32) == 484 and bench.b_alg(8) == 196 and bench.b_alg(64) == 868
+    c3, c5 = bench.parse_args(["--config", "c3"]), bench.parse_args(["--config", "c5"])
+    assert (c3.samples, c3.bin_bp, c5.samples, c5.bin_bp) == (8, 200, 64, 50)
+    assert bench.parse_args(["--samples", "16"]).metric.endswith("hg38 200bp x 16 samples")
+    from consenrich_amd.sharding import hg38_chain_lengths, lpt_assign
+    lens = hg38_chain_lengths(200)
+    bins = [sum(lens[i] for i in r) for r in lpt_assign(lens, 8)]
+    e = bench.expected_speedup(bins, sum(lens))
+    assert 1.5 < e["default"]["speedup_vs_1gpu"] < 3.0 < e["ulp2"]["speedup_vs_1gpu"] < 7.67
+    assert e["bound"].startswith("LPT makespan bound: 7.67")
