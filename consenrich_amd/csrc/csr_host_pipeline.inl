@@ -38,7 +38,9 @@ enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
 // Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
 // 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
 // step: poll first, block only if the stream is still busy after ~200 us.
-static hipError_t wait_stream(csr_ctx *c) {
+// site: which wait of the pipeline this is (0 = the settle point's mailbox read, 1 = the state chain's verdict): each keeps its own
+// estimate -- a step has both, of very different lengths
+static hipError_t wait_stream(csr_ctx *c, int site = 0) {
     if (c->spinWait) {
         // a short burst of polls (the waits on a shard's critical path are tens of microseconds), then polls 20 us apart, then
         // a blocking wait: a rank never burns a core for the length of a latency-bound launch (8 ranks per node).  Two details
@@ -55,21 +57,21 @@ static hipError_t wait_stream(csr_ctx *c) {
         auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
         for (int i = 0; i < 128; ++i) {
             const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) { c->lastWaitUs = elapsed_us(); return hipSuccess; }
+            if (q == hipSuccess) { c->lastWaitUs[site] = elapsed_us(); return hipSuccess; }
             if (q != hipErrorNotReady) return q;
         }
-        const double expect = c->lastWaitUs;
+        const double expect = c->lastWaitUs[site];
         for (;;) {
             const double el = elapsed_us();
             if (el > 8000.0) break;
             const bool nearEnd = expect > 0.0 && el > expect - 150.0 && el < expect + 250.0;
             if (!nearEnd) std::this_thread::sleep_for(std::chrono::microseconds(20));
             const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) { c->lastWaitUs = elapsed_us(); return hipSuccess; }
+            if (q == hipSuccess) { c->lastWaitUs[site] = elapsed_us(); return hipSuccess; }
             if (q != hipErrorNotReady) return q;
         }
         const hipError_t r = hipStreamSynchronize(c->stream);
-        c->lastWaitUs = elapsed_us();
+        c->lastWaitUs[site] = elapsed_us();
         return r;
     }
     return hipStreamSynchronize(c->stream);
@@ -504,7 +506,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         }
         unsigned int ctl[4];
         HIPOK(hipMemcpyAsync(ctl, a.ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
-        HIPOK(wait_stream(c));
+        HIPOK(wait_stream(c, 1));
         c->rs.fix_launches++;
         if (q.sbDbg) {
             unsigned long long h[8];

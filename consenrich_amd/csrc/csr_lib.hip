@@ -171,7 +171,7 @@ struct csr_ctx {
     bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
     bool pfBlockedStale = false;        // ... Pf alone (default mode: the covariance chain of a pipelined step writes it in the reference layout only)
     bool sideSumsDone = false;          // the pending side-stream work already includes the per-chain sums (join_side only waits)
-    double lastWaitUs = 0.0;            // how long the previous host wait for the stream lasted (wait_stream polls around that moment)
+    double lastWaitUs[2] = {0.0, 0.0};  // how long the previous host wait for the stream lasted, per wait site (wait_stream polls around that moment)
     bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
     int pendEstep = 0;
     static constexpr bool fuseEstep = true;     // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
