@@ -38,6 +38,13 @@ enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
 // Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
 // 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
 // step: poll first, block only if the stream is still busy after ~200 us.
+// The calling thread's timer slack, lowered for the length of a wait loop (the kernel's default of 50 us turns a 20-us sleep into
+// ~75); the caller's setting is put back on the way out.
+struct TimerSlack {
+    long old;
+    TimerSlack() : old(prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL)) { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
+    ~TimerSlack() { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
+};
 // site: which wait of the pipeline this is (0 = the settle point's mailbox read, 1 = the state chain's verdict): each keeps its own
 // estimate -- a step has both, of very different lengths
 static hipError_t wait_stream(csr_ctx *c, int site = 0) {
@@ -48,11 +55,7 @@ static hipError_t wait_stream(csr_ctx *c, int site = 0) {
         // THE WAIT (the kernel's default of 50 us turns a 20-us sleep into ~75; the caller's setting is put back on the way out),
         // and around the moment the PREVIOUS wait of this context ended (steps repeat) the loop polls without sleeping -- at most
         // ~0.4 ms of spinning per wait.
-        struct Slack {
-            long old;
-            Slack() : old(prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL)) { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
-            ~Slack() { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
-        } slack;
+        TimerSlack slack;
         const auto t0 = std::chrono::steady_clock::now();
         auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
         for (int i = 0; i < 128; ++i) {
@@ -1486,6 +1489,9 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     HIPOK(hipEventRecord(c->evFork, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
     hipStream_t imp = natTail ? c->side : c->stream;
+    // (the smoother is what the group's residuals wait for: when it reads the reference layout it is launched FIRST, the
+    // epilogue's kernels of the side stream after it -- they were forked above and do not wait for it)
+    if (natTail) CHECK(backward_impl(c, true, dmask, true, true, 0, true));
     if (!runs.empty()) {
         // ONE launch over the wavefront-groups from the first to the last block of these chains: the mask trims what lies between
         // (round 4: a launch per run of chains serialised four 60-us launches behind the state chain for a scattered last group)
@@ -1508,7 +1514,7 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     }
     LAUNCH_CHECK("k_fwd_dstat");
     HIPOK(hipEventRecord(c->evJoin, c->side));
-    CHECK(backward_impl(c, true, dmask, true, true, 0, natTail));
+    if (!natTail) CHECK(backward_impl(c, true, dmask, true, true, 0, false));
     CHECK(flush_pending_check(c));              // (the residual launches below cover a part of the batch each: no folded check)
     if (what & CSR_EXPORT_RESID)
         for (const ChainRun &r : runs) CHECK(launch_resid(c, r.off, r.len, false));
@@ -1592,11 +1598,17 @@ static int step_pipelined(csr_ctx *c, uint32_t flags, uint32_t what, bool *handl
     // ---- while the state chain runs: tails of the chains that are final, an eighth of the batch at a time, on the tail stream
     c->stream = c->tail;
     int rc = 0;
+    // (the end of the launch is on the step's critical path -- the last tail starts behind it: the loop's sleeps run with a lowered
+    // timer slack and, around the moment the PREVIOUS launch of this context ended, it polls without sleeping)
+    TimerSlack slack;
+    const auto tLoop = std::chrono::steady_clock::now();
+    const double expectEnd = c->lastSbLoopUs;
     for (;;) {
         const hipError_t qs = hipStreamQuery(mainStream);
-        if (qs != hipErrorNotReady) { if (qs != hipSuccess) rc = fail("state chain: %s", hipGetErrorString(qs)); break; }
+        const double el = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tLoop).count();
+        if (qs != hipErrorNotReady) { if (qs != hipSuccess) rc = fail("state chain: %s", hipGetErrorString(qs)); else c->lastSbLoopUs = el; break; }
         // (bounded sleep-poll: the launch lasts milliseconds and a tail group is worth launching 20-50 us late; round 3 spun here)
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (!(expectEnd > 0.0 && el > expectEnd - 100.0 && el < expectEnd + 200.0)) std::this_thread::sleep_for(std::chrono::microseconds(20));
         if (phase >= 6) continue;
         std::vector<unsigned char> grp((size_t)nc, 0);
         int64_t bins = 0;

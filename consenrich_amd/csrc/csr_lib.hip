@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <chrono>
@@ -171,6 +172,7 @@ struct csr_ctx {
     bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
     bool pfBlockedStale = false;        // ... Pf alone (default mode: the covariance chain of a pipelined step writes it in the reference layout only)
     bool sideSumsDone = false;          // the pending side-stream work already includes the per-chain sums (join_side only waits)
+    double lastSbLoopUs = 0.0;          // how long the host watched the previous single launch of the state chain (step_pipelined)
     double lastWaitUs[2] = {0.0, 0.0};  // how long the previous host wait for the stream lasted, per wait site (wait_stream polls around that moment)
     bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
     int pendEstep = 0;
