@@ -213,6 +213,7 @@ SYMBOLS = {
     "csr_batch_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, DP, DP]),
     "csr_batch_step_forward": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, DP, DP]),
     "csr_batch_objective_terms": (C.c_int, [C.c_void_p, C.POINTER(ObjectiveCfg), C.POINTER(ObjectiveTerms)]),
+    "csr_batch_phase_tracks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, DP, DP, C.POINTER(C.c_int32)]),
     "csr_batch_forward_masked": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, DP, DP]),
     "csr_qseed_same_track": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), C.POINTER(QseedSampleCfg), DP, DP,
                                        DP, I64P, C.POINTER(QseedSampleDiag)]),

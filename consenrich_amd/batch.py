@@ -234,6 +234,20 @@ class DeviceBatch:
         L.check(self._lib.csr_batch_forward_masked(self._ctx, int(flags), mask, L.dp(sd), L.dp(sn)))
         return sd, sn
 
+    def phase_tracks(self, chain: int, pad: float, with_fit: bool = False, use_lambda: bool = False):
+        """Per-bin float64 tracks of one chain behind the two per-phase diagnostics of `runConsenrich` that read the (m, n)
+        matrices (csr_batch_phase_tracks): `rel` = smoothed level - weighted mean of the background-adjusted observations
+        (core.py:2663-2697); with_fit (a background proposal is resident): `fit` = sum_j iv (r - proposal)^2 and `cnt` = its
+        cell count (core.py:4546-4552, 4587-4596).  Returns (rel, fit or None, cnt or None)."""
+        n = self.chain_lens[chain]
+        rel = np.empty(n, np.float64)
+        fit = np.empty(n, np.float64) if with_fit else None
+        cnt = np.empty(n, np.int32) if with_fit else None
+        L.check(self._lib.csr_batch_phase_tracks(self._ctx, int(chain), int(bool(use_lambda)), float(pad), L.dp(rel),
+                                                 L.dp(fit) if with_fit else None,
+                                                 cnt.ctypes.data_as(C.POINTER(C.c_int32)) if with_fit else None))
+        return rel, fit, cnt
+
     def objective_terms(self, nu: float, lam_first: float, lam: float, negative_penalty_multiplier=1.0, pad=1.0e-4,
                         use_lambda_penalty=False, use_kappa_penalty=True, use_lambda_weights=False, use_nonnegative=True):
         """Everything of the reference's penalised objective (core.py:4418-4538) except the forward NLL, per chain, from

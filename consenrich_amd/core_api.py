@@ -19,9 +19,11 @@ only, core.py:3900-3901) and its logging knobs (logIndentLevel, logRunRole) are 
 `cforwardPass` / `cforwardPassLevel` (core.py:4284, 4391), whose loops never read it (pyx:6393-6632) -- this
 package's own `cforwardPass` mirror accepts and ignores it the same way.  `intervalSizeBP` feeds the one diagnostic it
 feeds there (relative sign changes per kb, core.py:2647-2700, 4980).
-The run-diagnostics mapping carries the reference's complete key set (core.py:5943-5999); the only values reported as None
-that the reference computes are the `background_objective*` entries of `post_process_noise_fit` (a diagnostic of the background
-solve that enters no stop rule; `ChainFit.post_process_noise_fit`)."""
+The run-diagnostics mapping carries the reference's complete key set (core.py:5943-5999), and every record of
+`post_process_noise_fit["fixed_background_ecm"]` the keys the reference's own contract test reads (test_core.py:4111-4163:
+multiplier summaries and bound hits, sign-change rate, background-fit objective, the ECM's convergence state and -- with
+`trackOptimizationPath` -- its per-iteration rows): `PassDiagnostics`, from per-bin tracks the device forms out of the resident
+matrices (`csr_batch_phase_tracks`) and (n,) tracks downloaded per phase, only when `returnDiagnostics` asks for them."""
 from __future__ import annotations
 
 import operator
@@ -536,7 +538,15 @@ def relative_sign_change_per_kb(state_level, data, munc, *, interval_size_bp, ba
         mean[k0:k1] = out
 
     _map_cols(cols, x.size)
-    arr = x - mean
+    return sign_change_per_kb(x - mean, interval_size_bp)
+
+
+def sign_change_per_kb(values, interval_size_bp):
+    """core._signChangePerKB (core.py:2614-2644): sign changes of a track per kb of its span; values below 1 % of the mean
+    magnitude (and exact zeros) do not count as a side."""
+    if values is None or interval_size_bp is None or int(interval_size_bp) <= 0:
+        return None
+    arr = np.asarray(values, np.float64).reshape(-1)
     if arr.size == 0:
         return None
     fin = arr[np.isfinite(arr)]
@@ -554,6 +564,157 @@ def relative_sign_change_per_kb(state_level, data, munc, *, interval_size_bp, ba
     if not np.isfinite(span_kb) or span_kb <= 0.0:
         return None
     return metadata_float(float(changes) / span_kb)
+
+
+def multiplier_summary(values, lower, upper, skip_first=False):
+    """core._observationLambdaSummary / _processKappaSummary (core.py:2338-2375): (mean, median) of the finite multipliers clipped
+    to their bounds; the first kappa multiplies nothing and is left out (skip_first).  A float32 track is selected in float32
+    (half the bytes to partition) and averaged in float64: the same two numbers as the reference's float64 expressions, since
+    float32 -> float64 is exact and order-preserving."""
+    if values is None:
+        return None, None
+    arr = np.asarray(values).reshape(-1)
+    if arr.dtype != np.float32:
+        arr = arr.astype(np.float64)
+    if skip_first and arr.size > 1:
+        arr = arr[1:]
+    ok = np.isfinite(arr)
+    fin = arr if bool(ok.all()) else arr[ok]
+    if fin.size == 0:
+        return None, None
+    clipped = np.clip(fin, fin.dtype.type(lower), fin.dtype.type(upper)) if fin.dtype == np.float32 and \
+        float(np.float32(lower)) == float(lower) and float(np.float32(upper)) == float(upper) else \
+        np.clip(fin.astype(np.float64), float(lower), float(upper))
+    k = clipped.size // 2
+    if clipped.size % 2:
+        median = float(np.partition(clipped, k)[k])
+    else:
+        part = np.partition(clipped, [k - 1, k])
+        median = (float(part[k - 1]) + float(part[k])) / 2.0
+    return metadata_float(float(np.mean(clipped.astype(np.float64, copy=False)))), metadata_float(median)
+
+
+def background_fit_objective(data, munc, state_level, lam, background, *, pad, lambda_bounds, penalties, use_nonnegative,
+                             negative_penalty_multiplier) -> dict:
+    """`_scoreBackgroundFitObjective` (core.py:4540-4606) of a background PROPOSAL against the phase that produced it, with the
+    matrices that phase's update forms (core.py:5064-5076): float32 inverse variances 1 / max(munc + pad, 1e-8) times the
+    clipped observation precision, float32 residuals data - smoothed level; then in float64
+    0.5 sum w (r - g)^2 + roughness penalties (`_backgroundObjectivePenalty`, core.py:3182-3204) + negative-part penalty
+    0.5 (multiplier x median positive weight track) sum min(g, 0)^2, per finite cell of positive weight.
+    Evaluated range by range (`_map_cols`); the per-range sums are added in order."""
+    d, v = np.asarray(data, np.float32), np.asarray(munc, np.float32)
+    n = d.shape[1]
+    x = np.asarray(state_level, np.float32).reshape(-1)
+    g = np.asarray(background, np.float64).reshape(-1)
+    prec = None if lam is None else np.clip(np.asarray(lam, np.float32).reshape(1, n), np.float32(lambda_bounds[0]),
+                                            np.float32(lambda_bounds[1])).astype(np.float32)
+    track = np.zeros(n)
+
+    def cols(k0, k1):
+        inv = (np.float32(1.0) / np.maximum(v[:, k0:k1] + np.float32(pad), np.float32(1.0e-8))).astype(np.float32)
+        if prec is not None:
+            inv *= prec[:, k0:k1]
+        res = d[:, k0:k1] - x[None, k0:k1]
+        inv64, res64 = inv.astype(np.float64), res.astype(np.float64)
+        fit = res64 - g[None, k0:k1]
+        track[k0:k1] = np.sum(inv64, axis=0, dtype=np.float64)
+        return (float(np.sum(inv64 * fit * fit, dtype=np.float64)),
+                int(np.count_nonzero(np.isfinite(res64) & np.isfinite(inv64) & (inv64 > 0.0))))
+
+    parts = _map_cols(cols, n)
+    weighted = 0.5 * float(sum(p[0] for p in parts))
+    count = float(max(1, sum(p[1] for p in parts)))
+    lam_first, lam_second = penalties
+    d1 = np.diff(g)
+    first = 0.5 * float(lam_first) * float(np.dot(d1, d1)) if g.size >= 2 else 0.0
+    d2 = np.diff(g, n=2)
+    second = 0.5 * float(lam_second) * float(np.dot(d2, d2)) if g.size >= 3 else 0.0
+    negative = 0.0
+    mult = negative_penalty_multiplier
+    if use_nonnegative and mult is not None and float(mult) > 0.0:
+        pos = track[np.isfinite(track) & (track > 0.0)]
+        scale = float(np.median(pos)) if pos.size else 1.0
+        if not np.isfinite(scale) or scale <= 0.0:
+            scale = 1.0
+        negative = 0.5 * float(float(mult) * scale) * float(np.sum(np.minimum(g, 0.0) ** 2, dtype=np.float64))
+    objective = float(weighted + (first + second) + negative)
+    return {"background_weighted_residual_objective": weighted, "background_smoothness_penalty": float(first + second),
+            "background_first_difference_penalty": float(first), "background_second_difference_penalty": float(second),
+            "background_negative_penalty": float(negative), "background_objective": objective,
+            "background_objective_per_cell": float(objective / count), "background_effective_observation_count": count}
+
+
+class PassDiagnostics:
+    """The per-phase summaries the reference computes from its host arrays after every fixed-background ECM phase
+    (core.py:4946-4990 in the loop, :5456-5517 for the final phase) and after every background proposal (:5161-5197), for any
+    chain of a batch.  The two that read the (m, n) matrices -- the sign-change rate and the weighted residual term of the
+    background-fit objective -- come as per-bin float64 tracks from the device (`DeviceBatch.phase_tracks`: the reference's
+    per-cell arithmetic on the resident matrices); everything else is O(n) on (n,) tracks downloaded per phase.  They are
+    diagnostics only (no stop rule reads them): `driver.fit_batch` runs without this object unless they were asked for
+    (`returnDiagnostics`)."""
+
+    def __init__(self, cfg: FitConfig, model: ModelParams, interval_size_bp):
+        self.cfg, self.model, self.interval_size_bp = cfg, model, interval_size_bp
+        self.previous_per_cell = {}
+
+    def _phase(self, batch, c, with_fit):
+        cfg = self.cfg
+        batch.export(L.EXPORT_MULT)
+        lam = batch.download(c, "lambda") if cfg.use_lambda else None
+        kap = batch.download(c, "kappa") if cfg.use_kappa else None
+        lam_b, kap_b = self.model.lambda_bounds, self.model.kappa_bounds
+        lam_mean, lam_median = multiplier_summary(lam, *lam_b)
+        kap_mean, kap_median = multiplier_summary(kap, *kap_b, skip_first=True)
+        lam_lo, lam_hi = precision_bound_hits(lam, *lam_b)
+        kap_lo, kap_hi = precision_bound_hits(kap, *kap_b, skip_first=True)
+        rel, fit, cnt = batch.phase_tracks(c, float(cfg.pad), with_fit=with_fit, use_lambda=cfg.use_lambda)
+        out = {"observation_lambda_mean": lam_mean, "observation_lambda_median": lam_median,
+               "process_kappa_mean": kap_mean, "process_kappa_median": kap_median,
+               "observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
+               "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
+               "relative_sign_change_per_kb": sign_change_per_kb(rel, self.interval_size_bp)}
+        return out, fit, cnt
+
+    def phase(self, batch, c) -> dict:
+        """after an ECM phase that no background update follows (the final phase; the single phase without a background fit)"""
+        return self._phase(batch, c, False)[0]
+
+    def loop_pass(self, batch, c, update_info) -> dict:
+        """after `background_update` (its per-chain record: `update_info`), BEFORE `background_apply`: the phase's summaries and
+        the objective of the proposal (`_scoreBackgroundFitObjective`, core.py:4540-4606) with its pass-to-pass test"""
+        cfg = self.cfg
+        out, fit, cnt = self._phase(batch, c, True)
+        g = np.asarray(batch.download(c, "background_next"), np.float64)
+        weighted = 0.5 * float(np.sum(fit, dtype=np.float64))
+        count = float(max(1, int(np.sum(cnt, dtype=np.int64))))
+        lam_first, lam_second = cfg.penalties
+        d1, d2 = np.diff(g), np.diff(g, n=2)
+        first = 0.5 * float(lam_first) * float(np.dot(d1, d1)) if g.size >= 2 else 0.0
+        second = 0.5 * float(lam_second) * float(np.dot(d2, d2)) if g.size >= 3 else 0.0
+        negative = 0.0
+        mult = cfg.neg_multiplier
+        if cfg.use_nonnegative and mult is not None and float(mult) > 0.0:
+            # median of the positive weight track: the update's own (same float32 inverse variances, core.py:4562-4575 / 8287-8296)
+            scale = float(update_info.get("weight_scale", 1.0))
+            if not np.isfinite(scale) or scale <= 0.0:
+                scale = 1.0
+            negative = 0.5 * float(float(mult) * scale) * float(np.sum(np.minimum(g, 0.0) ** 2, dtype=np.float64))
+        objective = float(weighted + (first + second) + negative)
+        cur, prev = objective / count, self.previous_per_cell.get(c, float("nan"))
+        change = tol = float("nan")
+        stable = False
+        if np.isfinite(prev) and np.isfinite(cur):                                       # core.py:5172-5194
+            change = abs(cur - prev)
+            tol = float(cfg.outer_nll_rtol) * max(abs(cur), abs(prev), 1.0)
+            stable = bool(change <= tol)
+        self.previous_per_cell[c] = cur
+        out.update({"background_objective": metadata_float(objective), "background_objective_per_cell": metadata_float(cur),
+                    "background_objective_change_per_cell": metadata_float(change),
+                    "background_objective_threshold_per_cell": metadata_float(tol),
+                    "background_objective_stable": stable,
+                    "background_weighted_residual_objective": metadata_float(weighted),
+                    "background_fit_effective_observation_count": int(count)})
+        return out
 
 
 def _metadata_value(value):
@@ -642,15 +803,22 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
     nis = np.asarray(final["NIS"], np.float64)
     nis = nis[np.isfinite(nis)]
     lam_b, kap_b = plan.model.lambda_bounds, plan.model.kappa_bounds
-    # the multipliers of the last ECM phase are the final ones (the final pass runs WITH them): bound-hit fractions (core.py:5473-5484)
-    lam_lo, lam_hi = precision_bound_hits(lam, *lam_b)
-    kap_lo, kap_hi = precision_bound_hits(kap, *kap_b, skip_first=True)
-    post = fit.post_process_noise_fit(cfg, extras={
-        "observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
-        "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
-        "relative_sign_change_per_kb": relative_sign_change_per_kb(
-            fit.ecm_state_level, plan.data, plan.munc, interval_size_bp=plan.interval_size_bp,
-            background=final.get("background"), pad=float(cfg.pad))})
+    # the fit-level copies of the LAST phase's summaries (core.py:5473-5517 -> 5622-5627): taken from that phase's record when the
+    # fit ran with `PassDiagnostics`, else evaluated here (the multipliers of the last ECM phase are the final ones)
+    last = fit.loop_diagnostics[-1] if fit.loop_diagnostics else {}
+    keys = ("observation_lambda_lower_bound_hits", "observation_lambda_upper_bound_hits", "process_kappa_lower_bound_hits",
+            "process_kappa_upper_bound_hits", "relative_sign_change_per_kb")
+    if all(k in last for k in keys):
+        extras = {k: last[k] for k in keys}
+    else:
+        lam_lo, lam_hi = precision_bound_hits(lam, *lam_b)
+        kap_lo, kap_hi = precision_bound_hits(kap, *kap_b, skip_first=True)
+        extras = {"observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
+                  "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
+                  "relative_sign_change_per_kb": relative_sign_change_per_kb(
+                      fit.ecm_state_level, plan.data, plan.munc, interval_size_bp=plan.interval_size_bp,
+                      background=final.get("background"), pad=float(cfg.pad))}
+    post = fit.post_process_noise_fit(cfg, extras=extras)
     # process-noise calibration record (core.py:5686-5737, 5921-5942)
     support = process_noise_calibration_support(plan.data, plan.munc, float(cfg.pad))
     q_full = np.zeros((2, 2), np.float64)
@@ -805,7 +973,9 @@ def run_plan(plan: RunPlan, device: int = 0):
             initial_background=None if plan.initial_background is None else [plan.initial_background],
             return_background=True, return_precision_diagnostics=True, download=True,
             initial_lambda=plan.initial_lambda is not None, initial_kappa=plan.initial_kappa is not None,
-            keep_ecm_state=bool(plan.ret["diagnostics"]) and plan.interval_size_bp is not None)
+            keep_ecm_state=False,
+            pass_diagnostics=PassDiagnostics(cfg, plan.model, plan.interval_size_bp) if plan.ret["diagnostics"] else None,
+            track_path=bool(plan.ret["track_path"]))
         fit, res = fits[0], results[0]
         final = {"stateSmoothed": res[0], "stateCovarSmoothed": res[1], "postFitResiduals": res[2], "NIS": res[3],
                  "intervalToBlockMap": res[4], "background": res[5], "outputTracks": res[6]["outputTracks"],

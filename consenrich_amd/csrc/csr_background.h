@@ -515,6 +515,55 @@ __global__ __launch_bounds__(256) void k_bg_batch_stats(Prm p, BgBatch a) {
     a.rhs[g] = rs;
 }
 
+// the two per-phase diagnostics of `runConsenrich` that read the (m, n) matrices, per bin of ONE chain:
+//   rel = level - inverse-variance weighted mean of the background-adjusted observations, the reference's row-by-row float64
+//         accumulation (core.py:2663-2697: finite data, finite positive munc + pad, w = 1 / max(munc + pad, 1e-12)); NaN where no
+//         observation counts;
+//   fit = sum_j iv (r - g)^2, cnt = #cells with finite r and finite positive iv -- the matrices of the background update
+//         (float32 iv = 1 / max(munc + pad, 1e-8) (* clip(lambda)), float32 r = data - level; core.py:5064-5076) against the
+//         PROPOSAL g in float64 (core.py:4546-4552, 4587-4596).
+struct PhaseArgs {
+    int64_t off, len, Npad;
+    int m, xsStride, useLambda, withFit;
+    const float *data, *munc, *xsNat, *lamNat, *bgCur, *bgNext;
+    float padf, wMinf, wMaxf;
+    double pad;
+    double *rel, *fit;
+    int *cnt;
+};
+__global__ __launch_bounds__(256) void k_phase_tracks(PhaseArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.len) return;
+    const int64_t g = a.off + i;
+    const float lvl = a.xsNat[g * a.xsStride];
+    const double x = (double)lvl, bg = a.bgCur ? (double)a.bgCur[g] : 0.0;
+    const bool xok = isfinite(x);
+    float lam = 1.f;
+    if (a.useLambda) lam = fminf(fmaxf(a.lamNat[g], a.wMinf), a.wMaxf);
+    const double gn = a.withFit ? (double)a.bgNext[g] : 0.0;
+    double tot = 0.0, ws = 0.0, f = 0.0;
+    int cn = 0;
+    for (int j = 0; j < a.m; ++j) {
+        const float d32 = a.data[(int64_t)j * a.Npad + g], v32 = a.munc[(int64_t)j * a.Npad + g];
+        const double row = (double)d32, den = (double)v32 + a.pad;
+        if (xok && isfinite(row) && isfinite(den) && den > 0.0) {
+            const double w = 1.0 / fmax(den, 1.0e-12);
+            tot += (row - bg) * w;
+            ws += w;
+        }
+        if (a.withFit) {
+            float iv = __fdiv_rn(1.0f, fmaxf(v32 + a.padf, 1.0e-8f));
+            if (a.useLambda) iv *= lam;
+            const float res = d32 - lvl;
+            const double iv64 = (double)iv, fr = (double)res - gn;
+            f += iv64 * fr * fr;
+            cn += (isfinite(res) && isfinite(iv) && iv > 0.0f) ? 1 : 0;
+        }
+    }
+    a.rel[i] = ws > 0.0 ? x - tot / ws : __longlong_as_double(0x7ff8000000000000ll);
+    if (a.withFit) { a.fit[i] = f; a.cnt[i] = cn; }
+}
+
 constexpr int BG_GPW = 32;           // 64-bin groups per wavefront record
 
 // mode 0: maskPrev = (current background < 0)  (initialBackground, core.py:8306-8316)

@@ -845,6 +845,59 @@ extern "C" int csr_batch_objective_terms(csr_ctx *c, const csr_objective_cfg *cf
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// per-phase diagnostics tracks of one chain (k_phase_tracks) -- what `runConsenrich` evaluates on the host after
+// every fixed-background ECM phase (core.py:4980, 5485) and every background proposal (core.py:5161), from resident arrays
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int csr_batch_phase_tracks(csr_ctx *c, int32_t chain, int32_t use_lambda, double pad, double *rel, double *fit,
+                                      int32_t *cnt) {
+    CHECK(need(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (!rel) return fail("null argument");
+    if ((fit == nullptr) != (cnt == nullptr)) return fail("fit and cnt go together");
+    if (!std::isfinite(pad) || pad < 0.0) return fail("pad must be finite and nonnegative");
+    CHECK(settle(c));
+    if (!c->haveBwd) return fail("smoothed state not resident: run the ECM / forward-backward pass first");
+    const bool withFit = fit != nullptr;
+    if (withFit && !c->bg.ready) return fail("no background proposal: run csr_batch_background_update first");
+    const bool useLam = withFit && use_lambda;
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+        if (useLam) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        CHECK(flush_export(c, L));
+    }
+    const int64_t n = c->chains[chain].n;
+    PhaseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.off = c->chains[chain].off; a.len = n; a.Npad = c->Npad;
+    a.m = c->p.m; a.xsStride = c->mdl.state_dim; a.useLambda = useLam ? 1 : 0; a.withFit = withFit ? 1 : 0;
+    a.data = c->p.data; a.munc = c->p.munc; a.xsNat = c->nat[CSR_ARR_XS];
+    a.lamNat = useLam ? c->nat[CSR_ARR_LAMBDA] : nullptr;
+    a.bgCur = c->bg.haveCur ? c->nat[CSR_ARR_BACKGROUND] : nullptr;
+    a.bgNext = withFit ? c->bg.bat.bgNext : nullptr;
+    a.padf = (float)c->mdl.pad; a.wMinf = (float)c->mdl.w_min; a.wMaxf = (float)c->mdl.w_max;
+    a.pad = pad;
+    if (n == 0) return 0;
+    const size_t bytesD = ((size_t)n * 8 + 255) / 256 * 256;
+    CHECK(c->qsBuf.reserve(2 * bytesD + (size_t)n * 4));
+    char *base = (char *)c->qsBuf.ptr;
+    a.rel = (double *)base; a.fit = (double *)(base + bytesD); a.cnt = (int *)(base + 2 * bytesD);
+    {
+        Scope sc(c, "phase_tracks");
+        hipLaunchKernelGGL(k_phase_tracks, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    }
+    LAUNCH_CHECK("k_phase_tracks");
+    HIPOK(hipMemcpyAsync(rel, a.rel, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (withFit) {
+        HIPOK(hipMemcpyAsync(fit, a.fit, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipMemcpyAsync(cnt, a.cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPOK(wait_stream(c));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
 // ---------------------------------------------------------------------------------------------------------------
 static int fold_stage(csr_ctx *c, size_t bytes, char **base) {

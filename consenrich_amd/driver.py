@@ -141,9 +141,17 @@ class ChainFit:
         core.py:3355-3417) with its complete key set.  `extras`: values only the caller can compute from host arrays (the
         multiplier bound-hit fractions, the sign-change rate).  The `background_objective*` keys -- a diagnostic of the
         background solve alone that enters no stop rule (core.py:5160-5197; the rule reads the shift, the OUTER objective and the
-        inner convergence, :5252-5376) -- are not computed on this path and are reported as None."""
+        inner convergence, :5252-5376) -- come from the last in-loop record when the fit ran with `pass_diagnostics`
+        (`core_api.runConsenrich` with returnDiagnostics does), else None."""
         def finite(v):
             return None if (v is None or not math.isfinite(float(v))) else float(v)
+
+        def scalar(v):              # core._diagnosticScalar (core.py:2315-2327): plain Python values, non-finite floats -> None
+            if isinstance(v, np.generic):
+                v = v.item()
+            if isinstance(v, float):
+                return v if math.isfinite(v) else None
+            return v
 
         loop = [r for r in self.loop_diagnostics if not r.get("final_fixed_background_ecm")]
         last = loop[-1] if loop else {}
@@ -166,9 +174,11 @@ class ChainFit:
             "outer_stop_reason": str(self.outer_stop_reason),
             "background_shift": finite(last.get("background_shift", 0.0)),
             "background_shift_threshold": finite(last.get("background_shift_threshold")),
-            "background_objective": None, "background_objective_per_cell": None,
-            "background_objective_change_per_cell": None, "background_objective_threshold_per_cell": None,
-            "background_objective_stable": False,
+            "background_objective": finite(last.get("background_objective")),
+            "background_objective_per_cell": finite(last.get("background_objective_per_cell")),
+            "background_objective_change_per_cell": finite(last.get("background_objective_change_per_cell")),
+            "background_objective_threshold_per_cell": finite(last.get("background_objective_threshold_per_cell")),
+            "background_objective_stable": bool(last.get("background_objective_stable", False)),
             "outer_nll": finite(fwd[-1]) if fwd else None, "outer_nll_change": finite(nll_change),
             "outer_nll_threshold": finite(nll_tol), "outer_nll_stable": nll_stable,
             "outer_objective": finite(last.get("outer_objective")),
@@ -186,7 +196,8 @@ class ChainFit:
             "warm_start": dict(self.warm_start),
             "all_ecm_converged": (bool(conv) and all(conv)) if conv else None,
             "max_nll_increase_count": max(incr) if incr else None,
-            "fixed_background_ecm": [dict(r) for r in self.loop_diagnostics],
+            "fixed_background_ecm": [{k: ([dict(row) for row in v] if k == "optimization_path" else scalar(v))
+                                      for k, v in r.items()} for r in self.loop_diagnostics],
         }
         if extras:
             out.update(extras)
@@ -200,8 +211,35 @@ def warm_start_source(cfg: "FitConfig") -> str:
     return "zero_centered_banded_weighted_data" if cfg.zero_center else "banded_weighted_data"
 
 
+def ecm_phase_record(out, path, cfg: "FitConfig", outer_pass: int, track_path: bool = False) -> dict:
+    """One ECM phase as the reference records it: the diagnostics mapping `cfixedBackgroundECM(..., returnDiagnostics=True)`
+    returns (pyx:8404-8440: iteration counts, convergence state, first / last NLL; with `trackOptimizationPath` the per-iteration
+    rows of pyx:8337-8402) after `_normalizeFixedBackgroundECMDiagnostics` (core.py:3336-3352: source and outer pass added),
+    from the batch ECM's per-chain record and NLL path.  A phase on <= 5 bins is the filter + smoother fallback (pyx:7998-8129):
+    zero iterations, `skipped`, not converged -- like there."""
+    from .cconsenrich import _replay_path
+
+    skipped = bool(out.skipped)
+    inner_ok = bool(out.converged) and not skipped
+    hi = bool(out.has_initial_nll) and not skipped
+    rec = {"iters_done": 0 if skipped else int(out.iters_done), "max_iters": int(cfg.ecm_iters), "converged": inner_ok,
+           "skipped": skipped, "skip_reason": "too_few_intervals" if skipped else None,
+           "fallback": "filter_smoother_only" if skipped else None,
+           "stable_iters": 0 if skipped else int(out.stable_iters), "patience_target": 2,
+           "initial_nll": float(out.final_nll) if skipped else (float(out.initial_nll) if hi else None),
+           "final_nll": float(out.final_nll),
+           "final_abs_rel_change": float(out.abs_rel_change) if hi else None,
+           "final_rel_improvement": float(out.rel_improvement) if hi else None,
+           "nll_increase_count": 0 if skipped else int(out.nll_increase_count),
+           "diagnostics_source": "cfixedBackgroundECM", "outer_pass": int(outer_pass)}
+    if track_path:
+        rows = [] if skipped else [float(v) for v in np.asarray(path)[: int(out.iters_done)]]
+        rec["optimization_path"] = _replay_path("", rows, float(np.float32(cfg.ecm_rtol)), False)
+    return rec
+
+
 def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False, initial_lambda: bool = False,
-              initial_kappa: bool = False) -> List[ChainFit]:
+              initial_kappa: bool = False, pass_diagnostics=None, track_path: bool = False) -> List[ChainFit]:
     """Steps 0-2 (the alternation loop, core.py:4860-5376) on a configured batch with data uploaded.  The fit that is
     resident afterwards is the one of each chain's last in-loop ECM phase against the background of THAT phase -- the
     reference never returns it: `run_consenrich_batch` continues with the final phases.  keep_background: start from the
@@ -209,7 +247,11 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
     initial_lambda / initial_kappa: the caller uploaded warm-start multipliers (`upload_multipliers`; the reference's
     initialObservationPrecision / initialProcessPrecision): the first ECM phase starts from them either way (they are the
     resident multipliers); an initial lambda also weights the background warm start (core.py:4663-4676 passes
-    observationPrecision = lambdaExpLocal), and both are recorded in the warm-start summary (core.py:4689-4695)."""
+    observationPrecision = lambdaExpLocal), and both are recorded in the warm-start summary (core.py:4689-4695).
+    pass_diagnostics: optional object with `loop_pass(batch, chain, update_record)` / `phase(batch, chain)` returning the per-phase summaries
+    the reference computes on the host (multiplier means / medians / bound hits, sign-change rate, background-fit
+    objective; core.py:4946-4990, 5161-5197) -- `core_api.PassDiagnostics`; they are merged into the phase records and enter
+    no decision.  track_path: keep the per-iteration rows of every ECM phase (`trackOptimizationPath`)."""
     nc = len(batch.chain_lens)
     fits = [ChainFit() for _ in range(nc)]
     active = [True] * nc
@@ -252,9 +294,9 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
     for p in range(planned):
         if not have_stats:
             batch.stats()
-        outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn,
-                            chain_mask=active)
+        outs, paths = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
+                                use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn,
+                                chain_mask=active)
         for c in range(nc):
             if active[c]:
                 fits[c].ecm_iters.append(int(outs[c].iters_done))
@@ -264,16 +306,22 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
             for c in range(nc):                         # core.py:4994-5062: one phase, no background model
                 fits[c].converged = True
                 fits[c].outer_stop_reason = "fit_background_false"
-                fits[c].loop_diagnostics.append({"outer_pass": 1, "iters_done": int(outs[c].iters_done),
-                                                 "final_nll": float(outs[c].final_nll),
-                                                 "converged": bool(outs[c].converged) or bool(outs[c].skipped == 1),
-                                                 "background_shift": 0.0, "background_shift_threshold": 0.0})
+                rec = ecm_phase_record(outs[c], paths[c], cfg, 1, track_path)
+                rec.update({"background_shift": 0.0, "background_shift_threshold": 0.0, "background_shift_stable": True})
+                if pass_diagnostics is not None:                    # core.py:5009-5033
+                    rec.update(pass_diagnostics.phase(batch, c))
+                rec.update({"outer_inner_ecm_converged": bool(rec["converged"]), "outer_stable_iters": 0,
+                            "outer_patience_target": int(cfg.patience)})
+                fits[c].loop_diagnostics.append(rec)
             break
         info = batch.background_update(cfg.penalties[0], cfg.penalties[1], zero_center=cfg.zero_center,
                                        use_nonnegative=cfg.use_nonnegative,
                                        negative_penalty_multiplier=cfg.neg_multiplier, use_lambda=cfg.use_lambda,
                                        use_initial=True)
         take = list(active)
+        # host-side summaries of the phase and of the proposal (they read the CURRENT background and the proposal: before the apply)
+        extra = [pass_diagnostics.loop_pass(batch, c, info[c]) if (pass_diagnostics is not None and active[c]) else {}
+                 for c in range(nc)]
         batch.background_apply(take)            # the proposal of a pass is always adopted (core.py:5243)
         # penalised objective of the adopted background (core.py:5248-5251)
         batch.stats()
@@ -298,17 +346,15 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
             prev_obj[c] = cur
             fits[c].objective.append(dict(t, forward_nll=float(fnll[c]), penalized_objective=obj,
                                           penalized_objective_per_cell=cur, stable=obj_stable))
-            inner_ok = bool(outs[c].converged) or bool(outs[c].skipped == 1)
+            rec = ecm_phase_record(outs[c], paths[c], cfg, p + 1, track_path)
+            inner_ok = bool(rec["converged"])
             ok = gate["background_shift_stable"] and obj_stable and inner_ok
             stable[c] = stable[c] + 1 if ok else 0
             last_inner[c], last_obj_stable[c] = inner_ok, obj_stable
             tol_obj = cfg.outer_nll_rtol * max(abs(cur), abs(fits[c].objective[-2]["penalized_objective_per_cell"]), 1.0) \
                 if len(fits[c].objective) >= 2 else float("nan")
             fits[c].loop_diagnostics.append({
-                "outer_pass": p + 1, "iters_done": int(outs[c].iters_done), "max_iters": int(cfg.ecm_iters),
-                "final_nll": float(outs[c].final_nll), "converged": inner_ok,
-                "nll_increase_count": int(outs[c].nll_increase_count), "diagnostics_source": "cfixedBackgroundECM",
-                **gate,
+                **rec, **extra[c], **gate,
                 "outer_ecm_fit_nll": float(outs[c].final_nll), "outer_forward_nll": float(fnll[c]),
                 "outer_objective": obj, "outer_objective_per_cell": cur,
                 "outer_objective_change_per_cell": abs(cur - fits[c].objective[-2]["penalized_objective_per_cell"])
@@ -376,7 +422,8 @@ def precision_diagnostics(batch: DeviceBatch, cfg: FitConfig, chain: int, q0, st
 def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_intervals: int, model_q0=None,
                          initial_background=None, return_background: bool = True,
                          return_precision_diagnostics: bool = True, download: bool = True,
-                         initial_lambda: bool = False, initial_kappa: bool = False, keep_ecm_state: bool = False):
+                         initial_lambda: bool = False, initial_kappa: bool = False, keep_ecm_state: bool = False,
+                         pass_diagnostics=None, track_path: bool = False):
     """Steps 0-5 of the module docstring.  Returns (fits, results): `fits` the per-chain history, `results` one tuple per
     chain in the reference's order (core.py:6126-6142 with returnScales=True): (stateSmoothed (n,2) float32,
     stateCovarSmoothed (n,2,2), postFitResiduals (n,m), NIS (n,), intervalToBlockMap (n,) int32[, background (n,)]
@@ -389,7 +436,8 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     warm start from the weighted data when the background is fitted (core.py:4663), zeros otherwise.
     initial_lambda / initial_kappa: warm-start multipliers were uploaded (`fit_batch`).
     keep_ecm_state: keep the smoothed level of every chain's LAST ECM phase on the host (`ChainFit.ecm_state_level`; the
-    reference's sign-change diagnostic reads that state, core.py:4980 / 5485 -- not the final pass's)."""
+    reference's sign-change diagnostic reads that state, core.py:4980 / 5485 -- not the final pass's).
+    pass_diagnostics / track_path: `fit_batch`; the final phase's record gets the same summaries (core.py:5456-5517)."""
     nc = len(batch.chain_lens)
     d = batch.d
     cfg = FitConfig(**{**cfg.__dict__})
@@ -400,24 +448,24 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     else:
         cfg.background_warm_start = bool(cfg.fit_background)
     fits = fit_batch(batch, cfg, keep_background=initial_background is not None, initial_lambda=initial_lambda,
-                     initial_kappa=initial_kappa)
+                     initial_kappa=initial_kappa, pass_diagnostics=pass_diagnostics, track_path=track_path)
 
     mult_flags = (L.USE_LAMBDA if cfg.use_lambda else 0) | (L.USE_KAPPA if cfg.use_kappa else 0)
     apn_flag = (L.USE_APN | L.USE_QSCALE) if cfg.use_apn else 0      # (the resident qScale track is all ones: core.py:5688)
     if cfg.fit_background:
         # final fixed-background ECM phase (core.py:5385-5440): every chain, converged background, warm-started multipliers
         batch.stats()
-        outs, _ = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
-                            use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn)
+        outs, paths = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
+                                use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn)
         for c in range(nc):
-            fits[c].final_ecm_iters = int(outs[c].iters_done)
+            rec = ecm_phase_record(outs[c], paths[c], cfg, fits[c].passes + 1, track_path)         # core.py:5441-5455
+            rec["final_fixed_background_ecm"] = True
+            if pass_diagnostics is not None:
+                rec.update(pass_diagnostics.phase(batch, c))
+            fits[c].final_ecm_iters = int(rec["iters_done"])
             fits[c].final_ecm_nll = float(outs[c].final_nll)
-            fits[c].final_ecm_converged = bool(outs[c].converged) or bool(outs[c].skipped == 1)
-            fits[c].loop_diagnostics.append({"outer_pass": fits[c].passes + 1, "iters_done": int(outs[c].iters_done),     # core.py:5448-5455
-                                             "max_iters": int(cfg.ecm_iters), "final_nll": float(outs[c].final_nll),
-                                             "converged": fits[c].final_ecm_converged,
-                                             "nll_increase_count": int(outs[c].nll_increase_count),
-                                             "diagnostics_source": "cfixedBackgroundECM", "final_fixed_background_ecm": True})
+            fits[c].final_ecm_converged = bool(rec["converged"])
+            fits[c].loop_diagnostics.append(rec)
     if keep_ecm_state:
         # every chain's last ECM phase: the final one, or (no background fit) the loop's single phase -- a chain that left
         # the alternation early still took part in the final phase when there is one

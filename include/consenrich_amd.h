@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSR_ABI_VERSION 4
+#define CSR_ABI_VERSION 5
 
 /* ---- model / flags ------------------------------------------------------------------------------------- */
 
@@ -328,6 +328,18 @@ typedef struct csr_objective_terms {
     int64_t effective_observation_count;
 } csr_objective_terms;
 int csr_batch_objective_terms(csr_ctx *ctx, const csr_objective_cfg *cfg, csr_objective_terms *out);
+/* The two per-phase diagnostics of `runConsenrich` that read the (m, n) matrices, as per-bin float64 tracks of ONE chain from
+ * the resident data / variances, the smoothed level of the last ECM phase and the CURRENT background:
+ *   rel[i]  = level_i - sum_j (data_ji - bg_i) w_ji / sum_j w_ji with w_ji = 1 / max(munc_ji + pad, 1e-12), summed row by row in
+ *             float64 over the cells with finite data and finite positive munc_ji + pad, NaN where there is none: the track whose
+ *             sign changes per kb `_relativeSignChangePerKB` counts (core.py:2647-2700; called at core.py:4980, 5485);
+ *   fit[i]  = sum_j iv_ji (r_ji - g_i)^2, cnt[i] = #cells with finite r and finite positive iv (both NULL: skipped), with the
+ *             matrices of the background update (float32 iv = 1 / max(munc + pad, 1e-8) (* clip(lambda) if use_lambda), float32
+ *             r = data - level, model pad; core.py:5064-5076) and g = the PROPOSAL of the last csr_batch_background_update:
+ *             0.5 sum(fit) is `background_weighted_residual_objective`, sum(cnt) the effective observation count of
+ *             `_scoreBackgroundFitObjective` (core.py:4540-4606; called at core.py:5161).
+ * rel / fit: n doubles, cnt: n int32 (host).  The caller's part is O(n). */
+int csr_batch_phase_tracks(csr_ctx *ctx, int32_t chain, int32_t use_lambda, double pad, double *rel, double *fit, int32_t *cnt);
 /* csr_batch_forward for the chains with chain_mask[c] != 0 only (NULL: all); the others keep their resident results. */
 int csr_batch_forward_masked(csr_ctx *ctx, uint32_t flags, const unsigned char *chain_mask, double *sum_d,
                              double *sum_nll);

@@ -25,6 +25,7 @@ import numpy as np
 
 from . import background as bgo
 from . import oracle as orc
+from . import passdiag as pdg
 
 
 MASKED_HALF = 0.5 * float(np.float32(1.0e30))      # constants.py:387, core.py:2983-2985
@@ -104,6 +105,26 @@ def _apn_kwargs(cfg, n=None):
     return {"ECM_useAPN": True, "APN_minQ": float(cfg["apn"][0]), "APN_maxQ": float(cfg["apn"][1]), "processQScale": np.ones(int(n), np.float32)}
 
 
+def ecm_record(diag, iters, nll, cfg, outer_pass):
+    """core.py:3336-3352 `_normalizeFixedBackgroundECMDiagnostics` of the ECM's own mapping (pyx:8404-8440); the oracle's native
+    returns the NLL path as plain floats: with `track_path` they become the reference's per-iteration rows (pyx:8337-8402)."""
+    rec = {}
+    for key, value in dict(diag).items():
+        if isinstance(value, np.generic):
+            value = value.item()
+        if isinstance(value, float) and not np.isfinite(value):
+            value = None
+        rec[str(key)] = value
+    if "optimization_path" in rec:
+        rec["optimization_path"] = pdg.path_rows(rec["optimization_path"], cfg["ecm_rtol"])
+    rec.setdefault("iters_done", int(iters))
+    rec.setdefault("max_iters", int(cfg["ecm_iters"]))
+    rec.setdefault("final_nll", float(nll))
+    rec.setdefault("diagnostics_source", "cfixedBackgroundECM")
+    rec["outer_pass"] = int(outer_pass)
+    return rec
+
+
 def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, initial_kappa=None):
     data = np.ascontiguousarray(data, np.float32)
     munc = np.ascontiguousarray(munc, np.float32)
@@ -126,10 +147,12 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
               ECM_useObsPrecisionReweighting=cfg["use_lambda"], ECM_useProcessPrecisionReweighting=cfg["use_kappa"],
               obsPrecisionMultiplierMin=cfg["lambda_bounds"][0], obsPrecisionMultiplierMax=cfg["lambda_bounds"][1],
               procPrecisionMultiplierMin=cfg["kappa_bounds"][0], procPrecisionMultiplierMax=cfg["kappa_bounds"][1],
-              logIterations=False, **_apn_kwargs(cfg, n))
+              logIterations=False, trackOptimizationPath=bool(cfg.get("track_path")), **_apn_kwargs(cfg, n))
     if d == 2:
         kw["matrixF"] = np.asarray(cfg["F"], np.float32)
     out = None
+    prev_bg_obj = float("nan")
+    neg_active = bool(cfg["use_nonnegative"] and cfg["neg_multiplier"] is not None and cfg["neg_multiplier"] > 0.0)   # core.py:4078
     inner_ok = obj_stable = False
     for p in range(planned_outer_passes(cfg)):
         adj = np.ascontiguousarray(data - bg[None, :], dtype=np.float32)
@@ -137,15 +160,32 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
         iters, nll, xs, Ps, lag, res, lam, kap, diag = out
         hist["ecm_iters"].append(int(iters))
         hist["nll"].append(float(nll))
+        rec = ecm_record(diag, iters, nll, cfg, p + 1)
+        rec.update(pdg.phase_summaries(data, munc, xs[:, 0], lam, kap, bg, cfg))               # core.py:4946-4984
         if not cfg["fit_background"]:
             hist["converged"] = True                       # core.py:5038-5040
             hist["stop_reason"] = "fit_background_false"
+            rec.update({"background_shift": 0.0, "background_shift_threshold": 0.0, "background_shift_stable": True,
+                        "outer_inner_ecm_converged": bool(diag["converged"]), "outer_stable_iters": 0,
+                        "outer_patience_target": int(cfg["patience"])})
+            hist["loop"].append(rec)
             break
         w, r, _, _ = bgo.weight_rhs_tracks(data, munc, xs[:, 0], np.float32(cfg["pad"]),
                                            lam if cfg["use_lambda"] else None, cfg["lambda_bounds"])
         nxt, info = bgo.solve_background(w, r, 0, zero_center=cfg["zero_center"], use_nonnegative=cfg["use_nonnegative"],
                                          multiplier=cfg["neg_multiplier"], initial=bg,
                                          penalties_override=(lam_first, lam2), return_info=True)
+        # objective of the proposal against the phase that produced it (core.py:5161-5197)
+        inv_m, res_m = pdg.update_matrices(data, munc, xs[:, 0], lam if cfg["use_lambda"] else None, cfg["pad"], cfg["lambda_bounds"])
+        bgo_ = pdg.background_fit_objective(res_m, inv_m, nxt, lam_first, lam2, neg_active, cfg["neg_multiplier"])
+        cur_bg = bgo_["background_objective_per_cell"]
+        bg_change = bg_tol = float("nan")
+        bg_stable = False
+        if np.isfinite(prev_bg_obj) and np.isfinite(cur_bg):
+            bg_change = abs(cur_bg - prev_bg_obj)
+            bg_tol = cfg["outer_nll_rtol"] * max(abs(cur_bg), abs(prev_bg_obj), 1.0)
+            bg_stable = bool(bg_change <= bg_tol)
+        prev_bg_obj = cur_bg
         gate = background_shift_gate(w, nxt, bg, cfg["shift_rtol"])
         shift = gate["background_shift"]
         hist["shift"].append(shift)
@@ -174,7 +214,15 @@ def fit_chain(data, munc, cfg, initial_background=None, initial_lambda=None, ini
             stable += 1
         else:
             stable = 0
-        hist["loop"].append({"outer_pass": p + 1, "iters_done": int(iters), "final_nll": float(nll),
+        none = lambda v: float(v) if np.isfinite(v) else None                       # metadataFloat
+        hist["loop"].append({**rec,
+                             "background_objective": none(bgo_["background_objective"]),             # core.py:5273-5300
+                             "background_objective_per_cell": none(cur_bg),
+                             "background_objective_change_per_cell": none(bg_change),
+                             "background_objective_threshold_per_cell": none(bg_tol),
+                             "background_objective_stable": bg_stable,
+                             "background_weighted_residual_objective": none(bgo_["background_weighted_residual_objective"]),
+                             "background_fit_effective_observation_count": int(bgo_["background_effective_observation_count"]),
                              "converged": inner_ok, "background_shift": gate["background_shift"],
                              "background_shift_threshold": gate["background_shift_threshold"],
                              "background_shift_stable": gate["background_shift_stable"],
@@ -253,10 +301,13 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
         out = ecm(matrixData=adj, matrixPluginMuncInit=munc, lambdaExpInit=lam, processPrecExpInit=kap,
                   ECM_fixedBackgroundIters=cfg["ecm_iters"], ECM_fixedBackgroundRtol=cfg["ecm_rtol"],
                   t_innerIters=cfg["inner_iters"], ECM_robustTNu=cfg["nu"], returnIntermediates=True,
-                  returnDiagnostics=True, logIterations=False, **common)
+                  returnDiagnostics=True, logIterations=False, trackOptimizationPath=bool(cfg.get("track_path")), **common)
         iters, nll, _xs, _Ps, _lag, _res, lam, kap, diag = out
         ecm_xs_level = np.asarray(_xs, np.float32)[:, 0].copy()             # ... of the final phase (core.py:5485)
         final = dict(final_ecm_iters=int(iters), final_ecm_nll=float(nll), final_ecm_converged=bool(diag["converged"]))
+        final_rec = ecm_record(diag, iters, nll, cfg, hist["passes"] + 1)                      # core.py:5441-5455
+        final_rec["final_fixed_background_ecm"] = True
+        final_rec.update(pdg.phase_summaries(data, munc, ecm_xs_level, lam, kap, bg, cfg))      # core.py:5456-5517
     xf, Pf, pn = np.empty((n, d), np.float32), np.empty((n, d, d), np.float32), np.empty((n, d, d), np.float32)
     D = np.empty(n, np.float32)
     fwd = orc.cforwardPass if d == 2 else orc.cforwardPassLevel
@@ -278,9 +329,7 @@ def run_consenrich_chain(data, munc, cfg, initial_background=None, initial_lambd
                           "observation_precision": lam0 is not None, "process_precision": kap0 is not None}
     hist["ecm_calls"] = len(hist["ecm_iters"]) + (1 if cfg["fit_background"] else 0)
     if cfg["fit_background"]:
-        hist["loop"].append({"outer_pass": hist["passes"] + 1, "iters_done": final["final_ecm_iters"],
-                             "final_nll": final["final_ecm_nll"], "converged": final["final_ecm_converged"],
-                             "final_fixed_background_ecm": True})                             # core.py:5448-5455
+        hist["loop"].append(final_rec)
     hist.update(final, warm_start_passes=warm_passes, final_nll=float(nll), final_forward_nis=float(phi),
                 out_xs=np.asarray(xs, np.float32), out_Ps=np.asarray(Ps, np.float32), out_resid=np.asarray(res, np.float32),
                 out_NIS=np.asarray(D, np.float32), out_block_map=bm, out_background=bg, out_lam=lam, out_kap=kap,

@@ -61,14 +61,17 @@ if not os.environ.get("NO_CORE_API"):
               t_innerIters=5, ECM_robustTNu=8.0, ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=True,
               ECM_useAPN=False, ECM_outerIters=8, ECM_minOuterIters=3, ECM_backgroundShiftRtol=5.0e-3, ECM_outerNLLRtol=5.0e-5,
               ECM_backgroundSmoothness=128.0, fitBackground=True, returnScales=True, returnBackground=True,
-              initialProcessQ=np.diag([1e-3, 1e-4]).astype(np.float32), returnPrecisionDiagnostics=True)
+              initialProcessQ=np.diag([1e-3, 1e-4]).astype(np.float32), returnPrecisionDiagnostics=True,
+              # ... and what the CLI itself asks for on every chromosome (consenrich.py:9216, 9241-9243): the run diagnostics with
+              # their per-phase records (device tracks + O(n) host summaries per ECM phase, core_api.PassDiagnostics)
+              intervalSizeBP=200, returnDiagnostics=True)
     with DeviceBatch(0) as gen:                     # the bench recipe's matrices, brought to the host once (not timed)
         gen.configure(ModelParams(state_dim=2), m, lengths)
         gen.synthesize(1234)
         host = [gen.download_inputs(c) for c in range(len(lengths))]
 
-    def one_call(d_, v_):
-        k = dict(kw)
+    def one_call(d_, v_, diagnostics=True):
+        k = dict(kw, returnDiagnostics=diagnostics)
         t0 = time.perf_counter()
         plan = core_api.resolve_call(d_, v_, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
         t1 = time.perf_counter()
@@ -80,6 +83,7 @@ if not os.environ.get("NO_CORE_API"):
 
     one_call(*host[0])                              # warm-up (first-touch of the pinned staging buffers)
     res, fit, t_chr1 = one_call(*host[0])
+    _, _, t_chr1_plain = one_call(*host[0], diagnostics=False)
     # split of the device part of one call: upload / fit / download, on a context of its own
     k = dict(kw)
     plan = core_api.resolve_call(host[0][0], host[0][1], k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k)
@@ -113,8 +117,11 @@ if not os.environ.get("NO_CORE_API"):
         genome_batch = time.perf_counter() - t
     print(json.dumps({"core_api_runConsenrich": {
         "settings": "CLI defaults (50 ECM iterations, rtol 1e-6, 5 inner sweeps, process re-weighting on, background fitted, 8 outer passes, "
-                    "min 3), fixed Q0 = diag(1e-3, 1e-4), hg38 @200bp x %d, library default (bit-exact) mode" % m,
-        "chr1_call": {k_: round(v_, 4) for k_, v_ in t_chr1.items()}, "chr1_device_part": {k_: round(v_, 4) for k_, v_ in split.items()},
+                    "min 3), returnDiagnostics + returnPrecisionDiagnostics like the CLI's call, fixed Q0 = diag(1e-3, 1e-4), hg38 @200bp x %d, "
+                    "library default (bit-exact) mode" % m,
+        "chr1_call": {k_: round(v_, 4) for k_, v_ in t_chr1.items()},
+        "chr1_call_returnDiagnostics_false": {k_: round(v_, 4) for k_, v_ in t_chr1_plain.items()},
+        "chr1_ecm_phases_recorded": len(res[-1]["post_process_noise_fit"]["fixed_background_ecm"]), "chr1_device_part": {k_: round(v_, 4) for k_, v_ in split.items()},
         "chr1_outer_passes": int(fit.passes), "chr1_ecm_iterations": [int(v_) for v_ in fit.ecm_iters],
         "chromosomes": len(lengths), "sequential_calls_total_s": round(genome_sequential, 3), "sequential_outer_passes": seq_passes,
         "one_batch_fit_s": round(genome_batch, 3), "one_batch_outer_passes": [int(f_.passes) for f_ in fitsb]}}))

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(L):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/consenrich_amd.h but not exported"
     assert set(declared) == set(L.SYMBOLS), "ctypes binding and header disagree"
-    assert L.lib().csr_abi_version() == 4
+    assert L.lib().csr_abi_version() == 5
 
 
 def test_struct_layouts_match_header(L):

@@ -125,6 +125,45 @@ def _check_contract(name, out, data):
         assert all(len(gs[k]) == m for k in ("mean", "median", "sd", "iqr", "count")) and all(v >= 0.0 for v in gs["sd"])
         post = diag["post_process_noise_fit"]
         assert post["planned_outer_passes"] == 3 and post["requested_outer_passes"] == 2       # max(min 3, requested 2)
+        assert "background_prior" not in diag
+        # test_core.py:4111-4163: the per-phase records
+        records = post["fixed_background_ecm"]
+        assert records
+        loop = [r for r in records if not r.get("final_fixed_background_ecm")]
+        assert loop
+        for key in ("observation_lambda_mean", "observation_lambda_median", "background_objective_per_cell",
+                    "background_objective_change_per_cell", "background_objective_threshold_per_cell",
+                    "observation_lambda_lower_bound_hits", "observation_lambda_upper_bound_hits",
+                    "process_kappa_lower_bound_hits", "process_kappa_upper_bound_hits"):
+            assert key in loop[-1], key
+        for key in ("observation_lambda_lower_bound_hits", "observation_lambda_upper_bound_hits",
+                    "process_kappa_lower_bound_hits", "process_kappa_upper_bound_hits"):
+            assert 0.0 <= loop[-1][key] <= 1.0
+        assert loop[-1]["relative_sign_change_per_kb"] >= 0.0
+        last = records[-1]
+        assert last["final_fixed_background_ecm"] is True
+        assert "final_abs_rel_change" in last and "stable_iters" in last and "patience_target" in last
+        assert last["relative_sign_change_per_kb"] >= 0.0
+        assert "background_objective_per_cell" not in last and "outer_objective_per_cell" not in last
+        rows = last["optimization_path"]
+        assert rows and [r["iter"] for r in rows] == sorted(r["iter"] for r in rows)
+        assert rows[0]["reset_iteration"] is True and rows[0]["change"] is None and rows[0]["threshold"] is None
+        # test_core.py:4186-4203
+        assert all(np.isfinite(float(r["objective_value"])) for r in rows) and all(r["objective_name"] == "nll" for r in rows)
+        q_info = diag["process_noise_calibration"]
+        assert q_info["processNoisePolicy"] == "fixedDiagonal" and q_info["processNoiseCalibrationStatus"] == "estimated"
+        assert "blockMode" not in q_info and "process_q_calibration" not in diag
+        want_level, want_trend = q_info["qSeedLevelFinal"], q_info["qSeedTrendFinal"]
+        assert q_info["processNoiseCalibrationReason"] == "data_derived_q_estimate"
+        assert q_info["preKappaQLevel"] == pytest.approx(want_level, rel=5.0e-6)
+        assert q_info["preKappaQTrend"] == pytest.approx(want_trend, rel=5.0e-6)
+        np.testing.assert_allclose(q_info["matrixQ0Final"], np.diag([want_level, want_trend]), rtol=5.0e-6)
+        assert "processQScaleSummary" in q_info and "processQScale" not in q_info
+        # the fit-level copies are the last phase's / the last in-loop record's (core.py:5611-5627)
+        assert post["relative_sign_change_per_kb"] == last["relative_sign_change_per_kb"]
+        assert post["background_objective_per_cell"] == loop[-1]["background_objective_per_cell"]
+        assert post["background_objective_change_per_cell"] == loop[-1]["background_objective_change_per_cell"]
+        assert loop[0]["background_objective_change_per_cell"] is None and loop[0]["background_objective_stable"] is False
     elif name == "level_smoke":
         assert len(out) == 6                                     # 4 + block map + run diagnostics
         np.testing.assert_array_equal(xs[:, 1], np.zeros(n, np.float32))
@@ -505,6 +544,30 @@ def test_host_restatements_of_the_diagnostics_helpers():
     assert sup["processNoiseCalibrationSkipReason"] == "no_active_adjacent_transitions"
 
 
+def test_sign_change_helpers_give_the_references_known_answers():
+    """test_core.py:4007-4041: the literal inputs and answers the reference's contract test holds for `_signChangePerKB` and
+    `_relativeSignChangePerKB`; :165-174 for the penalty split -- on the product's helpers AND on the twin's restatement."""
+    from consenrich_amd import core_api as ca
+    from oracle import passdiag as pdg
+
+    for sign, rel in ((ca.sign_change_per_kb, lambda s_, d_, v_, bp, **k: ca.relative_sign_change_per_kb(s_, d_, v_, interval_size_bp=bp, **k)),
+                      (pdg.sign_change_per_kb, pdg.relative_sign_change_per_kb)):
+        assert sign(np.asarray([1.0, -0.005, 1.0], np.float32), 1000) == pytest.approx(0.0)
+        assert sign(np.asarray([1.0, -0.02, 1.0], np.float32), 1000) == pytest.approx(2.0 / 3.0)
+        state = np.asarray([2.0, 2.0, 2.0], np.float32)
+        data = np.asarray([[1.0, 3.0, 1.0], [3.0, 1.0, 3.0]], np.float32)
+        munc = np.asarray([[0.1, 0.1, 0.1], [10.0, 10.0, 10.0]], np.float32)
+        assert rel(state, data, munc, 1000, pad=0.0) == pytest.approx(2.0 / 3.0)
+        bg = np.asarray([0.1, -0.2, 0.3], np.float32)
+        assert rel(state, data + bg[None, :], munc, 1000, background=bg, pad=0.0) == pytest.approx(2.0 / 3.0)
+    target = np.linspace(-0.4, 0.7, 9)
+    lam_first, lam_second = ca.background_penalties(3, 2.0)
+    total, first, second = pdg.objective_penalty(target, lam_first, lam_second)
+    assert total - first - second == pytest.approx(0.0, abs=1.0e-12)
+    assert first == pytest.approx(0.5 * lam_first * 8 * (1.1 / 8) ** 2) and second == pytest.approx(0.0, abs=1e-20)
+    assert (lam_first, lam_second) == (max(1.0, 2.0 * 9 / 4.0), max(1.0, 2.0 * 81 / 16.0))       # core.py:7480-7493
+
+
 def test_host_diagnostics_in_ranges_equal_the_whole_matrix_formulas():
     """The per-call entry evaluates its host-side summaries range by range / row by row on a thread pool; on a matrix large enough
     to take those paths (several 2^18-bin ranges) the results must be what the reference's whole-matrix expressions give."""
@@ -546,6 +609,24 @@ def test_host_diagnostics_in_ranges_equal_the_whole_matrix_formulas():
     assert ca.relative_sign_change_per_kb(state, data, munc, interval_size_bp=25, background=bg, pad=1.0e-4) == want
     # rows through the pool come back in order
     assert ca._map_rows(lambda r: float(r[0]), munc) == [float(munc[j, 0]) for j in range(m)]
+    # background-fit objective (core.py:4540-4606): range by range == the whole-matrix restatement of the twin
+    from oracle import passdiag as pdg
+    lam = np.exp(rng.normal(0, 0.8, size=n)).astype(np.float32)                    # some outside [0.25, 4]
+    level = rng.normal(size=n).astype(np.float32)
+    g = (bg - np.float32(0.05)).astype(np.float32)                                  # partly negative
+    kwo = dict(pad=1.0e-4, lambda_bounds=(0.25, 4.0), penalties=(16.0, 256.0), use_nonnegative=True, negative_penalty_multiplier=1.5)
+    assert np.isnan(ca.background_fit_objective(data, munc, level, lam, g, **kwo)["background_objective"])    # NaN cells: like np.sum there
+    clean = np.nan_to_num(data)
+    got = ca.background_fit_objective(clean, munc, level, lam, g, **kwo)
+    inv, res = pdg.update_matrices(clean, munc, level, lam, 1.0e-4, (0.25, 4.0))
+    want_o = pdg.background_fit_objective(res, inv, g, 16.0, 256.0, True, 1.5)
+    assert set(got) == set(want_o)
+    for key in want_o:
+        assert got[key] == pytest.approx(want_o[key], rel=1e-12), key
+    assert got["background_effective_observation_count"] == want_o["background_effective_observation_count"]
+    assert got["background_negative_penalty"] > 0.0 and got["background_second_difference_penalty"] > 0.0
+    for args in ((lam, 0.25, 4.0, False), (lam, 0.25, 4.0, True)):
+        assert ca.multiplier_summary(*args) == (pdg.kappa_summary(*args[:3]) if args[3] else pdg.lambda_summary(*args[:3]))
 
 
 def test_an_initial_lambda_weights_the_background_warm_start():
@@ -634,9 +715,130 @@ def test_reference_contract_cases_on_the_device_match_the_twin(name):
         for key in ("planned_outer_passes", "actual_outer_passes", "outer_stop_reason", "outer_converged"):
             assert pg[key] == pr[key], (name, key, pg[key], pr[key])
         assert [r["iters_done"] for r in pg["fixed_background_ecm"]] == [r["iters_done"] for r in pr["fixed_background_ecm"]]
+        _compare_phase_records(pg["fixed_background_ecm"], pr["fixed_background_ecm"], data.shape[1], name)
+        for key in ("background_objective", "background_objective_per_cell", "background_objective_change_per_cell",
+                    "background_objective_threshold_per_cell", "relative_sign_change_per_kb"):
+            assert (pg[key] is None) == (pr[key] is None), (name, key)
+            if pr[key] is not None:
+                assert pg[key] == pytest.approx(pr[key], rel=1e-3, abs=2.0 / data.shape[1]), (name, key)
+        assert pg["background_objective_stable"] == pr["background_objective_stable"]
         assert dg["final_nll"] == pytest.approx(dr["final_nll"], rel=1e-6)
         assert dg["process_q_diagnostics"]["policy"] == dr["process_q_diagnostics"]["policy"]
         np.testing.assert_allclose(dg["process_q_diagnostics"]["baseQLevel"], dr["process_q_diagnostics"]["baseQLevel"], rtol=1e-6)
+
+
+def _compare_phase_records(got, want, n, name):
+    """every key the twin's record of an ECM phase carries is in the device's, with the same discrete values and close numbers
+    (fractions of n bins: within two bins; differences of NLLs: absolute)"""
+    assert len(got) == len(want)
+    for rg, rr in zip(got, want):
+        assert set(rr) <= set(rg), (name, sorted(set(rr) - set(rg)))
+        for key, w in rr.items():
+            g = rg[key]
+            if key == "optimization_path":
+                assert [r["iter"] for r in g] == [r["iter"] for r in w]
+                assert [set(r) for r in g] == [set(r) for r in w]
+                assert [(r["reset_iteration"], r["converged"], r["stable_iters"]) for r in g] == \
+                       [(r["reset_iteration"], r["converged"], r["stable_iters"]) for r in w]
+                np.testing.assert_allclose([r["objective_value"] for r in g], [r["objective_value"] for r in w], rtol=1e-6)
+            elif w is None or isinstance(w, (bool, str, int)):
+                assert g == w, (name, key, g, w)
+            else:
+                assert g is not None, (name, key)
+                assert g == pytest.approx(w, rel=1e-3, abs=max(2.0 / n, 1e-5)), (name, key, g, w)
+
+
+def _case_records_without_background_fit():
+    data, munc, kw = _case_outer_pass_smoke()
+    return data, munc, dict(kw, fitBackground=False, returnPrecisionDiagnostics=False)
+
+
+def _check_records_without_background_fit(out):
+    """core.py:4994-5040: ONE phase, its record carries the phase summaries and a zero shift, no background objective"""
+    post = out[-1]["post_process_noise_fit"]
+    records = post["fixed_background_ecm"]
+    assert len(records) == 1 and post["outer_stop_reason"] == "fit_background_false" and post["outer_converged"] is True
+    r = records[0]
+    assert r["background_shift"] == 0.0 and r["background_shift_threshold"] == 0.0 and r["background_shift_stable"] is True
+    assert "background_objective_per_cell" not in r and "final_fixed_background_ecm" not in r
+    assert r["observation_lambda_mean"] is not None and r["process_kappa_median"] is not None
+    assert r["relative_sign_change_per_kb"] >= 0.0 and r["outer_stable_iters"] == 0 and r["outer_patience_target"] == 2
+    assert r["optimization_path"] and r["optimization_path"][0]["reset_iteration"] is True
+    assert post["background_objective"] is None and post["background_objective_stable"] is False
+    assert post["relative_sign_change_per_kb"] == r["relative_sign_change_per_kb"]
+
+
+def test_phase_record_without_a_background_fit_on_the_cpu_twin():
+    data, munc, kw = _case_records_without_background_fit()
+    _, out = _twin_call(data, munc, kw)
+    _check_records_without_background_fit(out)
+
+
+@pytest.mark.gpu
+def test_phase_record_without_a_background_fit_on_the_device_matches_the_twin():
+    data, munc, kw = _case_records_without_background_fit()
+    out = _device_call(data, munc, kw)
+    _check_records_without_background_fit(out)
+    _, ref = _twin_call(data, munc, kw)
+    _compare_phase_records(out[-1]["post_process_noise_fit"]["fixed_background_ecm"],
+                           ref[-1]["post_process_noise_fit"]["fixed_background_ecm"], data.shape[1], "no background fit")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("state_dim", [2, 1])
+def test_phase_tracks_equal_the_whole_matrix_restatement(state_dim):
+    """`csr_batch_phase_tracks` (the per-bin tracks behind the sign-change rate and the background-fit objective) against the
+    twin's whole-matrix NumPy restatement of core.py:2656-2696 / 4546-4552 on the SAME fit (smoothed level, multipliers,
+    current background and proposal downloaded from the device): the weighted-mean track bit for bit (same float64 row-by-row
+    accumulation), the per-bin objective sums to float64 rounding, the cell counts exactly.  Two chains (the second one's bins
+    start at an offset), masked cells, a nonzero current background; the multipliers are the ECM's own (within their bounds)."""
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from oracle import passdiag as pdg
+
+    rng = np.random.default_rng(3)
+    m, lens = 5, [3001, 777]
+    mp = ModelParams(state_dim=state_dim)
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, lens)
+        host = []
+        for c, n in enumerate(lens):
+            sig = np.sin(np.arange(n) / 40.0)
+            data = (sig[None, :] + 0.3 * rng.normal(size=(m, n))).astype(np.float32)
+            munc = (0.2 * np.exp(rng.normal(0, 0.4, size=(m, n)))).astype(np.float32)
+            munc[1, 10:20] = np.float32(1.0e30)
+            munc[:, 50] = np.float32(1.0e30)
+            b.upload(c, data, munc)
+            b.set_background(c, (0.05 * np.cos(np.arange(n) / 90.0)).astype(np.float32))
+            host.append((data, munc))
+        b.stats()
+        b.ecm(max_iters=2, inner_iters=2, rtol=1e-6, nu=8.0, use_lambda=True, use_kappa=True)
+        info = b.background_update(16.0, 256.0, use_lambda=True, use_initial=True)
+        b.export(L.EXPORT_SMOOTH | L.EXPORT_MULT)
+        pad32 = float(np.float32(mp.pad))
+        for c, n in enumerate(lens):
+            data, munc = host[c]
+            rel, fit, cnt = b.phase_tracks(c, 1.0e-4, with_fit=True, use_lambda=True)
+            only_rel, none_fit, none_cnt = b.phase_tracks(c, 1.0e-4)
+            assert none_fit is None and none_cnt is None
+            np.testing.assert_array_equal(only_rel, rel)
+            level, lam = b.download(c, "xs")[:, 0], b.download(c, "lambda")
+            cur, nxt = b.download(c, "background"), b.download(c, "background_next")
+            assert np.abs(cur).max() > 0.01 and float(np.abs(nxt - cur).max()) > 0.0
+            np.testing.assert_array_equal(rel, pdg.relative_level_track(level, data, munc, background=cur, pad=1.0e-4))
+            inv, res = pdg.update_matrices(data, munc, level, lam, pad32, mp.lambda_bounds)
+            inv64, fr = inv.astype(np.float64), res.astype(np.float64) - nxt.astype(np.float64)[None, :]
+            np.testing.assert_allclose(fit, np.sum(inv64 * fr * fr, axis=0), rtol=1e-14)
+            np.testing.assert_array_equal(cnt, np.count_nonzero(np.isfinite(res) & np.isfinite(inv) & (inv > 0.0), axis=0))
+            want = pdg.background_fit_objective(res, inv, nxt, 16.0, 256.0, True, 1.0)
+            assert 0.5 * float(fit.sum()) == pytest.approx(want["background_weighted_residual_objective"], rel=1e-12)
+            assert int(cnt.sum()) == int(want["background_effective_observation_count"]) == m * n
+            track = inv64.sum(axis=0)                           # the update's weight track: its median is the penalty scale
+            assert info[c]["weight_scale"] == pytest.approx(float(np.median(track[track > 0.0])), rel=1e-12)
+        with pytest.raises(L.ConsenrichAMDError, match="pad must be finite and nonnegative"):
+            b.phase_tracks(0, -1.0)
 
 
 def _variant_cases():

@@ -13,7 +13,8 @@ def twin_cfg(plan):
                 use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, apn=mp.apn,
                 fit_background=cfg.fit_background, zero_center=cfg.zero_center, use_nonnegative=cfg.use_nonnegative,
                 neg_multiplier=cfg.neg_multiplier, outer_passes=cfg.outer_passes, min_outer=cfg.min_outer,
-                shift_rtol=cfg.shift_rtol, patience=cfg.patience, outer_nll_rtol=cfg.outer_nll_rtol)
+                shift_rtol=cfg.shift_rtol, patience=cfg.patience, outer_nll_rtol=cfg.outer_nll_rtol,
+                interval_size_bp=plan.interval_size_bp, track_path=bool(plan.ret["track_path"]))
 
 
 def twin_run(plan):
