@@ -234,15 +234,21 @@ class DeviceBatch:
         L.check(self._lib.csr_batch_forward_masked(self._ctx, int(flags), mask, L.dp(sd), L.dp(sn)))
         return sd, sn
 
-    def phase_tracks(self, chain: int, pad: float, with_fit: bool = False, use_lambda: bool = False):
+    def phase_tracks(self, chain: int, pad: float, with_fit: bool = False, use_lambda: bool = False, out=None):
         """Per-bin float64 tracks of one chain behind the two per-phase diagnostics of `runConsenrich` that read the (m, n)
         matrices (csr_batch_phase_tracks): `rel` = smoothed level - weighted mean of the background-adjusted observations
         (core.py:2663-2697); with_fit (a background proposal is resident): `fit` = sum_j iv (r - proposal)^2 and `cnt` = its
         cell count (core.py:4546-4552, 4587-4596).  Returns (rel, fit or None, cnt or None)."""
         n = self.chain_lens[chain]
-        rel = np.empty(n, np.float64)
-        fit = np.empty(n, np.float64) if with_fit else None
-        cnt = np.empty(n, np.int32) if with_fit else None
+        if out is not None:                 # caller-owned (n,) float64 / float64 / int32 buffers (re-used: no first-touch faults)
+            rel, fit, cnt = out[0], (out[1] if with_fit else None), (out[2] if with_fit else None)
+            for a, t in ((rel, np.float64), (fit, np.float64), (cnt, np.int32)):
+                if a is not None and (a.dtype != t or a.shape != (n,) or not a.flags.c_contiguous):
+                    raise ValueError("phase_tracks: out buffers must be contiguous (n,) float64, float64, int32")
+        else:
+            rel = np.empty(n, np.float64)
+            fit = np.empty(n, np.float64) if with_fit else None
+            cnt = np.empty(n, np.int32) if with_fit else None
         L.check(self._lib.csr_batch_phase_tracks(self._ctx, int(chain), int(bool(use_lambda)), float(pad), L.dp(rel),
                                                  L.dp(fit) if with_fit else None,
                                                  cnt.ctypes.data_as(C.POINTER(C.c_int32)) if with_fit else None))
@@ -399,11 +405,14 @@ class DeviceBatch:
         L.check(self._lib.csr_synchronize(self._ctx))
 
     # -- results -------------------------------------------------------------------------------------------------
-    def download(self, chain: int, name: str) -> np.ndarray:
+    def download(self, chain: int, name: str, out=None) -> np.ndarray:
         n, d, m = self.chain_lens[chain], self.d, self.m
         shape = {"D": (n,), "xf": (n, d), "Pf": (n, d, d), "pnoise": (max(n - 1, 0), d, d), "xs": (n, d),
                  "Ps": (n, d, d), "lag": (max(n - 1, 0), d, d), "resid": (n, m)}.get(name, (n,))
-        out = np.empty(shape, np.float32)
+        if out is None:
+            out = np.empty(shape, np.float32)
+        elif out.dtype != np.float32 or out.shape != shape or not out.flags.c_contiguous:
+            raise ValueError(f"download({name!r}): out must be a contiguous float32 array of shape {shape}")
         L.check(self._lib.csr_batch_download(self._ctx, chain, _ARR[name], out.ctypes.data_as(C.c_void_p)))
         return out
 

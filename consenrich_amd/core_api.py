@@ -566,6 +566,15 @@ def sign_change_per_kb(values, interval_size_bp):
     return metadata_float(float(changes) / span_kb)
 
 
+def _sum_squares(v) -> float:
+    """sum of squares in float64 with NumPy's own pairwise reduction -- NOT `np.dot`: a BLAS level-1 call wakes one spinning
+    thread per host core, and inside a CPU quota (a container's share of a large host) that stalls the whole process, the
+    device's launch path included, for the rest of the scheduler period (measured: ~70 ms per call next to a 12 ms ECM phase).
+    The reference's own `np.dot` here has no fixed summation order either (it is whatever its BLAS does)."""
+    v = np.asarray(v, np.float64)
+    return float(np.sum(v * v, dtype=np.float64))
+
+
 def multiplier_summary(values, lower, upper, skip_first=False):
     """core._observationLambdaSummary / _processKappaSummary (core.py:2338-2375): (mean, median) of the finite multipliers clipped
     to their bounds; the first kappa multiplies nothing and is left out (skip_first).  A float32 track is selected in float32
@@ -626,9 +635,9 @@ def background_fit_objective(data, munc, state_level, lam, background, *, pad, l
     count = float(max(1, sum(p[1] for p in parts)))
     lam_first, lam_second = penalties
     d1 = np.diff(g)
-    first = 0.5 * float(lam_first) * float(np.dot(d1, d1)) if g.size >= 2 else 0.0
+    first = 0.5 * float(lam_first) * _sum_squares(d1) if g.size >= 2 else 0.0
     d2 = np.diff(g, n=2)
-    second = 0.5 * float(lam_second) * float(np.dot(d2, d2)) if g.size >= 3 else 0.0
+    second = 0.5 * float(lam_second) * _sum_squares(d2) if g.size >= 3 else 0.0
     negative = 0.0
     mult = negative_penalty_multiplier
     if use_nonnegative and mult is not None and float(mult) > 0.0:
@@ -649,55 +658,93 @@ class PassDiagnostics:
     (core.py:4946-4990 in the loop, :5456-5517 for the final phase) and after every background proposal (:5161-5197), for any
     chain of a batch.  The two that read the (m, n) matrices -- the sign-change rate and the weighted residual term of the
     background-fit objective -- come as per-bin float64 tracks from the device (`DeviceBatch.phase_tracks`: the reference's
-    per-cell arithmetic on the resident matrices); everything else is O(n) on (n,) tracks downloaded per phase.  They are
-    diagnostics only (no stop rule reads them): `driver.fit_batch` runs without this object unless they were asked for
-    (`returnDiagnostics`)."""
+    per-cell arithmetic on the resident matrices); everything else is O(n) on (n,) tracks downloaded per phase, on a worker thread
+    while the device runs the next phase.  They are diagnostics only (no stop rule reads them): `driver.fit_batch` runs without
+    this object unless they were asked for (`returnDiagnostics`)."""
 
-    def __init__(self, cfg: FitConfig, model: ModelParams, interval_size_bp):
+    def __init__(self, cfg: FitConfig, model: ModelParams, interval_size_bp, overlap: bool = True):
         self.cfg, self.model, self.interval_size_bp = cfg, model, interval_size_bp
         self.previous_per_cell = {}
+        # overlap: the device calls (downloads, the tracks kernel) happen in the caller's thread at once; the NumPy part runs on ONE
+        # worker thread, in submission order (the pass-to-pass test of the objective needs that), while the caller goes on to
+        # launch the next phase -- the methods then return a Future of the summary instead of the summary
+        self._pool = None
+        self._sets, self._turn, self._busy = {}, 0, [None, None]
+        if overlap:
+            from concurrent.futures import ThreadPoolExecutor
 
-    def _phase(self, batch, c, with_fit):
+            self._pool = ThreadPoolExecutor(max_workers=1)
+
+    def _run(self, fn, *args):
+        if self._pool is None:
+            return fn(*args)
+        job = self._pool.submit(fn, *args)
+        self._busy[self._turn ^ 1] = job            # (the set `_buffers` just handed out)
+        return job
+
+    def _buffers(self, n):
+        """Two sets of host tracks per chain length, used in turn: the worker reads one set while the next phase's downloads fill
+        the other; fresh arrays per phase would spend more time in first-touch page faults than in the copies."""
+        sets = self._sets.setdefault(n, [None, None])
+        k = self._turn
+        self._turn ^= 1
+        if self._busy[k] is not None:               # the job that read this set two phases ago (one worker, in order: long done)
+            self._busy[k].result()
+            self._busy[k] = None
+        if sets[k] is None:
+            sets[k] = {"lambda": np.empty(n, np.float32), "kappa": np.empty(n, np.float32), "g": np.empty(n, np.float32),
+                       "rel": np.empty(n, np.float64), "fit": np.empty(n, np.float64), "cnt": np.empty(n, np.int32)}
+        return sets[k]
+
+    def _fetch(self, batch, c, with_fit):
         cfg = self.cfg
+        buf = self._buffers(batch.chain_lens[c])
         batch.export(L.EXPORT_MULT)
-        lam = batch.download(c, "lambda") if cfg.use_lambda else None
-        kap = batch.download(c, "kappa") if cfg.use_kappa else None
+        lam = batch.download(c, "lambda", out=buf["lambda"]) if cfg.use_lambda else None
+        kap = batch.download(c, "kappa", out=buf["kappa"]) if cfg.use_kappa else None
+        rel, fit, cnt = batch.phase_tracks(c, float(cfg.pad), with_fit=with_fit, use_lambda=cfg.use_lambda,
+                                           out=(buf["rel"], buf["fit"], buf["cnt"]))
+        return lam, kap, rel, fit, cnt, buf
+
+    def _summaries(self, lam, kap, rel) -> dict:
         lam_b, kap_b = self.model.lambda_bounds, self.model.kappa_bounds
         lam_mean, lam_median = multiplier_summary(lam, *lam_b)
         kap_mean, kap_median = multiplier_summary(kap, *kap_b, skip_first=True)
         lam_lo, lam_hi = precision_bound_hits(lam, *lam_b)
         kap_lo, kap_hi = precision_bound_hits(kap, *kap_b, skip_first=True)
-        rel, fit, cnt = batch.phase_tracks(c, float(cfg.pad), with_fit=with_fit, use_lambda=cfg.use_lambda)
-        out = {"observation_lambda_mean": lam_mean, "observation_lambda_median": lam_median,
-               "process_kappa_mean": kap_mean, "process_kappa_median": kap_median,
-               "observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
-               "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
-               "relative_sign_change_per_kb": sign_change_per_kb(rel, self.interval_size_bp)}
-        return out, fit, cnt
+        return {"observation_lambda_mean": lam_mean, "observation_lambda_median": lam_median,
+                "process_kappa_mean": kap_mean, "process_kappa_median": kap_median,
+                "observation_lambda_lower_bound_hits": lam_lo, "observation_lambda_upper_bound_hits": lam_hi,
+                "process_kappa_lower_bound_hits": kap_lo, "process_kappa_upper_bound_hits": kap_hi,
+                "relative_sign_change_per_kb": sign_change_per_kb(rel, self.interval_size_bp)}
 
-    def phase(self, batch, c) -> dict:
+    def phase(self, batch, c):
         """after an ECM phase that no background update follows (the final phase; the single phase without a background fit)"""
-        return self._phase(batch, c, False)[0]
+        lam, kap, rel, _, _, _ = self._fetch(batch, c, False)
+        return self._run(self._summaries, lam, kap, rel)
 
-    def loop_pass(self, batch, c, update_info) -> dict:
+    def loop_pass(self, batch, c, update_info):
         """after `background_update` (its per-chain record: `update_info`), BEFORE `background_apply`: the phase's summaries and
         the objective of the proposal (`_scoreBackgroundFitObjective`, core.py:4540-4606) with its pass-to-pass test"""
+        lam, kap, rel, fit, cnt, buf = self._fetch(batch, c, True)
+        g = batch.download(c, "background_next", out=buf["g"])
+        return self._run(self._loop_summaries, c, lam, kap, rel, fit, cnt, g, float(update_info.get("weight_scale", 1.0)))
+
+    def _loop_summaries(self, c, lam, kap, rel, fit, cnt, g, weight_scale) -> dict:
         cfg = self.cfg
-        out, fit, cnt = self._phase(batch, c, True)
-        g = np.asarray(batch.download(c, "background_next"), np.float64)
+        out = self._summaries(lam, kap, rel)
+        g = np.asarray(g, np.float64)
         weighted = 0.5 * float(np.sum(fit, dtype=np.float64))
         count = float(max(1, int(np.sum(cnt, dtype=np.int64))))
         lam_first, lam_second = cfg.penalties
         d1, d2 = np.diff(g), np.diff(g, n=2)
-        first = 0.5 * float(lam_first) * float(np.dot(d1, d1)) if g.size >= 2 else 0.0
-        second = 0.5 * float(lam_second) * float(np.dot(d2, d2)) if g.size >= 3 else 0.0
+        first = 0.5 * float(lam_first) * _sum_squares(d1) if g.size >= 2 else 0.0
+        second = 0.5 * float(lam_second) * _sum_squares(d2) if g.size >= 3 else 0.0
         negative = 0.0
         mult = cfg.neg_multiplier
         if cfg.use_nonnegative and mult is not None and float(mult) > 0.0:
             # median of the positive weight track: the update's own (same float32 inverse variances, core.py:4562-4575 / 8287-8296)
-            scale = float(update_info.get("weight_scale", 1.0))
-            if not np.isfinite(scale) or scale <= 0.0:
-                scale = 1.0
+            scale = weight_scale if (np.isfinite(weight_scale) and weight_scale > 0.0) else 1.0
             negative = 0.5 * float(float(mult) * scale) * float(np.sum(np.minimum(g, 0.0) ** 2, dtype=np.float64))
         objective = float(weighted + (first + second) + negative)
         cur, prev = objective / count, self.previous_per_cell.get(c, float("nan"))
@@ -715,6 +762,11 @@ class PassDiagnostics:
                     "background_weighted_residual_objective": metadata_float(weighted),
                     "background_fit_effective_observation_count": int(count)})
         return out
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
 
 
 def _metadata_value(value):
@@ -968,14 +1020,16 @@ def run_plan(plan: RunPlan, device: int = 0):
         b.upload(0, plan.data, plan.munc)
         if plan.initial_lambda is not None or plan.initial_kappa is not None:       # warm-started multipliers (core.py:4637-4648)
             b.upload_multipliers(0, plan.initial_lambda, plan.initial_kappa, None)
+        passes = PassDiagnostics(cfg, plan.model, plan.interval_size_bp) if plan.ret["diagnostics"] else None
         fits, results = run_consenrich_batch(
             b, cfg, block_len_intervals=plan.block_len_intervals, model_q0=None if plan.q0 is None else _pad_q(plan.q0),
             initial_background=None if plan.initial_background is None else [plan.initial_background],
             return_background=True, return_precision_diagnostics=True, download=True,
             initial_lambda=plan.initial_lambda is not None, initial_kappa=plan.initial_kappa is not None,
             keep_ecm_state=False,
-            pass_diagnostics=PassDiagnostics(cfg, plan.model, plan.interval_size_bp) if plan.ret["diagnostics"] else None,
-            track_path=bool(plan.ret["track_path"]))
+            pass_diagnostics=passes, track_path=bool(plan.ret["track_path"]))
+        if passes is not None:
+            passes.close()
         fit, res = fits[0], results[0]
         final = {"stateSmoothed": res[0], "stateCovarSmoothed": res[1], "postFitResiduals": res[2], "NIS": res[3],
                  "intervalToBlockMap": res[4], "background": res[5], "outputTracks": res[6]["outputTracks"],

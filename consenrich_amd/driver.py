@@ -250,12 +250,13 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
     observationPrecision = lambdaExpLocal), and both are recorded in the warm-start summary (core.py:4689-4695).
     pass_diagnostics: optional object with `loop_pass(batch, chain, update_record)` / `phase(batch, chain)` returning the per-phase summaries
     the reference computes on the host (multiplier means / medians / bound hits, sign-change rate, background-fit
-    objective; core.py:4946-4990, 5161-5197) -- `core_api.PassDiagnostics`; they are merged into the phase records and enter
-    no decision.  track_path: keep the per-iteration rows of every ECM phase (`trackOptimizationPath`)."""
+    objective; core.py:4946-4990, 5161-5197) as a dict or a Future of one -- `core_api.PassDiagnostics`; they are merged into the
+    phase records (before this function returns) and enter no decision.  track_path: keep the per-iteration rows of every ECM phase (`trackOptimizationPath`)."""
     nc = len(batch.chain_lens)
     fits = [ChainFit() for _ in range(nc)]
     active = [True] * nc
     stable = [0] * nc
+    pending = []                            # (summary still being computed, the record it belongs to): `_merge_summaries`
     if not keep_background:
         for c in range(nc):
             batch.set_background(c, None)
@@ -309,7 +310,7 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
                 rec = ecm_phase_record(outs[c], paths[c], cfg, 1, track_path)
                 rec.update({"background_shift": 0.0, "background_shift_threshold": 0.0, "background_shift_stable": True})
                 if pass_diagnostics is not None:                    # core.py:5009-5033
-                    rec.update(pass_diagnostics.phase(batch, c))
+                    pending.append((pass_diagnostics.phase(batch, c), rec))
                 rec.update({"outer_inner_ecm_converged": bool(rec["converged"]), "outer_stable_iters": 0,
                             "outer_patience_target": int(cfg.patience)})
                 fits[c].loop_diagnostics.append(rec)
@@ -353,8 +354,11 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
             last_inner[c], last_obj_stable[c] = inner_ok, obj_stable
             tol_obj = cfg.outer_nll_rtol * max(abs(cur), abs(fits[c].objective[-2]["penalized_objective_per_cell"]), 1.0) \
                 if len(fits[c].objective) >= 2 else float("nan")
-            fits[c].loop_diagnostics.append({
-                **rec, **extra[c], **gate,
+            if pass_diagnostics is not None:
+                pending.append((extra[c], rec))
+            fits[c].loop_diagnostics.append(rec)
+            rec.update({
+                **gate,
                 "outer_ecm_fit_nll": float(outs[c].final_nll), "outer_forward_nll": float(fnll[c]),
                 "outer_objective": obj, "outer_objective_per_cell": cur,
                 "outer_objective_change_per_cell": abs(cur - fits[c].objective[-2]["penalized_objective_per_cell"])
@@ -385,7 +389,16 @@ def fit_batch(batch: DeviceBatch, cfg: FitConfig, keep_background: bool = False,
                 fits[c].outer_stop_reason = "max_outer_passes_objective"
             elif stable[c] < cfg.patience:
                 fits[c].outer_stop_reason = "max_outer_passes_patience"
+    _merge_summaries(pending)
     return fits
+
+
+def _merge_summaries(pending) -> None:
+    """`pass_diagnostics` may hand back its summaries as Futures (the host part runs beside the device's next phase): merge each
+    into the record it belongs to; the keys are disjoint from the record's own."""
+    for summary, record in pending:
+        record.update(summary.result() if hasattr(summary, "result") else summary)
+    pending.clear()
 
 
 def precision_diagnostics(batch: DeviceBatch, cfg: FitConfig, chain: int, q0, stateModel: str) -> dict:
@@ -457,11 +470,12 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
         batch.stats()
         outs, paths = batch.ecm(max_iters=cfg.ecm_iters, inner_iters=cfg.inner_iters, rtol=cfg.ecm_rtol, nu=cfg.nu,
                                 use_lambda=cfg.use_lambda, use_kappa=cfg.use_kappa, use_apn=cfg.use_apn, use_qscale=cfg.use_apn)
+        pending = []
         for c in range(nc):
             rec = ecm_phase_record(outs[c], paths[c], cfg, fits[c].passes + 1, track_path)         # core.py:5441-5455
             rec["final_fixed_background_ecm"] = True
             if pass_diagnostics is not None:
-                rec.update(pass_diagnostics.phase(batch, c))
+                pending.append((pass_diagnostics.phase(batch, c), rec))
             fits[c].final_ecm_iters = int(rec["iters_done"])
             fits[c].final_ecm_nll = float(outs[c].final_nll)
             fits[c].final_ecm_converged = bool(rec["converged"])
@@ -478,6 +492,8 @@ def run_consenrich_batch(batch: DeviceBatch, cfg: FitConfig, *, block_len_interv
     batch.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
     if return_precision_diagnostics:
         batch.diagnostics(mult_flags | (L.USE_QSCALE if cfg.use_apn else 0))
+    if cfg.fit_background:
+        _merge_summaries(pending)              # (computed beside the final pass)
     for c in range(nc):
         fits[c].final_nll = float(sum_nll[c])
         fits[c].final_forward_nis = float(sum_d[c]) / float(batch.chain_lens[c])      # phiHat = sumD / n (pyx:6627)
