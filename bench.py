@@ -65,7 +65,7 @@ CONFIGS = {
 # the LPT shards of 2 / 4 / 8 ranks emulated on ONE GPU (scripts/shards.sh -> SCALING_MODEL_SOURCE; c4 shape).  The default mode's
 # fixed part is the state chain's critical path on the rank's longest chromosome (every rank of <= 8 holds one of chr1..chr8:
 # 0.73-1.24 M bins); the throughput mode's is launch / drain latency of its serial kernels.  Used for `expected` at N > 1 only.
-SCALING_MODEL = {"default": {"fixed_ms": 1.37, "per_mbin_ms": 0.1827}, "ulp2": {"fixed_ms": 0.110, "per_mbin_ms": 0.1409}}
+SCALING_MODEL = {"default": {"fixed_ms": 1.546, "per_mbin_ms": 0.1663}, "ulp2": {"fixed_ms": 0.116, "per_mbin_ms": 0.1347}}
 SCALING_MODEL_SOURCE = "profiles/r05_shards_exact_mode.txt, profiles/r05_shards_throughput_mode.txt"
 
 
