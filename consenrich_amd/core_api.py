@@ -178,9 +178,14 @@ def background_penalties(blockLenIntervals, smoothness=1.0):
 def track_summary(values) -> dict:
     """core._metadataTrackSummary (core.py:2390-2409)."""
     a = np.asarray(values, np.float64).reshape(-1)
-    a = a[np.isfinite(a)]
+    ok = np.isfinite(a)
+    if not bool(ok.all()):
+        a = a[ok]
     if a.size == 0:
         return {k: None for k in ("min", "q05", "median", "mean", "q95", "max")}
+    lo, hi = float(a.min()), float(a.max())
+    if lo == hi:                    # a constant track (base Q, unit scales): every order statistic is that value, no selection passes
+        return {"min": lo, "q05": lo, "median": lo, "mean": float(a.mean()), "q95": lo, "max": lo}
     return {"min": float(a.min()), "q05": float(np.quantile(a, 0.05)), "median": float(np.median(a)),
             "mean": float(a.mean()), "q95": float(np.quantile(a, 0.95)), "max": float(a.max())}
 
@@ -788,6 +793,25 @@ def _metadata_value(value):
     return value
 
 
+def input_only_summaries(plan: RunPlan) -> dict:
+    """The parts of the run diagnostics that read nothing but the call's inputs: the support record of the process-noise
+    calibration (core.py:3046-3100) and the summary of the observation-noise trace sum_j max(munc_j + pad, 1e-12) (replicates
+    added in their order, bin range by bin range).  `run_plan` starts them on a thread beside the device fit."""
+    pad_f = float(plan.cfg.pad)
+    n = plan.data.shape[1]
+    r_trace = np.empty(n)
+
+    def trace_cols(k0, k1):
+        acc = np.zeros(k1 - k0)
+        for row in plan.munc:
+            acc += np.maximum(np.asarray(row[k0:k1], np.float64) + pad_f, 1.0e-12)
+        r_trace[k0:k1] = acc
+
+    _map_cols(trace_cols, n)
+    return {"observation_r_trace": track_summary(r_trace),
+            "support": process_noise_calibration_support(plan.data, plan.munc, pad_f)}
+
+
 def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
     """The reference's `runDiagnostics` (core.py:5944-5999) from the arrays of the final pass: the keys its own tests read
     (test_core.py:4055-4110) and the per-pass record; host arithmetic on downloaded tracks, same formulas."""
@@ -816,16 +840,9 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
 
     for cnt, mean, med, sd, iqr in _map_rows(gain_row, plan.munc):
         gain["count"].append(cnt); gain["mean"].append(mean); gain["median"].append(med); gain["sd"].append(sd); gain["iqr"].append(iqr)
-    # trace of the observation noise: sum over the replicates in their order, bin range by bin range
-    r_trace = np.empty(n)
-
-    def trace_cols(k0, k1):
-        acc = np.zeros(k1 - k0)
-        for row in plan.munc:
-            acc += np.maximum(np.asarray(row[k0:k1], np.float64) + pad_f, 1.0e-12)
-        r_trace[k0:k1] = acc
-
-    _map_cols(trace_cols, n)
+    early = plan.ret.pop("_early", None)            # input-only summaries started beside the device fit (`run_plan`), if any
+    early = early.result() if early is not None else input_only_summaries(plan)
+    r_trace_summary, support = early["observation_r_trace"], early["support"]
     # effective process noise tracks (core.py:2420-2519): base / kappa, or the stored process noise without kappa
     base_l = np.full(n, q0[0, 0])
     base_t = np.full(n, q0[1, 1]) if d == 2 else np.zeros(n)
@@ -872,7 +889,6 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
                       background=final.get("background"), pad=float(cfg.pad))}
     post = fit.post_process_noise_fit(cfg, extras=extras)
     # process-noise calibration record (core.py:5686-5737, 5921-5942)
-    support = process_noise_calibration_support(plan.data, plan.munc, float(cfg.pad))
     q_full = np.zeros((2, 2), np.float64)
     q_full[:d, :d] = q0[:d, :d]
     common = dict(Q0=q_full if d == 2 else q_full[:1, :1], state_model=plan.state_model, minQ=float(plan.ret["min_q"]),
@@ -906,7 +922,7 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
             "process_precision_reweighting_requested": bool(plan.requested_kappa),
             "process_precision_reweighting_effective": bool(cfg.use_kappa),
             "process_precision_reweighting_disabled_by_apn": disabled, "adaptive_process_noise_effective": use_apn,
-            "process_q_policy": policy, "process_q_diagnostics": qd, "observation_r_trace": track_summary(r_trace)}
+            "process_q_policy": policy, "process_q_diagnostics": qd, "observation_r_trace": r_trace_summary}
 
 
 def assemble_result(plan: RunPlan, fit: ChainFit, final: dict) -> tuple:
@@ -1015,6 +1031,13 @@ def run_plan(plan: RunPlan, device: int = 0):
     """The device part: one chromosome as a one-chain batch through `run_consenrich_batch`; returns (ChainFit, final arrays)."""
     m, n = plan.data.shape
     cfg = plan.cfg
+    early_pool = None
+    if plan.ret["diagnostics"] or plan.ret["precision"]:
+        from concurrent.futures import ThreadPoolExecutor
+
+        early_pool = ThreadPoolExecutor(max_workers=1)
+        plan.ret["_early"] = early_pool.submit(input_only_summaries, plan)
+        early_pool.shutdown(wait=False)                 # (the submitted job still runs to its end)
     with DeviceBatch(device) as b:
         b.configure(plan.model, m, [n])
         b.upload(0, plan.data, plan.munc)
