@@ -3,8 +3,10 @@
 CPU part: the signature IS the reference's (names, order, defaults -- the literal list of core.py:3861-3916 is data here);
 `resolve_call` raises the reference's ValueErrors and maps the arguments; the three literal invocations the reference's own
 contract tests make (test_core.py:3992-4110 outer-pass smoke, :4206-4257 level model, :6051-6090 adaptive process noise)
-replayed on the CPU twin give the reference's tuple shapes, dtypes, keys and finite numbers.
-GPU part: the same three invocations through the product on the device, against the twin."""
+replayed on the CPU twin give the reference's tuple shapes, dtypes, keys and finite numbers -- including what that test reads of
+every ECM phase record (:4111-4203); seven more reference-held cases (:1270 Q bounds, :1297 t_innerIters reaches the ECM, :1882
+silence, :2850 interval-level precision, :4289 / :4356 / :6094 through the seams the reference spies on).
+GPU part: the same invocations through the product on the device, against the twin."""
 import inspect
 
 import numpy as np
@@ -725,6 +727,134 @@ def test_reference_contract_cases_on_the_device_match_the_twin(name):
         assert dg["final_nll"] == pytest.approx(dr["final_nll"], rel=1e-6)
         assert dg["process_q_diagnostics"]["policy"] == dr["process_q_diagnostics"]["policy"]
         np.testing.assert_allclose(dg["process_q_diagnostics"]["baseQLevel"], dr["process_q_diagnostics"]["baseQLevel"], rtol=1e-6)
+
+
+# ---- four more reference-held cases (test_core.py:1270-1295, 1297-1351, 1882-1921, 2850-2911), mirrored literally ----------------
+@pytest.mark.parametrize("q_kwargs, message", [({"minQ": 2.0e-4, "maxQ": 1.0}, "minQ"), ({"minQ": 1.0e-6, "maxQ": 5.0e-5}, "maxQ")])
+def test_fixed_process_q_respects_q_bounds(q_kwargs, message):
+    """test_core.py:1270-1295: the fixed process Q (1e-4) must lie within [minQ, maxQ] -- raised before anything touches a device"""
+    from consenrich_amd import core_api
+
+    kwargs = dict(deltaF=0.1, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0, stateUpperBound=0.0,
+                  blockLenIntervals=2, ECM_fixedBackgroundIters=1, processNoiseCalibration="fixed", **q_kwargs)
+    with pytest.raises(ValueError, match=message):
+        core_api.runConsenrich(np.zeros((2, 4), np.float32), np.ones((2, 4), np.float32), **kwargs)
+
+
+def _case_t_inner_iters():
+    """test_core.py:1319-1336"""
+    return dict(deltaF=0.1, minQ=1.0e-4, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+                stateUpperBound=0.0, blockLenIntervals=2, ECM_fixedBackgroundIters=1, ECM_outerIters=1, ECM_minOuterIters=1,
+                ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=False, fitBackground=False,
+                processNoiseCalibration="fixed")
+
+
+def test_t_inner_iters_reaches_the_ecm_on_the_cpu_twin(monkeypatch):
+    """test_core.py:1297-1351: a non-integer t_innerIters raises, an integer one is what the ECM native receives"""
+    from consenrich_amd import core_api
+    from oracle import oracle as orc
+
+    seen, original = [], orc.cfixedBackgroundECM
+
+    def spy(*args, **kwargs):
+        seen.append(kwargs["t_innerIters"])
+        return original(*args, **kwargs)
+
+    monkeypatch.setattr(orc, "cfixedBackgroundECM", spy)
+    data, munc, kw = np.zeros((2, 5), np.float32), np.ones((2, 5), np.float32), _case_t_inner_iters()
+    with pytest.raises(ValueError, match="t_innerIters"):
+        core_api.runConsenrich(data, munc, **kw, t_innerIters=1.5)
+    _twin_call(data, munc, dict(kw, t_innerIters=4))
+    assert seen == [4]
+
+
+@pytest.mark.gpu
+def test_t_inner_iters_reaches_the_ecm_on_the_device(monkeypatch):
+    from consenrich_amd.batch import DeviceBatch
+
+    seen, original = [], DeviceBatch.ecm
+
+    def spy(self, *args, **kwargs):
+        seen.append(kwargs["inner_iters"])
+        return original(self, *args, **kwargs)
+
+    monkeypatch.setattr(DeviceBatch, "ecm", spy)
+    out = _device_call(np.zeros((2, 5), np.float32), np.ones((2, 5), np.float32), dict(_case_t_inner_iters(), t_innerIters=4))
+    assert seen == [4] and out[0].shape == (5, 2)
+
+
+def _case_silent():
+    """test_core.py:1882-1916"""
+    rng = np.random.default_rng(11)
+    n = 18
+    grid = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    data = np.vstack([grid + 0.01 * rng.normal(size=n), grid + 0.02 * rng.normal(size=n) + 0.05]).astype(np.float32)
+    munc = np.full_like(data, 0.1, dtype=np.float32)
+    kw = dict(deltaF=0.1, minQ=1.0e-4, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=6, pad=1.0e-4, ECM_fixedBackgroundIters=1, ECM_fixedBackgroundRtol=0.0,
+              ECM_outerIters=1, ECM_minOuterIters=1, ECM_backgroundShiftRtol=0.0, ECM_outerNLLRtol=0.0, fitBackground=False,
+              processNoiseCalibration="fixed", returnScales=True)
+    return data, munc, kw
+
+
+def test_a_default_call_is_silent_on_the_cpu_twin(capfd):
+    """test_core.py:1882-1921: nothing on stdout / stderr from a default call"""
+    data, munc, kw = _case_silent()
+    _twin_call(data, munc, kw)
+    captured = capfd.readouterr()
+    assert captured.out == "" and captured.err == ""
+
+
+@pytest.mark.gpu
+def test_a_default_call_is_silent_on_the_device(capfd):
+    data, munc, kw = _case_silent()
+    _device_call(data, munc, kw)                     # (the library is loaded by now: an earlier test of this module ran on the device)
+    capfd.readouterr()
+    out = _device_call(data, munc, kw)
+    captured = capfd.readouterr()
+    assert captured.out == "" and captured.err == "" and np.all(np.isfinite(out[0]))
+
+
+def _case_interval_level_precision():
+    """test_core.py:2850-2858"""
+    from consenrich_amd import core_api
+
+    n, m = 10, 2
+    return dict(matrixData=np.zeros((m, n), np.float32), matrixPluginMuncInit=np.full((m, n), 0.2, np.float32),
+                matrixF=core_api.construct_matrix_f(0.1).astype(np.float32), matrixQ0=np.diag([1.0e-4, 1.0e-4]).astype(np.float32),         # constructMatrixQ(minDiagQ=1e-4): diag (core.py:3781)
+                intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0, stateCovarInit=1.0), n, m
+
+
+def _check_interval_level_precision(mod):
+    """test_core.py:2860-2891 on a module with the reference's callables: the observation precision is one value per INTERVAL"""
+    base, n, m = _case_interval_level_precision()
+    out = mod.cfixedBackgroundECM(**base, ECM_fixedBackgroundIters=1, ECM_fixedBackgroundRtol=0.0, ECM_useObsPrecisionReweighting=True,
+                                  ECM_useProcessPrecisionReweighting=False, returnIntermediates=True, t_innerIters=1)
+    assert np.asarray(out[6]).shape == (n,)
+    with pytest.raises(ValueError):
+        mod.cforwardPass(**base, lambdaExp=np.ones((m, n), np.float32), ECM_useObsPrecisionReweighting=True)
+
+
+def test_observation_precision_is_interval_level_only_on_the_oracle_and_in_the_call():
+    """test_core.py:2850-2911"""
+    from consenrich_amd import core_api
+    from oracle import oracle as orc
+
+    _check_interval_level_precision(orc)
+    base, n, m = _case_interval_level_precision()
+    with pytest.raises(ValueError):                                     # test_core.py:2893-2910
+        core_api.runConsenrich(base["matrixData"], base["matrixPluginMuncInit"], deltaF=0.1, minQ=1.0e-4, maxQ=0.5, stateInit=0.0,
+                               stateCovarInit=1.0, boundState=False, stateLowerBound=0.0, stateUpperBound=0.0, blockLenIntervals=4,
+                               ECM_fixedBackgroundIters=1, initialObservationPrecision=np.ones((1, n), np.float32))
+
+
+@pytest.mark.gpu
+def test_observation_precision_is_interval_level_only_on_the_device():
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import cconsenrich as amd
+
+    _check_interval_level_precision(amd)
 
 
 def _compare_phase_records(got, want, n, name):
