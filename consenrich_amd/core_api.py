@@ -1044,15 +1044,17 @@ def run_plan(plan: RunPlan, device: int = 0):
         if plan.initial_lambda is not None or plan.initial_kappa is not None:       # warm-started multipliers (core.py:4637-4648)
             b.upload_multipliers(0, plan.initial_lambda, plan.initial_kappa, None)
         passes = PassDiagnostics(cfg, plan.model, plan.interval_size_bp) if plan.ret["diagnostics"] else None
-        fits, results = run_consenrich_batch(
-            b, cfg, block_len_intervals=plan.block_len_intervals, model_q0=None if plan.q0 is None else _pad_q(plan.q0),
-            initial_background=None if plan.initial_background is None else [plan.initial_background],
-            return_background=True, return_precision_diagnostics=True, download=True,
-            initial_lambda=plan.initial_lambda is not None, initial_kappa=plan.initial_kappa is not None,
-            keep_ecm_state=False,
-            pass_diagnostics=passes, track_path=bool(plan.ret["track_path"]))
-        if passes is not None:
-            passes.close()
+        try:
+            fits, results = run_consenrich_batch(
+                b, cfg, block_len_intervals=plan.block_len_intervals, model_q0=None if plan.q0 is None else _pad_q(plan.q0),
+                initial_background=None if plan.initial_background is None else [plan.initial_background],
+                return_background=True, return_precision_diagnostics=True, download=True,
+                initial_lambda=plan.initial_lambda is not None, initial_kappa=plan.initial_kappa is not None,
+                keep_ecm_state=False,
+                pass_diagnostics=passes, track_path=bool(plan.ret["track_path"]))
+        finally:
+            if passes is not None:
+                passes.close()
         fit, res = fits[0], results[0]
         final = {"stateSmoothed": res[0], "stateCovarSmoothed": res[1], "postFitResiduals": res[2], "NIS": res[3],
                  "intervalToBlockMap": res[4], "background": res[5], "outputTracks": res[6]["outputTracks"],

@@ -86,7 +86,17 @@ def _case_apn_smoke():
     return data, munc, kw
 
 
-CASES = {"outer_pass_smoke": _case_outer_pass_smoke, "level_smoke": _case_level_smoke, "apn_smoke": _case_apn_smoke}
+def _case_background_smoke():
+    """test_core.py:4164-4181: the same matrices, one pass, the background returned"""
+    data, munc, _ = _case_outer_pass_smoke()
+    kw = dict(deltaF=0.1, minQ=1.0e-6, maxQ=1.0, stateInit=0.0, stateCovarInit=1.0, boundState=False, stateLowerBound=0.0,
+              stateUpperBound=0.0, blockLenIntervals=8, ECM_fixedBackgroundIters=1, ECM_outerIters=1,
+              processNoiseWarmupECMIters=1, returnBackground=True)
+    return data, munc, kw
+
+
+CASES = {"outer_pass_smoke": _case_outer_pass_smoke, "level_smoke": _case_level_smoke, "apn_smoke": _case_apn_smoke,
+         "background_smoke": _case_background_smoke}
 
 
 def _twin_call(data, munc, kw):
@@ -172,6 +182,10 @@ def _check_contract(name, out, data):
         np.testing.assert_array_equal(Ps[:, 0, 1], np.zeros(n, np.float32))
         np.testing.assert_array_equal(Ps[:, 1, 1], np.zeros(n, np.float32))
         assert out[-1]["state_model"] == "level"
+    elif name == "background_smoke":                             # test_core.py:4182-4185
+        assert len(out) == 6
+        background = np.asarray(out[-1])
+        assert background.shape == (n,) and np.isfinite(background).all()
     else:
         assert len(out) == 5                                     # returnScales only
 
