@@ -26,7 +26,10 @@ multiplier summaries and bound hits, sign-change rate, background-fit objective,
 matrices (`csr_batch_phase_tracks`) and (n,) tracks downloaded per phase, only when `returnDiagnostics` asks for them."""
 from __future__ import annotations
 
+import atexit
 import operator
+import os
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -56,6 +59,60 @@ def set_device(device: int) -> None:
     """GPU the next calls run on (one process per GPU: a rank sets its LOCAL_RANK once)."""
     global _DEVICE
     _DEVICE = int(device)
+
+
+# One device context per GPU is kept between calls (streams, mailboxes, work buffers: 40-60 ms per call to create and destroy; the
+# reference's CLI makes one call per chromosome).  `csr_batch_configure` releases everything of the previous batch before it lays
+# out the next one, like the per-call callables of `cconsenrich` do on the library's default context.  A call that fails drops
+# its context; concurrent calls from other threads get contexts of their own.  CONSENRICH_AMD_CORE_API_KEEP_CONTEXT=0: a fresh
+# context per call.  `release_device()` frees the kept context's device memory.
+_KEPT: dict = {}
+_KEPT_LOCK = threading.Lock()
+
+
+def _keep_contexts() -> bool:
+    return os.environ.get("CONSENRICH_AMD_CORE_API_KEEP_CONTEXT", "1") != "0"
+
+
+class _Context:
+    """`with _Context(device) as batch:` -- the kept context of that GPU if it is free, else a temporary one."""
+
+    def __init__(self, device: int):
+        self.device, self.batch, self.kept = int(device), None, False
+
+    def __enter__(self) -> DeviceBatch:
+        if _keep_contexts() and _KEPT_LOCK.acquire(blocking=False):
+            self.kept = True
+            self.batch = _KEPT.pop(self.device, None)
+        if self.batch is None:
+            try:
+                self.batch = DeviceBatch(self.device)
+            except BaseException:
+                if self.kept:
+                    _KEPT_LOCK.release()
+                raise
+        return self.batch
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if self.kept and exc_type is None:
+                _KEPT[self.device] = self.batch
+            else:
+                self.batch.close()
+        finally:
+            if self.kept:
+                _KEPT_LOCK.release()
+        return False
+
+
+def release_device(device: Optional[int] = None) -> None:
+    """Destroy the context(s) kept between calls (all GPUs when `device` is None)."""
+    with _KEPT_LOCK:
+        for dev in [d for d in list(_KEPT) if device is None or d == int(device)]:
+            _KEPT.pop(dev).close()
+
+
+atexit.register(release_device)
 
 
 # ---- the reference's argument checks (core.py:2202-2291, 2703-2780), restated with its messages -------------------------------
@@ -191,8 +248,6 @@ def track_summary(values) -> dict:
 
 
 def _workers() -> int:
-    import os
-
     try:
         return max(1, min(8, len(os.sched_getaffinity(0))))
     except AttributeError:          # not on Linux
@@ -1038,7 +1093,7 @@ def run_plan(plan: RunPlan, device: int = 0):
         early_pool = ThreadPoolExecutor(max_workers=1)
         plan.ret["_early"] = early_pool.submit(input_only_summaries, plan)
         early_pool.shutdown(wait=False)                 # (the submitted job still runs to its end)
-    with DeviceBatch(device) as b:
+    with _Context(device) as b:
         b.configure(plan.model, m, [n])
         b.upload(0, plan.data, plan.munc)
         if plan.initial_lambda is not None or plan.initial_kappa is not None:       # warm-started multipliers (core.py:4637-4648)

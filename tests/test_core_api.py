@@ -871,6 +871,55 @@ def test_observation_precision_is_interval_level_only_on_the_device():
     _check_interval_level_precision(amd)
 
 
+@pytest.mark.gpu
+def test_a_kept_context_gives_what_fresh_contexts_give(monkeypatch):
+    """`core_api` keeps one device context per GPU between calls (the reference's CLI calls once per chromosome).  A sequence
+    of calls of different shapes, state models and options through the kept context returns, array for array and BIT FOR BIT,
+    what the same calls return on a fresh context each -- nothing of a call survives `csr_batch_configure`."""
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import core_api
+
+    variants, data, munc = _variant_cases()
+    calls = [(data, munc, _case_outer_pass_smoke()[2]), _case_level_smoke(), (data, munc, variants["fixed_q_and_mask"]),
+             _case_apn_smoke(), (data, munc, variants["given_q_and_warm_starts"]), (data, munc, _case_outer_pass_smoke()[2])]
+    big = np.random.default_rng(8)
+    n_big = 5000
+    calls.insert(2, ((np.sin(np.arange(n_big) / 50.0)[None, :] + 0.2 * big.normal(size=(6, n_big))).astype(np.float32),
+                     np.full((6, n_big), 0.1, np.float32), dict(_case_background_smoke()[2], blockLenIntervals=50)))
+
+    def run_all():
+        outs = []
+        for d_, v_, kw in calls:
+            k = dict(kw)
+            outs.append(core_api.runConsenrich(d_, v_, k.pop("deltaF"), k.pop("minQ"), k.pop("maxQ"), **k))
+        return outs
+
+    core_api.release_device()
+    monkeypatch.setenv("CONSENRICH_AMD_CORE_API_KEEP_CONTEXT", "0")
+    fresh = run_all()
+    assert not core_api._KEPT
+    monkeypatch.setenv("CONSENRICH_AMD_CORE_API_KEEP_CONTEXT", "1")
+    kept = run_all()
+    assert list(core_api._KEPT) == [0]
+    for i, (a, b) in enumerate(zip(kept, fresh)):
+        assert len(a) == len(b)
+        for j, (x, y) in enumerate(zip(a, b)):
+            if isinstance(x, np.ndarray):
+                np.testing.assert_array_equal(x, y, err_msg=f"call {i} item {j}")
+            elif isinstance(x, dict) and "outputTracks" in x:
+                for key in TRACK_KEYS:
+                    np.testing.assert_array_equal(x["outputTracks"][key], y["outputTracks"][key], err_msg=f"call {i} {key}")
+            elif isinstance(x, dict):
+                assert x["post_process_noise_fit"] == y["post_process_noise_fit"] and x["final_nll"] == y["final_nll"], f"call {i}"
+    # a failing call drops its context; the next call starts a new one
+    with pytest.raises(Exception):
+        with core_api._Context(0) as b:
+            raise RuntimeError("boom")
+    assert not core_api._KEPT
+    core_api.release_device()
+
+
 def _compare_phase_records(got, want, n, name):
     """every key the twin's record of an ECM phase carries is in the device's, with the same discrete values and close numbers
     (fractions of n bins: within two bins; differences of NLLs: absolute)"""
