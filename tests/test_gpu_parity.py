@@ -1352,11 +1352,17 @@ def test_run_consenrich_batch_matches_cpu_twin(product, oracle, use_lambda):
     cfg = FitConfig(penalties=pen, ecm_iters=6, ecm_rtol=1e-4, inner_iters=3, outer_passes=8, min_outer=2, patience=1,
                     shift_rtol=2e-2, neg_multiplier=2.0, use_lambda=use_lambda)
     ocfg = _twin_cfg(mp, cfg, pen)
+    ocfg.update(interval_size_bp=25, track_path=True)
+    from consenrich_amd.core_api import PassDiagnostics
+
+    passes = PassDiagnostics(cfg, mp, 25)       # the per-phase records, four chains of four lengths through its two buffer sets
     with DeviceBatch(0, x_tol_ulps=0) as b:
         b.configure(mp, m, n_list)
         for c, (data, munc) in enumerate(ins):
             b.upload(c, data, munc)
-        fits, results = run_consenrich_batch(b, cfg, block_len_intervals=500, model_q0=np.asarray(mp.Q0, np.float32))
+        fits, results = run_consenrich_batch(b, cfg, block_len_intervals=500, model_q0=np.asarray(mp.Q0, np.float32),
+                                             pass_diagnostics=passes, track_path=True)
+        passes.close()
         # the f3 writer emits the state / uncertainty tracks of THAT final pass (consenrich.py:9476, 9797-9805)
         text_state = b.bedgraph_bytes(1, "xs", "chrT", 0, 25, end_cap=25 * n_list[1] - 7, transform="round4")
         text_unc = b.bedgraph_bytes(1, "Ps", "chrT", 0, 25, end_cap=25 * n_list[1] - 7, transform="sqrt")
@@ -1387,6 +1393,13 @@ def test_run_consenrich_batch_matches_cpu_twin(product, oracle, use_lambda):
                 assert og[k_g] == pytest.approx(orf[k_r], rel=2e-3, abs=1e-9), (c, k_g)
             assert og["penalized_objective_per_cell"] == pytest.approx(orf["penalized_objective_per_cell"], rel=1e-6)
         _check_run_result(results[c], ref, f, m, worst, f"chain{c}")
+        # every ECM phase record of every chain (core.py:4946-4990, 5161-5197, 5456-5517) against the twin's whole-matrix restatement
+        from test_core_api import _compare_phase_records
+        assert len(f.loop_diagnostics) == f.passes + 1 and f.loop_diagnostics[-1]["final_fixed_background_ecm"] is True
+        assert "background_objective_per_cell" in f.loop_diagnostics[0] and "optimization_path" in f.loop_diagnostics[0]
+        _compare_phase_records(f.post_process_noise_fit(cfg)["fixed_background_ecm"],
+                               [{k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in r.items()} for r in ref["loop"]],
+                               n_list[c], f"chain{c}")
         # the ten per-interval diagnostic tracks against the NumPy restatement of core.py:7734-7878 on the twin's final pass
         want = odiag.output_diagnostic_tracks(
             stateCovarForward=ref["out_Pf"], matrixMunc=munc, matrixQ0=np.asarray(mp.Q0, np.float32),
