@@ -718,53 +718,59 @@ class PassDiagnostics:
     (core.py:4946-4990 in the loop, :5456-5517 for the final phase) and after every background proposal (:5161-5197), for any
     chain of a batch.  The two that read the (m, n) matrices -- the sign-change rate and the weighted residual term of the
     background-fit objective -- come as per-bin float64 tracks from the device (`DeviceBatch.phase_tracks`: the reference's
-    per-cell arithmetic on the resident matrices); everything else is O(n) on (n,) tracks downloaded per phase, on a worker thread
+    per-cell arithmetic on the resident matrices); everything else is O(n) on (n,) tracks downloaded per phase, on worker threads
     while the device runs the next phase.  They are diagnostics only (no stop rule reads them): `driver.fit_batch` runs without
     this object unless they were asked for (`returnDiagnostics`)."""
 
-    def __init__(self, cfg: FitConfig, model: ModelParams, interval_size_bp, overlap: bool = True):
+    def __init__(self, cfg: FitConfig, model: ModelParams, interval_size_bp, overlap: bool = True, workers: Optional[int] = None):
         self.cfg, self.model, self.interval_size_bp = cfg, model, interval_size_bp
         self.previous_per_cell = {}
-        # overlap: the device calls (downloads, the tracks kernel) happen in the caller's thread at once; the NumPy part runs on ONE
-        # worker thread, in submission order (the pass-to-pass test of the objective needs that), while the caller goes on to
-        # launch the next phase -- the methods then return a Future of the summary instead of the summary
+        # overlap: the device calls (downloads, the tracks kernel) happen in the caller's thread at once; the NumPy part runs on a
+        # few worker threads while the caller goes on to launch the next phase -- the methods then return a Future of the
+        # summary instead of the summary.  The jobs of ONE chain run in submission order (the pass-to-pass test of the objective
+        # needs that): each waits for its chain's previous job, which was queued before it and is therefore running or done.
         self._pool = None
-        self._sets, self._turn, self._busy = {}, 0, [None, None]
+        self._sets, self._slot, self._busy, self._prev = {}, {}, {}, {}
         if overlap:
             from concurrent.futures import ThreadPoolExecutor
 
-            self._pool = ThreadPoolExecutor(max_workers=1)
+            self._pool = ThreadPoolExecutor(max_workers=max(1, min(4, _workers()) if workers is None else int(workers)))
 
-    def _run(self, fn, *args):
+    @staticmethod
+    def _after(prev, fn, *args):
+        if prev is not None:
+            prev.result()
+        return fn(*args)
+
+    def _run(self, c, key, fn, *args):
         if self._pool is None:
             return fn(*args)
-        job = self._pool.submit(fn, *args)
-        self._busy[self._turn ^ 1] = job            # (the set `_buffers` just handed out)
+        job = self._pool.submit(self._after, self._prev.get(c), fn, *args)
+        self._prev[c] = self._busy[key] = job
         return job
 
-    def _buffers(self, n):
-        """Two sets of host tracks per chain length, used in turn: the worker reads one set while the next phase's downloads fill
-        the other; fresh arrays per phase would spend more time in first-touch page faults than in the copies."""
-        sets = self._sets.setdefault(n, [None, None])
-        k = self._turn
-        self._turn ^= 1
-        if self._busy[k] is not None:               # the job that read this set two phases ago (one worker, in order: long done)
-            self._busy[k].result()
-            self._busy[k] = None
-        if sets[k] is None:
-            sets[k] = {"lambda": np.empty(n, np.float32), "kappa": np.empty(n, np.float32), "g": np.empty(n, np.float32),
-                       "rel": np.empty(n, np.float64), "fit": np.empty(n, np.float64), "cnt": np.empty(n, np.int32)}
-        return sets[k]
+    def _buffers(self, c, n):
+        """Two sets of host tracks per chain, used in turn: a worker reads one set while the chain's next phase fills the other;
+        fresh arrays per phase would spend more time in first-touch page faults than in the copies."""
+        slot = self._slot.get(c, 0)
+        self._slot[c] = slot ^ 1
+        key = (c, slot)
+        if self._busy.get(key) is not None:         # the job that read this set two phases ago
+            self._busy.pop(key).result()
+        if key not in self._sets or self._sets[key]["rel"].shape != (n,):
+            self._sets[key] = {"lambda": np.empty(n, np.float32), "kappa": np.empty(n, np.float32), "g": np.empty(n, np.float32),
+                               "rel": np.empty(n, np.float64), "fit": np.empty(n, np.float64), "cnt": np.empty(n, np.int32)}
+        return key, self._sets[key]
 
     def _fetch(self, batch, c, with_fit):
         cfg = self.cfg
-        buf = self._buffers(batch.chain_lens[c])
+        key, buf = self._buffers(c, batch.chain_lens[c])
         batch.export(L.EXPORT_MULT)
         lam = batch.download(c, "lambda", out=buf["lambda"]) if cfg.use_lambda else None
         kap = batch.download(c, "kappa", out=buf["kappa"]) if cfg.use_kappa else None
         rel, fit, cnt = batch.phase_tracks(c, float(cfg.pad), with_fit=with_fit, use_lambda=cfg.use_lambda,
                                            out=(buf["rel"], buf["fit"], buf["cnt"]))
-        return lam, kap, rel, fit, cnt, buf
+        return lam, kap, rel, fit, cnt, buf, key
 
     def _summaries(self, lam, kap, rel) -> dict:
         lam_b, kap_b = self.model.lambda_bounds, self.model.kappa_bounds
@@ -780,15 +786,15 @@ class PassDiagnostics:
 
     def phase(self, batch, c):
         """after an ECM phase that no background update follows (the final phase; the single phase without a background fit)"""
-        lam, kap, rel, _, _, _ = self._fetch(batch, c, False)
-        return self._run(self._summaries, lam, kap, rel)
+        lam, kap, rel, _, _, _, key = self._fetch(batch, c, False)
+        return self._run(c, key, self._summaries, lam, kap, rel)
 
     def loop_pass(self, batch, c, update_info):
         """after `background_update` (its per-chain record: `update_info`), BEFORE `background_apply`: the phase's summaries and
         the objective of the proposal (`_scoreBackgroundFitObjective`, core.py:4540-4606) with its pass-to-pass test"""
-        lam, kap, rel, fit, cnt, buf = self._fetch(batch, c, True)
+        lam, kap, rel, fit, cnt, buf, key = self._fetch(batch, c, True)
         g = batch.download(c, "background_next", out=buf["g"])
-        return self._run(self._loop_summaries, c, lam, kap, rel, fit, cnt, g, float(update_info.get("weight_scale", 1.0)))
+        return self._run(c, key, self._loop_summaries, c, lam, kap, rel, fit, cnt, g, float(update_info.get("weight_scale", 1.0)))
 
     def _loop_summaries(self, c, lam, kap, rel, fit, cnt, g, weight_scale) -> dict:
         cfg = self.cfg

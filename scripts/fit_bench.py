@@ -19,12 +19,25 @@ b.configure(ModelParams(state_dim=2), m, lengths); b.synthesize(1234)
 cfg = FitConfig(penalties=bg_cases.penalties(750, 128.0), ecm_iters=int(os.environ.get("ECM_ITERS", "50")), ecm_rtol=1e-6,
                 inner_iters=5, outer_passes=int(os.environ.get("OUTER", "8")), min_outer=3, patience=2, shift_rtol=5e-3,
                 seed_q=bool(os.environ.get("SEED_Q")))
-b.synchronize(); b.profile(True)
-t = time.perf_counter(); fits, _ = run_consenrich_batch(b, cfg, block_len_intervals=750, download=False); b.synchronize(); wall = time.perf_counter() - t
-kt = b.kernel_times(); b.profile(False)
+# DIAG=1: with the reference's per-phase run diagnostics for every chromosome (core_api.PassDiagnostics: per-bin tracks from the
+# device, O(n) summaries on a worker thread); PROFILE=0: without the per-kernel event timing (it costs ~0.15 s of wall time)
+passes = None
+if os.environ.get("DIAG"):
+    from consenrich_amd.core_api import PassDiagnostics
+    passes = PassDiagnostics(cfg, ModelParams(state_dim=2), 200)
+prof = os.environ.get("PROFILE", "1") != "0"
+b.synchronize(); b.profile(prof)
+t = time.perf_counter()
+fits, _ = run_consenrich_batch(b, cfg, block_len_intervals=750, download=False, pass_diagnostics=passes)
+b.synchronize(); wall = time.perf_counter() - t
+if passes is not None:
+    passes.close()
+kt = b.kernel_times() if prof else {}; b.profile(False)
 ecm_total = sum(sum(f.ecm_iters) for f in fits)
 print(json.dumps({"seed_q": cfg.seed_q, "q0_first_chain": None if fits[0].q0 is None else [float(fits[0].q0[0, 0]), float(fits[0].q0[1, 1])],
                   "workload": f"hg38 @200bp x {m}, {len(lengths)} chromosomes, {sum(lengths)} bins", "wall_s": round(wall, 3),
+                  "kernel_timing": prof, "per_phase_diagnostics": passes is not None,
+                  "phase_records_first_chain": len(fits[0].loop_diagnostics),
                   "outer_passes": [f.passes for f in fits], "converged": [f.converged for f in fits],
                   "ecm_iterations_total_over_chains": ecm_total, "ecm_iters_first_chain": fits[0].ecm_iters,
                   "final_ecm_iters": [f.final_ecm_iters for f in fits], "final_nll_first_chain": fits[0].final_nll,
