@@ -1329,6 +1329,50 @@ def _check_run_result(res, ref, fit, m, worst, tag):
     assert diag["precision_track_diagnostics"] is True
 
 
+def _seed_smoother(mod, resid, background, working_munc, q, state_model, bound_state):
+    """The reference's `_runSeedSmoother` (consenrich.py:7578-7686), keyword for keyword: a forward + backward
+    pass of (residuals - background) against a working variance with ONE block and no multipliers, through the module's callables."""
+    n = resid.shape[1]
+    d = 1 if state_model == "level" else 2
+    seed_data = np.ascontiguousarray(resid - np.asarray(background, np.float32).reshape(1, -1), dtype=np.float32)
+    xf, pf, pn = np.empty((n, d), np.float32), np.empty((n, d, d), np.float32), np.empty((n, d, d), np.float32)
+    vec_d = np.empty(n, np.float32)
+    common = dict(matrixData=seed_data, matrixPluginMuncInit=working_munc, intervalToBlockMap=np.zeros(n, np.int32), blockCount=1,
+                  stateInit=0.0, stateCovarInit=1000.0, pad=1.0e-4, chunkSize=0, stateForward=xf, stateCovarForward=pf,
+                  pNoiseForward=pn, vectorD=vec_d, returnNLL=True, storeNLLInD=False, lambdaExp=None, processPrecExp=None,
+                  ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=False, ECM_useAPN=False)
+    back = dict(matrixData=seed_data, stateForward=xf, stateCovarForward=pf, pNoiseForward=pn, chunkSize=0, stateSmoothed=None,
+                stateCovarSmoothed=None, lagCovSmoothed=None, postFitResiduals=None)
+    if d == 1:
+        mod.cforwardPassLevel(matrixQ0=np.ascontiguousarray(q[:1, :1], dtype=np.float32), **common)
+        xs, ps, _lag, _res = mod.cbackwardPassLevel(**back)
+    else:
+        f = np.asarray(cases.F_TREND, np.float32)
+        mod.cforwardPass(matrixF=f, matrixQ0=np.ascontiguousarray(q[:2, :2], dtype=np.float32),
+                         projectStateDuringFiltering=bool(bound_state), stateLowerBound=-1.0, stateUpperBound=1.0, **common)
+        xs, ps, _lag, _res = mod.cbackwardPass(matrixF=f, **back)
+    return np.asarray(xs, np.float32), np.asarray(ps, np.float32)
+
+
+@pytest.mark.parametrize("state_model", ["levelTrend", "level"])
+def test_seed_smoother_call_through_the_drop_in_callables(product, oracle, state_model):
+    """SURVEY 8(f) rank 4, second half: the munc stage's seed smoother is nothing but this call pair (blockCount 1, chunkSize 0,
+    every output preallocated or None, the bound-state keywords passed and ignored); product == oracle on it."""
+    n, m = 40000, 5
+    data, munc = cases.synth(n, m, 321)
+    background = (0.2 * np.sin(np.arange(n) / 700.0)).astype(np.float32)
+    working = (munc * np.float32(1.7) + np.float32(0.05)).astype(np.float32)
+    q = np.diag([1.0e-3, 1.0e-4]).astype(np.float32)
+    got = _seed_smoother(product, data, background, working, q, state_model, True)
+    want = _seed_smoother(oracle, data, background, working, q, state_model, True)
+    for name, g, w in (("stateSmoothed", got[0], want[0]), ("stateCovarSmoothed", got[1], want[1])):
+        assert g.shape == w.shape and g.dtype == np.float32
+        a, b = g.astype(np.float64).reshape(n, -1), w.astype(np.float64).reshape(n, -1)
+        # state vectors: relative to the level of the bin (test_full_size_chain_matches_oracle); covariances: plain
+        scale = np.abs(b).max(axis=1, keepdims=True) if name == "stateSmoothed" else np.abs(b)
+        assert np.all(np.abs(a - b) <= RTOL * scale + ATOL), (state_model, name)
+
+
 @pytest.mark.parametrize("use_lambda", [False, True], ids=["kappa", "kappa+lambda"])
 def test_run_consenrich_batch_matches_cpu_twin(product, oracle, use_lambda):
     """`run_consenrich_batch` = background warm start -> outer alternation [ECM phase with warm-started
