@@ -1399,7 +1399,8 @@ def test_run_consenrich_batch_matches_cpu_twin(product, oracle, use_lambda):
     ocfg.update(interval_size_bp=25, track_path=True)
     from consenrich_amd.core_api import PassDiagnostics
 
-    passes = PassDiagnostics(cfg, mp, 25)       # the per-phase records, four chains of four lengths through its two buffer sets
+    # the per-phase records, four chains of four lengths through their buffer sets: on worker threads / in the caller's thread
+    passes = PassDiagnostics(cfg, mp, 25, overlap=bool(use_lambda))
     with DeviceBatch(0, x_tol_ulps=0) as b:
         b.configure(mp, m, n_list)
         for c, (data, munc) in enumerate(ins):
