@@ -323,6 +323,7 @@ extern "C" int csr_batch_upload_multipliers(csr_ctx *c, int32_t chain, const flo
         LAUNCH_CHECK("k_import_f32");
         HIPOK(hipStreamSynchronize(c->stream));
     }
+    c->multGen += 1;
     c->haveFwd = c->haveBwd = false;
     return 0;
 }

@@ -401,6 +401,7 @@ static int ensure_sb_view(csr_ctx *c) {
 // to the fixed point (= the sequential recursion, whatever the superblock length); one tiled launch brings the filtered state
 // back into the batch's blocked layout for the epilogue and the smoother.
 static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool withPf);
+static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active);
 // phase 0: the whole chain.  phase 1 (a step that pipelines its tail per chain, step_pipelined): stop right after the launch of
 // the barrier-free kernel, with per-chain "done" words the host can watch -- c->sbp.active says that this happened (otherwise
 // the whole chain ran, as in phase 0).  phase 2: wait for that launch (or run the pass form if it bailed out); the filtered
@@ -705,6 +706,12 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool with
 static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned char *active, bool defer = false,
                         bool side = false, bool natOut = false, bool split = false) {
     if (!c->statsValid) return fail("csr_batch_stats must run before the forward pass");
+    // the resident statistics carry {S2c, log R} as a float32 pair (computed in the 2-ulp mode) and the context is back in the
+    // bit-exact mode: that mode's D / NLL / lambda E-step promise float64 statistics -- recompute them
+    if (c->p.statsF32 && c->xTolUlps == 0) CHECK(csr_batch_stats(c));
+    // a MASKED pass rewrites the blocked xf / Pf of its own chains only: when the resident pass left them in the reference layout
+    // alone, the chains outside the mask get their blocked copies back first (they keep their resident results)
+    if (active != nullptr && c->haveFwd && (c->fwdBlockedStale || c->pfBlockedStale)) CHECK(ensure_blocked_fwd(c, nullptr));
     c->sbp.active = false;
     join_pf(c);         // (an early export nobody asked for afterwards still reads the arrays this pass overwrites)
     c->pfNat = c->pnNat = false;
@@ -894,7 +901,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
 
 // The resident forward pass left xf / Pf in the reference layout only and a reader needs the blocked copies after all (a
 // smoother pass without reference-layout outputs, per-chain base matrices): bring them back through LDS tiles.
-static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active = nullptr) {
+static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active) {
     if (!c->fwdBlockedStale && !c->pfBlockedStale) return 0;
     float *natXf, *natPf;
     CHECK(nat_array(c, CSR_ARR_XF, &natXf));
@@ -909,6 +916,26 @@ static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active = nullptr)
                        reinterpret_cast<const float4 *>(natPf), p.tPf, (int64_t)0);
     LAUNCH_CHECK("k_import_tiled");
     if (active == nullptr) c->fwdBlockedStale = c->pfBlockedStale = false;      // (a masked import leaves the other chains stale)
+    return 0;
+}
+
+// The resident smoother wrote xs / Ps / lag in the reference layout only (a step, forward_backward) and a MASKED ECM call is about
+// to rewrite the blocked copies of its own chains: the chains outside the mask get theirs back first, so that the conversions
+// that follow the call (exports, per-phase tracks, the background update: all from the blocked copies) return what is resident.
+static int ensure_blocked_smooth(csr_ctx *c) {
+    if (!c->haveBwd || !c->smoothNat || c->mdl.state_dim != 2) return 0;
+    float *xs, *Ps, *lag;
+    CHECK(nat_array(c, CSR_ARR_XS, &xs));
+    CHECK(nat_array(c, CSR_ARR_PS, &Ps));
+    CHECK(nat_array(c, CSR_ARR_LAG, &lag));
+    Prm p = c->p;
+    p.chainActive = nullptr;
+    const dim3 grid((int)(c->NG * (c->B / 32)));
+    Scope sc(c, "state_reblock_out");
+    hipLaunchKernelGGL(k_import_tiled<float2>, grid, dim3(256), 0, c->stream, p, reinterpret_cast<const float2 *>(xs), p.tXs, (int64_t)0);
+    hipLaunchKernelGGL(k_import_tiled<float4>, grid, dim3(256), 0, c->stream, p, reinterpret_cast<const float4 *>(Ps), p.tPs, (int64_t)0);
+    hipLaunchKernelGGL(k_import_tiled<float4>, grid, dim3(256), 0, c->stream, p, reinterpret_cast<const float4 *>(lag), p.tLag, (int64_t)0);
+    LAUNCH_CHECK("k_import_tiled (smoothed)");
     return 0;
 }
 
@@ -1137,6 +1164,7 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
     CHECK(settle(c));
     if (!cfg || !out) return fail("null argument");
     if (!c->statsValid) CHECK(csr_batch_stats(c));
+    c->multGen += 1;        // the E-steps rewrite the resident multipliers
     const int nc = (int)c->chains.size();
     uint32_t fl = flags & (F_QSCALE);
     if (cfg->use_lambda) fl |= F_LAMBDA;
@@ -1158,11 +1186,13 @@ extern "C" int csr_batch_ecm_masked(csr_ctx *c, const csr_ecm_cfg *cfg, uint32_t
     // tiny chains: filter + smoother + NLL only (pyx:7998-8129)
     bool anyTiny = false, anyBig = false;
     auto masked = [&](int i) { return chain_mask != nullptr && chain_mask[i] == 0; };
+    bool anyMasked = false;
     for (int i = 0; i < nc; ++i) {
-        if (masked(i)) { out[i].skipped = 2; continue; }
+        if (masked(i)) { out[i].skipped = 2; anyMasked = true; continue; }
         if (c->chains[i].n <= 5) { act[i] = 1; anyTiny = true; out[i].skipped = 1; }
         else anyBig = true;
     }
+    if (anyMasked && (anyTiny || anyBig)) CHECK(ensure_blocked_smooth(c));
     if (anyTiny) {
         CHECK(push_active());
         CHECK(forward_impl(c, fl | F_NLL, true, c->dActive, true));
@@ -1361,6 +1391,23 @@ static int add_export(csr_ctx *c, ExpList &L, int id, const float *src, int E, i
     return 0;
 }
 
+// the smoothed state / one multiplier array into the reference layout unless the array there already is this fit's / these
+// multipliers' (csr_ctx::natXsStamp, natMultStamp)
+static int add_export_xs(csr_ctx *c, ExpList &L) {
+    if (c->smoothNat || c->natXsStamp == c->fitGen) return 0;
+    CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
+    c->natXsStamp = c->fitGen;
+    return 0;
+}
+static int add_export_mult(csr_ctx *c, ExpList &L, int id) {
+    const int k = id == CSR_ARR_LAMBDA ? 0 : (id == CSR_ARR_KAPPA ? 1 : 2);
+    if (c->nat[id] && c->natMultStamp[k] == c->multGen) return 0;
+    const float *src = k == 0 ? c->p.tLam : (k == 1 ? c->p.tKap : c->p.tQs);
+    CHECK(add_export(c, L, id, src, 1, 1, 0));
+    c->natMultStamp[k] = c->multGen;
+    return 0;
+}
+
 // residuals of the bins [off, off + nb) of the batch's natural layout (whole chains: off and nb are multiples of 64)
 static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck) {
     const int d = c->mdl.state_dim;
@@ -1445,7 +1492,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     }
     if (what & (CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID)) {
         if (!c->haveBwd) return fail("no smoothed results to export");
-        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)p.tXs, 2, nv, 0));
+        CHECK(add_export_xs(c, L));
     }
     if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat) {      // smoothNat: the smoother already wrote the natural arrays
         CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
@@ -1453,9 +1500,9 @@ static int export_impl(csr_ctx *c, uint32_t what) {
     }
     if (what & CSR_EXPORT_SMOOTH) c->natSmoothGen = c->fitGen;
     if (what & CSR_EXPORT_MULT) {
-        CHECK(add_export(c, L, CSR_ARR_LAMBDA, p.tLam, 1, 1, 0));
-        CHECK(add_export(c, L, CSR_ARR_KAPPA, p.tKap, 1, 1, 0));
-        CHECK(add_export(c, L, CSR_ARR_QSCALE, p.tQs, 1, 1, 0));
+        CHECK(add_export_mult(c, L, CSR_ARR_LAMBDA));
+        CHECK(add_export_mult(c, L, CSR_ARR_KAPPA));
+        CHECK(add_export_mult(c, L, CSR_ARR_QSCALE));
     }
     CHECK(flush_export(c, L));
     if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true));

@@ -66,6 +66,7 @@ extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n
         flags |= e.flag;
         float *dst;
         CHECK(nat_array(c, e.id, &dst));
+        if (e.flag) c->natMultStamp[e.id == CSR_ARR_LAMBDA ? 0 : (e.id == CSR_ARR_KAPPA ? 1 : 2)] = ~0ull;     // (not the resident multipliers)
         if (e.rows > 0)
             HIPOK(hipMemcpyAsync(dst + ci.off * e.comps, e.src, sizeof(float) * e.comps * e.rows, hipMemcpyHostToDevice,
                                  c->stream));
@@ -365,8 +366,8 @@ extern "C" int csr_batch_background_update(csr_ctx *c, const csr_bg_cfg *cfg, cs
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        if (!zeroState && !c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
-        if (cfg->use_lambda) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        if (!zeroState) CHECK(add_export_xs(c, L));
+        if (cfg->use_lambda) CHECK(add_export_mult(c, L, CSR_ARR_LAMBDA));
         CHECK(flush_export(c, L));
     }
     a.xsNat = zeroState ? nullptr : c->nat[CSR_ARR_XS]; a.xsStride = c->mdl.state_dim;
@@ -756,8 +757,8 @@ extern "C" int csr_batch_objective_terms(csr_ctx *c, const csr_objective_cfg *cf
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        if (needLam) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
-        if (cfg->use_kappa_penalty) CHECK(add_export(c, L, CSR_ARR_KAPPA, c->p.tKap, 1, 1, 0));
+        if (needLam) CHECK(add_export_mult(c, L, CSR_ARR_LAMBDA));
+        if (cfg->use_kappa_penalty) CHECK(add_export_mult(c, L, CSR_ARR_KAPPA));
         CHECK(flush_export(c, L));
     }
     ObjArgs o;
@@ -863,8 +864,8 @@ extern "C" int csr_batch_phase_tracks(csr_ctx *c, int32_t chain, int32_t use_lam
     {
         ExpList L;
         memset(&L, 0, sizeof(L));
-        if (!c->smoothNat) CHECK(add_export(c, L, CSR_ARR_XS, (const float *)c->p.tXs, 2, c->mdl.state_dim, 0));
-        if (useLam) CHECK(add_export(c, L, CSR_ARR_LAMBDA, c->p.tLam, 1, 1, 0));
+        CHECK(add_export_xs(c, L));
+        if (useLam) CHECK(add_export_mult(c, L, CSR_ARR_LAMBDA));
         CHECK(flush_export(c, L));
     }
     const int64_t n = c->chains[chain].n;

@@ -152,6 +152,9 @@ extern "C" int csr_backward_pass(const csr_model *mdl, int64_t m, int64_t n, con
     c->haveFwd = true;
     c->fwdInternal = false;
     c->fwdQCompact = false;
+    // the caller's xf / Pf ARE the blocked copies now: whatever a previous resident pass left in the reference layout is not theirs
+    c->fwdBlockedStale = c->pfBlockedStale = false;
+    c->fwdNat = c->xfNat = c->pfNat = c->pnNat = false;
     c->fwdFlags = 0;
     CHECK(backward_impl(c, true, nullptr));
     CHECK(csr_batch_export(c, CSR_EXPORT_SMOOTH | CSR_EXPORT_RESID));

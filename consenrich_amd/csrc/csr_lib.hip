@@ -156,6 +156,10 @@ struct csr_ctx {
     bool statsValid = false;
     bool haveFwd = false, haveBwd = false;
     uint64_t fitGen = 0, natSmoothGen = ~0ull;     // generation of the resident smoothed fit / of the natural xs + Ps arrays (csr_batch_gather_tracks)
+    // Conversions of the smoothed state / the multipliers into the reference layout are remembered: a caller that asks chain by
+    // chain (the per-phase run diagnostics: 22 chains x every ECM phase) converts the batch once per phase, not once per chain.
+    // multGen counts changes of the resident multipliers (uploads, ECM calls); the stamps say what the arrays were converted from.
+    uint64_t multGen = 0, natMultStamp[3] = {~0ull, ~0ull, ~0ull}, natXsStamp = ~0ull;
     bool smoothNat = false;     // the last smoother pass wrote xs / Ps / lag straight into the natural arrays (the
                                 // block-transposed copies are stale; nothing but the ECM E-steps reads those)
     bool pendNatOut = false;
@@ -359,10 +363,13 @@ static void free_batch(csr_ctx *c) {
     c->sbp.active = false;
     c->pfPending = false;
     c->xfNat = false;
+    c->fwdNat = c->pfNat = c->pnNat = c->dNat = c->smoothNat = false;
+    c->fwdBlockedStale = c->pfBlockedStale = false;     // (the reference-layout arrays they point at are gone)
     c->ckF[0] = c->ckF[1] = c->ckB[0] = c->ckB[1] = nullptr;
     c->wsSavedF = c->wsSavedB = 0;
     c->wsActive = c->wsCold = false;
     for (auto &n : c->nat) n = nullptr;
+    c->natXsStamp = c->natMultStamp[0] = c->natMultStamp[1] = c->natMultStamp[2] = ~0ull;
 }
 
 // Warm-up windows that gave zero re-runs on the bench workload with margin (hg38 x 32 synthetic: the state chain needs

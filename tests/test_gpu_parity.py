@@ -1921,7 +1921,7 @@ def _genome_workload_against_oracle(oracle, bin_bp, m, full, variants):
                 assert rs["x_tol_ulps"] == v["x_tol_ulps"], rs            # the mode the variant names is the mode that ran
                 worst = {"nll_rel": 0.0, "phi_rel": 0.0, "chains_checked_in_full": 0.0, "steps": float(v.get("steps", 1)),
                          "x_tol_ulps": float(rs["x_tol_ulps"]), "pipeline_redos": float(rs["pipeline_redos"]),
-                         "tail_groups": float(rs["tail_groups"]),
+                         "tail_groups": float(rs["tail_groups"]), "state_chain_bailouts": float(rs["sb_bailouts"]),
                          "nat_first_use_off_main": float(rs["nat_first_use_off_main"])}
                 batches.append((b, sd, sn, worst))
             b0 = batches[0][0]
@@ -2124,11 +2124,15 @@ def test_bench_workload_exact_mode_matches_oracle(product, oracle):
 def test_config5_hg38_50bp_x64_matches_oracle(product, oracle):
     """BASELINE config 5: hg38 autosomes @50 bp (57 500 042 bins) x 64 samples in ONE batch on one MI355X (29 GB of inputs),
     throughput mode AND default bit-exact mode (a second batch, same oracle passes): phiHat and NLL of every chromosome against the oracle, every output array of the two shortest
-    chromosomes (chr21, chr22: ~1 M bins each).  MFMA eligibility of the m = 64 observation update: none -- it is a
-    length-m weighted reduction per bin (pyx:443-456), no dense contraction; the bound is HBM."""
-    w, we = _genome_workload_against_oracle(oracle, 50, 64, full=(20, 21),
+    chromosomes (chr21, chr22: ~1 M bins each) AND of chr1 (4 979 129 bins, ~200 superblocks: the longest critical path of the
+    state chain and the likeliest place for one of its bounded waits to run out -- `state_chain_bailouts` must stay 0).  MFMA
+    eligibility of the m = 64 observation update: none -- it is a length-m weighted reduction per bin (pyx:443-456), no dense
+    contraction; the bound is HBM."""
+    w, we = _genome_workload_against_oracle(oracle, 50, 64, full=(0, 20, 21),
                                             variants=[dict(x_tol_ulps=2), dict(x_tol_ulps=0)])
     _record_worst("c5_hg38_50bp_x64_ulp2", w)
+    assert w["chains_checked_in_full"] == 3 and we["chains_checked_in_full"] == 3
+    assert w["state_chain_bailouts"] == 0 and we["state_chain_bailouts"] == 0
     assert w["nll_rel"] <= 1e-8 and w["phi_rel"] <= 1e-5
     assert w["xs_level_rel"] <= 2e-6 and w["xs_trend_vs_level"] <= 2e-6
     assert w["D_frac_outside_1e-5"] <= 1e-2 and w["D_rel_max"] <= 5e-4

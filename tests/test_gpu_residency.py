@@ -1,0 +1,184 @@
+"""GPU tests of what stays RESIDENT between calls of one context (run with -m gpu): a pass may leave some of its results in the
+reference layout only (round 5's byte cuts) -- every later call that reads or partly rewrites the blocked copies must find them.
+Round-5 advisor findings: masked passes after a step, imported forward results after a lean forward pass, a mode toggle between
+the statistics and the forward pass, conversions remembered per fit."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+
+F = np.asarray(cases.F_TREND, np.float32)
+Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+ARRS = ("xf", "Pf", "xs", "Ps", "lag")
+
+
+@pytest.fixture(scope="module")
+def product():
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import cconsenrich
+
+    return cconsenrich
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+
+    orc.lib()
+    return orc
+
+
+def _oracle_pass(oracle, d_, v_):
+    n = d_.shape[1]
+    xf, Pf, pn, D = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros(n, np.float32)
+    oracle.cforwardPass(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=Q0, intervalToBlockMap=np.zeros(n, np.int32),
+                        blockCount=1, stateInit=0.0, stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf,
+                        pNoiseForward=pn, vectorD=D, returnNLL=True)
+    bw = oracle.cbackwardPass(matrixData=d_, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+    return {"xf": xf, "Pf": Pf, "xs": bw[0], "Ps": bw[1], "lag": bw[2][: n - 1]}
+
+
+def _close(got, ref, lvl, msg):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if got.ndim == 2 and got.shape[1] == 2:
+        assert np.all(np.abs(got - ref) <= 1e-5 * lvl + 2e-6), msg
+    else:
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6, err_msg=msg)
+
+
+@pytest.mark.parametrize("natin", ["1", "0"], ids=["natin", "blocked-smoother"])
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+@pytest.mark.parametrize("then", ["forward_masked", "ecm_masked"])
+def test_a_masked_pass_after_a_step_leaves_the_other_chains_resident(product, oracle, monkeypatch, xtol, natin, then):
+    """csr_batch_step leaves xf / Pf (2-ulp mode) or Pf (default mode, pipelined tails) and the smoothed arrays in the reference
+    layout only.  A masked forward pass / a masked ECM call rewrites the blocked copies of ITS chains; the chains outside the mask
+    must come back from every later conversion exactly as the step left them (csr_batch_forward_masked / csr_batch_ecm_masked:
+    'chain c is left exactly as it is') -- and equal to the oracle."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    monkeypatch.setenv("CONSENRICH_AMD_NATIN", natin)
+    n_list, m = [70000, 33000, 4, 50001], 4
+    sets = [cases.synth(n, m, 8800 + c, outlier_frac=0.01) for c, n in enumerate(n_list)]
+    mask = [True, False, True, False]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+    with DeviceBatch(0, x_tol_ulps=xtol) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        for c, (d_, v_) in enumerate(sets):
+            b.upload(c, d_, v_)
+        b.step(L.RETURN_NLL, what)
+        before = {(c, a): b.download(c, a) for c in range(len(n_list)) for a in ARRS}
+        if then == "forward_masked":
+            b.forward_masked(L.RETURN_NLL, mask)
+            b.backward()
+            b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH)
+            check = range(len(n_list))          # same data, same flags: the masked chains are recomputed to the same values
+        else:
+            outs, _ = b.ecm(max_iters=2, inner_iters=2, rtol=0.0, use_kappa=True, chain_mask=mask)
+            assert [int(o.skipped) for o in outs] == [0, 2, 1, 2]
+            b.export(L.EXPORT_FORWARD | L.EXPORT_SMOOTH)
+            check = [c for c in range(len(n_list)) if not mask[c]]
+        for c in check:
+            ref = _oracle_pass(oracle, *sets[c]) if n_list[c] > 8 else None
+            for a in ARRS:
+                got = b.download(c, a)
+                assert np.array_equal(got, before[(c, a)]), (then, xtol, natin, c, a)
+                if ref is not None:
+                    lvl = np.maximum(np.abs(ref["xs"][:, :1].astype(np.float64)), 1.0)
+                    _close(got[: ref[a].shape[0]], ref[a], lvl, (c, a))
+
+
+@pytest.mark.parametrize("xtol", [2, 0], ids=["ulp2", "exact"])
+def test_backward_pass_on_imported_forward_results_after_a_lean_forward_pass(product, oracle, xtol):
+    """cforwardPass(A) in the 2-ulp mode leaves A's xf / Pf in the reference layout only; a following cbackwardPass with the
+    forward results of ANOTHER chain -- of the same (m, n), then of a different n (a reconfiguration) -- must smooth what the
+    caller passed, not what was resident."""
+    m = 4
+    product.set_validation(xtol)
+    try:
+        for n_a, n_b in ((30000, 30000), (30000, 21000)):
+            dA, vA = cases.synth(n_a, m, 4100)
+            dB, vB = cases.synth(n_b, m, 4200)
+            kw = dict(matrixF=F, matrixQ0=Q0, stateInit=0.0, stateCovarInit=1000.0)
+            product.cforwardPass(matrixData=dA, matrixPluginMuncInit=vA, intervalToBlockMap=np.zeros(n_a, np.int32), blockCount=1,
+                                 **kw)
+            ref = _oracle_pass(oracle, dB, vB)
+            pn = np.zeros((n_b, 2, 2), np.float32)
+            pn[:] = Q0
+            got = product.cbackwardPass(matrixData=dB, matrixF=F, stateForward=ref["xf"], stateCovarForward=ref["Pf"],
+                                        pNoiseForward=pn)
+            lvl = np.maximum(np.abs(ref["xs"][:, :1].astype(np.float64)), 1.0)
+            _close(got[0], ref["xs"], lvl, ("xs", n_a, n_b))
+            _close(got[1], ref["Ps"], lvl, ("Ps", n_a, n_b))
+            _close(got[2][: n_b - 1], ref["lag"], lvl, ("lag", n_a, n_b))
+    finally:
+        product.set_validation(0)
+
+
+def test_statistics_of_the_throughput_mode_are_recomputed_when_the_context_turns_exact(product):
+    """set_validation(2); stats(); set_validation(0); forward(): the resident {S2c, log R} are a float32 pair (a property of the
+    2-ulp mode's statistics) -- the bit-exact mode promises float64 statistics and recomputes them: D and the NLL equal a
+    context that was exact all along, bit for bit."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [60000, 9000], 8
+    sets = [cases.synth(n, m, 5100 + c, outlier_frac=0.01) for c, n in enumerate(n_list)]
+
+    def run(toggle):
+        with DeviceBatch(0, x_tol_ulps=2 if toggle else 0) as b:
+            b.configure(ModelParams(state_dim=2), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            b.stats()
+            if toggle:
+                b.set_validation(0)
+            sd, sn = b.forward(L.RETURN_NLL)
+            b.export(L.EXPORT_FORWARD)
+            assert b.run_stats()["x_tol_ulps"] == 0
+            return np.array(sd), np.array(sn), [b.download(c, "D") for c in range(len(n_list))]
+
+    a, t = run(False), run(True)
+    assert np.array_equal(a[0], t[0]) and np.array_equal(a[1], t[1])
+    for x, y in zip(a[2], t[2]):
+        assert np.array_equal(x, y)
+
+
+def test_remembered_conversions_follow_the_resident_fit(product):
+    """The conversions of the multipliers / the smoothed state into the reference layout are remembered per fit (the per-phase
+    run diagnostics ask chain by chain): a second export of the same fit launches nothing, a new ECM call or an upload is seen."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [20000, 7000], 4
+    sets = [cases.synth(n, m, 6100 + c, outlier_frac=0.02) for c, n in enumerate(n_list)]
+    with DeviceBatch(0) as b:
+        b.configure(ModelParams(state_dim=2), m, n_list)
+        for c, (d_, v_) in enumerate(sets):
+            b.upload(c, d_, v_)
+        b.stats()
+        b.ecm(max_iters=1, inner_iters=2, rtol=0.0, use_kappa=True)
+        b.export(L.EXPORT_MULT | L.EXPORT_SMOOTH)
+        k1, x1 = b.download(0, "kappa"), b.download(0, "xs")
+        b.profile(True)
+        b.export(L.EXPORT_MULT | L.EXPORT_SMOOTH)
+        rel, _, _ = b.phase_tracks(1, 1e-4)
+        times = b.kernel_times()
+        b.profile(False)
+        assert "export_natural" not in times, times                 # nothing to convert: same fit, same multipliers
+        assert np.array_equal(k1, b.download(0, "kappa")) and np.array_equal(x1, b.download(0, "xs"))
+        b.ecm(max_iters=2, inner_iters=2, rtol=0.0, use_kappa=True)
+        b.export(L.EXPORT_MULT | L.EXPORT_SMOOTH)
+        k2, x2 = b.download(0, "kappa"), b.download(0, "xs")
+        assert not np.array_equal(k1, k2) and not np.array_equal(x1, x2)
+        new = np.full(n_list[0], 1.5, np.float32)
+        b.upload_multipliers(0, kappa=new)
+        b.export(L.EXPORT_MULT)
+        assert np.array_equal(b.download(0, "kappa"), new)
+        assert np.array_equal(b.download(1, "kappa"), b.download(1, "kappa")) and np.all(np.isfinite(rel))

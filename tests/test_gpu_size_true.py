@@ -1,0 +1,320 @@
+"""Size-true parity of the LOOPS (run with -m gpu on an MI355X): the ECM iteration and the whole fit are quoted at genome size
+(bench.py's `ecm` extra, scripts/fit_bench.py) -- here they are checked at those shapes against the oracle, in BOTH validation
+modes: multi-chain schedules (per-chain convergence masks, warm-started windows, replays, tail groups) only show their
+mistakes on many long chains.  Every test records its measured worst errors (`gpurun_out/parity_worst_*.json`, copied to
+`profiles/r06_parity_worst_*`)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import gpu_available
+from test_gpu_parity import ATOL, RTOL, _bg_batch_fixture, _record_worst, _twin_cfg
+
+pytestmark = pytest.mark.gpu
+
+F = np.asarray(cases.F_TREND, np.float32)
+
+
+@pytest.fixture(scope="module")
+def product():
+    if not gpu_available():
+        pytest.fail("GPU tests selected but no HIP device / library: the product has no CPU fallback")
+    from consenrich_amd import cconsenrich
+
+    return cconsenrich
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+
+    orc.lib()
+    return orc
+
+
+def _frac_outside(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float((np.abs(got - ref) > RTOL * np.abs(ref) + ATOL).mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (a) csr_batch_ecm on the 22-chain genome batch
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_batch_ecm_on_the_genome_batch_matches_oracle_in_both_modes(product, oracle):
+    """`csr_batch_ecm` on the config-3 shaped batch -- the 22 hg38 autosomes @200 bp x 8 samples, kappa re-weighting on, 3
+    iterations x 5 inner sweeps, rtol 0: what bench.py's `ecm` extra times (pyx:7660-8442) -- against the oracle's
+    `cfixedBackgroundECM` per chromosome on the inputs read back from the device: iteration count and NLL path of EVERY
+    chromosome, smoothed state / covariance / lag / kappa / residuals of chr1, chr10 and chr22, in the default bit-exact mode
+    and in the 2-ulp mode (one fresh batch each, the same oracle passes)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.sharding import hg38_chain_lengths
+
+    lengths = hg38_chain_lengths(200)
+    m, iters, inner = 8, 3, 5
+    full = (0, 9, 21)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+
+    def host_side(n, d_, v_):
+        r = oracle.cfixedBackgroundECM(
+            matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=Q0, intervalToBlockMap=(np.arange(n) // 500).astype(np.int32),
+            blockCount=(n + 499) // 500, stateInit=0.0, stateCovarInit=1000.0, ECM_fixedBackgroundIters=iters,
+            ECM_fixedBackgroundRtol=0.0, pad=1e-4, ECM_robustTNu=8.0, procPrecisionMultiplierMin=5e-3, procPrecisionMultiplierMax=5e3,
+            ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=True, t_innerIters=inner,
+            returnIntermediates=True, returnDiagnostics=True, trackOptimizationPath=True, logIterations=False)
+        return r
+
+    runs = []
+    batches = []
+    try:
+        for xtol in (0, 2):
+            b = DeviceBatch(0, x_tol_ulps=xtol)
+            batches.append(b)
+            b.configure(ModelParams(state_dim=2), m, lengths)
+            b.synthesize(1234)
+            b.stats()
+            outs, paths = b.ecm(max_iters=iters, inner_iters=inner, rtol=0.0, use_lambda=False, use_kappa=True)
+            b.export(L.EXPORT_SMOOTH | L.EXPORT_RESID | L.EXPORT_MULT)
+            rs = b.run_stats()
+            assert rs["x_tol_ulps"] == xtol
+            runs.append((xtol, b, outs, paths, {"x_tol_ulps": float(xtol), "pipeline_redos": float(rs["pipeline_redos"]),
+                                                "sb_bailouts": float(rs["sb_bailouts"]), "nll_path_rel": 0.0,
+                                                "chains_checked_in_full": 0.0}))
+        b0 = batches[0]
+        order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
+        with ThreadPoolExecutor(max_workers=6) as pool:
+            pending = []
+
+            def drain(limit):
+                while len(pending) > limit:
+                    c, n, fut = pending.pop(0)
+                    o = fut.result()
+                    opath = np.asarray(o[8]["optimization_path"], np.float64)
+                    for xtol, b, outs, paths, w in runs:
+                        assert int(outs[c].iters_done) == int(o[0]) == iters, (xtol, c, int(outs[c].iters_done), o[0])
+                        assert int(outs[c].converged) == int(bool(o[8]["converged"])), (xtol, c)
+                        gpath = paths[c][:iters]
+                        w["nll_path_rel"] = max(w["nll_path_rel"], float(np.max(np.abs(gpath - opath) / np.abs(opath))))
+                        assert outs[c].final_nll == pytest.approx(float(o[1]), rel=1e-7), (xtol, c)
+                        if c not in full:
+                            continue
+                        w["chains_checked_in_full"] += 1.0
+                        lvl = np.maximum(np.abs(o[2][:, :1].astype(np.float64)), 1.0)
+                        xs = b.download(c, "xs").astype(np.float64)
+                        err = np.abs(xs - o[2])
+                        w["xs_level_rel"] = max(w.get("xs_level_rel", 0.0), float((err[:, 0] / lvl[:, 0]).max()))
+                        w["xs_trend_vs_level"] = max(w.get("xs_trend_vs_level", 0.0), float((err[:, 1] / lvl[:, 0]).max()))
+                        w["xs_values_differing"] = w.get("xs_values_differing", 0.0) + float(np.count_nonzero(xs != o[2]))
+                        assert np.all(err <= RTOL * lvl + ATOL), (xtol, c, "xs")
+                        for name, ref in (("Ps", o[3]), ("lag", o[4][: n - 1])):
+                            got = b.download(c, name).astype(np.float64)
+                            rel = np.abs(got - ref) / (np.abs(ref) + ATOL / RTOL)
+                            w[f"{name}_rel"] = max(w.get(f"{name}_rel", 0.0), float(rel.max()))
+                            np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL, err_msg=f"{xtol} chain {c} {name}")
+                        res = b.download(c, "resid").astype(np.float64)
+                        w["resid_rel"] = max(w.get("resid_rel", 0.0), float((np.abs(res - o[5]) / lvl).max()))
+                        assert np.all(np.abs(res - o[5]) <= RTOL * lvl + ATOL), (xtol, c, "resid")
+                        kap = b.download(c, "kappa").astype(np.float64)
+                        w["kappa_rel_max"] = max(w.get("kappa_rel_max", 0.0), float((np.abs(kap - o[7]) / np.abs(o[7])).max()))
+                        w["kappa_frac_outside_1e-5"] = max(w.get("kappa_frac_outside_1e-5", 0.0), _frac_outside(kap, o[7]))
+
+                for c in order:
+                    n = lengths[c]
+                    d_, v_ = b0.download_inputs(c)
+                    pending.append((c, n, pool.submit(host_side, n, d_, v_)))
+                    del d_, v_
+                    drain(5)
+                drain(0)
+    finally:
+        for b in batches:
+            b.close()
+    we, wt = runs[0][4], runs[1][4]
+    _record_worst("ecm_c3_hg38_200bp_x8_exact", we)
+    _record_worst("ecm_c3_hg38_200bp_x8_ulp2", wt)
+    for w in (we, wt):
+        assert w["chains_checked_in_full"] == len(full) and w["sb_bailouts"] == 0
+    # default mode: the gates of the config-4 exact test (kappa amplifies nothing that is bit-identical)
+    assert we["nll_path_rel"] <= 1e-10
+    assert we["xs_level_rel"] <= 2.5e-7 and we["xs_trend_vs_level"] <= 2.5e-7 and we["resid_rel"] <= 1e-6
+    assert we["kappa_frac_outside_1e-5"] <= 1e-5 and we["kappa_rel_max"] <= 1e-4
+    # 2-ulp mode: the gates of the config-4 2-ulp test; kappa is one of the quantities that amplify an ulp of the level
+    assert wt["nll_path_rel"] <= 1e-8
+    assert wt["xs_level_rel"] <= 2e-6 and wt["xs_trend_vs_level"] <= 2e-6
+    assert wt["kappa_frac_outside_1e-5"] <= 2e-2 and wt["kappa_rel_max"] <= 5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (b) the whole fit with the CLI's defaults at chromosome size
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_whole_fit_with_the_cli_defaults_at_chromosome_size_in_both_modes(product, oracle):
+    """`run_consenrich_batch` with the reference CLI's REAL defaults (constants.py:266-281: up to 32 outer passes, at least 3,
+    50 ECM iterations, rtol 1e-6, t_inner 5, background smoothness 128 over 750-bin blocks, Q0 seeded per chromosome from the
+    data) on a batch of three chains of the sizes of chr20, chr21 and chr22 @200 bp x 8 samples against the CPU twin
+    (oracle/driver.py) run per chromosome: outer pass counts, ECM iteration counts of every pass, stop reasons and the final
+    phase EQUAL in the default mode, every returned track within 1e-5; the same batch in the 2-ulp mode with its discrete
+    decisions REPORTED (equal or not) and its tracks gated."""
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+    from consenrich_amd.driver import FitConfig, run_consenrich_batch
+    from oracle import background as bgo
+    from oracle import driver as odrv
+    from oracle import qseed as oq
+
+    n_list, m = [322221, 233550, 254093, 60000], 8
+    mp = ModelParams(state_dim=2)
+    ins = _bg_batch_fixture(n_list[:3], m, 9100, bg_amp=0.3)
+    ins[1] = _bg_batch_fixture([n_list[1]], m, 9150, bg_amp=1.0)[0]
+    # (the chromosome-sized chains of this recipe are still moving after 32 passes; a fourth, shorter chain meets the stop rule
+    # around pass 25 -- the batch then carries on without it)
+    ins.append(_bg_batch_fixture([n_list[3]], m, 9100, bg_amp=0.3)[0])
+    pen = bgo.penalties(750, 128.0)
+    cfg = FitConfig(penalties=pen, seed_q=True)
+    assert (cfg.outer_passes, cfg.min_outer, cfg.ecm_iters, cfg.inner_iters, cfg.patience) == (32, 3, 50, 5, 2)
+
+    def twin(c):
+        data, munc = ins[c]
+        Q, _ = oq.estimate_initial_process_noise(oq, matrixData=data, matrixMunc=munc, pad=cfg.pad, stateModel="levelTrend",
+                                                 minQ=cfg.min_q, maxQ=cfg.max_q, deltaF=cfg.delta_f, robustTNu=cfg.nu)
+        tw = _twin_cfg(mp, cfg, pen, Q0=Q)
+        tw["block_len_intervals"] = 750
+        return Q, odrv.run_consenrich_chain(data, munc, tw)
+
+    got = {}
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        futs = [pool.submit(twin, c) for c in range(len(n_list))]           # the twin runs beside the device fits
+        for xtol in (0, 2):
+            with DeviceBatch(0, x_tol_ulps=xtol) as b:
+                b.configure(mp, m, n_list)
+                for c, (data, munc) in enumerate(ins):
+                    b.upload(c, data, munc)
+                fits, results = run_consenrich_batch(b, cfg, block_len_intervals=750)
+                rs = b.run_stats()
+                assert rs["x_tol_ulps"] == xtol
+                got[xtol] = (fits, results, rs)
+        refs = [f.result() for f in futs]
+
+    for xtol in (0, 2):
+        fits, results, rs = got[xtol]
+        worst = {"x_tol_ulps": float(xtol), "pipeline_redos": float(rs["pipeline_redos"]), "sb_bailouts": float(rs["sb_bailouts"])}
+        decisions_equal = True
+        for c, (Q, ref) in enumerate(refs):
+            f = fits[c]
+            assert np.array_equal(f.q0, Q), (xtol, c)
+            same = (f.passes == ref["passes"] and f.converged == ref["converged"] and f.ecm_iters == ref["ecm_iters"]
+                    and f.outer_stop_reason == ref["stop_reason"] and f.final_ecm_iters == ref["final_ecm_iters"]
+                    and f.final_ecm_converged == ref["final_ecm_converged"] and f.irls_passes == ref["irls_passes"])
+            worst[f"chain{c}:passes"] = float(f.passes)
+            worst[f"chain{c}:passes_twin"] = float(ref["passes"])
+            worst[f"chain{c}:ecm_iterations"] = float(sum(f.ecm_iters))
+            worst[f"chain{c}:ecm_iterations_twin"] = float(sum(ref["ecm_iters"]))
+            worst[f"chain{c}:decisions_equal"] = float(same)
+            decisions_equal = decisions_equal and same
+            if xtol == 0:
+                assert same, (c, f.passes, ref["passes"], f.ecm_iters, ref["ecm_iters"], f.outer_stop_reason, ref["stop_reason"])
+                np.testing.assert_allclose(f.nll, ref["nll"], rtol=1e-7)
+                np.testing.assert_allclose(f.shift, ref["shift"], rtol=1e-3, atol=1e-7)
+            xs, Ps, resid, nis, _bm, bg, diag = results[c]
+            n = n_list[c]
+            assert xs.shape == (n, 2) and resid.shape == (n, m)
+            if not same:
+                continue            # (2-ulp mode only: a different number of passes is a different fit -- reported, not gated)
+            lvl = np.maximum(np.abs(ref["out_xs"][:, :1]).astype(np.float64), 1.0)
+            scale = max(float(np.abs(ref["out_background"]).max()), 1e-3)
+            e = {"bg": float(np.abs(bg - ref["out_background"]).max()) / scale,
+                 "xs": float((np.abs(xs.astype(np.float64) - ref["out_xs"]) / lvl).max()),
+                 "Ps": float((np.abs(Ps.astype(np.float64) - ref["out_Ps"]) / (np.abs(ref["out_Ps"]) + ATOL / RTOL)).max()),
+                 "resid": float((np.abs(resid.astype(np.float64) - ref["out_resid"]) / lvl).max()),
+                 "uncertainty": float((np.abs(np.sqrt(Ps[:, 0, 0].astype(np.float64)) - np.sqrt(ref["out_Ps"][:, 0, 0].astype(np.float64)))
+                                       / np.sqrt(ref["out_Ps"][:, 0, 0].astype(np.float64))).max()),
+                 "NIS_frac_outside_1e-5": _frac_outside(nis, ref["out_NIS"]),
+                 "kappa_frac_outside_1e-5": _frac_outside(diag["processPrecExp"], ref["out_kap"])}
+            worst.update({f"chain{c}:{k}": v for k, v in e.items()})
+            # the tracks the reference writes to disk (state, uncertainty) and every other returned array: 1e-5
+            gate = 1.0 if xtol == 0 else 3.0        # (2-ulp: a few float32 ulps per pass through ~100 ECM iterations)
+            assert e["xs"] <= gate * 1e-5 and e["uncertainty"] <= gate * 1e-5 and e["Ps"] <= gate * 1e-5, (xtol, c, e)
+            assert e["resid"] <= gate * 1e-5 and e["bg"] <= gate * 2e-5, (xtol, c, e)
+            assert e["NIS_frac_outside_1e-5"] <= (1e-3 if xtol == 0 else 5e-2), (xtol, c, e)
+        worst["decisions_equal"] = float(decisions_equal)
+        _record_worst(f"fit_cli_defaults_chr20_21_22_x8_{'exact' if xtol == 0 else 'ulp2'}", worst)
+    assert any(ref["converged"] for _q, ref in refs), [r["passes"] for _q, r in refs]        # the stop rule was met by a chain
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (d) long-memory data at chromosome size
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+def test_long_memory_process_noise_at_chromosome_size(product, oracle, xtol):
+    """Q0 = diag(1e-6, 1e-7) -- the floor the reference's own Q0 seed clamps to (core.py:3621-3780, minQ = 1e-6): the filter's
+    memory is ~30 x longer than with the bench recipe's 1e-3, speculation windows lengthen themselves and repair runs multiply.
+    One chr1-sized chain and one chr21-sized chain x 8 samples through `csr_batch_step`, every array of both against the oracle,
+    first and second step; the adapted windows and re-run counts are recorded."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [1244783, 233550], 8
+    q = ((1.0e-6, 0.0), (0.0, 1.0e-7))
+    Q0 = np.asarray(q, np.float32)
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+    worst = {"x_tol_ulps": float(xtol)}
+    with DeviceBatch(0, x_tol_ulps=xtol) as b:
+        b.configure(ModelParams(state_dim=2, Q0=q), m, n_list)
+        b.synthesize(4321)
+        ins = [b.download_inputs(c) for c in range(len(n_list))]
+
+        def host_side(c):
+            d_, v_ = ins[c]
+            n = n_list[c]
+            xf, Pf, pn = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+            D = np.zeros(n, np.float32)
+            r = oracle.cforwardPass(matrixData=d_, matrixPluginMuncInit=v_, matrixF=F, matrixQ0=Q0,
+                                    intervalToBlockMap=np.zeros(n, np.int32), blockCount=1, stateInit=0.0, stateCovarInit=1000.0,
+                                    stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn, vectorD=D, returnNLL=True)
+            bw = oracle.cbackwardPass(matrixData=d_, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+            return dict(phi=r[0], nll=r[3], xf=xf, Pf=Pf, D=D, xs=bw[0], Ps=bw[1], lag=bw[2][: n - 1], resid=bw[3])
+
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            futs = [pool.submit(host_side, c) for c in range(len(n_list))]
+            snaps = []
+            for step in range(2):
+                sd, sn = b.step(L.RETURN_NLL, what)
+                snaps.append((np.array(sd), np.array(sn),
+                              {(c, a): b.download(c, a) for c in range(len(n_list)) for a in ("xf", "Pf", "D", "xs", "Ps", "lag", "resid")}))
+            rs = b.run_stats()
+            refs = [f.result() for f in futs]
+    assert rs["x_tol_ulps"] == xtol
+    for k in ("warm_p", "warm_x", "warm_b", "reruns_p", "reruns_x", "reruns_b", "pipeline_redos", "sb_bailouts", "fix_launches",
+              "block_len", "tail_groups"):
+        worst[k] = float(rs[k])
+    for step, (sd, sn, arrs) in enumerate(snaps):
+        for c, o in enumerate(refs):
+            n = n_list[c]
+            worst["nll_rel"] = max(worst.get("nll_rel", 0.0), abs(sn[c] - o["nll"]) / abs(o["nll"]))
+            worst["phi_rel"] = max(worst.get("phi_rel", 0.0), abs(sd[c] / n - o["phi"]) / abs(o["phi"]))
+            lvl = np.maximum(np.abs(o["xs"][:, :1].astype(np.float64)), 1.0)
+            for a in ("xf", "xs"):
+                err = np.abs(arrs[(c, a)].astype(np.float64) - o[a])
+                worst[f"{a}_level_rel"] = max(worst.get(f"{a}_level_rel", 0.0), float((err[:, 0] / lvl[:, 0]).max()))
+                worst[f"{a}_trend_vs_level"] = max(worst.get(f"{a}_trend_vs_level", 0.0), float((err[:, 1] / lvl[:, 0]).max()))
+                rms = float(np.sqrt(np.mean(o[a][:, 1].astype(np.float64) ** 2)))
+                worst[f"{a}_trend_vs_trend_rms"] = max(worst.get(f"{a}_trend_vs_trend_rms", 0.0), float(err[:, 1].max()) / rms)
+                worst[f"{a}_values_differing"] = worst.get(f"{a}_values_differing", 0.0) + float(np.count_nonzero(arrs[(c, a)] != o[a]))
+                assert np.all(err <= RTOL * lvl + ATOL), (xtol, step, c, a)
+            for a in ("Pf", "Ps", "lag"):
+                got, ref = arrs[(c, a)].astype(np.float64), o[a].astype(np.float64)
+                worst[f"{a}_rel"] = max(worst.get(f"{a}_rel", 0.0), float((np.abs(got - ref) / (np.abs(ref) + ATOL / RTOL)).max()))
+                np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL, err_msg=f"{xtol} step {step} chain {c} {a}")
+            res = arrs[(c, "resid")].astype(np.float64)
+            worst["resid_rel"] = max(worst.get("resid_rel", 0.0), float((np.abs(res - o["resid"]) / lvl).max()))
+            assert np.all(np.abs(res - o["resid"]) <= RTOL * lvl + ATOL), (xtol, step, c, "resid")
+            gD = arrs[(c, "D")].astype(np.float64)
+            worst["D_rel_max"] = max(worst.get("D_rel_max", 0.0), float((np.abs(gD - o["D"]) / (np.abs(o["D"]) + ATOL / RTOL)).max()))
+            worst["D_frac_outside_1e-5"] = max(worst.get("D_frac_outside_1e-5", 0.0), _frac_outside(gD, o["D"]))
+    _record_worst(f"long_memory_q0_1e-6_chr1_chr21_x8_{'exact' if xtol == 0 else 'ulp2'}", worst)
+    assert worst["sb_bailouts"] == 0
+    if xtol == 0:
+        assert worst["nll_rel"] <= 1e-10 and worst["xs_level_rel"] <= 2.5e-7 and worst["D_frac_outside_1e-5"] <= 1e-5
+    else:
+        assert worst["nll_rel"] <= 1e-8 and worst["xs_level_rel"] <= 2e-6
+        assert worst["D_frac_outside_1e-5"] <= 2e-2 and worst["D_rel_max"] <= 2e-3
