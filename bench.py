@@ -69,6 +69,31 @@ SCALING_MODEL = {"default": {"fixed_ms": 1.546, "per_mbin_ms": 0.1663}, "ulp2": 
 SCALING_MODEL_SOURCE = "profiles/r05_shards_exact_mode.txt, profiles/r05_shards_throughput_mode.txt"
 
 
+PARITY_RECORD = {"c2": "c2_1e6_x4_forward_only_ulp2", "c3": "c3_hg38_200bp_x8_ulp2", "c4": "c4_hg38_200bp_x32_ulp2",
+                 "c5": "c5_hg38_50bp_x64_ulp2"}
+
+
+def throughput_mode_parity(config: str):
+    """Which returned arrays the 2-ulp mode holds to north_star's 1e-5 on this workload and which it does not: from the MEASURED
+    worst errors the full-size parity test of the config recorded (tests/test_gpu_parity.py -> profiles/rNN_parity_worst_*_ulp2.json,
+    the latest round committed; every bin of every checked chain against the oracle)."""
+    import glob
+
+    name = PARITY_RECORD.get(config)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_parity_worst_{name}.json"))) if name else []
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        w = json.load(fh)
+    held = {"level (xs, xf)": max(w.get("xs_level_rel", 0.0), w.get("xf_level_rel", 0.0)),
+            "uncertainty / Ps": w.get("Ps_rel"), "Pf": w.get("Pf_rel"), "lag": w.get("lag_rel"), "resid": w.get("resid_rel"),
+            "NLL": w.get("nll_rel"), "trend vs the level's scale (the gate)": max(w.get("xs_trend_vs_level", 0.0), w.get("xf_trend_vs_level", 0.0))}
+    return {"holds_1e-5": {k: v for k, v in held.items() if v is not None and v <= 1e-5},
+            "outside_1e-5": {"NIS": {"fraction_of_bins": w.get("D_frac_outside_1e-5"), "worst_relative": w.get("D_rel_max")},
+                             "trend_vs_its_own_rms": max(w.get("xs_trend_vs_trend_rms", 0.0), w.get("xf_trend_vs_trend_rms", 0.0))},
+            "source": os.path.relpath(files[-1], ROOT), "chains_checked_in_full": w.get("chains_checked_in_full")}
+
+
 def b_alg(m: int, forward_only: bool = False) -> int:
     """algorithmic bytes per bin, data read once: forward + backward 12 m + 100; forward only 8 m + 60."""
     return 8 * m + 60 if forward_only else 12 * m + 100
@@ -436,6 +461,7 @@ def main() -> int:
             "block_len": trs["block_len"], "warm_bins": [trs["warm_p"], trs["warm_x"], trs["warm_b"]],
             "reruns": [trs["reruns_p"], trs["reruns_x"], trs["reruns_b"]], "pipeline_redos": trs["pipeline_redos"],
             "kernels_rank0": tk,
+            "parity": throughput_mode_parity(args.config),
             "contract": "opt-in (DeviceBatch(x_tol_ulps=2)): a speculative carry is accepted within 2 float32 ulps; a single "
                         "pass stays within a few ulps of the reference on every bin, also on hard data "
                         "(tests/test_hard_data.py); iterated through the ECM loop on ill-conditioned data it inherits the "
@@ -517,6 +543,10 @@ def main() -> int:
         out.update(extras)
         if world > 1 and args.config == "c4":
             out["expected"] = expected_speedup(ranks_info["bins"], total_bins)
+            # measured against the model: > 1 = faster than the emulated shards said
+            out["speedup_vs_expected"] = out["expected"]["default"]["ms_per_step"] / ms_per_step
+            if "throughput_mode" in out:
+                out["throughput_mode"]["speedup_vs_expected"] = out["expected"]["ulp2"]["ms_per_step"] / out["throughput_mode"]["ms_per_step"]
         if gather_note:
             out["gather_note"] = gather_note
         if not args.no_cpu_baseline and world == 1:

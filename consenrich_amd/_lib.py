@@ -146,7 +146,7 @@ class RunStats(C.Structure):
         ("reruns_b", C.c_int64), ("block_len", C.c_int32), ("warm_p", C.c_int32), ("warm_x", C.c_int32),
         ("warm_b", C.c_int32), ("x_tol_ulps", C.c_int32), ("pipeline_redos", C.c_int32),
         ("local_repairs", C.c_int64), ("ws_warm_f", C.c_int32), ("ws_warm_b", C.c_int32), ("sb_bailouts", C.c_int64), ("tail_groups", C.c_int64),
-        ("nat_first_use_off_main", C.c_int64),
+        ("nat_first_use_off_main", C.c_int64), ("step_closes", C.c_int64),
     ]
 
 
@@ -214,6 +214,7 @@ SYMBOLS = {
     "csr_batch_step_forward": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, DP, DP]),
     "csr_batch_objective_terms": (C.c_int, [C.c_void_p, C.POINTER(ObjectiveCfg), C.POINTER(ObjectiveTerms)]),
     "csr_batch_phase_tracks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, DP, DP, C.POINTER(C.c_int32)]),
+    "csr_batch_gain_summary": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, DP]),
     "csr_batch_forward_masked": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, DP, DP]),
     "csr_qseed_same_track": (C.c_int, [C.c_int64, C.c_int64, DP, DP, C.POINTER(C.c_uint8), C.POINTER(QseedSampleCfg), DP, DP,
                                        DP, I64P, C.POINTER(QseedSampleDiag)]),

@@ -254,6 +254,40 @@ class DeviceBatch:
                                                  cnt.ctypes.data_as(C.POINTER(C.c_int32)) if with_fit else None))
         return rel, fit, cnt
 
+    def gain_summary(self, chain: int, pad: float, use_lambda: bool = False, lambda_bounds=(0.25, 4.0)) -> dict:
+        """`_finalForwardReplicateGainContigSummary` (core.py:7671-7731) of one chain from the resident forward pass
+        (csr_batch_gain_summary: moments and the six order statistics around the quartile positions per replicate, exact); the
+        quartiles are interpolated here the way NumPy's 'linear' method does (np.median / np.quantile of the reference)."""
+        out = np.empty((self.m, 9))
+        L.check(self._lib.csr_batch_gain_summary(self._ctx, int(chain), int(bool(use_lambda)), float(pad), float(lambda_bounds[0]),
+                                                 float(lambda_bounds[1]), L.dp(out)))
+        cnt = out[:, 0].astype(np.int64)
+        res = {"count": [int(v) for v in cnt], "mean": [], "median": [], "sd": [], "iqr": []}
+
+        def lerp(a, b, t):          # numpy.lib._function_base_impl._lerp
+            d = b - a
+            v = a + d * t
+            if t >= 0.5:
+                v = b - d * (1.0 - t)
+            return a if d == 0 else v
+
+        for j in range(self.m):
+            if cnt[j] == 0:
+                for k in ("mean", "median", "sd", "iqr"):
+                    res[k].append(float("nan"))
+                continue
+            q = []
+            for i, frac in enumerate((0.25, 0.5, 0.75)):
+                pos = (cnt[j] - 1) * frac
+                t = pos - np.floor(pos)
+                q.append(lerp(out[j, 3 + 2 * i], out[j, 4 + 2 * i], float(t)))
+            lo, hi = out[j, 5], out[j, 6]
+            res["mean"].append(float(out[j, 1]))
+            res["median"].append(float(lo if cnt[j] % 2 else 0.5 * (lo + hi)))     # np.median: the mean of the two middle values
+            res["sd"].append(float(out[j, 2]))
+            res["iqr"].append(float(q[2] - q[0]))
+        return res
+
     def objective_terms(self, nu: float, lam_first: float, lam: float, negative_penalty_multiplier=1.0, pad=1.0e-4,
                         use_lambda_penalty=False, use_kappa_penalty=True, use_lambda_weights=False, use_nonnegative=True):
         """Everything of the reference's penalised objective (core.py:4418-4538) except the forward NLL, per chain, from

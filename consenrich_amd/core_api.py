@@ -896,11 +896,16 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
             g = g[ok]
         if g.size == 0:
             return 0, float("nan"), float("nan"), float("nan"), float("nan")
-        q25, q50, q75 = np.quantile(g, [0.25, 0.5, 0.75])
-        return int(g.size), float(g.mean()), float(q50), float(np.std(g)), float(q75 - q25)
+        q25, q75 = np.quantile(g, [0.25, 0.75])
+        return int(g.size), float(g.mean()), float(np.median(g)), float(np.std(g)), float(q75 - q25)
 
-    for cnt, mean, med, sd, iqr in _map_rows(gain_row, plan.munc):
-        gain["count"].append(cnt); gain["mean"].append(mean); gain["median"].append(med); gain["sd"].append(sd); gain["iqr"].append(iqr)
+    if final.get("gainSummary") is not None:
+        # the device evaluated it on the resident final pass (DeviceBatch.gain_summary: exact order statistics by radix select,
+        # no (m, n) float64 rows on the host)
+        gain = {k: list(v) for k, v in final["gainSummary"].items()}
+    else:
+        for cnt, mean, med, sd, iqr in _map_rows(gain_row, plan.munc):
+            gain["count"].append(cnt); gain["mean"].append(mean); gain["median"].append(med); gain["sd"].append(sd); gain["iqr"].append(iqr)
     early = plan.ret.pop("_early", None)            # input-only summaries started beside the device fit (`run_plan`), if any
     early = early.result() if early is not None else input_only_summaries(plan)
     r_trace_summary, support = early["observation_r_trace"], early["support"]
@@ -1122,6 +1127,9 @@ def run_plan(plan: RunPlan, device: int = 0):
                  "lambdaExp": res[6]["lambdaExp"], "processPrecExp": res[6]["processPrecExp"],
                  "matrixQ0": res[6]["matrixQ0"], "stateCovarForward": b.download(0, "Pf"),
                  "pNoiseForward": b.download(0, "pnoise")}
+        if plan.ret["diagnostics"] or plan.ret["precision"]:
+            final["gainSummary"] = b.gain_summary(0, float(cfg.pad), use_lambda=bool(cfg.use_lambda),
+                                                  lambda_bounds=plan.model.lambda_bounds)
     d = plan.model.state_dim
     final["matrixQ0"] = np.asarray(final["matrixQ0"], np.float32)[:d, :d] if d == 1 else np.asarray(final["matrixQ0"], np.float32)
     return fit, final

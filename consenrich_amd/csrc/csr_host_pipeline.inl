@@ -38,12 +38,18 @@ enum { ST_P = 0, ST_X = 1, ST_B = 2, ST_DEBUG = 3 };
 // Host wait for the library's stream.  The waits on the pipeline's critical path are short (tens of microseconds at
 // 1/8-genome batch sizes), where the wake-up latency of a blocking hipStreamSynchronize is a measurable share of the
 // step: poll first, block only if the stream is still busy after ~200 us.
-// The calling thread's timer slack, lowered for the length of a wait loop (the kernel's default of 50 us turns a 20-us sleep into
-// ~75); the caller's setting is put back on the way out.
+// OPT-IN (CONSENRICH_AMD_TIMER_SLACK=1; round 6: off by default -- a library call should not change an attribute of its caller's
+// thread for 0.05 ms of a benchmark step): the calling thread's timer slack, lowered for the length of a wait loop (the kernel's
+// default of 50 us turns a 20-us sleep into ~75); the caller's setting is put back on the way out.
+static const bool g_timerSlackOptIn = [] { const char *e = getenv("CONSENRICH_AMD_TIMER_SLACK"); return e && atoi(e) != 0; }();
 struct TimerSlack {
-    long old;
-    TimerSlack() : old(prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL)) { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
-    ~TimerSlack() { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
+    long old = 0;
+    TimerSlack() {
+        if (!g_timerSlackOptIn) return;
+        old = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+        if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    }
+    ~TimerSlack() { if (g_timerSlackOptIn && old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
 };
 // site: which wait of the pipeline this is (0 = the settle point's mailbox read, 1 = the state chain's verdict): each keeps its own
 // estimate -- a step has both, of very different lengths
@@ -104,7 +110,44 @@ static int flush_pending_check(csr_ctx *c) {
     c->rs.fix_launches++;
     return 0;
 }
+// Host wait for the sequence word a step's closing kernel publishes (StepFin): same polling policy as wait_stream, on a word of
+// pinned memory instead of the stream's state.  A kernel that never publishes (a fault) shows as a stream error or as an idle
+// stream without the word: both fail loudly.
+static int wait_fin(csr_ctx *c) {
+    volatile unsigned int *word = c->hFin + c->finSeqWord;
+    const unsigned int want = c->finSeq;
+    auto ready = [&]() { return __atomic_load_n(const_cast<unsigned int *>(word), __ATOMIC_ACQUIRE) == want; };
+    TimerSlack slack;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    for (int i = 0; i < 512; ++i)
+        if (ready()) { c->lastWaitUs[0] = elapsed_us(); return 0; }
+    const double expect = c->lastWaitUs[0];
+    for (int it = 0;; ++it) {
+        const double el = elapsed_us();
+        if (ready()) { c->lastWaitUs[0] = el; return 0; }
+        if (el > 20000.0) break;
+        const bool nearEnd = expect > 0.0 && el > expect - 150.0 && el < expect + 250.0;
+        if (!nearEnd) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((it & 255) == 255) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail("step close: %s", hipGetErrorString(q));
+        }
+    }
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->lastWaitUs[0] = elapsed_us();
+    if (!ready()) return fail("step close: the closing kernel ended without publishing the mailbox");
+    return 0;
+}
 static int read_mail(csr_ctx *c, size_t bytes) {
+    if (c->finPending && c->finFast && !c->pendChk.valid) {
+        // the step's closing kernel publishes the mailbox itself: no copy command, no stream wait
+        c->finPending = false;
+        CHECK(wait_fin(c));
+        memcpy(c->hMail, c->hFin, bytes);
+        return 0;
+    }
+    c->finPending = false;
     CHECK(flush_pending_check(c));
     HIPOK(hipMemcpyAsync(c->hMail, c->dMail, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPOK(wait_stream(c));
@@ -163,7 +206,9 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
             else hipLaunchKernelGGL(k_chain_spec<CH>, dim3(grid), dim3(64), 0, c->stream, p);
         } else {
             bool launched = false;
-            if constexpr (CH::FAMILY == FAM_FWD_FUSED) {
+            // (round 6: the LDS-DMA ring and the reference-layout-input forms exist for F = [[1, f], [0, 1]] only -- what the reference's
+            // constructMatrixF builds; any other `matrixF` runs the plain-load general instances: same results, fewer kernels to build)
+            if constexpr (CH::FAMILY == FAM_FWD_FUSED && CH::UNITF) {
                 // ECM sweeps and other passes without reference-layout outputs: inputs through the LDS-DMA ring
                 if (c->useDmaFused && c->useDmaWarm && p.natOut && !pcq && p.warm > 0) {
                     // reference-layout outputs: ring for the warm-up only, tile walker for the main phase
@@ -203,7 +248,7 @@ static int run_chain(csr_ctx *c, Prm p, const char *name, const char *fixName, i
                     launched = true;
                 }
             }
-            if constexpr (CH::FAMILY == FAM_BWD_TREND) {
+            if constexpr (CH::FAMILY == FAM_BWD_TREND && CH::UNITF) {
                 if (p.natIn && p.natOut && !pcq) {
                     // reference-layout inputs AND outputs, both through the LDS tiles (the forward pass wrote no blocked xf / Pf)
                     if (p.qFromMult) hipLaunchKernelGGL((k_smooth_natin<CH, false>), dim3(grid), dim3(64), sizeof(NatTiles), c->stream, p);
@@ -447,12 +492,7 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
     q.prevKind = CK_NONE;
     const int mode = unit_f(c, p) ? ((p.F01 == 1.0 && c->unitF1Enabled) ? 2 : 1) : 0;
     const int grid = (int)((v.NB + 3) / 4);
-    q.sbDbg = nullptr;
-    if (getenv("CONSENRICH_AMD_SB_DEBUG")) {
-        if (!c->sbDbg) CHECK(dalloc(c, &c->sbDbg, 12 + (int64_t)c->chains.size()));
-        if (!resume) HIPOK(hipMemsetAsync(c->sbDbg, 0, 8 * (12 + c->chains.size()), c->stream));
-        q.sbDbg = c->sbDbg;
-    }
+    q.sbDbg = nullptr;          // (the instrumented instances of round 4's studies, CONSENRICH_AMD_SB_DEBUG, were retired in round 6)
     auto launch = [&](int which, int fix) {
         float2 *xf = reinterpret_cast<float2 *>(natXf);
         if (fix) {        // repair passes in delta form (k_sb_delta)
@@ -491,11 +531,9 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
             Scope sc(c, "fwd_state_chain");
             float2 *xf = reinterpret_cast<float2 *>(natXf);
             // (the repair runs' LDS ring: > 64 KB of dynamic LDS has to be asked for once per kernel)
-            const bool dbg = q.sbDbg != nullptr;
             using KFn = void (*)(Prm, const float4 *, const float4 *, float2 *, SbAsync);
-            const KFn fns[6] = {&k_sb_async<0, false>, &k_sb_async<1, false>, &k_sb_async<2, false>,
-                                &k_sb_async<0, true>, &k_sb_async<1, true>, &k_sb_async<2, true>};
-            const int which = mode + (dbg ? 3 : 0);
+            const KFn fns[3] = {&k_sb_async<0, false>, &k_sb_async<1, false>, &k_sb_async<2, false>};
+            const int which = mode;
             if (!c->sbAsyncLdsRaised[which]) {
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[which]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_ASYNC_LDS));
                 c->sbAsyncLdsRaised[which] = true;
@@ -512,28 +550,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         HIPOK(hipMemcpyAsync(ctl, a.ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
         HIPOK(wait_stream(c, 1));
         c->rs.fix_launches++;
-        if (q.sbDbg) {
-            unsigned long long h[8];
-            HIPOK(hipMemcpy(h, c->sbDbg, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[csr] barrier-free state chain: last speculative walk ends %.1f us after the start, last wavefront leaves at %.1f us; %u delta runs, %u abandoned\n",
-                    (double)(h[1] - h[0]) * 0.01, (double)(h[2] - h[0]) * 0.01, ctl[2], ctl[3]);
-            fprintf(stderr, "[csr]   delta runs: %llu batches, %.2f rounds per batch, %llu with more than 20 rounds; %.0f ns per batch inside the runs; busiest wavefront %.1f us in runs over %llu batches\n",
-                    h[3], h[3] ? (double)h[4] / (double)h[3] : 0.0, h[5], h[3] ? (double)h[6] * 10.0 / (double)h[3] : 0.0,
-                    (double)(h[7] >> 24) * 0.01, h[7] & 0xffffffull);
-            {
-                unsigned long long sec[4];
-                HIPOK(hipMemcpy(sec, c->sbDbg + 8 + c->chains.size(), 32, hipMemcpyDeviceToHost));
-                const double nbt = h[3] ? (double)h[3] : 1.0;
-                fprintf(stderr, "[csr]   s_memtime ticks per batch: group top %.0f, batch prologue %.0f, rounds %.0f, batch epilogue %.0f\n",
-                        (double)sec[0] / nbt, (double)sec[1] / nbt, (double)sec[2] / nbt, (double)sec[3] / nbt);
-            }
-            std::vector<unsigned long long> fin(c->chains.size());
-            HIPOK(hipMemcpy(fin.data(), c->sbDbg + 8, 8 * fin.size(), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[csr]   chains final at (us, bins):");
-            for (size_t i = 0; i < fin.size(); ++i) fprintf(stderr, " %.0f:%lld", (double)(fin[i] - h[0]) * 0.01, (long long)c->chains[i].n);
-            fprintf(stderr, "\n");
-            q.sbDbg = nullptr;
-        }
         if (ctl[1] == 0) {
             done = true;
             c->rs.reruns_x += ctl[2];
@@ -570,15 +586,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
         burst = c->dbgLog ? 1 : std::min(32, burst * 2);
     }
     if (!done) return fail("fwd_state_chain (systolic superblocks): fix-up did not reach a fixed point");
-    if (q.sbDbg) {
-        unsigned long long h[8];
-        HIPOK(hipMemcpyAsync(h, c->sbDbg, 64, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipStreamSynchronize(c->stream));
-        fprintf(stderr, "[csr] delta repairs: superblocks re-run %llu, batches %llu, rounds %llu (%.2f per batch), fallback batches %llu, merged exits %llu; superblock %d bins, %lld superblocks\n",
-                h[0], h[1], h[2], h[1] ? (double)h[2] / (double)h[1] : 0.0, h[3], h[4], v.B, (long long)v.NB);
-        fprintf(stderr, "[csr]   slowest superblock: %.1f us, %llu batches, %llu rounds, %llu fallback batches; mean %.1f us per re-run superblock\n",
-                (double)(h[5] >> 40) * 0.01, (h[5] >> 28) & 0xfff, (h[5] >> 12) & 0xffff, h[5] & 0xfff, h[0] ? (double)h[6] * 0.01 / (double)h[0] : 0.0);
-    }
     if (!resume) {
         Scope sc(c, "state_reblock_out");
         hipLaunchKernelGGL(k_import_tiled<float2>, dim3((int)(c->NG * (c->B / 32))), dim3(256), 0, c->stream, p,
@@ -593,6 +600,12 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
 // join: left on the side stream behind the epilogue they starve for whole-CU slots while a bandwidth-bound kernel of the
 // main stream keeps the chip full (measured 0.64 ms instead of 0.01).
 static void join_side(csr_ctx *c) {
+    if (c->sumsInFin) {
+        // the forward pass left the per-chain sums to the kernel that closes the step and no such kernel took them: here they are
+        c->sumsInFin = false;
+        Scope sc(c, "chain_sums");
+        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, c->sidePrm, c->dChainFirst, c->dChainNb);
+    }
     if (c->sidePending) {
         (void)hipStreamWaitEvent(c->stream, c->evJoin, 0);
         c->sidePending = false;
@@ -792,7 +805,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 }
                 // constant process noise and nobody left to read the blocked xf / Pf but the smoother (which then reads the
                 // reference-layout arrays through its tiles): the tile walker stores nothing in the blocked layout
-                if (c->natOnlyEnabled && p.qFromMult && p.chainQ == nullptr && (nisInChain || !wantD) && (c->B % 8) == 0) {
+                if (c->natOnlyEnabled && p.qFromMult && p.chainQ == nullptr && (nisInChain || !wantD) && (c->B % 8) == 0 && unit_f(c, p)) {
                     p.natOnly = 1;
                     natOnly = true;
                 }
@@ -830,7 +843,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                     c->pfNat = true;
                     // a pipelined step with one constant process noise: the smoother of every group reads xf / Pf in the reference
                     // layout (k_smooth_natin) -- no blocked copy of Pf
-                    if (c->natOnlyEnabled && split && p.qFromMult && p.chainQ == nullptr && (c->B % 8) == 0) {
+                    if (c->natOnlyEnabled && split && p.qFromMult && p.chainQ == nullptr && (c->B % 8) == 0 && unit_f(c, p)) {
                         pc.natOnly = 1;
                         c->pfBlockedStale = true;
                     }
@@ -856,9 +869,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 const bool early = natOut && c->earlyPf && active == nullptr && c->natOutEnabled;
                 CHECK(state_chain_systolic(c, p, early, flags, split ? 1 : 0));
                 dX = false;
-            } else
-            if (unit_f(c, p)) CHECK(run_chain<FwdXTrendT<true>>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
-            else CHECK(run_chain<FwdXTrend>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
+            } else {
+                // (round 6: the form that validated the levelTrend state chain on the batch's own blocks -- it only ever ran under the
+                // retired switches CONSENRICH_AMD_FUSE=0 / CONSENRICH_AMD_SB_STATE=0 -- is gone)
+                return fail("internal: no state chain for this mode");
+            }
         } else {
             CHECK(run_chain<FwdPLevel>(c, p, "fwd_cov_chain", "fwd_cov_fix", ST_P, dP));
             CHECK(run_chain<FwdXLevel>(c, p, "fwd_state_chain", "fwd_state_fix", ST_X, dX));
@@ -868,6 +883,11 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             // stream) when one follows, so that its few microseconds leave the critical path
             join_side(c);
             hipStream_t st = c->stream;
+            if (c->finWanted && side && c->deferEnabled && active == nullptr) {
+                // csr_batch_step: the residual kernel that closes the step computes them (StepFin); join_side does if it never comes
+                c->sumsInFin = true;
+                c->sidePrm = p;
+            } else {
             if (side && c->deferEnabled) {
                 HIPOK(hipEventRecord(c->evFork, c->stream));
                 HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
@@ -882,6 +902,7 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 HIPOK(hipEventRecord(c->evJoin, c->side));
                 c->sidePending = true;
                 c->sideSumsDone = true;         // join_side only waits
+            }
             }
         } else
         if (wantD && !c->sbp.active) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
@@ -967,7 +988,8 @@ static int backward_impl(csr_ctx *c, bool wantLag, const unsigned char *active, 
         const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
         const bool natValid = c->fwdNat || (c->pfNat && (c->xfNat || preferNatIn));
         const bool need = c->fwdBlockedStale || c->pfBlockedStale;
-        if (c->natInEnabled && natOut && !pcq && !p.qFromKappa && natValid && (need || constQ) && (stage_warm(c, ST_B) % 8) == 0) {
+        if (c->natInEnabled && natOut && !pcq && !p.qFromKappa && natValid && (need || constQ) && (stage_warm(c, ST_B) % 8) == 0 &&
+            unit_f(c, p)) {
             float *natXf, *natPf;
             CHECK(nat_array(c, CSR_ARR_XF, &natXf));
             CHECK(nat_array(c, CSR_ARR_PF, &natPf));
@@ -1409,7 +1431,7 @@ static int add_export_mult(csr_ctx *c, ExpList &L, int id) {
 }
 
 // residuals of the bins [off, off + nb) of the batch's natural layout (whole chains: off and nb are multiples of 64)
-static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck) {
+static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck, bool mayClose = false) {
     const int d = c->mdl.state_dim;
     float *xs, *res;
     CHECK(nat_array(c, CSR_ARR_XS, &xs));
@@ -1424,17 +1446,36 @@ static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck) {
     if (pr.bg) pr.bg += off;
     xs += off * d;
     res += off * c->m;
+    StepFin fin;
+    memset(&fin, 0, sizeof(fin));
     if ((c->m & 3) == 0) {
-        const int K = (c->residTile == 1 || c->residTile == 2 || c->residTile == 4) ? c->residTile : 1;
+        constexpr int K = 2;        // 64-bin sub-tiles per workgroup: 2 measured best (0.665 vs 0.684 ms with 1 or 4, round 3)
         const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
         const dim3 grid((unsigned)((nb + K * 64 - 1) / (K * 64)));
-        if (K == 4 && lds <= 65536)
-            hipLaunchKernelGGL(k_resid_v4<4>, grid, dim3(256), lds, c->stream, pr, xs, d, res, nb);
-        else if (K == 2 && lds <= 65536)
-            hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, pr, xs, d, res, nb);
+        // this launch closes a step (csr_batch_step, nothing of the step follows it and its folded check is the last one pending):
+        // per-chain sums and the publication of the mailbox ride in it (csr_device.h StepFin)
+        const bool close = mayClose && c->finWanted && c->finEnabled && foldCheck && off == 0 && nb == c->Npad && !c->pendChk.valid &&
+                           !c->sidePending && !c->pfPending && lds <= 65536 && c->dFinCounter != nullptr;
+        if (close) {
+            fin.counter = c->dFinCounter;
+            fin.mailDev = reinterpret_cast<unsigned int *>(c->dMail);
+            fin.mailHost = c->dFinHost;
+            fin.hostSeq = c->dFinHost + c->finSeqWord;
+            fin.chainFirst = c->dChainFirst; fin.chainNb = c->dChainNb;
+            fin.mailWords = (unsigned int)(c->mailBytes / sizeof(unsigned int));
+            fin.seq = ++c->finSeq;
+            fin.nchains = (int)c->chains.size();
+            fin.doSums = c->sumsInFin ? 1 : 0;
+            pr.chainActive = nullptr;
+            hipLaunchKernelGGL((k_resid_v4<2, true>), grid, dim3(256), lds, c->stream, pr, xs, d, res, nb, fin);
+            c->sumsInFin = false;
+            c->finPending = true;
+            c->rs.step_closes += 1;
+        } else if (lds <= 65536)
+            hipLaunchKernelGGL((k_resid_v4<2, false>), grid, dim3(256), lds, c->stream, pr, xs, d, res, nb, fin);
         else
-            hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((nb + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
-                               c->stream, pr, xs, d, res, nb);
+            hipLaunchKernelGGL((k_resid_v4<1, false>), dim3((unsigned)((nb + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
+                               c->stream, pr, xs, d, res, nb, fin);
     } else
         hipLaunchKernelGGL(k_resid, dim3((int)((nb + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
                            pr, xs, d, res, nb);
@@ -1494,7 +1535,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         if (!c->haveBwd) return fail("no smoothed results to export");
         CHECK(add_export_xs(c, L));
     }
-    if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat) {      // smoothNat: the smoother already wrote the natural arrays
+    if ((what & CSR_EXPORT_SMOOTH) && !c->smoothNat && c->natSmoothGen != c->fitGen) {      // smoothNat: the smoother already wrote the natural arrays; natSmoothGen: converted before
         CHECK(add_export(c, L, CSR_ARR_PS, (const float *)p.tPs, 4, nm, 0));
         CHECK(add_export(c, L, CSR_ARR_LAG, (const float *)p.tLag, 4, nm, 1));
     }
@@ -1505,7 +1546,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export_mult(c, L, CSR_ARR_QSCALE));
     }
     CHECK(flush_export(c, L));
-    if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true));
+    if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true, !lateD));
     if (lateD) {
         join_side(c);
         CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
@@ -1532,7 +1573,7 @@ static int step_tail(csr_ctx *c, const Prm &pf, const unsigned char *dmask, cons
     // at once; the blocked copy of xf only the NIS / NLL epilogue needs is made on the side stream in front of it
     const bool constQ = c->fwdInternal && !(c->fwdFlags & (F_APN | F_QSCALE | F_KAPPA));
     const bool natTail = c->natOnlyEnabled && c->natInEnabled && c->pfNat && constQ && pf.chainQ == nullptr && (c->B % 8) == 0 &&
-                         (stage_warm(c, ST_B) % 8) == 0;
+                         (stage_warm(c, ST_B) % 8) == 0 && unit_f(c, pf);
     HIPOK(hipEventRecord(c->evFork, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
     hipStream_t imp = natTail ? c->side : c->stream;
@@ -1705,8 +1746,15 @@ extern "C" int csr_batch_step(csr_ctx *c, uint32_t flags, uint32_t what, double 
     bool handled = false;
     CHECK(step_pipelined(c, flags, what, &handled));
     if (!handled) {
+        // a step whose last launch is the residual kernel may be closed by that kernel (per-chain sums, mailbox: StepFin)
+        struct FinScope { csr_ctx *c; ~FinScope() { c->finWanted = c->finFast = false; } } finScope{c};
+        c->finWanted = c->finEnabled && (what & CSR_EXPORT_RESID) && (sum_d || sum_nll);
         CHECK(csr_batch_forward_backward(c, flags, nullptr, nullptr));
         if (what) CHECK(csr_batch_export(c, what));
+        c->finWanted = false;
+        c->finFast = c->finPending;
+        if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
+        return 0;
     }
     if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
     return 0;

@@ -898,6 +898,58 @@ extern "C" int csr_batch_phase_tracks(csr_ctx *c, int32_t chain, int32_t use_lam
     return 0;
 }
 
+// the final forward gain summary of the run diagnostics (core.py:7671-7731) for one chain: csrc/csr_gain.h
+extern "C" int csr_batch_gain_summary(csr_ctx *c, int32_t chain, int32_t use_lambda, double pad, double lam_lo, double lam_hi,
+                                      double *out) {
+    CHECK(need(c));
+    if (chain < 0 || chain >= (int)c->chains.size()) return fail("chain index out of range");
+    if (!out) return fail("null argument");
+    if (!std::isfinite(pad)) return fail("pad must be finite");
+    CHECK(settle(c));
+    if (!c->haveFwd) return fail("no forward results: run the final pass first");
+    CHECK(export_impl(c, CSR_EXPORT_FORWARD));
+    {
+        ExpList L;
+        memset(&L, 0, sizeof(L));
+        if (use_lambda) CHECK(add_export_mult(c, L, CSR_ARR_LAMBDA));
+        CHECK(flush_export(c, L));
+    }
+    const int m = (int)c->m;
+    const int64_t n = c->chains[chain].n;
+    GainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Pf = c->nat[CSR_ARR_PF]; a.lam = use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr; a.munc = c->p.munc;
+    a.off = c->chains[chain].off; a.len = n; a.Npad = c->Npad;
+    a.comps = c->mdl.state_dim * c->mdl.state_dim; a.m = m;
+    a.nwg = (int)((n + 256 * GAIN_ITEMS - 1) / (256 * GAIN_ITEMS));
+    a.pad = pad; a.lamLo = lam_lo; a.lamHi = lam_hi;
+    const size_t bPart = sizeof(double) * (size_t)m * (size_t)a.nwg, bHist = sizeof(unsigned int) * (size_t)m * GAIN_T * 256;
+    const size_t bSel = 8 * (size_t)m * GAIN_T, bOut = sizeof(double) * (size_t)m * GAIN_OUT;
+    CHECK(c->qsBuf.reserve(2 * bPart + bHist + 2 * bSel + bOut + 256));
+    char *base = (char *)c->qsBuf.ptr;
+    a.partA = (double *)base; a.partB = (double *)(base + bPart);
+    a.prefix = (unsigned long long *)(base + 2 * bPart); a.rank = (long long *)(base + 2 * bPart + bSel);
+    a.out = (double *)(base + 2 * bPart + 2 * bSel);
+    a.hist = (unsigned int *)(base + 2 * bPart + 2 * bSel + bOut);
+    HIPOK(hipMemsetAsync(a.hist, 0, bHist, c->stream));
+    const dim3 grid((unsigned)a.nwg, (unsigned)m);
+    {
+        Scope sc(c, "gain_summary");
+        for (int phase = 0; phase < 2; ++phase) {
+            hipLaunchKernelGGL(k_gain_moments, grid, dim3(256), 0, c->stream, a, phase);
+            hipLaunchKernelGGL(k_gain_fold, dim3((unsigned)m), dim3(64), 0, c->stream, a, phase);
+        }
+        for (int pass = 0; pass < 8; ++pass) {
+            hipLaunchKernelGGL(k_gain_hist, grid, dim3(256), 0, c->stream, a, pass);
+            hipLaunchKernelGGL(k_gain_pick, dim3((unsigned)m), dim3(64), 0, c->stream, a, pass);
+        }
+    }
+    LAUNCH_CHECK("k_gain_*");
+    HIPOK(hipMemcpyAsync(out, a.out, bOut, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(wait_stream(c));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // delete-block calibration natives (cuncertainty.pyx:97-157, 160-305)
 // ---------------------------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #include "csr_qseed.h"
 #include "csr_qseed_post.h"
 #include "csr_objective.h"
+#include "csr_gain.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -146,7 +147,6 @@ struct csr_ctx {
     int xTolUlps = 0;           // carry validation: 0 = bit-exact sequential semantics (DEFAULT of every context since round 3: the
                                 // only mode that holds the parity gate through the ECM loop on ill-conditioned data, tests/test_hard_data.py);
                                 // k > 0 = k-ulp acceptance, the opt-in throughput mode (csr_set_validation / CONSENRICH_AMD_XTOL_ULPS)
-    static constexpr int residTile = 2;     // residual kernel: 64-bin sub-tiles per workgroup; 2 measured best (0.665 vs 0.684 ms)
     // batch
     bool configured = false;
     csr_model mdl{};
@@ -167,10 +167,11 @@ struct csr_ctx {
     bool dNat = false;          // ... and its NIS/NLL epilogue wrote D there (nothing left to convert)
     static constexpr bool natOutD = true;       // the NIS / NLL epilogue writes D in the reference layout itself
     bool dstatLdsRaised = false;
-    // 2-ulp throughput mode (byte cuts of round 5; CONSENRICH_AMD_LEAN=0 switches all of them off -- the A/B switch of the tests):
-    bool statsF32Enabled = true;        // {S2c, log R} as one float32 pair
-    bool nisInChainEnabled = true;      // NIS / NLL terms inside the fused forward chain's tile walker (no epilogue kernel)
-    bool natOnlyEnabled = true;         // constant process noise: xf / Pf only in the reference layout, the smoother reads them there
+    // 2-ulp throughput mode, the byte cuts of round 5 (their A/B switch CONSENRICH_AMD_LEAN was retired in round 6; each of them
+    // still has its own conditions at the call site -- per-bin NLL in D, per-bin process noise, per-chain Q):
+    static constexpr bool statsF32Enabled = true;       // {S2c, log R} as one float32 pair
+    static constexpr bool nisInChainEnabled = true;     // NIS / NLL terms inside the fused forward chain's tile walker (no epilogue kernel)
+    static constexpr bool natOnlyEnabled = true;        // constant process noise: xf / Pf only in the reference layout, the smoother reads them there
     bool natInEnabled = true;           // CONSENRICH_AMD_NATIN=0 (tests): the smoother never reads the reference layout -- blocked copies
                                         // a forward pass did not write are brought back first (ensure_blocked_fwd)
     bool fwdBlockedStale = false;       // the resident forward pass wrote xf / Pf in the reference layout ONLY (blocked tXf / tPf are stale)
@@ -178,7 +179,7 @@ struct csr_ctx {
     bool sideSumsDone = false;          // the pending side-stream work already includes the per-chain sums (join_side only waits)
     double lastSbLoopUs = 0.0;          // how long the host watched the previous single launch of the state chain (step_pipelined)
     double lastWaitUs[2] = {0.0, 0.0};  // how long the previous host wait for the stream lasted, per wait site (wait_stream polls around that moment)
-    bool sbAsyncLdsRaised[6] = {false, false, false, false, false, false};   // per context = per device (HIP keeps the attribute per device)
+    bool sbAsyncLdsRaised[3] = {false, false, false};   // per context = per device (HIP keeps the attribute per device)
     int pendEstep = 0;
     static constexpr bool fuseEstep = true;     // ECM: kappa E-step inside the smoother chain (levelTrend, no lambda re-weighting)
     bool fwdInternal = false;   // forward results were produced by this library (vs imported through csr_backward_pass)
@@ -208,15 +209,15 @@ struct csr_ctx {
     // pipeline is re-run synchronously from the first stage that did re-run blocks.
     bool deferEnabled = true;
     static constexpr bool spinWait = true;
-    bool fuseFwd = true;        // tolerant validation: covariance and state chains advance in one kernel
+    static constexpr bool fuseFwd = true;       // tolerant validation: covariance and state chains advance in one kernel
     static constexpr bool unitF1Enabled = true; // F01 == 1: the superblock walker's predicted level is one float32 add
-    bool unitFEnabled = true;   // CONSENRICH_AMD_UNITF=0: the general-F instances of the levelTrend chains even for F = [[1, f], [0, 1]]
+    static constexpr bool unitFEnabled = true;  // F = [[1, f], [0, 1]] (constructMatrixF) runs the UF instances of the levelTrend chains; any other F the general ones
     bool seqState = false;      // bit-exact validation, levelTrend: one wavefront per chain walks the state chain sequentially (CONSENRICH_AMD_SEQ_STATE=1)
     // bit-exact validation, levelTrend (default): the state chain speculates on SUPERBLOCKS of sbBins bins with an sbWarm-bin
     // window -- two float32-rounded state trajectories need ~10^4 bins to coincide bit for bit (scripts/ubench/merge_time.c),
     // so the batch's own 32..256-bin blocks never validate; the gain / statistics records are re-blocked into a second view
     // of the batch (own block table and carries) for this one chain and the filtered state is re-blocked back
-    bool sbState = true;        // CONSENRICH_AMD_SB_STATE=0: off (speculation on the batch's own blocks, or seqState)
+    static constexpr bool sbState = true;       // (round 6: the form that speculated on the batch's own blocks is gone; CONSENRICH_AMD_SEQ_STATE=1 is the sequential yardstick)
     int sbBins = 8192;          // CONSENRICH_AMD_SB_BINS (default: chosen from the batch, ensure_sb_view)
     // k_sb_delta's fallback rule (CONSENRICH_AMD_SB_ADV = "min,from"): walk the rest of a batch when, from round `from` on, the
     // rounds have settled fewer than `min` bins each.  Measured flat between "give up after 20 rounds" (4,20) and "walk as soon
@@ -224,7 +225,6 @@ struct csr_ctx {
     // the levels flip densely a round and the steps it replaces cost the same.
     int sbAdvMin = 4, sbAdvFrom = 20;
     bool sbBinsPinned = false;  // CONSENRICH_AMD_SB_BINS given: no automatic choice of the superblock length
-    unsigned long long *sbDbg = nullptr;
     // CONSENRICH_AMD_SB_ASYNC=0: speculative pass + repair passes as separate launches (k_sb_sys / k_sb_delta) instead of the
     // barrier-free single launch (k_sb_async); sbSpinLimit bounds every wait inside it (polls of ~2 us; then: bail out to the pass form)
     bool sbAsync = true;
@@ -299,6 +299,17 @@ struct csr_ctx {
     // handed out: it is ordered against no other stream, so it does not matter which stream the caller is on at that moment
     hipStream_t zeroStream = nullptr;
     hipStream_t mainStream = nullptr;   // what `stream` is outside step_pipelined's tail groups (csr_run_stats.nat_first_use_off_main)
+    // The close of a throughput-mode step inside its residual kernel (csr_device.h StepFin; CONSENRICH_AMD_STEP_FIN=0: off): per-chain
+    // sums + the mailbox published into pinned host memory by the kernel itself, the host polls the sequence word.
+    bool finEnabled = true;
+    bool finWanted = false;     // csr_batch_step is launching a step that may end that way
+    bool sumsInFin = false;     // the forward pass left the per-chain sums to whoever closes the step (join_side launches them otherwise)
+    bool finPending = false;    // a closing kernel is in flight: hFin will carry sequence number finSeq
+    bool finFast = false;       // the mailbox read that follows is the step's own: poll instead of copy + stream wait
+    unsigned int finSeq = 0;
+    unsigned int *dFinCounter = nullptr;
+    unsigned int *hFin = nullptr, *dFinHost = nullptr;      // pinned host-coherent: mailbox words, then (64-byte aligned) the sequence word
+    size_t finSeqWord = 0;                                  // index of the sequence word in hFin
     struct SbPending { bool active = false; Prm p{}; } sbp;     // a state chain launched and not yet waited for (step_pipelined)
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -355,12 +366,13 @@ static void free_batch(csr_ctx *c) {
     c->sb = csr_ctx::SbView{};
     c->sbNatGain = c->sbNatSZ = nullptr;
     c->natSZValid = false;
-    c->sbDbg = nullptr;
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     if (c->hDone) { (void)hipHostFree(c->hDone); c->hDone = nullptr; c->dDone = nullptr; }
     if (c->hMaskPin) { (void)hipHostFree(c->hMaskPin); c->hMaskPin = nullptr; c->hMaskPinChains = 0; }
     for (auto &m : c->dMask) m = nullptr;
     c->sbp.active = false;
+    c->finWanted = c->sumsInFin = c->finPending = c->finFast = false;
+    c->dFinCounter = nullptr;
     c->pfPending = false;
     c->xfNat = false;
     c->fwdNat = c->pfNat = c->pnNat = c->dNat = c->smoothNat = false;
@@ -427,11 +439,8 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
     }
     if ((e = getenv("CONSENRICH_AMD_XTOL_ULPS"))) c->xTolUlps = atoi(e);
     if ((e = getenv("CONSENRICH_AMD_DEFER"))) c->deferEnabled = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_FUSE"))) c->fuseFwd = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_LEAN"))) c->statsF32Enabled = c->nisInChainEnabled = c->natOnlyEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_NATIN"))) c->natInEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SEQ_STATE"))) c->seqState = atoi(e) != 0;
-    if ((e = getenv("CONSENRICH_AMD_SB_STATE"))) c->sbState = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_WARMSTART"))) c->wsEnabled = atoi(e) != 0;
     if ((e = getenv("CONSENRICH_AMD_SB_ADV"))) {
         int a = 4, f = 20;
@@ -445,7 +454,7 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->tailFirstPct = std::min(100, std::max(1, a)); c->tailNextPct = std::min(100, std::max(1, b)); }
     }
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
-    if ((e = getenv("CONSENRICH_AMD_UNITF"))) c->unitFEnabled = atoi(e) != 0;
+    if ((e = getenv("CONSENRICH_AMD_STEP_FIN"))) c->finEnabled = atoi(e) != 0;
     c->dbgLog = getenv("CONSENRICH_AMD_DEBUG") != nullptr;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = c->useDmaFused = c->useDmaWarm = atoi(e) != 0;     // 0: the plain-load forms of the chains (yardstick of the LDS-DMA ring tests)
@@ -468,6 +477,7 @@ extern "C" void csr_destroy(csr_ctx *c) {
     for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf, &c->qpBuf, &c->stageBuf})
         if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) (void)hipHostFree(c->hMail);
+    if (c->hFin) (void)hipHostFree(c->hFin);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
@@ -618,5 +628,4 @@ extern "C" int csr_get_run_stats(csr_ctx *c, csr_run_stats *out) {
 #include "csr_host_single.inl"
 #include "csr_host_rows.inl"
 #include "csr_host_qseed.inl"
-#include "csr_host_debug.inl"
 #include "csr_host_comm.inl"

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSR_ABI_VERSION 5
+#define CSR_ABI_VERSION 6
 
 /* ---- model / flags ------------------------------------------------------------------------------------- */
 
@@ -340,6 +340,14 @@ int csr_batch_objective_terms(csr_ctx *ctx, const csr_objective_cfg *cfg, csr_ob
  *             `_scoreBackgroundFitObjective` (core.py:4540-4606; called at core.py:5161).
  * rel / fit: n doubles, cnt: n int32 (host).  The caller's part is O(n). */
 int csr_batch_phase_tracks(csr_ctx *ctx, int32_t chain, int32_t use_lambda, double pad, double *rel, double *fit, int32_t *cnt);
+/* The final forward gain summary of `runConsenrich`'s run diagnostics (`_finalForwardReplicateGainContigSummary`,
+ * core.py:7671-7731) for one chain, from the resident forward pass: per replicate j the gains
+ * g_k = max(Pf00_k, 0) * clip(lambda_k, lam_lo, lam_hi) / max(munc_jk + pad, 1e-12) in float64 (lambda = 1 unless use_lambda) and, over
+ * the FINITE ones, out[j*9 + ...] = {count, mean, standard deviation (np.std), then the six order statistics x[lo], x[hi] around
+ * the positions (count - 1) q of q = 0.25, 0.5, 0.75 (NumPy's 'linear' method interpolates between exactly these)}.  The
+ * reference sorts m rows of n float64 values on the host; here a byte-wise radix select on the device (csrc/csr_gain.h), exact.
+ * out: m * 9 doubles.  (ABI 6) */
+int csr_batch_gain_summary(csr_ctx *ctx, int32_t chain, int32_t use_lambda, double pad, double lam_lo, double lam_hi, double *out);
 /* csr_batch_forward for the chains with chain_mask[c] != 0 only (NULL: all); the others keep their resident results. */
 int csr_batch_forward_masked(csr_ctx *ctx, uint32_t flags, const unsigned char *chain_mask, double *sum_d,
                              double *sum_nll);
@@ -505,6 +513,8 @@ typedef struct csr_run_stats {
     int64_t nat_first_use_off_main; /* reference-layout arrays whose first use (allocation + zeroing) happened while a tail group's
                                    stream was current; harmless since ABI 4 (the zeroing is waited for on the host before the
                                    array is handed out) -- counted so that a test can show the path was exercised */
+    int64_t step_closes;        /* steps (csr_batch_step, throughput mode) whose last kernel -- the residuals -- also computed the
+                                   per-chain sums and published the mailbox into pinned host memory itself (ABI 6) */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

@@ -167,7 +167,7 @@ static int near_ulps(float a, float b, float scale, int k) {
 }
 static int same_P(const rulecfg *R, float a00, float a01, float a11, float b00, float b01, float b11) {
     if (a00 == b00 && a01 == b01 && a11 == b11) return 1;
-    if (R->k <= 0) return 0;
+    if (R->k <= 0 || R->rule == 3) return 0;        /* rule 3: the covariance carry must be bit-equal */
     return near_ulps(a00, b00, 0.f, R->k) && near_ulps(a11, b11, 0.f, R->k) && near_ulps(a01, b01, sqrtf(fabsf(a00 * a11)), R->k);
 }
 /* amp0, amp1: max over the block of |d level_j / d x0_in|, |d level_j / d x1_in| (rule 2) */
@@ -175,6 +175,12 @@ static int same_X(const rulecfg *R, const prob *P, float ax0, float ax1, float b
     if (ax0 == bx0 && ax1 == bx1) return 1;
     if (R->rule == 0) return 1;
     if (R->k <= 0) return 0;
+    if (R->rule == 3) {
+        /* rule 3 (round 6): the LEVEL bit-equal, the trend within k of ITS OWN ulps (the trend is 3-4 orders below the level:
+           k trend-ulps are ~1e-3 level-ulps) */
+        if (ax0 != bx0) return 0;
+        return fabsf(ax1 - bx1) <= (float)R->k * ulp_of(fmaxf(fabsf(ax1), fabsf(bx1)));
+    }
     const float mag = fmaxf(fmaxf(fabsf(ax0), fabsf(bx0)), 1.0f);
     const float ulp = ulp_of(mag);
     if (R->rule == 1) {
@@ -186,7 +192,9 @@ static int same_X(const rulecfg *R, const prob *P, float ax0, float ax1, float b
     return eff <= R->budget * (double)ulp;
 }
 
-typedef struct { int64_t rerun_f, rerun_b, blocks; double max_amp_f, max_amp_b; } estats;
+/* first_f / first_b: blocks whose carry-in fails against the neighbour's SPECULATIVE carry-out (what a first validation pass
+   sees); chain_f / chain_b: longest run of consecutive re-run blocks of the in-order repair (the chain reaction) */
+typedef struct { int64_t rerun_f, rerun_b, blocks; double max_amp_f, max_amp_b; int64_t first_f, first_b, chain_f, chain_b; } estats;
 
 static void forward_blocked(const prob *P, const float *kappa, int B, int W, const rulecfg *R, float *xf, float *Pf,
                             float *pn, estats *st) {
@@ -212,8 +220,15 @@ static void forward_blocked(const prob *P, const float *kappa, int B, int W, con
     if (R->rule >= 0) {
         for (int64_t b = 1; b < NB; ++b) {
             const fcarry a = cout[b - 1], q = cin[b];
+            if (!(same_P(R, a.p00, a.p01, a.p11, q.p00, q.p01, q.p11) &&
+                  same_X(R, P, a.x0, a.x1, q.x0, q.x1, amp[2 * b], amp[2 * b + 1]))) st->first_f++;
+        }
+        int64_t run = 0;
+        for (int64_t b = 1; b < NB; ++b) {
+            const fcarry a = cout[b - 1], q = cin[b];
             const int ok = same_P(R, a.p00, a.p01, a.p11, q.p00, q.p01, q.p11) &&
                            same_X(R, P, a.x0, a.x1, q.x0, q.x1, amp[2 * b], amp[2 * b + 1]);
+            if (ok) run = 0; else { run++; if (run > st->chain_f) st->chain_f = run; }
             if (!ok) {
                 fcarry c = a;
                 const int64_t s = b * B, e = s + B < n ? s + B : n;
@@ -251,8 +266,15 @@ static void backward_blocked(const prob *P, int B, int W, const rulecfg *R, cons
     if (R->rule >= 0) {
         for (int64_t b = NB - 2; b >= 0; --b) {
             const bcarry a = cout[b + 1], q = cin[b];
-            const int ok = same_P(R, a.p00, a.p01, a.p11, q.p00, q.p01, q.p11) && (a.p10 == q.p10 || R->k > 0) &&
+            if (!(same_P(R, a.p00, a.p01, a.p11, q.p00, q.p01, q.p11) && (a.p10 == q.p10 || (R->k > 0 && R->rule != 3)) &&
+                  same_X(R, P, a.x0, a.x1, q.x0, q.x1, amp[2 * b], amp[2 * b + 1]))) st->first_b++;
+        }
+        int64_t run = 0;
+        for (int64_t b = NB - 2; b >= 0; --b) {
+            const bcarry a = cout[b + 1], q = cin[b];
+            const int ok = same_P(R, a.p00, a.p01, a.p11, q.p00, q.p01, q.p11) && (a.p10 == q.p10 || (R->k > 0 && R->rule != 3)) &&
                            same_X(R, P, a.x0, a.x1, q.x0, q.x1, amp[2 * b], amp[2 * b + 1]);
+            if (ok) run = 0; else { run++; if (run > st->chain_b) st->chain_b = run; }
             if (!ok) {
                 bcarry c = a;
                 const int64_t s = b * B, e = s + B < n ? s + B : n;
@@ -290,6 +312,58 @@ int emul_ecm(int64_t m, int64_t n, const float *data, const float *munc, double 
     memcpy(kappa_out, kap, sizeof(float) * n);
     if (stats_out) { stats_out[0] = (double)st.rerun_f; stats_out[1] = (double)st.rerun_b; stats_out[2] = (double)st.blocks;
                      stats_out[3] = st.max_amp_f; stats_out[4] = st.max_amp_b; }
+    free(xf); free(Pf); free(pn); free(xs); free(Ps); free(lag); free(kap);
+    return 0;
+}
+
+/* emul_ecm + the filtered state of the iteration's closing forward pass (pyx:8300: the NLL pass with the final kappa) and the
+ * per-bin NIS of that pass; stats_out gets 9 entries (the five of emul_ecm, then first_f, first_b, chain_f, chain_b).
+ * sweeps_fwd_only > 0: no ECM, just that many plain forward+backward passes with kappa_init (the bench recipe's step). */
+int emul_ecm2(int64_t m, int64_t n, const float *data, const float *munc, double F01, double Q00, double Q11, double pad,
+              double kmin, double kmax, double nu, int iters, int inner, int B, int Wf, int Wb, int rule, int k, double budget,
+              const float *kappa_init, float *xs_out, float *kappa_out, float *xf_out, float *nis_out, double *stats_out) {
+    prob P = {m, n, data, munc, F01, Q00, Q11, pad, kmin, kmax, nu, 0.0, 1000.0};
+    rulecfg R = {rule, k, budget};
+    float *xf = malloc(sizeof(float) * n * 2), *Pf = malloc(sizeof(float) * n * 4), *pn = calloc(n * 4, sizeof(float));
+    float *xs = malloc(sizeof(float) * n * 2), *Ps = malloc(sizeof(float) * n * 4), *lag = calloc(n * 4, sizeof(float));
+    float *kap = malloc(sizeof(float) * n);
+    for (int64_t i = 0; i < n; ++i) kap[i] = kappa_init ? kappa_init[i] : 1.0f;
+    estats st; memset(&st, 0, sizeof st);
+    if (B <= 0 || B > n) B = (int)n;
+    for (int it = 0; it < iters; ++it) {
+        for (int in = 0; in < inner; ++in) {
+            forward_blocked(&P, iters > 0 && inner > 0 ? kap : NULL, B, Wf, &R, xf, Pf, pn, &st);
+            backward_blocked(&P, B, Wb, &R, xf, Pf, pn, xs, Ps, lag, &st);
+            estep_kappa(&P, xs, Ps, lag, kap);
+        }
+    }
+    forward_blocked(&P, kap, B, Wf, &R, xf, Pf, pn, &st);
+    if (iters == 0) backward_blocked(&P, B, Wb, &R, xf, Pf, pn, xs, Ps, lag, &st);
+    memcpy(xs_out, xs, sizeof(float) * n * 2);
+    memcpy(kappa_out, kap, sizeof(float) * n);
+    if (xf_out) memcpy(xf_out, xf, sizeof(float) * n * 2);
+    if (nis_out) {
+        /* NIS of bin k from the filtered moments of bin k-1 (pyx:443-470): quadForm / m with the stored float32 carries */
+        double x0 = 0.0, x1 = 0.0, p00 = 1000.0, p01 = 0.0, p11 = 1000.0;
+        for (int64_t kk = 0; kk < n; ++kk) {
+            const double kp = clampd((double)kap[kk], kmin, kmax);
+            const double xp0 = R32(x0 + F01 * x1);
+            const double t00 = p00 + F01 * p01, t01 = p01 + F01 * p11;
+            const double a00 = R32(t00 + t01 * F01 + (1.0 / kp) * Q00);
+            double s0 = 0, s1 = 0, s2 = 0;
+            for (int64_t j = 0; j < m; ++j) {
+                double r = (double)munc[j * n + kk] + pad; if (r < 1e-12) r = 1e-12;
+                const double w = 1.0 / r, in = (double)data[j * n + kk] - xp0;
+                s0 += w; s1 += w * in; s2 += w * in * in;
+            }
+            const double is = 1.0 + a00 * s0;
+            nis_out[kk] = (float)((s2 - (a00 / is) * s1 * s1) / (double)m);
+            x0 = xf[kk * 2]; x1 = xf[kk * 2 + 1]; p00 = Pf[kk * 4]; p01 = Pf[kk * 4 + 1]; p11 = Pf[kk * 4 + 3];
+        }
+    }
+    if (stats_out) { stats_out[0] = (double)st.rerun_f; stats_out[1] = (double)st.rerun_b; stats_out[2] = (double)st.blocks;
+                     stats_out[3] = st.max_amp_f; stats_out[4] = st.max_amp_b; stats_out[5] = (double)st.first_f;
+                     stats_out[6] = (double)st.first_b; stats_out[7] = (double)st.chain_f; stats_out[8] = (double)st.chain_b; }
     free(xf); free(Pf); free(pn); free(xs); free(Ps); free(lag); free(kap);
     return 0;
 }

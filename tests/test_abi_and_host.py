@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(L):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/consenrich_amd.h but not exported"
     assert set(declared) == set(L.SYMBOLS), "ctypes binding and header disagree"
-    assert L.lib().csr_abi_version() == 5
+    assert L.lib().csr_abi_version() == 6
 
 
 def test_struct_layouts_match_header(L):
@@ -47,7 +47,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.FwdIO) == 8 * 2 + 8 * 5 + 8 + 8 * 4
     assert C.sizeof(L.EcmCfg) == 8 * 4 + 4 * 4
     assert C.sizeof(L.EcmOut) == 8 * 7 + 4 * 4
-    assert C.sizeof(L.RunStats) == 8 * 5 + 4 * 6 + 8 + 4 * 2 + 8 + 8 + 8
+    assert C.sizeof(L.RunStats) == 8 * 5 + 4 * 6 + 8 + 4 * 2 + 8 + 8 + 8 + 8
 
 
 def _has_gpu(L):

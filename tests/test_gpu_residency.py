@@ -132,7 +132,8 @@ def test_statistics_of_the_throughput_mode_are_recomputed_when_the_context_turns
     sets = [cases.synth(n, m, 5100 + c, outlier_frac=0.01) for c, n in enumerate(n_list)]
 
     def run(toggle):
-        with DeviceBatch(0, x_tol_ulps=2 if toggle else 0) as b:
+        # (one block length for both: the per-chain sums are reduced block by block)
+        with DeviceBatch(0, block_len=64, x_tol_ulps=2 if toggle else 0) as b:
             b.configure(ModelParams(state_dim=2), m, n_list)
             for c, (d_, v_) in enumerate(sets):
                 b.upload(c, d_, v_)
@@ -182,3 +183,89 @@ def test_remembered_conversions_follow_the_resident_fit(product):
         b.export(L.EXPORT_MULT)
         assert np.array_equal(b.download(0, "kappa"), new)
         assert np.array_equal(b.download(1, "kappa"), b.download(1, "kappa")) and np.all(np.isfinite(rel))
+
+
+@pytest.mark.parametrize("warm", [(-1, -1, -1), (16, 16, 16)], ids=["default-windows", "failing-validation"])
+def test_a_step_closed_by_its_residual_kernel_equals_the_step_closed_by_the_host(product, monkeypatch, warm):
+    """Throughput mode: the residual kernel that ends `csr_batch_step` also computes the per-chain sums and publishes the mailbox
+    into pinned host memory (csr_device.h StepFin; the host polls a sequence word instead of waiting for a copy behind the
+    kernel).  Same sums bit for bit (the 1024-thread partition of k_chain_sums played by 256 threads), same arrays, same
+    validation verdicts as the step closed by the host (CONSENRICH_AMD_STEP_FIN=0) -- also when windows far too short make the
+    optimistic validation fail and the pipeline replay (the replay closes the ordinary way)."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [300000, 120000, 64, 1, 30001], 8
+    sets = [cases.synth(n, m, 9900 + c, outlier_frac=0.01) for c, n in enumerate(n_list)]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+
+    def run(fin):
+        monkeypatch.setenv("CONSENRICH_AMD_STEP_FIN", fin)
+        out = {}
+        with DeviceBatch(0, warm=warm, x_tol_ulps=2) as b:
+            b.configure(ModelParams(state_dim=2), m, n_list)
+            for c, (d_, v_) in enumerate(sets):
+                b.upload(c, d_, v_)
+            for step in range(3):
+                sd, sn = b.step(L.RETURN_NLL, what)
+                out[("sd", step)], out[("sn", step)] = np.array(sd), np.array(sn)
+            for c in range(len(n_list)):
+                for a in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
+                    out[(c, a)] = b.download(c, a)
+            # a step without sums and one without residuals close the ordinary way; the next full step closes itself again
+            b.step(L.RETURN_NLL, what, want_sums=False)
+            b.step(L.RETURN_NLL, L.EXPORT_SMOOTH)
+            sd, sn = b.step(L.RETURN_NLL, what)
+            out[("sd", "last")], out[("sn", "last")] = np.array(sd), np.array(sn)
+            rs = b.run_stats()
+        return out, rs
+
+    ref, rs0 = run("0")
+    got, rs1 = run("1")
+    assert rs0["step_closes"] == 0 and rs1["step_closes"] >= 1, (rs0, rs1)
+    if warm[0] < 0:
+        assert rs1["step_closes"] == 4 and rs1["pipeline_redos"] <= 1, rs1
+    else:
+        assert rs1["pipeline_redos"] >= 1, rs1
+    for key, val in ref.items():
+        assert np.array_equal(val, got[key]), key
+    assert np.all(np.isfinite(got[("sn", "last")])) and np.array_equal(got[("sn", 0)], got[("sn", "last")])
+
+
+@pytest.mark.parametrize("use_lambda", [False, True], ids=["plain", "lambda"])
+def test_gain_summary_on_the_device_equals_the_reference_expression(product, use_lambda):
+    """`DeviceBatch.gain_summary` (csr_batch_gain_summary: per-replicate moments + exact order statistics by radix select on the
+    resident final pass) against `_finalForwardReplicateGainContigSummary` restated with NumPy on the downloaded arrays
+    (core.py:7671-7731: np.mean / np.median / np.std / np.quantile of the finite float64 gains): counts, medians and
+    inter-quartile ranges EQUAL (the gains are the same float64 values, the selection is exact), mean and sd to 1e-12."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [300001, 1000, 5, 2, 1, 4096], 5
+    mp = ModelParams(state_dim=2)
+    sets = [cases.synth(n, m, 7700 + c, mask_frac=0.03, outlier_frac=0.01) for c, n in enumerate(n_list)]
+    sets[3][1][:] = np.float32(1.0e30)              # a chain whose every cell is masked: gains ~1e-27, still finite
+    flags = L.RETURN_NLL | (L.USE_LAMBDA if use_lambda else 0)
+    with DeviceBatch(0) as b:
+        b.configure(mp, m, n_list)
+        for c, (d_, v_) in enumerate(sets):
+            b.upload(c, d_, v_)
+            if use_lambda:
+                lam, _kap, _qs = cases.multipliers(n_list[c], 7800 + c)
+                b.upload_multipliers(c, lam, None, None)
+        b.stats()
+        b.forward(flags)
+        b.export(L.EXPORT_FORWARD | L.EXPORT_MULT)
+        for c, n in enumerate(n_list):
+            got = b.gain_summary(c, 1.0e-4, use_lambda=use_lambda, lambda_bounds=mp.lambda_bounds)
+            p00 = np.maximum(b.download(c, "Pf").astype(np.float64)[:, 0, 0], 0.0)
+            prec = np.clip(b.download(c, "lambda").astype(np.float64), *mp.lambda_bounds) if use_lambda else np.ones(n)
+            for j in range(m):
+                g = (p00 * prec) / np.maximum(sets[c][1][j].astype(np.float64) + 1.0e-4, 1.0e-12)
+                g = g[np.isfinite(g)]
+                assert got["count"][j] == g.size == n
+                q25, q75 = np.quantile(g, [0.25, 0.75])
+                assert got["median"][j] == float(np.median(g)), (c, j)
+                assert got["iqr"][j] == float(q75 - q25), (c, j)
+                assert got["mean"][j] == pytest.approx(float(np.mean(g)), rel=1e-12)
+                assert got["sd"][j] == pytest.approx(float(np.std(g)), rel=1e-10, abs=1e-300)
