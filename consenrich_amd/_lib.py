@@ -146,7 +146,7 @@ class RunStats(C.Structure):
         ("reruns_b", C.c_int64), ("block_len", C.c_int32), ("warm_p", C.c_int32), ("warm_x", C.c_int32),
         ("warm_b", C.c_int32), ("x_tol_ulps", C.c_int32), ("pipeline_redos", C.c_int32),
         ("local_repairs", C.c_int64), ("ws_warm_f", C.c_int32), ("ws_warm_b", C.c_int32), ("sb_bailouts", C.c_int64), ("tail_groups", C.c_int64),
-        ("nat_first_use_off_main", C.c_int64), ("step_closes", C.c_int64),
+        ("nat_first_use_off_main", C.c_int64),
     ]
 
 

@@ -3343,8 +3343,8 @@ __global__ __launch_bounds__(256) void k_fwd_dstat(Prm p) {
 
 // per-chain sums in block order (fixed partition and fixed-shape tree: deterministic).  The partition is that of 1024 threads
 // (16 wavefronts); a workgroup of NT < 1024 threads plays them in turn -- thread t is the virtual threads t, t + NT, ... (same
-// lane, wavefront t / 64 + v NT / 64) -- so the sums have the same bits whichever kernel computes them (k_chain_sums, or the
-// residual kernel that closes a step, StepFin).  sd, sn: 16 doubles of LDS each.
+// lane, wavefront t / 64 + v NT / 64) -- so the sums have the same bits whichever kernel computes them (round 6 tried them inside
+// the residual kernel, profiles/r06_step_close_ab.txt).  sd, sn: 16 doubles of LDS each.
 // Four independent accumulators per thread keep the loads of a long chain (10^4 blocks) in flight together.
 template <int NT>
 __device__ __forceinline__ void chain_sums_dev(const Prm &p, int c, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks,
@@ -3403,46 +3403,6 @@ __device__ __forceinline__ void chain_sums_dev(const Prm &p, int c, const int64_
 __global__ __launch_bounds__(1024) void k_chain_sums(Prm p, const int64_t *chainFirstBlock, const int64_t *chainNumBlocks) {
     __shared__ double sd[16], sn[16];
     chain_sums_dev<1024>(p, blockIdx.x, chainFirstBlock, chainNumBlocks, sd, sn);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The close of a step inside its LAST kernel (the residual kernel of csr_batch_step, throughput mode): the per-chain sums
-// (workgroup i takes chains i, i + grid, ...) and the mailbox -- stage counters + per-chain sums -- written straight into
-// pinned host memory by the last workgroup to finish, followed by the step's sequence number (release, system scope).  The
-// host polls that word instead of waiting for a copy command behind the kernel: one kernel boundary, one copy and the
-// runtime's completion handling leave the critical path of a latency-bound step (~20 us of a 0.37-ms 1/8-genome step).
-// ---------------------------------------------------------------------------------------------------------------
-struct StepFin {
-    unsigned int *counter;          // device: workgroups that have finished (reset by the last one)
-    unsigned int *mailDev;          // device mailbox
-    unsigned int *mailHost;         // pinned, host-coherent mirror
-    unsigned int *hostSeq;          // pinned: the sequence number of the last step published
-    const int64_t *chainFirst, *chainNb;
-    unsigned int mailWords, seq;
-    int nchains, doSums;
-};
-template <int NT>
-__device__ __forceinline__ void step_fin(const Prm &p, const StepFin &f) {
-    __shared__ double finSd[16], finSn[16];
-    __shared__ unsigned int finLast;
-    if (f.doSums)
-        for (int c = (int)blockIdx.x; c < f.nchains; c += (int)gridDim.x) chain_sums_dev<NT>(p, c, f.chainFirst, f.chainNb, finSd, finSn);
-    __threadfence();                // this workgroup's stores (residuals, sums, counters of the folded check) before its arrival
-    __syncthreads();
-    if (threadIdx.x == 0) finLast = atomicAdd(f.counter, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!finLast) return;
-    __threadfence();
-    for (unsigned int i = threadIdx.x; i < f.mailWords; i += NT) {
-        const unsigned int v = atomicOr(f.mailDev + i, 0u);          // (through L2: what the other workgroups wrote)
-        __hip_atomic_store(f.mailHost + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *f.counter = 0u;
-        __hip_atomic_store(f.hostSeq, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // neighbour k+1 of (b, s) in the blocked layout, or -1 at the chain end
@@ -3770,8 +3730,8 @@ __global__ __launch_bounds__(256) void k_resid(Prm p, const float *xsNat, int xs
 // vectorised variant for m % 4 == 0: 16-byte loads of four consecutive bins per sample row, 16-byte stores of four
 // consecutive samples of one bin.  One workgroup = K * 64 bins x m samples: K independent 16-byte loads per thread and
 // sweep are in flight together (K = 1 leaves the kernel latency-bound: 2 loads per thread at m = 32).
-template <int K, bool FIN = false>
-__global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins, StepFin fin) {
+template <int K>
+__global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int xsStride, float *resid, int64_t nBins) {
     extern __shared__ float tileR[];                 // [m][K*64+4]: the row stride keeps float4 rows 16-B aligned
     constexpr int RS = K * 64 + 4;
     resid_prologue_check(p);
@@ -3823,7 +3783,6 @@ __global__ __launch_bounds__(256) void k_resid_v4(Prm p, const float *xsNat, int
             *reinterpret_cast<float4 *>(resid + (g0 + bin) * (int64_t)p.m + j) = o;
         }
     }
-    if constexpr (FIN) step_fin<256>(p, fin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

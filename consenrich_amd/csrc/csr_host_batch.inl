@@ -202,16 +202,6 @@ extern "C" int csr_batch_configure(csr_ctx *c, const csr_model *mdl, int64_t m, 
     c->hMail = nullptr;
     HIPOK(hipHostMalloc((void **)&c->hMail, c->mailBytes));
     memset(c->hMail, 0, c->mailBytes);
-    // the mirror a step's closing kernel writes itself (StepFin): coherent (fine-grained) pinned memory, polled by the host
-    if (c->hFin) (void)hipHostFree(c->hFin);
-    c->hFin = nullptr;
-    c->finSeqWord = ((c->mailBytes + 63) / 64 * 64) / sizeof(unsigned int);
-    HIPOK(hipHostMalloc((void **)&c->hFin, (c->finSeqWord + 16) * sizeof(unsigned int), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(c->hFin, 0, (c->finSeqWord + 16) * sizeof(unsigned int));
-    HIPOK(hipHostGetDevicePointer((void **)&c->dFinHost, c->hFin, 0));
-    c->finSeq = 0;
-    CHECK(dalloc(c, &c->dFinCounter, 1));
-    HIPOK(hipMemsetAsync(c->dFinCounter, 0, sizeof(unsigned int), c->stream));
     char *ci_, *coa, *cob;
     CHECK(dalloc(c, &ci_, nb * 32)); CHECK(dalloc(c, &coa, nb * 32)); CHECK(dalloc(c, &cob, nb * 32));
     p.carryIn = ci_; p.carryOutA = coa; p.carryOutB = cob;

@@ -110,44 +110,7 @@ static int flush_pending_check(csr_ctx *c) {
     c->rs.fix_launches++;
     return 0;
 }
-// Host wait for the sequence word a step's closing kernel publishes (StepFin): same polling policy as wait_stream, on a word of
-// pinned memory instead of the stream's state.  A kernel that never publishes (a fault) shows as a stream error or as an idle
-// stream without the word: both fail loudly.
-static int wait_fin(csr_ctx *c) {
-    volatile unsigned int *word = c->hFin + c->finSeqWord;
-    const unsigned int want = c->finSeq;
-    auto ready = [&]() { return __atomic_load_n(const_cast<unsigned int *>(word), __ATOMIC_ACQUIRE) == want; };
-    TimerSlack slack;
-    const auto t0 = std::chrono::steady_clock::now();
-    auto elapsed_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
-    for (int i = 0; i < 512; ++i)
-        if (ready()) { c->lastWaitUs[0] = elapsed_us(); return 0; }
-    const double expect = c->lastWaitUs[0];
-    for (int it = 0;; ++it) {
-        const double el = elapsed_us();
-        if (ready()) { c->lastWaitUs[0] = el; return 0; }
-        if (el > 20000.0) break;
-        const bool nearEnd = expect > 0.0 && el > expect - 150.0 && el < expect + 250.0;
-        if (!nearEnd) std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if ((it & 255) == 255) {
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q != hipSuccess && q != hipErrorNotReady) return fail("step close: %s", hipGetErrorString(q));
-        }
-    }
-    HIPOK(hipStreamSynchronize(c->stream));
-    c->lastWaitUs[0] = elapsed_us();
-    if (!ready()) return fail("step close: the closing kernel ended without publishing the mailbox");
-    return 0;
-}
 static int read_mail(csr_ctx *c, size_t bytes) {
-    if (c->finPending && c->finFast && !c->pendChk.valid) {
-        // the step's closing kernel publishes the mailbox itself: no copy command, no stream wait
-        c->finPending = false;
-        CHECK(wait_fin(c));
-        memcpy(c->hMail, c->hFin, bytes);
-        return 0;
-    }
-    c->finPending = false;
     CHECK(flush_pending_check(c));
     HIPOK(hipMemcpyAsync(c->hMail, c->dMail, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPOK(wait_stream(c));
@@ -600,12 +563,6 @@ static int state_chain_systolic(csr_ctx *c, const Prm &p, bool earlyExports = fa
 // join: left on the side stream behind the epilogue they starve for whole-CU slots while a bandwidth-bound kernel of the
 // main stream keeps the chip full (measured 0.64 ms instead of 0.01).
 static void join_side(csr_ctx *c) {
-    if (c->sumsInFin) {
-        // the forward pass left the per-chain sums to the kernel that closes the step and no such kernel took them: here they are
-        c->sumsInFin = false;
-        Scope sc(c, "chain_sums");
-        hipLaunchKernelGGL(k_chain_sums, dim3((int)c->chains.size()), dim3(1024), 0, c->stream, c->sidePrm, c->dChainFirst, c->dChainNb);
-    }
     if (c->sidePending) {
         (void)hipStreamWaitEvent(c->stream, c->evJoin, 0);
         c->sidePending = false;
@@ -653,6 +610,32 @@ static void join_pf(csr_ctx *c) {
         c->pfPending = false;
     }
 }
+// constant process noise as rows of the reference-layout array (skipped when the array already holds exactly this fill)
+static void pn_fill_values(const csr_ctx *c, const Prm &p, float q[4]) {
+    q[0] = (float)p.Q00;
+    q[1] = c->mdl.state_dim == 2 ? (float)p.Q01 : 0.f;
+    q[2] = c->mdl.state_dim == 2 ? (float)p.Q10 : 0.f;
+    q[3] = c->mdl.state_dim == 2 ? (float)p.Q11 : 0.f;
+}
+static bool pn_fill_current(const csr_ctx *c, const Prm &p) {
+    float q[4];
+    pn_fill_values(c, p, q);
+    return c->pnFillValid && c->nat[CSR_ARR_PNOISE] != nullptr && memcmp(q, c->pnFillQ, sizeof(q)) == 0;
+}
+static int launch_pn_fill(csr_ctx *c, const Prm &p, float *dst, hipStream_t st) {
+    const int nm = c->mdl.state_dim * c->mdl.state_dim;
+    const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
+    float q[4];
+    pn_fill_values(c, p, q);
+    Scope sc(c, "export_natural", st);
+    if (nm == 4) hipLaunchKernelGGL(k_fill_rows<4>, dim3(grid), dim3(256), 0, st, dst, c->Npad, q[0], q[1], q[2], q[3]);
+    else hipLaunchKernelGGL(k_fill_rows<1>, dim3(grid), dim3(256), 0, st, dst, c->Npad, q[0], 0.f, 0.f, 0.f);
+    LAUNCH_CHECK("k_fill_rows");
+    memcpy(c->pnFillQ, q, sizeof(q));
+    c->pnFillValid = true;
+    return 0;
+}
+
 // Bit-exact mode: the state chain keeps at most 5/8 of the SIMDs busy for milliseconds and is bound by latency, not by
 // bandwidth.  The reference-layout outputs that depend on the covariance chain alone -- Pf, and the process noise when it
 // is one constant matrix -- are written on the side stream underneath it instead of after the smoother.
@@ -665,12 +648,14 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool with
     const bool convQ = withPf && !constQ;
     if (!withPf && !constQ) return 0;
     const bool doPf = withPf && !c->pfNat;          // (the covariance chain may have written Pf in the reference layout itself)
-    if (!doPf && !constQ && !convQ) return 0;
+    const bool fill = constQ && !pn_fill_current(c, p);
+    if (constQ && !fill) c->pnNat = true;           // the array already holds this constant fill
+    if (!doPf && !fill && !convQ) { if (withPf) c->pfNat = true; return 0; }
     // (a reference-layout array is allocated -- and zeroed ON THE MAIN STREAM -- at its first use: before the fork, so that the
     // side stream's writes are ordered behind the zeroing)
     float *dstPf = nullptr, *dstPn = nullptr;
     if (doPf) CHECK(nat_array(c, CSR_ARR_PF, &dstPf));
-    if (constQ || convQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
+    if (fill || convQ) CHECK(nat_array(c, CSR_ARR_PNOISE, &dstPn));
     HIPOK(hipEventRecord(c->evFork2, c->stream));
     HIPOK(hipStreamWaitEvent(c->side, c->evFork2, 0));
     if (doPf || convQ) {
@@ -696,17 +681,9 @@ static int early_cov_exports(csr_ctx *c, const Prm &p, uint32_t flags, bool with
     }
     LAUNCH_CHECK("k_export_tiled (early Pf)");
     if (withPf) c->pfNat = true;
-    if (convQ) c->pnNat = true;
-    if (constQ) {
-        float *dst = dstPn;
-        const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
-        Scope sc(c, "export_natural", c->side);
-        if (nm == 4)
-            hipLaunchKernelGGL(k_fill_rows<4>, dim3(grid), dim3(256), 0, c->side, dst, c->Npad, (float)p.Q00, (float)p.Q01,
-                               (float)p.Q10, (float)p.Q11);
-        else
-            hipLaunchKernelGGL(k_fill_rows<1>, dim3(grid), dim3(256), 0, c->side, dst, c->Npad, (float)p.Q00, 0.f, 0.f, 0.f);
-        LAUNCH_CHECK("k_fill_rows (early pNoise)");
+    if (convQ) { c->pnNat = true; c->pnFillValid = false; }
+    if (fill) {
+        CHECK(launch_pn_fill(c, p, dstPn, c->side));
         c->pnNat = true;
     }
     HIPOK(hipEventRecord(c->evPf, c->side));
@@ -883,11 +860,6 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
             // stream) when one follows, so that its few microseconds leave the critical path
             join_side(c);
             hipStream_t st = c->stream;
-            if (c->finWanted && side && c->deferEnabled && active == nullptr) {
-                // csr_batch_step: the residual kernel that closes the step computes them (StepFin); join_side does if it never comes
-                c->sumsInFin = true;
-                c->sidePrm = p;
-            } else {
             if (side && c->deferEnabled) {
                 HIPOK(hipEventRecord(c->evFork, c->stream));
                 HIPOK(hipStreamWaitEvent(c->side, c->evFork, 0));
@@ -902,7 +874,6 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
                 HIPOK(hipEventRecord(c->evJoin, c->side));
                 c->sidePending = true;
                 c->sideSumsDone = true;         // join_side only waits
-            }
             }
         } else
         if (wantD && !c->sbp.active) CHECK(forward_epilogue(c, p, side && c->deferEnabled));
@@ -1431,7 +1402,7 @@ static int add_export_mult(csr_ctx *c, ExpList &L, int id) {
 }
 
 // residuals of the bins [off, off + nb) of the batch's natural layout (whole chains: off and nb are multiples of 64)
-static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck, bool mayClose = false) {
+static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck) {
     const int d = c->mdl.state_dim;
     float *xs, *res;
     CHECK(nat_array(c, CSR_ARR_XS, &xs));
@@ -1446,36 +1417,15 @@ static int launch_resid(csr_ctx *c, int64_t off, int64_t nb, bool foldCheck, boo
     if (pr.bg) pr.bg += off;
     xs += off * d;
     res += off * c->m;
-    StepFin fin;
-    memset(&fin, 0, sizeof(fin));
     if ((c->m & 3) == 0) {
         constexpr int K = 2;        // 64-bin sub-tiles per workgroup: 2 measured best (0.665 vs 0.684 ms with 1 or 4, round 3)
         const size_t lds = sizeof(float) * (size_t)(K * 64 + 4) * c->m;
         const dim3 grid((unsigned)((nb + K * 64 - 1) / (K * 64)));
-        // this launch closes a step (csr_batch_step, nothing of the step follows it and its folded check is the last one pending):
-        // per-chain sums and the publication of the mailbox ride in it (csr_device.h StepFin)
-        const bool close = mayClose && c->finWanted && c->finEnabled && foldCheck && off == 0 && nb == c->Npad && !c->pendChk.valid &&
-                           !c->sidePending && !c->pfPending && lds <= 65536 && c->dFinCounter != nullptr;
-        if (close) {
-            fin.counter = c->dFinCounter;
-            fin.mailDev = reinterpret_cast<unsigned int *>(c->dMail);
-            fin.mailHost = c->dFinHost;
-            fin.hostSeq = c->dFinHost + c->finSeqWord;
-            fin.chainFirst = c->dChainFirst; fin.chainNb = c->dChainNb;
-            fin.mailWords = (unsigned int)(c->mailBytes / sizeof(unsigned int));
-            fin.seq = ++c->finSeq;
-            fin.nchains = (int)c->chains.size();
-            fin.doSums = c->sumsInFin ? 1 : 0;
-            pr.chainActive = nullptr;
-            hipLaunchKernelGGL((k_resid_v4<2, true>), grid, dim3(256), lds, c->stream, pr, xs, d, res, nb, fin);
-            c->sumsInFin = false;
-            c->finPending = true;
-            c->rs.step_closes += 1;
-        } else if (lds <= 65536)
-            hipLaunchKernelGGL((k_resid_v4<2, false>), grid, dim3(256), lds, c->stream, pr, xs, d, res, nb, fin);
+        if (lds <= 65536)
+            hipLaunchKernelGGL(k_resid_v4<2>, grid, dim3(256), lds, c->stream, pr, xs, d, res, nb);
         else
-            hipLaunchKernelGGL((k_resid_v4<1, false>), dim3((unsigned)((nb + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
-                               c->stream, pr, xs, d, res, nb, fin);
+            hipLaunchKernelGGL(k_resid_v4<1>, dim3((unsigned)((nb + 63) / 64)), dim3(256), sizeof(float) * 68 * c->m,
+                               c->stream, pr, xs, d, res, nb);
     } else
         hipLaunchKernelGGL(k_resid, dim3((int)((nb + 63) / 64)), dim3(256), sizeof(float) * 65 * c->m, c->stream,
                            pr, xs, d, res, nb);
@@ -1510,18 +1460,14 @@ static int export_impl(csr_ctx *c, uint32_t what) {
             // (the constant process noise was filled underneath the state chain as well)
         } else if (constQ && p.chainQ == nullptr) {
             // one Q0 for every bin of every chain: a streaming fill (rows past a chain's n-1 are padding nobody reads)
-            float *dst;
-            CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));
-            const unsigned grid = (unsigned)std::min<int64_t>((c->Npad + 255) / 256, 8192);
-            Scope sc(c, "export_natural");
-            if (nm == 4)
-                hipLaunchKernelGGL(k_fill_rows<4>, dim3(grid), dim3(256), 0, c->stream, dst, c->Npad, (float)p.Q00,
-                                   (float)p.Q01, (float)p.Q10, (float)p.Q11);
-            else
-                hipLaunchKernelGGL(k_fill_rows<1>, dim3(grid), dim3(256), 0, c->stream, dst, c->Npad, (float)p.Q00, 0.f, 0.f,
-                                   0.f);
+            if (!pn_fill_current(c, p)) {
+                float *dst;
+                CHECK(nat_array(c, CSR_ARR_PNOISE, &dst));
+                CHECK(launch_pn_fill(c, p, dst, c->stream));
+            }
         } else {
-        CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
+            CHECK(add_export(c, L, CSR_ARR_PNOISE, constQ ? nullptr : (const float *)p.tQ, 4, nm, 1));
+            c->pnFillValid = false;
         }
         if (constQ && p.chainQ != nullptr) {
             ExpDesc &e = L.d[L.count - 1];
@@ -1546,7 +1492,7 @@ static int export_impl(csr_ctx *c, uint32_t what) {
         CHECK(add_export_mult(c, L, CSR_ARR_QSCALE));
     }
     CHECK(flush_export(c, L));
-    if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true, !lateD));
+    if (what & CSR_EXPORT_RESID) CHECK(launch_resid(c, 0, c->Npad, true));
     if (lateD) {
         join_side(c);
         CHECK(add_export(c, L, CSR_ARR_D, p.tD, 1, 1, 0));
@@ -1746,15 +1692,8 @@ extern "C" int csr_batch_step(csr_ctx *c, uint32_t flags, uint32_t what, double 
     bool handled = false;
     CHECK(step_pipelined(c, flags, what, &handled));
     if (!handled) {
-        // a step whose last launch is the residual kernel may be closed by that kernel (per-chain sums, mailbox: StepFin)
-        struct FinScope { csr_ctx *c; ~FinScope() { c->finWanted = c->finFast = false; } } finScope{c};
-        c->finWanted = c->finEnabled && (what & CSR_EXPORT_RESID) && (sum_d || sum_nll);
         CHECK(csr_batch_forward_backward(c, flags, nullptr, nullptr));
         if (what) CHECK(csr_batch_export(c, what));
-        c->finWanted = false;
-        c->finFast = c->finPending;
-        if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
-        return 0;
     }
     if (sum_d || sum_nll) return csr_batch_sums(c, sum_d, sum_nll);
     return 0;

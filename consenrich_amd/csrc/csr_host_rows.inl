@@ -67,6 +67,7 @@ extern "C" int csr_output_diagnostics(const csr_model *mdl, int64_t m, int64_t n
         float *dst;
         CHECK(nat_array(c, e.id, &dst));
         if (e.flag) c->natMultStamp[e.id == CSR_ARR_LAMBDA ? 0 : (e.id == CSR_ARR_KAPPA ? 1 : 2)] = ~0ull;     // (not the resident multipliers)
+        if (e.id == CSR_ARR_PNOISE) c->pnFillValid = false;
         if (e.rows > 0)
             HIPOK(hipMemcpyAsync(dst + ci.off * e.comps, e.src, sizeof(float) * e.comps * e.rows, hipMemcpyHostToDevice,
                                  c->stream));

@@ -299,17 +299,6 @@ struct csr_ctx {
     // handed out: it is ordered against no other stream, so it does not matter which stream the caller is on at that moment
     hipStream_t zeroStream = nullptr;
     hipStream_t mainStream = nullptr;   // what `stream` is outside step_pipelined's tail groups (csr_run_stats.nat_first_use_off_main)
-    // The close of a throughput-mode step inside its residual kernel (csr_device.h StepFin; CONSENRICH_AMD_STEP_FIN=0: off): per-chain
-    // sums + the mailbox published into pinned host memory by the kernel itself, the host polls the sequence word.
-    bool finEnabled = true;
-    bool finWanted = false;     // csr_batch_step is launching a step that may end that way
-    bool sumsInFin = false;     // the forward pass left the per-chain sums to whoever closes the step (join_side launches them otherwise)
-    bool finPending = false;    // a closing kernel is in flight: hFin will carry sequence number finSeq
-    bool finFast = false;       // the mailbox read that follows is the step's own: poll instead of copy + stream wait
-    unsigned int finSeq = 0;
-    unsigned int *dFinCounter = nullptr;
-    unsigned int *hFin = nullptr, *dFinHost = nullptr;      // pinned host-coherent: mailbox words, then (64-byte aligned) the sequence word
-    size_t finSeqWord = 0;                                  // index of the sequence word in hFin
     struct SbPending { bool active = false; Prm p{}; } sbp;     // a state chain launched and not yet waited for (step_pipelined)
     unsigned int *hDone = nullptr, *dDone = nullptr;    // host-visible "chain is final" words (pinned; device alias)
     unsigned char *dMask[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -320,6 +309,10 @@ struct csr_ctx {
     int tailFirstPct = 60, tailNextPct = 40;
     bool tailSplit = true;      // CONSENRICH_AMD_TAIL_SPLIT=0: a step's tail follows the state chain for all chains at once
     bool pfPending = false, pfNat = false, pnNat = false;
+    // the reference-layout process-noise array holds the constant fill of THESE values in every row (k_fill_rows): a step with the
+    // same constant process noise does not write it again (a 1/8-genome step: one side-stream launch and two stream waits less)
+    bool pnFillValid = false;
+    float pnFillQ[4] = {0.f, 0.f, 0.f, 0.f};
     static constexpr bool earlyPf = true;       // Pf / constant pNoise are exported underneath the state chain
     // profiling
     bool profiling = false;
@@ -371,12 +364,11 @@ static void free_batch(csr_ctx *c) {
     if (c->hMaskPin) { (void)hipHostFree(c->hMaskPin); c->hMaskPin = nullptr; c->hMaskPinChains = 0; }
     for (auto &m : c->dMask) m = nullptr;
     c->sbp.active = false;
-    c->finWanted = c->sumsInFin = c->finPending = c->finFast = false;
-    c->dFinCounter = nullptr;
     c->pfPending = false;
     c->xfNat = false;
     c->fwdNat = c->pfNat = c->pnNat = c->dNat = c->smoothNat = false;
     c->fwdBlockedStale = c->pfBlockedStale = false;     // (the reference-layout arrays they point at are gone)
+    c->pnFillValid = false;
     c->ckF[0] = c->ckF[1] = c->ckB[0] = c->ckB[1] = nullptr;
     c->wsSavedF = c->wsSavedB = 0;
     c->wsActive = c->wsCold = false;
@@ -454,7 +446,6 @@ extern "C" csr_ctx *csr_create(int device_ordinal) {
         if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->tailFirstPct = std::min(100, std::max(1, a)); c->tailNextPct = std::min(100, std::max(1, b)); }
     }
     if ((e = getenv("CONSENRICH_AMD_SB_SPIN_LIMIT"))) c->sbSpinLimit = std::max(1, atoi(e));
-    if ((e = getenv("CONSENRICH_AMD_STEP_FIN"))) c->finEnabled = atoi(e) != 0;
     c->dbgLog = getenv("CONSENRICH_AMD_DEBUG") != nullptr;
     mode_warm_defaults(c);
     if ((e = getenv("CONSENRICH_AMD_DMA"))) c->useDma = c->useDmaFused = c->useDmaWarm = atoi(e) != 0;     // 0: the plain-load forms of the chains (yardstick of the LDS-DMA ring tests)
@@ -477,7 +468,6 @@ extern "C" void csr_destroy(csr_ctx *c) {
     for (DevBuf *b : {&c->bgBuf, &c->wrBuf, &c->textBuf, &c->qsBuf, &c->qpBuf, &c->stageBuf})
         if (b->ptr) { (void)hipFree(b->ptr); b->ptr = nullptr; b->cap = 0; }
     if (c->hMail) (void)hipHostFree(c->hMail);
-    if (c->hFin) (void)hipHostFree(c->hFin);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);

@@ -513,8 +513,6 @@ typedef struct csr_run_stats {
     int64_t nat_first_use_off_main; /* reference-layout arrays whose first use (allocation + zeroing) happened while a tail group's
                                    stream was current; harmless since ABI 4 (the zeroing is waited for on the host before the
                                    array is handed out) -- counted so that a test can show the path was exercised */
-    int64_t step_closes;        /* steps (csr_batch_step, throughput mode) whose last kernel -- the residuals -- also computed the
-                                   per-chain sums and published the mailbox into pinned host memory itself (ABI 6) */
 } csr_run_stats;
 int csr_get_run_stats(csr_ctx *ctx, csr_run_stats *out);
 

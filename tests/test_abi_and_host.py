@@ -47,7 +47,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.FwdIO) == 8 * 2 + 8 * 5 + 8 + 8 * 4
     assert C.sizeof(L.EcmCfg) == 8 * 4 + 4 * 4
     assert C.sizeof(L.EcmOut) == 8 * 7 + 4 * 4
-    assert C.sizeof(L.RunStats) == 8 * 5 + 4 * 6 + 8 + 4 * 2 + 8 + 8 + 8 + 8
+    assert C.sizeof(L.RunStats) == 8 * 5 + 4 * 6 + 8 + 4 * 2 + 8 + 8 + 8
 
 
 def _has_gpu(L):

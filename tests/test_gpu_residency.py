@@ -185,53 +185,6 @@ def test_remembered_conversions_follow_the_resident_fit(product):
         assert np.array_equal(b.download(1, "kappa"), b.download(1, "kappa")) and np.all(np.isfinite(rel))
 
 
-@pytest.mark.parametrize("warm", [(-1, -1, -1), (16, 16, 16)], ids=["default-windows", "failing-validation"])
-def test_a_step_closed_by_its_residual_kernel_equals_the_step_closed_by_the_host(product, monkeypatch, warm):
-    """Throughput mode: the residual kernel that ends `csr_batch_step` also computes the per-chain sums and publishes the mailbox
-    into pinned host memory (csr_device.h StepFin; the host polls a sequence word instead of waiting for a copy behind the
-    kernel).  Same sums bit for bit (the 1024-thread partition of k_chain_sums played by 256 threads), same arrays, same
-    validation verdicts as the step closed by the host (CONSENRICH_AMD_STEP_FIN=0) -- also when windows far too short make the
-    optimistic validation fail and the pipeline replay (the replay closes the ordinary way)."""
-    from consenrich_amd import _lib as L
-    from consenrich_amd.batch import DeviceBatch, ModelParams
-
-    n_list, m = [300000, 120000, 64, 1, 30001], 8
-    sets = [cases.synth(n, m, 9900 + c, outlier_frac=0.01) for c, n in enumerate(n_list)]
-    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
-
-    def run(fin):
-        monkeypatch.setenv("CONSENRICH_AMD_STEP_FIN", fin)
-        out = {}
-        with DeviceBatch(0, warm=warm, x_tol_ulps=2) as b:
-            b.configure(ModelParams(state_dim=2), m, n_list)
-            for c, (d_, v_) in enumerate(sets):
-                b.upload(c, d_, v_)
-            for step in range(3):
-                sd, sn = b.step(L.RETURN_NLL, what)
-                out[("sd", step)], out[("sn", step)] = np.array(sd), np.array(sn)
-            for c in range(len(n_list)):
-                for a in ("D", "xf", "Pf", "pnoise", "xs", "Ps", "lag", "resid"):
-                    out[(c, a)] = b.download(c, a)
-            # a step without sums and one without residuals close the ordinary way; the next full step closes itself again
-            b.step(L.RETURN_NLL, what, want_sums=False)
-            b.step(L.RETURN_NLL, L.EXPORT_SMOOTH)
-            sd, sn = b.step(L.RETURN_NLL, what)
-            out[("sd", "last")], out[("sn", "last")] = np.array(sd), np.array(sn)
-            rs = b.run_stats()
-        return out, rs
-
-    ref, rs0 = run("0")
-    got, rs1 = run("1")
-    assert rs0["step_closes"] == 0 and rs1["step_closes"] >= 1, (rs0, rs1)
-    if warm[0] < 0:
-        assert rs1["step_closes"] == 4 and rs1["pipeline_redos"] <= 1, rs1
-    else:
-        assert rs1["pipeline_redos"] >= 1, rs1
-    for key, val in ref.items():
-        assert np.array_equal(val, got[key]), key
-    assert np.all(np.isfinite(got[("sn", "last")])) and np.array_equal(got[("sn", 0)], got[("sn", "last")])
-
-
 @pytest.mark.parametrize("use_lambda", [False, True], ids=["plain", "lambda"])
 def test_gain_summary_on_the_device_equals_the_reference_expression(product, use_lambda):
     """`DeviceBatch.gain_summary` (csr_batch_gain_summary: per-replicate moments + exact order statistics by radix select on the
@@ -269,3 +222,45 @@ def test_gain_summary_on_the_device_equals_the_reference_expression(product, use
                 assert got["iqr"][j] == float(q75 - q25), (c, j)
                 assert got["mean"][j] == pytest.approx(float(np.mean(g)), rel=1e-12)
                 assert got["sd"][j] == pytest.approx(float(np.std(g)), rel=1e-10, abs=1e-300)
+
+
+@pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
+def test_constant_process_noise_rows_are_written_once_and_follow_the_model(product, xtol):
+    """The reference-layout process-noise rows of a pass with ONE constant Q are a fill; a following step with the same Q does not
+    write them again (csr_ctx::pnFillValid).  They must still follow the model: another Q0, per-bin process noise (kappa) in
+    between, a different Q0 again."""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n_list, m = [50000, 20000, 7], 4
+    sets = [cases.synth(n, m, 3300 + c) for c, n in enumerate(n_list)]
+    what = L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID
+    qa, qb = ((1e-3, 0.0), (0.0, 1e-4)), ((2e-3, 0.0), (0.0, 5e-5))
+
+    def rows(b, q):
+        want = np.asarray(q, np.float32)
+        for c, n in enumerate(n_list):
+            pn = b.download(c, "pnoise")
+            assert pn.shape == (n - 1, 2, 2) and np.all(pn == want[None]), (c, q)
+
+    with DeviceBatch(0, x_tol_ulps=xtol) as b:
+        b.configure(ModelParams(state_dim=2, Q0=qa), m, n_list)
+        for c, (d_, v_) in enumerate(sets):
+            b.upload(c, d_, v_)
+        b.step(L.RETURN_NLL, what)
+        rows(b, qa)
+        b.profile(True)
+        b.step(L.RETURN_NLL, what)
+        fills = b.kernel_times().get("export_natural", (0, 0.0))[0]
+        b.profile(False)
+        rows(b, qa)
+        b.set_model(ModelParams(state_dim=2, Q0=qb))
+        b.step(L.RETURN_NLL, what)
+        rows(b, qb)
+        for c, n in enumerate(n_list):                      # per-bin process noise in between: the rows are Q0 / kappa
+            b.upload_multipliers(c, None, np.full(n, 2.0, np.float32), None)
+        b.step(L.RETURN_NLL | L.USE_KAPPA, what)
+        assert np.allclose(b.download(0, "pnoise")[5], np.asarray(qb, np.float32) / 2.0)
+        b.step(L.RETURN_NLL, what)
+        rows(b, qb)
+    assert fills == 0, fills        # the second step with the same constant Q launched no conversion / fill at all
