@@ -59,7 +59,7 @@ if not os.environ.get("NO_CORE_API"):
     kw = dict(deltaF=1.0, minQ=1.0e-6, maxQ=1000.0, stateInit=0.0, stateCovarInit=1000.0, boundState=False, stateLowerBound=0.0,
               stateUpperBound=0.0, blockLenIntervals=750, pad=1.0e-4, ECM_fixedBackgroundIters=50, ECM_fixedBackgroundRtol=1.0e-6,
               t_innerIters=5, ECM_robustTNu=8.0, ECM_useObsPrecisionReweighting=False, ECM_useProcessPrecisionReweighting=True,
-              ECM_useAPN=False, ECM_outerIters=8, ECM_minOuterIters=3, ECM_backgroundShiftRtol=5.0e-3, ECM_outerNLLRtol=5.0e-5,
+              ECM_useAPN=False, ECM_outerIters=int(os.environ.get("OUTER", "32")), ECM_minOuterIters=3, ECM_backgroundShiftRtol=5.0e-3, ECM_outerNLLRtol=5.0e-5,
               ECM_backgroundSmoothness=128.0, fitBackground=True, returnScales=True, returnBackground=True,
               initialProcessQ=np.diag([1e-3, 1e-4]).astype(np.float32), returnPrecisionDiagnostics=True,
               # ... and what the CLI itself asks for on every chromosome (consenrich.py:9216, 9241-9243): the run diagnostics with
@@ -116,9 +116,11 @@ if not os.environ.get("NO_CORE_API"):
         bb.synchronize()
         genome_batch = time.perf_counter() - t
     print(json.dumps({"core_api_runConsenrich": {
-        "settings": "CLI defaults (50 ECM iterations, rtol 1e-6, 5 inner sweeps, process re-weighting on, background fitted, 8 outer passes, "
-                    "min 3), returnDiagnostics + returnPrecisionDiagnostics like the CLI's call, fixed Q0 = diag(1e-3, 1e-4), hg38 @200bp x %d, "
-                    "library default (bit-exact) mode" % m,
+        "settings": "the CLI's settings (50 ECM iterations, rtol 1e-6, 5 inner sweeps, process re-weighting on, background fitted, at most "
+                    "%d outer passes [OUTER; the CLI's default is 32, constants.py:277; rounds 3-5 quoted 8], at least 3), returnDiagnostics + "
+                    "returnPrecisionDiagnostics like the CLI's call, fixed Q0 = diag(1e-3, 1e-4), hg38 @200bp x %d, library default (bit-exact) "
+                    "mode" % (int(os.environ.get("OUTER", "32")), m),
+        "outer_passes_cap": int(os.environ.get("OUTER", "32")),
         "chr1_call": {k_: round(v_, 4) for k_, v_ in t_chr1.items()},
         "chr1_call_returnDiagnostics_false": {k_: round(v_, 4) for k_, v_ in t_chr1_plain.items()},
         "chr1_ecm_phases_recorded": len(res[-1]["post_process_noise_fit"]["fixed_background_ecm"]), "chr1_device_part": {k_: round(v_, 4) for k_, v_ in split.items()},

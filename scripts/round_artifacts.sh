@@ -7,7 +7,7 @@
 #   shards: step and ECM iteration of the LPT shards of a 2 / 4 / 8-GPU run emulated on one GPU, both modes
 #   misc  : step timelines, ECM kernel shares, whole-genome fit, per-call drop-in entries, exact-mode fuzz
 export TMPDIR=/tmp
-R=${R:-r05}
+R=${R:-r06}
 O=gpurun_out/p
 PART=${PART:-"bench pmc shards misc"}
 mkdir -p $O
@@ -23,6 +23,10 @@ bench)
     echo "bench $c done"
   done
   cp $O/${R}_bench_c4.json $O/${R}_bench.json
+  # long-memory process noise (the floor the reference's Q0 seed clamps to is 1e-6): windows lengthen, repair runs multiply
+  for q in 1e-5,1e-6 1e-6,1e-7; do
+    timeout -k 10 600 python3 bench.py --config c4 --q0 $q --no-cpu-baseline > $O/${R}_bench_q0_$q.json 2> $O/bench_q0_$q.err || echo "bench q0 $q FAILED"
+  done
   # the throughput-mode steps of c4 under the kernel trace (the bench line's `throughput_mode`)
   XTOL=2 STEPS=3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktx -o kt -- python3 scripts/one_step.py > $O/ktx.log 2>&1
   cp "$(find $O/ktx -name '*kernel_stats.csv' | head -1)" $O/${R}_kernel_stats_c4_throughput_mode.csv
@@ -56,8 +60,10 @@ misc)
   XTOL=2 SHARD=8:6 OUT=$O/tl timeout -k 10 200 bash scripts/step_timeline.sh > $O/${R}_step_timeline_throughput_mode_shard8.txt 2>&1
   rm -rf $O/tl
   ITERS=3 CPU=0 PROFILE=1 timeout -k 10 300 python3 scripts/ecm_bench.py > $O/${R}_ecm_kernels.txt 2>&1
-  timeout -k 10 300 python3 scripts/fit_bench.py > $O/${R}_fit_bench.json 2> $O/fit.err; echo "fit: $?"
-  timeout -k 10 600 python3 scripts/dropin_bench.py > $O/${R}_dropin_bench.json 2> $O/dropin.err; echo "dropin: $?"
+  PROFILE=0 timeout -k 10 300 python3 scripts/fit_bench.py > $O/${R}_fit_bench_plain.json 2> $O/fit.err; echo "fit: $?"
+  PROFILE=0 DIAG=1 timeout -k 10 300 python3 scripts/fit_bench.py > $O/${R}_fit_bench_with_phase_diagnostics.json 2>> $O/fit.err; echo "fit diag: $?"
+  OUTER=8 timeout -k 10 600 python3 scripts/dropin_bench.py > $O/${R}_dropin_bench_outer8.json 2> $O/dropin.err; echo "dropin 8: $?"
+  OUTER=32 NO_SINGLE=1 timeout -k 10 900 python3 scripts/dropin_bench.py > $O/${R}_dropin_bench.json 2>> $O/dropin.err; echo "dropin 32: $?"
   TRIALS=32 timeout -k 10 600 python3 scripts/fuzz_exact.py > $O/${R}_fuzz_exact.txt 2>&1; echo "fuzz: $?"
   ;;
 esac
