@@ -243,8 +243,21 @@ def track_summary(values) -> dict:
     lo, hi = float(a.min()), float(a.max())
     if lo == hi:                    # a constant track (base Q, unit scales): every order statistic is that value, no selection passes
         return {"min": lo, "q05": lo, "median": lo, "mean": float(a.mean()), "q95": lo, "max": lo}
-    return {"min": float(a.min()), "q05": float(np.quantile(a, 0.05)), "median": float(np.median(a)),
-            "mean": float(a.mean()), "q95": float(np.quantile(a, 0.95)), "max": float(a.max())}
+    # one selection pass for both quantiles (np.quantile partitions around all the positions it needs at once; the values are
+    # those of two separate calls), one for the median (np.median: the mean of the two middle values, not the lerp of np.quantile)
+    q05, q95 = np.quantile(a, [0.05, 0.95])
+    return {"min": lo, "q05": float(q05), "median": float(np.median(a)), "mean": float(a.mean()), "q95": float(q95), "max": hi}
+
+
+def track_summaries(tracks) -> list:
+    """`track_summary` of several tracks; long ones side by side on a few threads (NumPy's selection releases the GIL)."""
+    tracks = list(tracks)
+    if len(tracks) < 2 or max(np.size(t) for t in tracks) < (1 << 16) or _workers() < 2:
+        return [track_summary(t) for t in tracks]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(tracks), _workers())) as pool:
+        return list(pool.map(track_summary, tracks))
 
 
 def _workers() -> int:
@@ -922,7 +935,7 @@ def run_diagnostics(plan: RunPlan, fit: ChainFit, final: dict) -> dict:
         eff_l[1:] = np.where(ok, pn[: n - 1, 0, 0], eff_l[1:])
         if d == 2:
             eff_t[1:] = np.where(ok, pn[: n - 1, 1, 1], eff_t[1:])
-    lvl, trd, trace = track_summary(eff_l), track_summary(eff_t), track_summary(eff_l + eff_t)
+    lvl, trd, trace = track_summaries([eff_l, eff_t, eff_l + eff_t])
     use_apn = bool(plan.ret["use_apn"])
     policy = "adaptive_process_noise" if use_apn else ("student_t_kappa" if cfg.use_kappa else "base")
     disabled = bool(plan.requested_kappa and use_apn and not cfg.use_kappa)
