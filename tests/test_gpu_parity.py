@@ -2137,13 +2137,12 @@ def test_config5_hg38_50bp_x64_matches_oracle(product, oracle):
     assert we["nll_rel"] <= 2e-9 and we["phi_rel"] <= 1e-6
     assert we["xs_level_rel"] <= 2.5e-7 and we["xs_trend_vs_level"] <= 2.5e-7
     # Round 6, with chr1 in the checked set: on chr21 / chr22 alone the default mode differed from the oracle in 335 values and
-    # NIS nowhere (round 5); on chr1 -- 5 M bins, |level| up to ~60 against innovations of ~0.06 -- 1.1 M of its 10 M filtered-state
-    # values are ONE float32 ulp off (1.2e-7 relative) and NIS is outside 1e-5 on 0.42 % of its bins (never by more than 1e-4).
-    # Cause: the sufficient-statistics form computes the innovation as zbar - x with zbar = sum(z / R) / sum(1 / R) held as ONE
-    # float64 -- an absolute error of eps |zbar| ~ 1e-14, i.e. 1e-13 of the innovation -- where the reference sums (z_j - x) / R_j,
-    # each difference exact in float64; the 1000 x larger relative error flips a float32 rounding of the level every few 1e5 bins
-    # and a flipped level persists for ~1e4 bins.  Every array is still two orders inside 1e-5; the remedy would be a centred
-    # statistics record (zbar = float32 centre + float64 remainder, 24 B instead of 16): DESIGN section 3.
+    # NIS nowhere (round 5); on chr1 -- 5 M bins; the synthetic level drifts to -880 and passes through [256, 512) -- 1.1 M of its
+    # 10 M filtered-state values are ONE float32 ulp off (1.2e-7 relative) and NIS is outside 1e-5 on 0.42 % of its bins (never by
+    # more than 1e-4).  In that window one ulp of the level is the size of the trend's increments and the float32-rounded
+    # recursion keeps two implementations that agree to 1e-16 per operation apart at the ulp scale (scripts/ubench/flip_regime.c
+    # shows the same window with plain C on the CPU; scripts/exact_vs_seq_probe.py: the library equals its own sequential kernel
+    # bit for bit on that chain).  Every array is still two orders inside 1e-5.  DESIGN section 7, finding 3.
     assert we["D_frac_outside_1e-5"] <= 1e-2 and we["D_rel_max"] <= 5e-4
     assert we["xf_values_differing"] < 0.25 * w["xf_values_differing"]        # (the 2-ulp mode differs in half of the values)
 
