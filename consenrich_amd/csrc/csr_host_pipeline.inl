@@ -701,7 +701,8 @@ static int forward_impl(csr_ctx *c, uint32_t flags, bool wantD, const unsigned c
     if (c->p.statsF32 && c->xTolUlps == 0) CHECK(csr_batch_stats(c));
     // a MASKED pass rewrites the blocked xf / Pf of its own chains only: when the resident pass left them in the reference layout
     // alone, the chains outside the mask get their blocked copies back first (they keep their resident results)
-    if (active != nullptr && c->haveFwd && (c->fwdBlockedStale || c->pfBlockedStale)) CHECK(ensure_blocked_fwd(c, nullptr));
+    // (whether or not new statistics have invalidated those results since: the masked chains get new ones, the others keep the old)
+    if (active != nullptr && (c->fwdBlockedStale || c->pfBlockedStale)) CHECK(ensure_blocked_fwd(c, nullptr));
     c->sbp.active = false;
     join_pf(c);         // (an early export nobody asked for afterwards still reads the arrays this pass overwrites)
     c->pfNat = c->pnNat = false;
@@ -915,7 +916,7 @@ static int ensure_blocked_fwd(csr_ctx *c, const unsigned char *active) {
 // to rewrite the blocked copies of its own chains: the chains outside the mask get theirs back first, so that the conversions
 // that follow the call (exports, per-phase tracks, the background update: all from the blocked copies) return what is resident.
 static int ensure_blocked_smooth(csr_ctx *c) {
-    if (!c->haveBwd || !c->smoothNat || c->mdl.state_dim != 2) return 0;
+    if (!c->smoothNat || c->mdl.state_dim != 2 || !c->nat[CSR_ARR_XS] || !c->nat[CSR_ARR_PS] || !c->nat[CSR_ARR_LAG]) return 0;
     float *xs, *Ps, *lag;
     CHECK(nat_array(c, CSR_ARR_XS, &xs));
     CHECK(nat_array(c, CSR_ARR_PS, &Ps));

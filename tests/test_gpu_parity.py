@@ -2124,7 +2124,7 @@ def test_config5_hg38_50bp_x64_matches_oracle(product, oracle):
                                             variants=[dict(x_tol_ulps=2), dict(x_tol_ulps=0)])
     _record_worst("c5_hg38_50bp_x64_ulp2", w)
     assert w["chains_checked_in_full"] == 3 and we["chains_checked_in_full"] == 3
-    assert w["state_chain_bailouts"] == 0 and we["state_chain_bailouts"] == 0
+    assert (w["state_chain_bailouts"] == 0 and we["state_chain_bailouts"] == 0) or not _default_switches()      # (the suite also runs with bail-outs forced)
     assert w["nll_rel"] <= 1e-8 and w["phi_rel"] <= 1e-5
     assert w["xs_level_rel"] <= 2e-6 and w["xs_trend_vs_level"] <= 2e-6
     # (NIS amplifies one ulp of the level by ~2 ulp / |zbar - x|: on chr1 -- 5 M bins of a random walk, |level| up to ~60 -- it is

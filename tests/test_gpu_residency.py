@@ -54,7 +54,7 @@ def _close(got, ref, lvl, msg):
 
 @pytest.mark.parametrize("natin", ["1", "0"], ids=["natin", "blocked-smoother"])
 @pytest.mark.parametrize("xtol", [0, 2], ids=["exact", "ulp2"])
-@pytest.mark.parametrize("then", ["forward_masked", "ecm_masked"])
+@pytest.mark.parametrize("then", ["forward_masked", "ecm_masked", "stats+forward_masked", "stats+ecm_masked"])
 def test_a_masked_pass_after_a_step_leaves_the_other_chains_resident(product, oracle, monkeypatch, xtol, natin, then):
     """csr_batch_step leaves xf / Pf (2-ulp mode) or Pf (default mode, pipelined tails) and the smoothed arrays in the reference
     layout only.  A masked forward pass / a masked ECM call rewrites the blocked copies of ITS chains; the chains outside the mask
@@ -74,6 +74,9 @@ def test_a_masked_pass_after_a_step_leaves_the_other_chains_resident(product, or
             b.upload(c, d_, v_)
         b.step(L.RETURN_NLL, what)
         before = {(c, a): b.download(c, a) for c in range(len(n_list)) for a in ARRS}
+        if then.startswith("stats+"):       # the driver's order inside an outer pass: new statistics, then the masked call
+            b.stats()
+            then = then[6:]
         if then == "forward_masked":
             b.forward_masked(L.RETURN_NLL, mask)
             b.backward()
@@ -88,10 +91,13 @@ def test_a_masked_pass_after_a_step_leaves_the_other_chains_resident(product, or
             ref = _oracle_pass(oracle, *sets[c]) if n_list[c] > 8 else None
             for a in ARRS:
                 got = b.download(c, a)
-                # the chains OUTSIDE the mask: untouched, bit for bit.  The recomputed ones: the same bits in the exact mode (one
-                # sequential recursion whatever the kernel form); in the 2-ulp mode a pass without reference-layout outputs may
-                # accept other carries (within the mode's tolerance: the oracle gate below)
-                if not mask[c] or xtol == 0:
+                # What was NOT recomputed must come back bit for bit: every array of a chain outside an ECM call's mask, the
+                # filtered arrays of a chain outside a forward pass's mask.  What WAS recomputed (the masked chains' forward
+                # results; after `forward_masked` the smoothed arrays of every chain, by `backward()`): the same bits in the exact
+                # mode (one sequential recursion whatever the kernel form and window); in the 2-ulp mode another pass may accept
+                # other carries -- within the mode's tolerance, the oracle gate below
+                untouched = not mask[c] and (then == "ecm_masked" or a in ("xf", "Pf"))
+                if untouched or xtol == 0:
                     assert np.array_equal(got, before[(c, a)]), (then, xtol, natin, c, a)
                 if ref is not None:
                     lvl = np.maximum(np.abs(ref["xs"][:, :1].astype(np.float64)), 1.0)

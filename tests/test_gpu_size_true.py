@@ -11,7 +11,7 @@ import pytest
 
 import cases
 from conftest import gpu_available
-from test_gpu_parity import ATOL, RTOL, _bg_batch_fixture, _record_worst, _twin_cfg
+from test_gpu_parity import ATOL, RTOL, _bg_batch_fixture, _default_switches, _record_worst, _twin_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -135,7 +135,8 @@ def test_batch_ecm_on_the_genome_batch_matches_oracle_in_both_modes(product, ora
     _record_worst("ecm_c3_hg38_200bp_x8_exact", we)
     _record_worst("ecm_c3_hg38_200bp_x8_ulp2", wt)
     for w in (we, wt):
-        assert w["chains_checked_in_full"] == len(full) and w["sb_bailouts"] == 0
+        assert w["chains_checked_in_full"] == len(full)
+        assert w["sb_bailouts"] == 0 or not _default_switches()         # (the suite also runs with bail-outs forced)
     # Every array was gated bin by bin at 1e-5 above.  What the loop does to the last bits (measured, round 6): the default mode's
     # pass is bit-identical to the oracle's up to ~1e-5 of the trend values (one trend-ulp); the kappa E-step divides second
     # differences of the smoothed state by Q0 and turns those into kappa values that differ, and three iterations later 5 % of
@@ -341,7 +342,7 @@ def test_long_memory_process_noise_at_chromosome_size(product, oracle, xtol):
             worst["D_rel_max"] = max(worst.get("D_rel_max", 0.0), float((np.abs(gD - o["D"]) / (np.abs(o["D"]) + ATOL / RTOL)).max()))
             worst["D_frac_outside_1e-5"] = max(worst.get("D_frac_outside_1e-5", 0.0), _frac_outside(gD, o["D"]))
     _record_worst(f"long_memory_q0_1e-6_chr1_chr21_x8_{'exact' if xtol == 0 else 'ulp2'}", worst)
-    assert worst["sb_bailouts"] == 0
+    assert worst["sb_bailouts"] == 0 or not _default_switches()         # (the suite also runs with bail-outs forced)
     if xtol == 0:
         assert worst["nll_rel"] <= 1e-10 and worst["xs_level_rel"] <= 2.5e-7 and worst["D_frac_outside_1e-5"] <= 1e-5
     else:
