@@ -286,3 +286,30 @@ def test_bench_fails_loudly_without_a_gpu():
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "no CPU fallback" in r.stderr or "no HIP device" in r.stderr, r.stderr[-1500:]
 
+
+
+def test_bench_line_helpers_read_the_committed_records():
+    """`throughput_mode.parity` of a bench line comes from the committed full-size parity record of that config (which arrays the
+    2-ulp mode holds to 1e-5 on the workload, which it does not); `expected` at N > 1 from the model fitted to the emulated shards."""
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    for cfg in ("c2", "c3", "c4", "c5"):
+        rec = bench.throughput_mode_parity(cfg)
+        assert rec is not None and rec["source"].startswith("profiles/r0") and rec["source"].endswith("_ulp2.json"), cfg
+        assert all(v <= 1e-5 for v in rec["holds_1e-5"].values()) and "level (xs, xf)" in rec["holds_1e-5"], (cfg, rec)
+        nis = rec["outside_1e-5"]["NIS"]
+        if cfg != "c3":                 # (the c3 test records the two output tracks only)
+            assert 0.0 < nis["fraction_of_bins"] < 0.1, (cfg, rec)       # NIS is the array the mode does not hold
+    assert bench.throughput_mode_parity("no such config") is None
+    from consenrich_amd.sharding import hg38_chain_lengths, lpt_assign
+
+    lengths = hg38_chain_lengths(200)
+    bins = [sum(lengths[i] for i in part) for part in lpt_assign(lengths, 8)]
+    exp = bench.expected_speedup(bins, sum(lengths))
+    assert 1.5 < exp["default"]["speedup_vs_1gpu"] < 3.0 and 4.5 < exp["ulp2"]["speedup_vs_1gpu"] < 7.67, exp
+    assert os.path.isfile(os.path.join(root, bench.TRAFFIC_FILES[0])) and os.path.isfile(os.path.join(root, bench.TRAFFIC_FILES[2]))
