@@ -917,6 +917,7 @@ extern "C" int csr_batch_gain_summary(csr_ctx *c, int32_t chain, int32_t use_lam
     }
     const int m = (int)c->m;
     const int64_t n = c->chains[chain].n;
+    if (c->m > 65535) return fail("gain summary: more than 65535 replicates (one grid row each)");
     GainArgs a;
     memset(&a, 0, sizeof(a));
     a.Pf = c->nat[CSR_ARR_PF]; a.lam = use_lambda ? c->nat[CSR_ARR_LAMBDA] : nullptr; a.munc = c->p.munc;
