@@ -6,5 +6,5 @@ ALL="CONSENRICH_AMD_WARMSTART=0 CONSENRICH_AMD_SEQ_STATE=1 CONSENRICH_AMD_DEFER=
 for v in ${VARIANTS:-$ALL}; do
   out=$(env $v python3 -m pytest tests -m gpu -q 2>&1)
   echo "$v: $(echo "$out" | tail -n 1)"
-  echo "$out" | grep "^FAILED" || true
+  echo "$out" | grep -E "^(FAILED|E   )" | head -n 40 || true
 done
