@@ -1,9 +1,9 @@
 """Round-5 study, review item 5: would launching the head of a step (statistics + covariance chain) PER GROUP OF CHAINS, with a ready
 word per chain gating a superblock's first walk inside the ONE launch of the state chain, shorten the default-mode step?
 
-Input: the per-chain finish times of the state chain the GPU measures (CONSENRICH_AMD_SB_DEBUG=1 CONSENRICH_AMD_DEBUG=1
-CONSENRICH_AMD_TAIL_SPLIT=0 python3 scripts/one_step.py prints "chains final at (us, bins)"; file given as argv[1], several lines
-are averaged).  Chains are independent once their records stand (scripts/ubench/sb_async_sim.c with per-chain ready times confirms:
+Input: the per-chain finish times of the state chain the GPU measured in round 5 (the instrumented `k_sb_async` instances behind
+CONSENRICH_AMD_SB_DEBUG printed "chains final at (us, bins)"; they were retired in round 6, the measurement is kept as
+profiles/r05_state_chain_finish_times.txt; file given as argv[1], several lines are averaged).  Chains are independent once their records stand (scripts/ubench/sb_async_sim.c with per-chain ready times confirms:
 a chain's finish = its ready time + the time it takes alone), so the step ends at max_c(ready[group(c)] + F_c) + tail.
 head(g) = FIX + HEAD * bins(g) / bins (both head kernels are bandwidth-bound); SLOW: how much a chain's wavefronts slow down while
 heads of later groups share the chip with them.  Orders: what is known before the step (length) against an oracle that knows the
