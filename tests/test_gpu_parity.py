@@ -2291,4 +2291,7 @@ def test_bench_started_plainly_with_two_ranks_on_one_gpu(product):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["n_ranks_seen"] == 2 and d["config"]["comm"] == "file"
     assert d["value"] == pytest.approx(14375018 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    # what a measured N > 1 line is read against: the model's speed-ups for this job's LPT table and the measured / modelled ratio
+    assert d["expected"]["default"]["speedup_vs_1gpu"] > 1.0 and d["expected"]["ulp2"]["speedup_vs_1gpu"] > 1.5
+    assert d["speedup_vs_expected"] == pytest.approx(d["expected"]["default"]["ms_per_step"] / d["ms_per_step"], rel=1e-9)
 
