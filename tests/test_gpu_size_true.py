@@ -249,6 +249,9 @@ def test_whole_fit_with_the_cli_defaults_at_chromosome_size_in_both_modes(produc
             e["xs_level_over_sigma"] = float((dl / np.sqrt(np.maximum(ref["out_Ps"][:, 0, 0].astype(np.float64), 1e-30))).max())
             e["xs_level_frac_outside_1e-5"] = float((dl > RTOL * lvl[:, 0] + ATOL).mean())
             e["bg_abs"] = float(np.abs(bg - ref["out_background"]).max())
+            # the reference's own guard for this solve (core.py:8160-8187): eps (1 + (4 lamF + 16 lam) / mean(w > 0)), w = sum_j 1 / R_j
+            wtrack = (1.0 / np.maximum(ins[c][1].astype(np.float64) + float(cfg.pad), 1.0e-8)).sum(axis=0)
+            e["reference_roundoff_index"] = float(np.finfo(np.float64).eps * (1.0 + (4.0 * pen[0] + 16.0 * pen[1]) / wtrack[wtrack > 0].mean()))
             worst.update({f"chain{c}:{k}": v for k, v in e.items()})
             gates.append((xtol, c, e))
         worst["decisions_equal"] = float(decisions_equal)
@@ -265,6 +268,7 @@ def test_whole_fit_with_the_cli_defaults_at_chromosome_size_in_both_modes(produc
     for xtol, c, e in gates:
         assert e["uncertainty"] <= 1e-5 and e["Ps"] <= 1e-5 and e["resid"] <= 1e-5, (xtol, c, e)
         assert e["bg"] <= 2e-5 and e["xs"] <= 1e-4, (xtol, c, e)
+        assert e["bg"] <= 0.2 * e["reference_roundoff_index"], (xtol, c, e)     # well inside what the reference's own elimination is good for
         assert abs(e["xs_level_abs"] - e["bg_abs"]) <= 0.2 * e["bg_abs"] + 1e-6, (xtol, c, e)       # the level error IS the background's
         assert e["xs_level_over_sigma"] <= 5e-3, (xtol, c, e)           # 2.5 orders below what the uncertainty track claims to know
         assert e["NIS_frac_outside_1e-5"] <= (2e-2 if xtol == 0 else 5e-2), (xtol, c, e)
