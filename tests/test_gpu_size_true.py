@@ -356,3 +356,65 @@ def test_long_memory_process_noise_at_chromosome_size(product, oracle, xtol):
         # of the level, is outside 1e-5 on a fifth of the bins.  The default mode is bit-identical to the oracle here.
         assert worst["nll_rel"] <= 5e-8 and worst["xs_level_rel"] <= 5e-6 and worst["xf_level_rel"] <= 5e-6
         assert worst["D_frac_outside_1e-5"] <= 0.4 and worst["D_rel_max"] <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (e) the window of levels in which the float32-rounded recursion keeps two implementations apart at the ulp scale
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_levels_between_256_and_512_stay_within_one_ulp_and_sequential(product, oracle, monkeypatch):
+    """Where one float32 ulp of the level (3e-5 in [256, 512)) is the size of the trend's own increments, a level that rounds the
+    other way once kicks the trend by ~1e4 trend-ulps and the next level rounding differs with probability ~10 % per bin: two
+    implementations that agree to 1e-16 per operation -- the reference's per-cell sums, the sufficient statistics here -- keep
+    each other apart at the ulp scale instead of merging (`scripts/ubench/flip_regime.c`: the same window with plain C on the
+    CPU; DESIGN section 7, finding 3).  What must hold there: the default mode IS still the sequential recursion of its own
+    arithmetic (superblock forms == the sequential kernel, bit for bit), and against the oracle no level is off by more than
+    a couple of float32 ulps, every array within 1e-5.  (1.5 M bins x 32: measured 0.13 % of the level values off by <= 2 ulps in
+    short episodes, 6 % of the trend values, NIS outside 1e-5 on 0.1 % of the bins; shorter or narrower chains of the same recipe
+    -- 800 k x 64, 600 k x 16 -- never start the cycle and differ in 5-17 trend values.)"""
+    from consenrich_amd import _lib as L
+    from consenrich_amd.batch import DeviceBatch, ModelParams
+
+    n, m = int(os.environ.get("WINDOW_N", "1500000")), int(os.environ.get("WINDOW_M", "32"))
+    data, munc = cases.synth(n, m, 2640)
+    data = (data + np.float32(264.0)).astype(np.float32)
+    Q0 = np.diag([1e-3, 1e-4]).astype(np.float32)
+
+    def run(env):
+        for k in ("CONSENRICH_AMD_SEQ_STATE", "CONSENRICH_AMD_SB_ASYNC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with DeviceBatch(0, x_tol_ulps=0) as b:
+            b.configure(ModelParams(state_dim=2), m, [n])
+            b.upload(0, data, munc)
+            sd, sn = b.step(L.RETURN_NLL, L.EXPORT_FORWARD | L.EXPORT_SMOOTH | L.EXPORT_RESID)
+            return {a: b.download(0, a) for a in ("xf", "Pf", "D", "xs", "Ps", "lag", "resid")}, float(sn[0])
+
+    seq, nll_seq = run({"CONSENRICH_AMD_SEQ_STATE": "1"})
+    for env in ({}, {"CONSENRICH_AMD_SB_ASYNC": "0"}):
+        got, nll = run(env)
+        assert nll == nll_seq
+        for a, v in seq.items():
+            assert np.array_equal(v, got[a]), (env, a)
+    xf, Pf, pn = np.zeros((n, 2), np.float32), np.zeros((n, 2, 2), np.float32), np.zeros((n, 2, 2), np.float32)
+    D = np.zeros(n, np.float32)
+    r = oracle.cforwardPass(matrixData=data, matrixPluginMuncInit=munc, matrixF=F, matrixQ0=Q0, intervalToBlockMap=np.zeros(n, np.int32),
+                            blockCount=1, stateInit=0.0, stateCovarInit=1000.0, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn,
+                            vectorD=D, returnNLL=True)
+    bw = oracle.cbackwardPass(matrixData=data, matrixF=F, stateForward=xf, stateCovarForward=Pf, pNoiseForward=pn)
+    lvl = np.abs(xf[:, 0].astype(np.float64))
+    dl = np.abs(seq["xf"][:, 0].astype(np.float64) - xf[:, 0])
+    worst = {"level_min": float(lvl[1000:].min()), "level_max": float(lvl.max()), "xf_level_values_differing": float(np.count_nonzero(dl)),
+             "xf_level_frac_differing": float(np.mean(dl > 0)), "xf_level_rel_max": float((dl / np.maximum(lvl, 1.0)).max()),
+             "xf_trend_values_differing": float(np.count_nonzero(seq["xf"][:, 1] != xf[:, 1])),
+             "nll_rel": abs(nll_seq - float(r[3])) / abs(float(r[3])),
+             "D_frac_outside_1e-5": _frac_outside(seq["D"], D)}
+    _record_worst(f"level_window_256_512_x{m}_exact", worst)
+    assert 255.0 < worst["level_min"] and worst["level_max"] < 512.0, worst
+    assert worst["xf_level_rel_max"] <= 4e-7 and worst["xf_level_frac_differing"] <= 0.05 and worst["nll_rel"] <= 1e-9, worst
+    assert worst["D_frac_outside_1e-5"] <= 2e-2, worst
+    np.testing.assert_array_equal(seq["Pf"], Pf)
+    scale = np.maximum(lvl, 1.0)[:, None]
+    for a, ref in (("xf", xf), ("xs", bw[0]), ("resid", bw[3])):
+        assert np.all(np.abs(seq[a].astype(np.float64) - ref) <= RTOL * scale + ATOL), a
+    np.testing.assert_allclose(seq["Ps"], bw[1], rtol=RTOL, atol=ATOL)
